@@ -1,0 +1,345 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (tools_amd) never does: it fails loudly when its HIP library is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpsf_oracle.so")
+
+TAG_ABAR, TAG_R, TAG_NORMAL, TAG_PERTURB, TAG_GADGET, TAG_SAMPD, TAG_TARGET, TAG_GPV = 1, 2, 3, 4, 5, 6, 7, 8
+TAG_RING_R, TAG_RING_E, TAG_RING_A = 9, 10, 11
+
+OK, ERR_PARAM, ERR_NOT_PD, ERR_DOMAIN, ERR_MODULUS, ERR_NO_SOLUTION = range(6)
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("psf_oracle.c", "psf_oracle_gpv.c", "psf_oracle.h", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libpsf_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class GadgetParams(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("k", C.c_uint64), ("m_bar", C.c_uint64), ("base", C.c_uint64), ("q", C.c_uint64)]
+
+    def as_tuple(self):
+        return (self.n, self.k, self.m_bar, self.base, self.q)
+
+
+class _Psfp(C.Structure):
+    _fields_ = [("gp", GadgetParams), ("r", C.c_double), ("s", C.c_double), ("m", C.c_size_t),
+                ("A", C.POINTER(C.c_uint64)), ("R", C.POINTER(C.c_int8)), ("L", C.POINTER(C.c_double)),
+                ("Sk", C.POINTER(C.c_int64)), ("Sk_gso", C.POINTER(C.c_double))]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_det_exp.restype = C.c_double
+        _lib.orc_det_exp.argtypes = [C.c_double]
+        _lib.orc_sample_z.restype = C.c_int64
+        _lib.orc_sample_z.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_double, C.c_double]
+        _lib.orc_sample_normal.restype = C.c_double
+        _lib.orc_sample_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        _lib.orc_uniform_mod.restype = C.c_uint64
+        _lib.orc_uniform_mod.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+        _lib.orc_psfp_new.restype = C.POINTER(_Psfp)
+        _lib.orc_psfp_new.argtypes = [C.POINTER(GadgetParams), C.c_double, C.c_double]
+        _lib.orc_psfp_free.argtypes = [C.POINTER(_Psfp)]
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _i8(a):
+    return np.ascontiguousarray(a, dtype=np.int8)
+
+
+def _check(rc, allow=()):
+    if rc != OK and rc not in allow:
+        raise RuntimeError(f"oracle status {rc}")
+    return rc
+
+
+# ---------------------------------------------------------------- randomness primitives
+def philox(seed, c0, c1, c2, c3):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox4x32(C.c_uint64(seed), C.c_uint32(c0), C.c_uint32(c1), C.c_uint32(c2), C.c_uint32(c3), out)
+    return list(out)
+
+
+def det_exp(y):
+    return lib().orc_det_exp(y)
+
+
+def sample_z(seed, tag, index, coord, center, s):
+    return lib().orc_sample_z(seed, tag, index, coord, center, s)
+
+
+def sample_normal(seed, index, coord):
+    return lib().orc_sample_normal(seed, index, coord)
+
+
+def uniform_targets(seed, B, n, q, first_index=0):
+    """Synthetic uniform syndromes u in Z_q^{B x n} (benches/psf.rs:35,60,87), stream TAG_TARGET."""
+    u = np.empty((B, n), dtype=np.uint64)
+    L = lib()
+    for b in range(B):
+        for i in range(n):
+            u[b, i] = L.orc_uniform_mod(seed, TAG_TARGET, i, (first_index + b) & 0xFFFFFFFF, q)
+    return u
+
+
+# ---------------------------------------------------------------- deterministic helpers
+def gadget_params_default(n, q):
+    gp = GadgetParams()
+    _check(lib().orc_gadget_params_default(C.c_uint64(n), C.c_uint64(q), C.byref(gp)))
+    return gp
+
+
+def gadget_params_ring_default(n, q):
+    gp = GadgetParams()
+    _check(lib().orc_gadget_params_ring_default(C.c_uint64(n), C.c_uint64(q), C.byref(gp)))
+    return gp
+
+
+def gen_gadget_vec(k, base):
+    out = np.zeros(k, dtype=np.int64)
+    _check(lib().orc_gen_gadget_vec(C.c_uint64(k), C.c_uint64(base), _p(out, C.c_int64)))
+    return out
+
+
+def gen_gadget_mat(n, k, base):
+    out = np.zeros((n, n * k), dtype=np.int64)
+    _check(lib().orc_gen_gadget_mat(C.c_uint64(n), C.c_uint64(k), C.c_uint64(base), _p(out, C.c_int64)))
+    return out
+
+
+def find_solution_gadget_vec(value, q, k, base):
+    out = np.zeros(k, dtype=np.int64)
+    rc = lib().orc_find_solution_gadget_vec(C.c_uint64(value), C.c_uint64(q), C.c_uint64(k), C.c_uint64(base),
+                                            _p(out, C.c_int64))
+    _check(rc)
+    return out
+
+
+def find_solution_gadget_mat(value, q, k, base):
+    value = _u64(value)
+    rows, cols = value.shape
+    out = np.zeros((k * rows, cols), dtype=np.int64)
+    _check(lib().orc_find_solution_gadget_mat(_p(value, C.c_uint64), C.c_size_t(rows), C.c_size_t(cols),
+                                              C.c_uint64(q), C.c_uint64(k), C.c_uint64(base), _p(out, C.c_int64)))
+    return out
+
+
+def short_basis_gadget(gp):
+    w = gp.n * gp.k
+    out = np.zeros((w, w), dtype=np.int64)
+    _check(lib().orc_short_basis_gadget(C.byref(gp), _p(out, C.c_int64)))
+    return out
+
+
+def short_basis_gadget_block(gp):
+    out = np.zeros((gp.k, gp.k), dtype=np.int64)
+    _check(lib().orc_short_basis_gadget_block(C.byref(gp), _p(out, C.c_int64)))
+    return out
+
+
+def gso_columns(basis):
+    basis = _i64(basis)
+    d = basis.shape[0]
+    out = np.zeros((d, d), dtype=np.float64)
+    lib().orc_gso_columns(_p(basis, C.c_int64), C.c_size_t(d), _p(out, C.c_double))
+    return out
+
+
+def sample_r(seed, m_bar, w):
+    R = np.zeros((m_bar, w), dtype=np.int8)
+    lib().orc_sample_r(C.c_uint64(seed), C.c_size_t(m_bar), C.c_size_t(w), _p(R, C.c_int8))
+    return R
+
+
+def sample_a_bar(seed, n, m_bar, q):
+    a = np.zeros((n, m_bar), dtype=np.uint64)
+    lib().orc_sample_a_bar(C.c_uint64(seed), C.c_size_t(n), C.c_size_t(m_bar), C.c_uint64(q), _p(a, C.c_uint64))
+    return a
+
+
+def gen_trapdoor(gp, a_bar, R, tag=None):
+    a_bar, R = _u64(a_bar), _i8(R)
+    m = gp.m_bar + gp.n * gp.k
+    A = np.zeros((gp.n, m), dtype=np.uint64)
+    tagp = _p(_u64(tag), C.c_uint64) if tag is not None else None
+    _check(lib().orc_gen_trapdoor(C.byref(gp), _p(a_bar, C.c_uint64), tagp, _p(R, C.c_int8), _p(A, C.c_uint64)))
+    return A
+
+
+def gen_sa_l(R):
+    R = _i8(R)
+    mb, w = R.shape
+    out = np.zeros((mb + w, mb + w), dtype=np.int64)
+    _check(lib().orc_gen_sa_l(_p(R, C.c_int8), C.c_size_t(mb), C.c_size_t(w), _p(out, C.c_int64)))
+    return out
+
+
+def gen_sa_r(gp, A, tag=None):
+    A = _u64(A)
+    m = gp.m_bar + gp.n * gp.k
+    out = np.zeros((m, m), dtype=np.int64)
+    tagp = _p(_u64(tag), C.c_uint64) if tag is not None else None
+    _check(lib().orc_gen_sa_r(C.byref(gp), tagp, _p(A, C.c_uint64), _p(out, C.c_int64)))
+    return out
+
+
+def compute_w(gp, A, tag=None):
+    A = _u64(A)
+    out = np.zeros((gp.n * gp.k, gp.m_bar), dtype=np.int64)
+    tagp = _p(_u64(tag), C.c_uint64) if tag is not None else None
+    _check(lib().orc_compute_w(C.byref(gp), tagp, _p(A, C.c_uint64), _p(out, C.c_int64)))
+    return out
+
+
+def gen_short_basis_for_trapdoor(gp, A, R, tag=None):
+    A, R = _u64(A), _i8(R)
+    m = gp.m_bar + gp.n * gp.k
+    out = np.zeros((m, m), dtype=np.int64)
+    tagp = _p(_u64(tag), C.c_uint64) if tag is not None else None
+    _check(lib().orc_gen_short_basis_for_trapdoor(C.byref(gp), tagp, _p(A, C.c_uint64), _p(R, C.c_int8),
+                                                  _p(out, C.c_int64)))
+    return out
+
+
+# ---------------------------------------------------------------- PSFPerturbation
+class PSFPerturbation:
+    """Oracle mirror of mp_perturbation.rs:57-62 / :193-403."""
+
+    def __init__(self, gp, r, s):
+        self.gp, self.r, self.s = gp, float(r), float(s)
+        self._h = lib().orc_psfp_new(C.byref(gp), C.c_double(r), C.c_double(s))
+        if not self._h:
+            raise ValueError("bad parameters")
+        self.n, self.k, self.m_bar = gp.n, gp.k, gp.m_bar
+        self.w = gp.n * gp.k
+        self.m = self.m_bar + self.w
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_psfp_free(self._h)
+            self._h = None
+
+    # key material views (copies)
+    @property
+    def A(self):
+        return np.ctypeslib.as_array(self._h.contents.A, shape=(self.n, self.m)).copy()
+
+    @property
+    def R(self):
+        return np.ctypeslib.as_array(self._h.contents.R, shape=(self.m_bar, self.w)).copy()
+
+    @property
+    def L_packed(self):
+        return np.ctypeslib.as_array(self._h.contents.L, shape=(self.m * (self.m + 1) // 2,)).copy()
+
+    @property
+    def Sk(self):
+        return np.ctypeslib.as_array(self._h.contents.Sk, shape=(self.k, self.k)).copy()
+
+    @property
+    def Sk_gso(self):
+        return np.ctypeslib.as_array(self._h.contents.Sk_gso, shape=(self.k, self.k)).copy()
+
+    def L_dense(self):
+        Ld = np.zeros((self.m, self.m))
+        Ld[np.tril_indices(self.m)] = self.L_packed
+        return Ld
+
+    def trap_gen(self, seed):
+        return lib().orc_psfp_trap_gen(self._h, C.c_uint64(seed))
+
+    def load_key(self, A, R, L_packed):
+        A, R = _u64(A), _i8(R)
+        Lp = np.ascontiguousarray(L_packed, dtype=np.float64)
+        assert A.shape == (self.n, self.m) and R.shape == (self.m_bar, self.w) and Lp.size == self.m * (self.m + 1) // 2
+        _check(lib().orc_psfp_load_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8), _p(Lp, C.c_double)))
+
+    def compute_sqrt_sigma_2(self, R, s_cov):
+        R = _i8(R)
+        Lp = np.zeros(self.m * (self.m + 1) // 2)
+        rc = lib().orc_psfp_compute_sqrt_sigma_2(self._h, _p(R, C.c_int8), C.c_double(s_cov), _p(Lp, C.c_double))
+        return rc, Lp
+
+    def samp_p(self, seed, u, first_index=0, nthreads=0):
+        u = _u64(u).reshape(-1, self.n)
+        B = u.shape[0]
+        e = np.zeros((B, self.m), dtype=np.int64)
+        _check(lib().orc_psfp_samp_p(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B),
+                                     _p(u, C.c_uint64), _p(e, C.c_int64), C.c_int(nthreads)))
+        return e
+
+    def samp_p_trace(self, seed, index, u):
+        u = _u64(u).reshape(self.n)
+        d, x = np.zeros(self.m), np.zeros(self.m)
+        p, e = np.zeros(self.m, dtype=np.int64), np.zeros(self.m, dtype=np.int64)
+        v, z = np.zeros(self.n, dtype=np.uint64), np.zeros(self.w, dtype=np.int64)
+        _check(lib().orc_psfp_samp_p_trace(self._h, C.c_uint64(seed), C.c_uint64(index), _p(u, C.c_uint64),
+                                           _p(d, C.c_double), _p(x, C.c_double), _p(p, C.c_int64), _p(v, C.c_uint64),
+                                           _p(z, C.c_int64), _p(e, C.c_int64)))
+        return dict(d=d, x=x, p=p, v=v, z=z, e=e)
+
+    def samp_d(self, seed, B=1, first_index=0):
+        e = np.zeros((B, self.m), dtype=np.int64)
+        _check(lib().orc_psfp_samp_d(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(e, C.c_int64)))
+        return e
+
+    def f_a(self, e, allow_domain_error=False):
+        e = _i64(e).reshape(-1, self.m)
+        B = e.shape[0]
+        u = np.zeros((B, self.n), dtype=np.uint64)
+        rc = lib().orc_psfp_f_a(self._h, C.c_size_t(B), _p(e, C.c_int64), _p(u, C.c_uint64))
+        if rc == ERR_DOMAIN and not allow_domain_error:
+            raise AssertionError("sigma not in domain (mp_perturbation.rs:367)")
+        return u
+
+    def check_domain(self, e):
+        e = _i64(e)
+        if e.ndim == 1:
+            e = e.reshape(1, -1)
+        B, ln = e.shape
+        ok = np.zeros(B, dtype=np.uint8)
+        _check(lib().orc_psfp_check_domain(self._h, C.c_size_t(B), _p(e, C.c_int64), C.c_size_t(ln), _p(ok, C.c_uint8)))
+        return ok.astype(bool)
+
+    def gadget_sample(self, seed, index, v):
+        v = _u64(v).reshape(self.n)
+        z = np.zeros(self.w, dtype=np.int64)
+        _check(lib().orc_randomized_nearest_plane_gadget(self._h, C.c_uint64(seed), C.c_uint64(index),
+                                                         _p(v, C.c_uint64), _p(z, C.c_int64)))
+        return z
+
+
+def num_threads():
+    return lib().orc_num_threads()

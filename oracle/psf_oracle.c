@@ -1,0 +1,733 @@
+/*
+ * psf_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY).  See psf_oracle.h for the parity status.
+ *
+ * Restates, in plain C over flat arrays, the algorithms of qfall/tools (paths relative to the
+ * reference root):
+ *   src/sample/g_trapdoor/gadget_parameters.rs, gadget_classical.rs, trapdoor_distribution.rs,
+ *   short_basis_classical.rs, src/primitive/psf/mp_perturbation.rs.
+ * Each function cites the lines it follows.  Floating point: IEEE-754 binary64, explicit fma(),
+ * compiled with -ffp-contract=off, every summation order is written out below and is part of
+ * the contract the HIP kernels are bit-compared against.
+ */
+#include "psf_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+
+/* ------------------------------------------------------------------------------------------
+ * Randomness contract
+ * ---------------------------------------------------------------------------------------- */
+
+/* Philox4x32-10 (Salmon et al., SC'11); key = 64-bit seed, counter = (c0,c1,c2,c3). */
+void orc_philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int round = 0; round < 10; ++round) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline uint32_t tag_word(uint32_t tag, uint64_t index) { return tag | (uint32_t)((index >> 32) << 8); }
+
+static inline uint64_t mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) >> 64); }
+
+/* exp(y) for y <= 0 in pure IEEE arithmetic: k = floor(y*log2e + 1/2), r = y - k*ln2 (two-part),
+ * degree-13 Taylor polynomial by Horner/fma, scale by 2^k through the exponent field. */
+double orc_det_exp(double y) {
+  if (!(y > -708.0)) return 0.0;
+  if (y > 0.0) y = 0.0;
+  const double LOG2E = 1.4426950408889634, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  double kf = floor(y * LOG2E + 0.5);
+  double r = fma(kf, -LN2_HI, y);
+  r = fma(kf, -LN2_LO, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  int64_t k = (int64_t)kf;
+  uint64_t bits;
+  memcpy(&bits, &p, 8);
+  bits = (uint64_t)((int64_t)bits + (k << 52));
+  memcpy(&p, &bits, 8);
+  return p;
+}
+
+#define ORC_MAX_ATTEMPTS 65536u
+
+/* Z::sample_discrete_gauss / SampleZ of GPV08 as documented at CONTRIBUTING.md:35-45:
+ * candidates uniform in [center - ceil(6s), center + floor(6s)], accepted with probability
+ * rho_s(x - c) = exp(-pi (x-c)^2 / s^2)  (s = sigma*sqrt(2 pi)). */
+int64_t orc_sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center, double s) {
+  const double NEG_PI = -3.14159265358979323846;
+  double inv_s = 1.0 / s;
+  int64_t lo = (int64_t)ceil(center) - (int64_t)ceil(6.0 * s);
+  int64_t hi = (int64_t)floor(center) + (int64_t)floor(6.0 * s);
+  uint64_t N = (uint64_t)(hi - lo + 1);
+  uint32_t w[4];
+  for (uint32_t t = 0; t < ORC_MAX_ATTEMPTS; ++t) {
+    orc_philox4x32(seed, coord, (uint32_t)index, t, tag_word(tag, index), w);
+    uint64_t r64 = ((uint64_t)w[1] << 32) | w[0];
+    int64_t x = lo + (int64_t)mulhi64(r64, N);
+    double u = (double)((((uint64_t)w[3] << 32) | w[2]) >> 11) * 0x1.0p-53;
+    double a = ((double)x - center) * inv_s;
+    double rho = orc_det_exp(NEG_PI * (a * a));
+    if (u < rho) return x;
+  }
+  return (int64_t)floor(center + 0.5);
+}
+
+/* N(0,1) by Kinderman-Monahan ratio of uniforms: x = sqrt(2/e) v / u, accept iff u <= exp(-x^2/4). */
+double orc_sample_normal(uint64_t seed, uint64_t index, uint32_t coord) {
+  const double C_RU = 0.8577638849607068; /* sqrt(2/e) */
+  uint32_t w[4];
+  for (uint32_t t = 0; t < ORC_MAX_ATTEMPTS; ++t) {
+    orc_philox4x32(seed, coord, (uint32_t)index, t, tag_word(ORC_TAG_NORMAL, index), w);
+    double u = (double)(((((uint64_t)w[1] << 32) | w[0]) >> 11) + 1) * 0x1.0p-53; /* (0,1] */
+    uint64_t vv = (((uint64_t)w[3] << 32) | w[2]) >> 12;                          /* 52 bits */
+    double v = (double)(2 * vv + 1) * 0x1.0p-52 - 1.0;                            /* (-1,1), exact */
+    double x = (v * C_RU) / u;
+    double rho = orc_det_exp(-0.25 * (x * x));
+    if (u <= rho) return x;
+  }
+  return 0.0;
+}
+
+uint64_t orc_uniform_mod(uint64_t seed, uint32_t tag, uint32_t c0, uint32_t c1, uint64_t q) {
+  uint32_t w[4];
+  orc_philox4x32(seed, c0, c1, 0, tag, w);
+  return mulhi64(((uint64_t)w[1] << 32) | w[0], q);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * small integer helpers
+ * ---------------------------------------------------------------------------------------- */
+static uint64_t log_ceil(uint64_t x, uint64_t base) { /* smallest e with base^e >= x */
+  uint64_t e = 0;
+  u128 p = 1;
+  while (p < x) { p *= base; ++e; }
+  return e;
+}
+static int pow_u128(uint64_t base, uint64_t k, u128* out) {
+  u128 p = 1;
+  for (uint64_t i = 0; i < k; ++i) {
+    if (p > (((u128)1) << 100)) return 1;
+    p *= base;
+  }
+  *out = p;
+  return 0;
+}
+static inline uint64_t addmod(uint64_t a, uint64_t b, uint64_t q) { uint64_t s = a + b; return (s >= q || s < a) ? s - q : s; }
+static inline uint64_t submod(uint64_t a, uint64_t b, uint64_t q) { return a >= b ? a - b : a + q - b; }
+static inline uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((u128)a * b) % q); }
+static inline uint64_t reduce_i128(i128 v, uint64_t q) { i128 r = v % (i128)q; if (r < 0) r += q; return (uint64_t)r; }
+
+/* gadget_parameters.rs:113-133: base 2, k = ceil(log2 q), m_bar = n k + ceil(log2 n)^2 */
+int orc_gadget_params_default(uint64_t n, uint64_t q, orc_gadget_params* gp) {
+  if (n < 1 || q <= 1) return ORC_ERR_PARAM;
+  gp->n = n; gp->base = 2; gp->q = q;
+  gp->k = log_ceil(q, 2);
+  uint64_t ln = log_ceil(n, 2);
+  gp->m_bar = n * gp->k + ln * ln;
+  return ORC_OK;
+}
+/* gadget_parameters.rs:165-185: m_bar = k + 2 */
+int orc_gadget_params_ring_default(uint64_t n, uint64_t q, orc_gadget_params* gp) {
+  if (n < 1 || q <= 1) return ORC_ERR_PARAM;
+  gp->n = n; gp->base = 2; gp->q = q;
+  gp->k = log_ceil(q, 2);
+  gp->m_bar = gp->k + 2;
+  return ORC_OK;
+}
+
+/* gadget_classical.rs:128-136 */
+int orc_gen_gadget_vec(uint64_t k, uint64_t base, int64_t* out) {
+  if (k < 1) return ORC_ERR_PARAM;
+  int64_t entry = 1;
+  for (uint64_t i = 0; i < k; ++i) { out[i] = entry; entry *= (int64_t)base; }
+  return ORC_OK;
+}
+/* gadget_classical.rs:91-107: I_n (x) g^t */
+int orc_gen_gadget_mat(uint64_t n, uint64_t k, uint64_t base, int64_t* out) {
+  if (n < 1 || k < 1) return ORC_ERR_PARAM;
+  int64_t* g = (int64_t*)malloc(k * sizeof(int64_t));
+  orc_gen_gadget_vec(k, base, g);
+  memset(out, 0, n * n * k * sizeof(int64_t));
+  for (uint64_t j = 0; j < n; ++j)
+    for (uint64_t i = 0; i < k; ++i) out[j * (n * k) + j * k + i] = g[i];
+  free(g);
+  return ORC_OK;
+}
+/* gadget_classical.rs:169-182: LSB-first base-b digits of the least non-negative residue */
+int orc_find_solution_gadget_vec(uint64_t value, uint64_t q, uint64_t k, uint64_t base, int64_t* out) {
+  u128 bk;
+  if (pow_u128(base, k, &bk) == 0 && bk < q) return ORC_ERR_MODULUS; /* :170-172 */
+  value %= q;
+  for (uint64_t i = 0; i < k; ++i) {
+    uint64_t d = value % base;
+    out[i] = (int64_t)d;
+    value = (value - d) / base;
+  }
+  return ORC_OK;
+}
+/* gadget_classical.rs:219-229: out[k*j + i, col] = digit_i(value[j, col]) */
+int orc_find_solution_gadget_mat(const uint64_t* value, size_t rows, size_t cols, uint64_t q, uint64_t k,
+                                 uint64_t base, int64_t* out) {
+  int64_t* d = (int64_t*)malloc(k * sizeof(int64_t));
+  for (size_t i = 0; i < cols; ++i)
+    for (size_t j = 0; j < rows; ++j) {
+      int rc = orc_find_solution_gadget_vec(value[j * cols + i], q, k, base, d);
+      if (rc) { free(d); return rc; }
+      for (uint64_t t = 0; t < k; ++t) out[(k * j + t) * cols + i] = d[t];
+    }
+  free(d);
+  return ORC_OK;
+}
+/* gadget_classical.rs:249-272 */
+int orc_short_basis_gadget_block(const orc_gadget_params* gp, int64_t* sk) {
+  size_t k = gp->k;
+  memset(sk, 0, k * k * sizeof(int64_t));
+  for (size_t j = 0; j < k; ++j) sk[j * k + j] = (int64_t)gp->base;       /* :252-254 */
+  for (size_t i = 0; i + 1 < k; ++i) sk[(i + 1) * k + i] = -1;            /* :255-257 */
+  u128 bk;
+  int big = pow_u128(gp->base, gp->k, &bk);
+  if (big || bk != gp->q) {                                                /* :258-272 */
+    uint64_t q = gp->q;
+    for (size_t i = 0; i < k; ++i) {
+      uint64_t qi = q % gp->base;
+      sk[i * k + (k - 1)] = (int64_t)qi;
+      q = (q - qi) / gp->base;
+    }
+  }
+  return ORC_OK;
+}
+/* gadget_classical.rs:273-286: I_n (x) S_k */
+int orc_short_basis_gadget(const orc_gadget_params* gp, int64_t* out) {
+  size_t n = gp->n, k = gp->k, w = n * k;
+  int64_t* sk = (int64_t*)malloc(k * k * sizeof(int64_t));
+  orc_short_basis_gadget_block(gp, sk);
+  memset(out, 0, w * w * sizeof(int64_t));
+  for (size_t j = 0; j < n; ++j)
+    for (size_t a = 0; a < k; ++a)
+      for (size_t b = 0; b < k; ++b) out[(j * k + a) * w + (j * k + b)] = sk[a * k + b];
+  free(sk);
+  return ORC_OK;
+}
+
+/* MatQ::gso (mp_perturbation.rs:234): Gram-Schmidt on the COLUMNS, no normalisation.
+ * b~_i = b_i - sum_{l<i} (<b_i, b~_l> / <b~_l, b~_l>) b~_l ; dots are ascending fma chains. */
+void orc_gso_columns(const int64_t* basis, size_t dim, double* gso) {
+  double* norm2 = (double*)malloc(dim * sizeof(double));
+  for (size_t i = 0; i < dim; ++i) {
+    for (size_t t = 0; t < dim; ++t) gso[t * dim + i] = (double)basis[t * dim + i];
+    for (size_t l = 0; l < i; ++l) {
+      double num = 0.0;
+      for (size_t t = 0; t < dim; ++t) num = fma((double)basis[t * dim + i], gso[t * dim + l], num);
+      double mu = num / norm2[l];
+      for (size_t t = 0; t < dim; ++t) gso[t * dim + i] = fma(-mu, gso[t * dim + l], gso[t * dim + i]);
+    }
+    double nn = 0.0;
+    for (size_t t = 0; t < dim; ++t) nn = fma(gso[t * dim + i], gso[t * dim + i], nn);
+    norm2[i] = nn;
+  }
+  free(norm2);
+}
+
+/* trapdoor_distribution.rs:82-86: difference of two uniform bits; 64 entries per Philox block */
+void orc_sample_r(uint64_t seed, size_t m_bar, size_t w, int8_t* R) {
+  uint32_t wd[4];
+  for (size_t i = 0; i < m_bar; ++i)
+    for (size_t j = 0; j < w; ++j) {
+      if ((j & 63) == 0 || j == 0) orc_philox4x32(seed, (uint32_t)(j >> 6), (uint32_t)i, 0, ORC_TAG_R, wd);
+      uint32_t word = wd[(j & 63) >> 4];
+      uint32_t sh = 2 * (j & 15);
+      R[i * w + j] = (int8_t)((int)((word >> sh) & 1) - (int)((word >> (sh + 1)) & 1));
+    }
+}
+/* mp_perturbation.rs:222 MatZq::sample_uniform */
+void orc_sample_a_bar(uint64_t seed, size_t n, size_t m_bar, uint64_t q, uint64_t* a_bar) {
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < m_bar; ++j) a_bar[i * m_bar + j] = orc_uniform_mod(seed, ORC_TAG_ABAR, (uint32_t)j, (uint32_t)i, q);
+}
+
+/* gadget_classical.rs:56-68: A = [A_bar | tag*G - A_bar*R] */
+int orc_gen_trapdoor(const orc_gadget_params* gp, const uint64_t* a_bar, const uint64_t* tag, const int8_t* R, uint64_t* A) {
+  size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = mb + w;
+  uint64_t q = gp->q;
+  uint64_t* gvec = (uint64_t*)malloc(k * sizeof(uint64_t));
+  uint64_t e = 1 % q;
+  for (size_t t = 0; t < k; ++t) { gvec[t] = e; e = mulmod(e, gp->base % q, q); }
+  uint64_t* acc = (uint64_t*)malloc(w * sizeof(uint64_t));
+  for (size_t i = 0; i < n; ++i) {
+    for (size_t j = 0; j < mb; ++j) A[i * m + j] = a_bar[i * mb + j] % q;
+    memset(acc, 0, w * sizeof(uint64_t));
+    for (size_t t = 0; t < mb; ++t) {
+      uint64_t a = a_bar[i * mb + t] % q;
+      const int8_t* Rt = R + t * w;
+      for (size_t c = 0; c < w; ++c) {
+        if (Rt[c] == 1) acc[c] = addmod(acc[c], a, q);
+        else if (Rt[c] == -1) acc[c] = submod(acc[c], a, q);
+        else if (Rt[c] != 0) acc[c] = reduce_i128((i128)acc[c] + (i128)a * Rt[c], q);
+      }
+    }
+    for (size_t j = 0; j < n; ++j) {
+      uint64_t h = tag ? tag[i * n + j] % q : (i == j ? 1 % q : 0);
+      for (size_t t = 0; t < k; ++t) {
+        uint64_t hg = h ? mulmod(h, gvec[t], q) : 0;
+        A[i * m + mb + j * k + t] = submod(hg, acc[j * k + t], q);
+      }
+    }
+  }
+  free(acc); free(gvec);
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * short_basis_classical.rs
+ * ---------------------------------------------------------------------------------------- */
+/* :66-74  [ I | R ; 0 | I ] */
+int orc_gen_sa_l(const int8_t* R, size_t m_bar, size_t w, int64_t* out) {
+  size_t m = m_bar + w;
+  memset(out, 0, m * m * sizeof(int64_t));
+  for (size_t i = 0; i < m; ++i) out[i * m + i] = 1;
+  for (size_t i = 0; i < m_bar; ++i)
+    for (size_t j = 0; j < w; ++j) out[i * m + m_bar + j] = R[i * w + j];
+  return ORC_OK;
+}
+
+/* inverse of an n x n matrix mod q by Gauss-Jordan with unit pivots (tag.inverse(), :106) */
+static int mat_inverse_mod(const uint64_t* M, size_t n, uint64_t q, uint64_t* inv);
+
+/* :105-110  G W = -H^{-1} A [I | 0]^t mod q */
+int orc_compute_w(const orc_gadget_params* gp, const uint64_t* tag, const uint64_t* A, int64_t* W) {
+  size_t n = gp->n, k = gp->k, mb = gp->m_bar, m = mb + n * k;
+  uint64_t q = gp->q;
+  uint64_t* rhs = (uint64_t*)malloc(n * mb * sizeof(uint64_t));
+  uint64_t* tinv = NULL;
+  if (tag) {
+    tinv = (uint64_t*)malloc(n * n * sizeof(uint64_t));
+    if (mat_inverse_mod(tag, n, q, tinv)) { free(rhs); free(tinv); return ORC_ERR_PARAM; }
+  }
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < mb; ++j) {
+      uint64_t v;
+      if (tinv) {
+        u128 s = 0;
+        for (size_t t = 0; t < n; ++t) s = (s + (u128)tinv[i * n + t] * (A[t * m + j] % q)) % q;
+        v = (uint64_t)s;
+      } else v = A[i * m + j] % q;
+      rhs[i * mb + j] = v ? q - v : 0;
+    }
+  int rc = orc_find_solution_gadget_mat(rhs, n, mb, q, k, gp->base, W);
+  free(rhs); free(tinv);
+  return rc;
+}
+
+/* :77-102  [ 0 | I ; S' | W ], S' = column-reversed S iff base^k == q (:80-82) */
+int orc_gen_sa_r(const orc_gadget_params* gp, const uint64_t* tag, const uint64_t* A, int64_t* out) {
+  size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = mb + w;
+  int64_t* S = (int64_t*)malloc(w * w * sizeof(int64_t));
+  orc_short_basis_gadget(gp, S);
+  u128 bk;
+  int reversed = (pow_u128(gp->base, gp->k, &bk) == 0 && bk == gp->q);
+  int64_t* W = (int64_t*)malloc(w * mb * sizeof(int64_t));
+  int rc = orc_compute_w(gp, tag, A, W);
+  if (rc) { free(S); free(W); return rc; }
+  memset(out, 0, m * m * sizeof(int64_t));
+  for (size_t d = 0; d < mb; ++d) out[d * m + (w + d)] = 1;                     /* :90-93 */
+  for (size_t i = 0; i < w; ++i) {
+    for (size_t j = 0; j < w; ++j) out[(mb + i) * m + j] = S[i * w + (reversed ? (w - 1 - j) : j)];
+    for (size_t j = 0; j < mb; ++j) out[(mb + i) * m + w + j] = W[i * mb + j];
+  }
+  free(S); free(W);
+  return ORC_OK;
+}
+
+/* :54-63  S_A = sa_l * sa_r  (structured: top = [R S' | I + R W], bottom = [S' | W]) */
+int orc_gen_short_basis_for_trapdoor(const orc_gadget_params* gp, const uint64_t* tag, const uint64_t* A,
+                                     const int8_t* R, int64_t* out) {
+  size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = mb + w;
+  int64_t* sar = (int64_t*)malloc(m * m * sizeof(int64_t));
+  int rc = orc_gen_sa_r(gp, tag, A, sar);
+  if (rc) { free(sar); return rc; }
+  /* rows >= m_bar of sa_l are unit rows */
+  memcpy(out + mb * m, sar + mb * m, w * m * sizeof(int64_t));
+  for (size_t i = 0; i < mb; ++i) {
+    int64_t* o = out + i * m;
+    memcpy(o, sar + i * m, m * sizeof(int64_t));
+    for (size_t t = 0; t < w; ++t) {
+      int64_t rv = R[i * w + t];
+      if (!rv) continue;
+      const int64_t* srow = sar + (mb + t) * m;
+      for (size_t j = 0; j < m; ++j) o[j] += rv * srow[j];
+    }
+  }
+  free(sar);
+  return ORC_OK;
+}
+
+static uint64_t inv_mod(uint64_t a, uint64_t q, int* ok) {
+  i128 t = 0, nt = 1, r = q, nr = a % q;
+  while (nr != 0) {
+    i128 qq = r / nr;
+    i128 tmp = t - qq * nt; t = nt; nt = tmp;
+    tmp = r - qq * nr; r = nr; nr = tmp;
+  }
+  if (r != 1) { *ok = 0; return 0; }
+  *ok = 1;
+  if (t < 0) t += q;
+  return (uint64_t)t;
+}
+static int mat_inverse_mod(const uint64_t* M, size_t n, uint64_t q, uint64_t* inv) {
+  uint64_t* a = (uint64_t*)malloc(n * n * sizeof(uint64_t));
+  for (size_t i = 0; i < n * n; ++i) a[i] = M[i] % q;
+  for (size_t i = 0; i < n; ++i) for (size_t j = 0; j < n; ++j) inv[i * n + j] = (i == j) ? 1 % q : 0;
+  for (size_t c = 0; c < n; ++c) {
+    size_t p = n; uint64_t pinv = 0;
+    for (size_t r = c; r < n; ++r) { int ok; pinv = inv_mod(a[r * n + c], q, &ok); if (ok) { p = r; break; } }
+    if (p == n) { free(a); return 1; }
+    if (p != c) for (size_t j = 0; j < n; ++j) {
+      uint64_t t = a[p * n + j]; a[p * n + j] = a[c * n + j]; a[c * n + j] = t;
+      t = inv[p * n + j]; inv[p * n + j] = inv[c * n + j]; inv[c * n + j] = t;
+    }
+    for (size_t j = 0; j < n; ++j) { a[c * n + j] = mulmod(a[c * n + j], pinv, q); inv[c * n + j] = mulmod(inv[c * n + j], pinv, q); }
+    for (size_t r = 0; r < n; ++r) {
+      if (r == c) continue;
+      uint64_t f = a[r * n + c];
+      if (!f) continue;
+      for (size_t j = 0; j < n; ++j) {
+        a[r * n + j] = submod(a[r * n + j], mulmod(f, a[c * n + j], q), q);
+        inv[r * n + j] = submod(inv[r * n + j], mulmod(f, inv[c * n + j], q), q);
+      }
+    }
+  }
+  free(a);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * PSFPerturbation (mp_perturbation.rs)
+ * ---------------------------------------------------------------------------------------- */
+orc_psfp* orc_psfp_new(const orc_gadget_params* gp, double r, double s) {
+  if (!gp || gp->n < 1 || gp->k < 1 || gp->q <= 1 || !(r > 0) || !(s > 0)) return NULL;
+  orc_psfp* h = (orc_psfp*)calloc(1, sizeof(orc_psfp));
+  h->gp = *gp; h->r = r; h->s = s;
+  size_t w = gp->n * gp->k;
+  h->m = gp->m_bar + w;
+  h->A = (uint64_t*)calloc(gp->n * h->m, sizeof(uint64_t));
+  h->R = (int8_t*)calloc(gp->m_bar * w, 1);
+  h->L = (double*)calloc(h->m * (h->m + 1) / 2, sizeof(double));
+  h->Sk = (int64_t*)calloc(gp->k * gp->k, sizeof(int64_t));
+  h->Sk_gso = (double*)calloc(gp->k * gp->k, sizeof(double));
+  /* mp_perturbation.rs:233-234: short_basis_gadget + gso.  I_n (x) S_k is block diagonal, so its GSO is
+   * I_n (x) GSO(S_k); only the k x k block is stored. */
+  orc_short_basis_gadget_block(gp, h->Sk);
+  orc_gso_columns(h->Sk, gp->k, h->Sk_gso);
+  return h;
+}
+void orc_psfp_free(orc_psfp* h) {
+  if (!h) return;
+  free(h->A); free(h->R); free(h->L); free(h->Sk); free(h->Sk_gso); free(h);
+}
+
+/* mp_perturbation.rs:111-139 with Sigma = s_cov^2 I (the form trap_gen passes at :227-231):
+ *   Sigma_2 = (1/2pi) r^2 ((Sigma - (b^2+1) T T^t) - I),  T = [R; I_w];  returns its lower Cholesky factor. */
+int orc_psfp_compute_sqrt_sigma_2(const orc_psfp* h, const int8_t* R, double s_cov, double* Lp) {
+  const orc_gadget_params* gp = &h->gp;
+  size_t mb = gp->m_bar, w = gp->n * gp->k, m = mb + w;
+  const double TWO_PI = 6.283185307179586476925;
+  double nf_r2 = (1.0 / TWO_PI) * (h->r * h->r);            /* :113, :132-133 */
+  double s2 = s_cov * s_cov;
+  int64_t b2p1 = (int64_t)(gp->base * gp->base + 1);        /* :126 */
+  for (size_t i = 0; i < m; ++i) {
+    double* row = Lp + i * (i + 1) / 2;
+    for (size_t j = 0; j <= i; ++j) {
+      int64_t tt;
+      if (i < mb) { /* both in the R block */
+        int32_t acc = 0;
+        const int8_t *ri = R + i * w, *rj = R + j * w;
+        for (size_t c = 0; c < w; ++c) acc += (int32_t)ri[c] * rj[c];
+        tt = acc;
+      } else if (j < mb) tt = R[j * w + (i - mb)];
+      else tt = (i == j);
+      double sp = (i == j ? s2 : 0.0) - (double)(b2p1 * tt);   /* Sigma_p entry, :125-126 */
+      if (i == j) sp = sp - 1.0;                                /* - I, :134-135 */
+      row[j] = nf_r2 * sp;
+    }
+  }
+  /* cholesky_decomposition_flint (:138): row-wise Cholesky-Banachiewicz, ascending fma chains */
+  for (size_t i = 0; i < m; ++i) {
+    double* li = Lp + i * (i + 1) / 2;
+    for (size_t j = 0; j <= i; ++j) {
+      const double* lj = Lp + j * (j + 1) / 2;
+      double sum = li[j];
+      for (size_t t = 0; t < j; ++t) sum = fma(-li[t], lj[t], sum);
+      if (i == j) {
+        if (!(sum > 0.0)) return ORC_ERR_NOT_PD;            /* :109-110 */
+        li[j] = sqrt(sum);
+      } else li[j] = sum / lj[j];
+    }
+  }
+  return ORC_OK;
+}
+
+/* mp_perturbation.rs:221-244 (tag = identity, :223) */
+int orc_psfp_trap_gen(orc_psfp* h, uint64_t seed) {
+  const orc_gadget_params* gp = &h->gp;
+  size_t n = gp->n, mb = gp->m_bar, w = n * gp->k;
+  uint64_t* a_bar = (uint64_t*)malloc(n * mb * sizeof(uint64_t));
+  orc_sample_a_bar(seed, n, mb, gp->q, a_bar);                      /* :222 */
+  orc_sample_r(seed, mb, w, h->R);                                   /* gadget_classical.rs:62-64 */
+  int rc = orc_gen_trapdoor(gp, a_bar, NULL, h->R, h->A);            /* :225 */
+  free(a_bar);
+  if (rc) return rc;
+  return orc_psfp_compute_sqrt_sigma_2(h, h->R, h->s, h->L);          /* :227-231 */
+}
+
+int orc_psfp_load_key(orc_psfp* h, const uint64_t* A, const int8_t* R, const double* Lp) {
+  size_t n = h->gp.n, w = n * h->gp.k, m = h->m;
+  memcpy(h->A, A, n * m * sizeof(uint64_t));
+  memcpy(h->R, R, h->gp.m_bar * w);
+  memcpy(h->L, Lp, m * (m + 1) / 2 * sizeof(double));
+  return ORC_OK;
+}
+
+/* per-gadget-block tables: ||b~_i||^2 and s' = s_G / ||b~_i|| */
+static void gadget_tables(const orc_psfp* h, double* norm2, double* s2) {
+  size_t k = h->gp.k;
+  double sG = h->r * sqrt((double)(h->gp.base * h->gp.base + 1));   /* mp_perturbation.rs:180 */
+  for (size_t i = 0; i < k; ++i) {
+    double nn = 0.0;
+    for (size_t t = 0; t < k; ++t) nn = fma(h->Sk_gso[t * k + i], h->Sk_gso[t * k + i], nn);
+    norm2[i] = nn;
+    s2[i] = sG / sqrt(nn);
+  }
+}
+
+/* mp_perturbation.rs:173-191 + MatZ::sample_d_precomputed_gso (GPV08 SampleD) on I_n (x) S_k:
+ *   x = G^{-1}(v) (gadget_classical.rs:219-229); c = -x; for i = k-1..0 (per block j):
+ *   c' = <c, b~_i>/||b~_i||^2 ; z_i <- D_{Z, s_G/||b~_i||, c'} ; c -= z_i b_i ; result z = x + sum z_i b_i = -c. */
+static int gadget_sample_one(const orc_psfp* h, const double* norm2, const double* s2, uint64_t seed,
+                             uint64_t index, const uint64_t* v, int64_t* z) {
+  size_t n = h->gp.n, k = h->gp.k;
+  int64_t* c = (int64_t*)malloc(k * sizeof(int64_t));
+  for (size_t j = 0; j < n; ++j) {
+    int rc = orc_find_solution_gadget_vec(v[j], h->gp.q, k, h->gp.base, c);
+    if (rc) { free(c); return rc; }
+    for (size_t t = 0; t < k; ++t) c[t] = -c[t];
+    for (size_t ii = k; ii-- > 0;) {
+      double dot = 0.0;
+      for (size_t t = 0; t < k; ++t) dot = fma((double)c[t], h->Sk_gso[t * k + ii], dot);
+      double c2 = dot / norm2[ii];
+      int64_t zi = orc_sample_z(seed, ORC_TAG_GADGET, index, (uint32_t)(j * k + ii), c2, s2[ii]);
+      for (size_t t = 0; t < k; ++t) c[t] -= zi * h->Sk[t * k + ii];
+    }
+    for (size_t t = 0; t < k; ++t) z[j * k + t] = -c[t];
+  }
+  free(c);
+  return ORC_OK;
+}
+
+int orc_randomized_nearest_plane_gadget(const orc_psfp* h, uint64_t seed, uint64_t index, const uint64_t* v, int64_t* z) {
+  size_t k = h->gp.k;
+  double* norm2 = (double*)malloc(2 * k * sizeof(double));
+  gadget_tables(h, norm2, norm2 + k);
+  int rc = gadget_sample_one(h, norm2, norm2 + k, seed, index, v, z);
+  free(norm2);
+  return rc;
+}
+
+/* One preimage, every intermediate exposed (mp_perturbation.rs:304-336). */
+int orc_psfp_samp_p_trace(const orc_psfp* h, uint64_t seed, uint64_t index, const uint64_t* u,
+                          double* d, double* x, int64_t* p, uint64_t* v, int64_t* z, int64_t* e) {
+  const orc_gadget_params* gp = &h->gp;
+  size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = h->m;
+  uint64_t q = gp->q;
+  /* :315 sample_d_common_non_spherical(sqrt(Sigma_2), r): d <- N(0,1)^m ; x = sqrt(Sigma_2) d ; p_i <- D_{Z,r,x_i} */
+  for (size_t j = 0; j < m; ++j) d[j] = orc_sample_normal(seed, index, (uint32_t)j);
+  for (size_t i = 0; i < m; ++i) {
+    const double* li = h->L + i * (i + 1) / 2;
+    double acc = 0.0;
+    for (size_t j = 0; j <= i; ++j) acc = fma(li[j], d[j], acc);
+    x[i] = acc;
+  }
+  for (size_t i = 0; i < m; ++i) p[i] = orc_sample_z(seed, ORC_TAG_PERTURB, index, (uint32_t)i, x[i], h->r);
+  /* :318 v = u - A p */
+  for (size_t i = 0; i < n; ++i) {
+    i128 acc = 0;
+    const uint64_t* ai = h->A + i * m;
+    for (size_t j = 0; j < m; ++j) acc += (i128)ai[j] * p[j];
+    v[i] = submod(u[i] % q, reduce_i128(acc, q), q);
+  }
+  /* :321-326 */
+  int rc = orc_randomized_nearest_plane_gadget(h, seed, index, v, z);
+  if (rc) return rc;
+  /* :328-335 e = p + [R; I] z */
+  for (size_t i = 0; i < mb; ++i) {
+    int64_t acc = 0;
+    const int8_t* ri = h->R + i * w;
+    for (size_t c = 0; c < w; ++c) acc += (int64_t)ri[c] * z[c];
+    e[i] = p[i] + acc;
+  }
+  for (size_t c = 0; c < w; ++c) e[mb + c] = p[mb + c] + z[c];
+  return ORC_OK;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* Batch of B independent samp_p calls; identical results to the trace routine (same summation orders),
+ * restructured so that GRP preimages share each pass over sqrt(Sigma_2), A and R. */
+#define GRP 16
+int orc_psfp_samp_p(const orc_psfp* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u,
+                    int64_t* e, int nthreads) {
+  const orc_gadget_params* gp = &h->gp;
+  size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = h->m;
+  uint64_t q = gp->q;
+  size_t ngroups = (B + GRP - 1) / GRP;
+  int status = ORC_OK;
+  double* norm2 = (double*)malloc(2 * k * sizeof(double));
+  gadget_tables(h, norm2, norm2 + k);
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+  for (size_t g = 0; g < ngroups; ++g) {
+    size_t b0 = g * GRP, nb = (B - b0 < GRP) ? B - b0 : GRP;
+    double* D = (double*)calloc(m * GRP, sizeof(double));
+    int32_t* P = (int32_t*)calloc(m * GRP, sizeof(int32_t));
+    int32_t* Z = (int32_t*)calloc(w * GRP, sizeof(int32_t));
+    uint64_t* v = (uint64_t*)malloc(n * sizeof(uint64_t));
+    int64_t* zt = (int64_t*)malloc(w * sizeof(int64_t));
+    int64_t maxp = 0;
+    for (size_t j = 0; j < m; ++j)
+      for (size_t b = 0; b < nb; ++b) D[j * GRP + b] = orc_sample_normal(seed, first_index + b0 + b, (uint32_t)j);
+    for (size_t i = 0; i < m; ++i) {
+      const double* li = h->L + i * (i + 1) / 2;
+      double acc[GRP];
+      for (int b = 0; b < GRP; ++b) acc[b] = 0.0;
+      for (size_t j = 0; j <= i; ++j) {
+        double l = li[j];
+        const double* dj = D + j * GRP;
+        for (int b = 0; b < GRP; ++b) acc[b] = __builtin_fma(l, dj[b], acc[b]);
+      }
+      for (size_t b = 0; b < nb; ++b) {
+        int64_t pv = orc_sample_z(seed, ORC_TAG_PERTURB, first_index + b0 + b, (uint32_t)i, acc[b], h->r);
+        P[i * GRP + b] = (int32_t)pv;
+        int64_t ap = pv < 0 ? -pv : pv;
+        if (ap > maxp) maxp = ap;
+      }
+    }
+    /* v = u - A p : int64 chunks when q*max|p|*chunk fits, else 128-bit */
+    int fast = (q < ((uint64_t)1 << 31)) && (maxp < ((int64_t)1 << 24));
+    for (size_t b = 0; b < nb; ++b) {
+      for (size_t i = 0; i < n; ++i) {
+        const uint64_t* ai = h->A + i * m;
+        uint64_t red;
+        if (fast) {
+          i128 tot = 0;
+          for (size_t j0 = 0; j0 < m; j0 += 128) {
+            size_t j1 = j0 + 128 < m ? j0 + 128 : m;
+            int64_t acc = 0;
+            for (size_t j = j0; j < j1; ++j) acc += (int64_t)ai[j] * P[j * GRP + b];
+            tot += acc;
+          }
+          red = reduce_i128(tot, q);
+        } else {
+          i128 acc = 0;
+          for (size_t j = 0; j < m; ++j) acc += (i128)ai[j] * P[j * GRP + b];
+          red = reduce_i128(acc, q);
+        }
+        v[i] = submod(u[(b0 + b) * n + i] % q, red, q);
+      }
+      int rc = gadget_sample_one(h, norm2, norm2 + k, seed, first_index + b0 + b, v, zt);
+      if (rc) { status = rc; }
+      for (size_t c = 0; c < w; ++c) Z[c * GRP + b] = (int32_t)zt[c];
+    }
+    /* e = p + [R; I] z */
+    for (size_t i = 0; i < mb; ++i) {
+      int32_t acc[GRP];
+      for (int b = 0; b < GRP; ++b) acc[b] = 0;
+      const int8_t* ri = h->R + i * w;
+      for (size_t c = 0; c < w; ++c) {
+        int32_t rv = ri[c];
+        const int32_t* zc = Z + c * GRP;
+        for (int b = 0; b < GRP; ++b) acc[b] += rv * zc[b];
+      }
+      for (size_t b = 0; b < nb; ++b) e[(b0 + b) * m + i] = (int64_t)P[i * GRP + b] + acc[b];
+    }
+    for (size_t c = 0; c < w; ++c)
+      for (size_t b = 0; b < nb; ++b) e[(b0 + b) * m + mb + c] = (int64_t)P[(mb + c) * GRP + b] + Z[c * GRP + b];
+    free(D); free(P); free(Z); free(v); free(zt);
+  }
+  free(norm2);
+  return status;
+}
+
+/* mp_perturbation.rs:264-267: D_{Z^m, s*r} centred at 0 */
+int orc_psfp_samp_d(const orc_psfp* h, uint64_t seed, uint64_t first_index, size_t B, int64_t* e) {
+  size_t m = h->m;
+  double sr = h->s * h->r;
+  for (size_t b = 0; b < B; ++b)
+    for (size_t i = 0; i < m; ++i) e[b * m + i] = orc_sample_z(seed, ORC_TAG_SAMPD, first_index + b, (uint32_t)i, 0.0, sr);
+  return ORC_OK;
+}
+
+/* mp_perturbation.rs:396-402: column vector of length m with ||sigma||^2 <= s^2 m r^2 */
+int orc_psfp_check_domain(const orc_psfp* h, size_t B, const int64_t* e, size_t len, uint8_t* ok) {
+  size_t m = h->m;
+  double bound = ((h->s * h->s) * (double)m) * (h->r * h->r);
+  for (size_t b = 0; b < B; ++b) {
+    if (len != m) { ok[b] = 0; continue; }
+    u128 nn = 0;
+    for (size_t i = 0; i < m; ++i) { i128 v = e[b * len + i]; nn += (u128)(v * v); }
+    ok[b] = ((double)nn <= bound) ? 1 : 0;
+  }
+  return ORC_OK;
+}
+
+/* mp_perturbation.rs:366-369 */
+int orc_psfp_f_a(const orc_psfp* h, size_t B, const int64_t* e, uint64_t* u) {
+  size_t n = h->gp.n, m = h->m;
+  uint64_t q = h->gp.q;
+  int status = ORC_OK;
+  for (size_t b = 0; b < B; ++b) {
+    uint8_t ok;
+    orc_psfp_check_domain(h, 1, e + b * m, m, &ok);
+    if (!ok) status = ORC_ERR_DOMAIN;                               /* assert!, :367 */
+    for (size_t i = 0; i < n; ++i) {
+      i128 acc = 0;
+      const uint64_t* ai = h->A + i * m;
+      for (size_t j = 0; j < m; ++j) acc += (i128)ai[j] * e[b * m + j];
+      u[b * n + i] = reduce_i128(acc, q);
+    }
+  }
+  return status;
+}
