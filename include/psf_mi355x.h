@@ -1,0 +1,172 @@
+/*
+ * psf_mi355x.h -- C ABI of the MI355X-native preimage-sampling library (libpsf_mi355x.so).
+ *
+ * Drop-in boundary for ONE hot path of qfall/tools: the `PSF` trait (src/primitive/psf.rs:39-81)
+ * as implemented by PSFPerturbation (src/primitive/psf/mp_perturbation.rs), PSFGPV (gpv.rs) and
+ * PSFGPVRing (gpv_ring.rs), plus the gadget-lattice helpers under them
+ * (src/sample/g_trapdoor/{gadget_classical,gadget_ring,short_basis_classical,short_basis_ring}.rs).
+ * The reference has no FFI of its own for this path (it is Rust over qfall-math/FLINT); these entry
+ * points are what a Rust `extern "C"` block implementing `PSF` would bind -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns a psf_status; 0 = success.  The reference panics where this ABI returns
+ *     a non-zero status (mp_perturbation.rs:190,315,333,367); a shim turns status != 0 into panic!.
+ *   - matrices are flat, row-major; batches are "one row per call of the reference":
+ *       u : B x n   (Range  = MatZq n x 1 per call,   least non-negative residues)
+ *       e : B x m   (Domain = MatZ  m x 1 per call)
+ *   - one reference call == one row.  Batching (B > 1) is this library's extension: B independent
+ *     samp_p calls sharing (A, trapdoor).  Row b of a batch uses the randomness of global preimage
+ *     index `first_index + b`, so results do not depend on how a job is sharded over GPUs.
+ *   - randomness: the reference's trait takes no seed (psf.rs:48-80); here every sampling entry point
+ *     takes a 64-bit seed keying Philox4x32-10 streams (DESIGN.md "Randomness contract").
+ *   - `*_dev` variants take device pointers (HIP) and a hipStream_t (as void*); the plain variants
+ *     take host pointers and do the copies themselves.
+ *   - a handle is not thread-safe: one handle per host thread / HIP stream, mirroring the reference's
+ *     !Send + !Sync PSF values (gadget_parameters.rs:51, trapdoor_distribution.rs:22).
+ */
+#ifndef PSF_MI355X_H
+#define PSF_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int psf_status;
+enum {
+  PSF_OK = 0,
+  PSF_ERR_PARAM = 1,           /* malformed arguments (dimension / NULL / range)                         */
+  PSF_ERR_NOT_PD = 2,          /* Sigma_2 not positive definite: mp_perturbation.rs:109-110              */
+  PSF_ERR_DOMAIN = 3,          /* f_a on sigma outside D_n: assert! at mp_perturbation.rs:367, gpv.rs:191 */
+  PSF_ERR_MODULUS = 4,         /* base^k < q: gadget_classical.rs:170-172                                */
+  PSF_ERR_NO_SOLUTION = 5,     /* A x = u has no solution: gpv.rs:153-155 unwrap                         */
+  PSF_ERR_NO_KEY = 6,          /* samp_p / f_a before trap_gen / load_key                                */
+  PSF_ERR_HIP = 7,             /* HIP runtime error (no device, out of memory, launch failure)           */
+  PSF_ERR_UNSUPPORTED = 8,     /* parameter combination outside what the kernels cover                   */
+  PSF_ERR_SAMPLER = 9          /* a rejection sampler hit its attempt cap (numerically broken inputs)    */
+};
+
+const char* psf_status_string(psf_status);
+/* "gfx950" etc. of the device the library would run on; PSF_ERR_HIP if none */
+psf_status psf_device_info(int device, char* name, size_t name_len, int* compute_units);
+
+/* ------------------------------------------------------------------------------------------------
+ * GadgetParameters (gadget_parameters.rs:44-52); distribution is PlusMinusOneZero
+ * (trapdoor_distribution.rs:52-53, :82-86) for the classical variants, SampleZ (:58-59) for the ring.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t n;      /* security parameter / ring degree            */
+  uint64_t k;      /* gadget length, ceil(log_base q) by default  */
+  uint64_t m_bar;  /* n*k + ceil(log2 n)^2 (classical), k+2 (ring) */
+  uint64_t base;   /* gadget base (2 by default)                  */
+  uint64_t q;      /* modulus, 1 < q < 2^62                       */
+} psf_gadget_params;
+
+/* GadgetParameters::init_default (gadget_parameters.rs:113-133) */
+psf_status psf_gadget_params_default(uint64_t n, uint64_t q, psf_gadget_params* out);
+/* GadgetParametersRing::init_default (gadget_parameters.rs:165-185); modulus polynomial X^n + 1
+ * (common_moduli.rs:41-48) */
+psf_status psf_gadget_params_ring_default(uint64_t n, uint64_t q, psf_gadget_params* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Deterministic gadget helpers (host entry points; the batched digit decomposition runs on device)
+ * ---------------------------------------------------------------------------------------------- */
+/* gen_gadget_vec (gadget_classical.rs:128-136): out[k] = base^i */
+psf_status psf_gen_gadget_vec(uint64_t k, uint64_t base, int64_t* out);
+/* gen_gadget_mat (gadget_classical.rs:91-107): out[n x n*k] = I_n (x) g^t */
+psf_status psf_gen_gadget_mat(uint64_t n, uint64_t k, uint64_t base, int64_t* out);
+/* find_solution_gadget_mat (gadget_classical.rs:219-229; entry rule :169-182):
+ * value[rows x cols] in Z_q -> out[k*rows x cols], out[k*j+i, c] = i-th base-`base` digit of value[j,c].
+ * Runs the HIP digit-decomposition kernel.  PSF_ERR_MODULUS if base^k < q. */
+psf_status psf_find_solution_gadget_mat(int device, const uint64_t* value, size_t rows, size_t cols,
+                                        uint64_t q, uint64_t k, uint64_t base, int64_t* out);
+/* short_basis_gadget (gadget_classical.rs:248-287): out[nk x nk] = I_n (x) S_k */
+psf_status psf_short_basis_gadget(const psf_gadget_params* gp, int64_t* out);
+/* gen_short_basis_for_trapdoor (short_basis_classical.rs:54-63), tag = identity when NULL:
+ * out[m x m] = [I R; 0 I] * [0 I; S' W] */
+psf_status psf_gen_short_basis_for_trapdoor(const psf_gadget_params* gp, const uint64_t* tag /*n x n*/,
+                                            const uint64_t* A /*n x m*/, const int8_t* R /*m_bar x nk*/,
+                                            int64_t* out);
+/* rot_minus_matrix (rotation_matrix.rs:85-96): mat[rows x cols] -> out[rows x rows*cols] */
+psf_status psf_rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * PSFPerturbation (mp_perturbation.rs:57-62, impl PSF :193-403)
+ *   A        = MatZq  n x m            -> uint64_t[n*m]
+ *   Trapdoor = (R, sqrt(Sigma_2), (S, S~)) (mp_perturbation.rs:195)
+ *                R            : int8_t[m_bar * n*k]           entries in {-1,0,1}
+ *                sqrt(Sigma_2): double, lower triangular, packed by rows: row i holds i+1 entries,
+ *                               m(m+1)/2 doubles (the Cholesky factor of :138)
+ *                (S, S~)      : I_n (x) S_k and its GSO; a function of the parameters only, so it is
+ *                               rebuilt inside the handle instead of being passed around
+ *   Domain   = MatZ m x 1, Range = MatZq n x 1
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct psfp_handle psfp_handle;
+
+typedef struct {
+  psf_gadget_params gp;
+  double r;        /* rounding parameter (mp_perturbation.rs:60) */
+  double s;        /* Gaussian parameter (mp_perturbation.rs:61) */
+  int32_t device;  /* HIP device ordinal */
+  uint32_t flags;  /* reserved, 0 */
+} psfp_params;
+
+psf_status psfp_create(const psfp_params* params, psfp_handle** out);
+void       psfp_destroy(psfp_handle*);
+/* m = m_bar + n*k */
+size_t     psfp_m(const psfp_handle*);
+
+/* PSF::trap_gen (mp_perturbation.rs:221-244): samples A_bar, R on device, builds A = [A_bar | G - A_bar R]
+ * (gadget_classical.rs:56-68), Sigma_2 and its Cholesky factor (mp_perturbation.rs:111-139).
+ * PSF_ERR_NOT_PD if Sigma_2 is not positive definite (s too small). */
+psf_status psfp_trap_gen(psfp_handle*, uint64_t seed);
+/* PSFPerturbation::compute_sqrt_sigma_2 (mp_perturbation.rs:111-139) for Sigma = s_cov^2 * I using the
+ * handle's R; replaces the handle's sqrt(Sigma_2) (the doctest at :89-107). */
+psf_status psfp_compute_sqrt_sigma_2(psfp_handle*, double s_cov);
+/* install / read back key material (host buffers).  Any of the out pointers may be NULL. */
+psf_status psfp_load_key(psfp_handle*, const uint64_t* A, const int8_t* R, const double* sqrt_sigma2_packed);
+psf_status psfp_export_key(const psfp_handle*, uint64_t* A, int8_t* R, double* sqrt_sigma2_packed);
+/* the gadget part of the trapdoor tuple: S_k (k x k) and its Gram-Schmidt vectors (columns, k x k) */
+psf_status psfp_export_gadget_basis(const psfp_handle*, int64_t* Sk, double* Sk_gso);
+
+/* PSF::samp_d (mp_perturbation.rs:264-267): e[b] <- D_{Z^m, s*r} */
+psf_status psfp_samp_d(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, int64_t* e);
+/* PSF::samp_p (mp_perturbation.rs:304-336), B independent calls */
+psf_status psfp_samp_p(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
+/* PSF::f_a (mp_perturbation.rs:366-369): u[b] = A e[b] mod q; PSF_ERR_DOMAIN (u still written) if any
+ * row fails check_domain */
+psf_status psfp_f_a(psfp_handle*, size_t B, const int64_t* e, uint64_t* u);
+/* PSF::check_domain (mp_perturbation.rs:396-402) for rows of length `len`; ok[b] = 0/1 */
+psf_status psfp_check_domain(psfp_handle*, size_t B, const int64_t* e, size_t len, uint8_t* ok);
+
+/* device-resident variants: d_u, d_e are HIP device pointers, stream is a hipStream_t (NULL = default).
+ * Asynchronous with respect to the host; errors detected on device are reported by psfp_last_status. */
+psf_status psfp_samp_p_dev(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B,
+                           const uint64_t* d_u, int64_t* d_e, void* stream);
+psf_status psfp_samp_d_dev(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, int64_t* d_e, void* stream);
+psf_status psfp_f_a_dev(psfp_handle*, size_t B, const int64_t* d_e, uint64_t* d_u, uint8_t* d_ok, void* stream);
+/* synchronises the stream of the last *_dev call and returns the device-side status of that call */
+psf_status psfp_last_status(psfp_handle*);
+/* synthetic uniform targets u <- Z_q^{B x n} (benches/psf.rs:35,60,87) written to device memory */
+psf_status psfp_uniform_targets_dev(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, uint64_t* d_u, void* stream);
+
+/* stage-level access for parity tests and profiling (host buffers; NULL = skip):
+ * runs samp_p for B rows and copies out the intermediates of the reference's call stack
+ *   d : B x m  standard normals fed to sqrt(Sigma_2)        (mp_perturbation.rs:315)
+ *   x : B x m  centres  x = sqrt(Sigma_2) d
+ *   p : B x m  perturbation p_i <- D_{Z,r,x_i}
+ *   v : B x n  v = u - A p                                  (:318)
+ *   z : B x nk gadget preimage                               (:321-326)
+ */
+psf_status psfp_samp_p_stages(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u,
+                              double* d, double* x, int64_t* p, uint64_t* v, int64_t* z, int64_t* e);
+/* per-kernel average duration (ms) of the last samp_p*_dev/samp_p call, measured with HIP events on the
+ * launch stream when timing is enabled; names are ';'-separated in `names`. */
+psf_status psfp_enable_timing(psfp_handle*, int on);
+psf_status psfp_get_timing(psfp_handle*, char* names, size_t names_len, double* ms, size_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,60 @@
+"""ctypes loader for libpsf_mi355x.so (the C ABI declared in include/psf_mi355x.h).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is present, every
+compute entry point raises.  The oracle under oracle/ is never imported from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpsf_mi355x.so")
+
+OK, ERR_PARAM, ERR_NOT_PD, ERR_DOMAIN, ERR_MODULUS, ERR_NO_SOLUTION, ERR_NO_KEY, ERR_HIP, ERR_UNSUPPORTED, ERR_SAMPLER = range(10)
+
+
+class PsfError(RuntimeError):
+    """Non-zero psf_status; the reference panics in the same situations."""
+
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = lib().psf_status_string(status).decode() if _lib is not None else str(status)
+        super().__init__(f"{where}: psf_status {status} ({msg})")
+
+
+class GadgetParams(C.Structure):
+    """psf_gadget_params / GadgetParameters (gadget_parameters.rs:44-52)."""
+    _fields_ = [("n", C.c_uint64), ("k", C.c_uint64), ("m_bar", C.c_uint64), ("base", C.c_uint64), ("q", C.c_uint64)]
+
+
+class PsfpParams(C.Structure):
+    _fields_ = [("gp", GadgetParams), ("r", C.c_double), ("s", C.c_double), ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+class GpvParams(C.Structure):
+    _fields_ = [("gp", GadgetParams), ("s", C.c_double), ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). tools_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.psf_status_string.restype = C.c_char_p
+        L.psf_status_string.argtypes = [C.c_int]
+        L.psfp_m.restype = C.c_size_t
+        L.psfp_m.argtypes = [C.c_void_p]
+        L.psfp_destroy.restype = None
+        L.psfp_destroy.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(status, where=""):
+    if status != OK:
+        raise PsfError(status, where)

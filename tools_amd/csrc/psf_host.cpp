@@ -1,0 +1,214 @@
+// psf_host.cpp -- host-side mirror of the reference's deterministic gadget helpers (see psf_host.hpp).
+#include "psf_host.hpp"
+#include <algorithm>
+#include <cstring>
+
+namespace psf {
+
+// GadgetParameters::init_default (gadget_parameters.rs:113-133)
+psf_status gadget_params_default(uint64_t n, uint64_t q, psf_gadget_params* out) {
+  if (!out || n < 1 || q <= 1 || q >= (1ull << 62)) return PSF_ERR_PARAM;  // assert at :117, Modulus > 1
+  const uint64_t k = log_ceil_u64(q, 2), ln = log_ceil_u64(n, 2);
+  *out = psf_gadget_params{n, k, n * k + ln * ln, 2, q};
+  return PSF_OK;
+}
+
+// GadgetParametersRing::init_default (gadget_parameters.rs:165-185)
+psf_status gadget_params_ring_default(uint64_t n, uint64_t q, psf_gadget_params* out) {
+  if (!out || n < 1 || q <= 1 || q >= (1ull << 62)) return PSF_ERR_PARAM;
+  const uint64_t k = log_ceil_u64(q, 2);
+  *out = psf_gadget_params{n, k, k + 2, 2, q};
+  return PSF_OK;
+}
+
+// gadget_classical.rs:128-136
+std::vector<int64_t> gen_gadget_vec(uint64_t k, uint64_t base) {
+  std::vector<int64_t> g(k);
+  int64_t e = 1;
+  for (auto& v : g) { v = e; e *= (int64_t)base; }
+  return g;
+}
+std::vector<uint64_t> gen_gadget_vec_mod(uint64_t k, uint64_t base, uint64_t q) {
+  std::vector<uint64_t> g(k);
+  uint64_t e = 1 % q;
+  for (auto& v : g) { v = e; e = mulmod_u64(e, base % q, q); }
+  return g;
+}
+
+// gadget_classical.rs:91-107
+std::vector<int64_t> gen_gadget_mat(uint64_t n, uint64_t k, uint64_t base) {
+  const auto g = gen_gadget_vec(k, base);
+  std::vector<int64_t> G(n * n * k, 0);
+  for (uint64_t row = 0; row < n; ++row) std::copy(g.begin(), g.end(), G.begin() + row * (n * k) + row * k);
+  return G;
+}
+
+// gadget_classical.rs:249-272
+std::vector<int64_t> short_basis_gadget_block(const psf_gadget_params& gp) {
+  const size_t k = gp.k;
+  std::vector<int64_t> sk(k * k, 0);
+  for (size_t d = 0; d < k; ++d) {
+    sk[d * k + d] = (int64_t)gp.base;
+    if (d + 1 < k) sk[(d + 1) * k + d] = -1;
+  }
+  if (!is_power_of_base(gp.base, gp.k, gp.q)) {
+    uint64_t rest = gp.q;
+    for (size_t row = 0; row < k; ++row) {
+      sk[row * k + (k - 1)] = (int64_t)(rest % gp.base);
+      rest /= gp.base;
+    }
+  }
+  return sk;
+}
+
+// gadget_classical.rs:273-286
+std::vector<int64_t> short_basis_gadget(const psf_gadget_params& gp) {
+  const size_t k = gp.k, w = gp.n * gp.k;
+  const auto sk = short_basis_gadget_block(gp);
+  std::vector<int64_t> S(w * w, 0);
+  for (size_t blk = 0; blk < gp.n; ++blk)
+    for (size_t r = 0; r < k; ++r) std::copy(sk.begin() + r * k, sk.begin() + (r + 1) * k, S.begin() + (blk * k + r) * w + blk * k);
+  return S;
+}
+
+void gso_columns(const std::vector<int64_t>& basis, size_t dim, std::vector<double>& gso, std::vector<double>& norm2) {
+  gso.assign(dim * dim, 0.0);
+  norm2.assign(dim, 0.0);
+  for (size_t col = 0; col < dim; ++col) {
+    for (size_t t = 0; t < dim; ++t) gso[t * dim + col] = (double)basis[t * dim + col];
+    for (size_t prev = 0; prev < col; ++prev) {
+      double num = 0.0;
+      for (size_t t = 0; t < dim; ++t) num = std::fma((double)basis[t * dim + col], gso[t * dim + prev], num);
+      const double mu = num / norm2[prev];
+      for (size_t t = 0; t < dim; ++t) gso[t * dim + col] = std::fma(-mu, gso[t * dim + prev], gso[t * dim + col]);
+    }
+    double nn = 0.0;
+    for (size_t t = 0; t < dim; ++t) nn = std::fma(gso[t * dim + col], gso[t * dim + col], nn);
+    norm2[col] = nn;
+  }
+}
+
+// gadget_classical.rs:174-180
+void digits_of(uint64_t value, uint64_t q, uint64_t k, uint64_t base, int64_t* out) {
+  uint64_t rest = value % q;
+  for (uint64_t pos = 0; pos < k; ++pos) { out[pos] = (int64_t)(rest % base); rest /= base; }
+}
+
+static bool inverse_mod(uint64_t a, uint64_t q, uint64_t* inv) {
+  i128 r0 = q, r1 = a % q, t0 = 0, t1 = 1;
+  while (r1 != 0) {
+    const i128 quo = r0 / r1;
+    std::swap(r0, r1); r1 -= quo * r0;  // (r0, r1) <- (r1, r0 - quo r1)
+    std::swap(t0, t1); t1 -= quo * t0;
+  }
+  if (r0 != 1) return false;
+  if (t0 < 0) t0 += q;
+  *inv = (uint64_t)t0;
+  return true;
+}
+
+bool mat_inverse_mod(const std::vector<uint64_t>& M, size_t n, uint64_t q, std::vector<uint64_t>& inv) {
+  std::vector<uint64_t> a(M);
+  for (auto& v : a) v %= q;
+  inv.assign(n * n, 0);
+  for (size_t d = 0; d < n; ++d) inv[d * n + d] = 1 % q;
+  for (size_t col = 0; col < n; ++col) {
+    size_t piv = n;
+    uint64_t pinv = 0;
+    for (size_t r = col; r < n && piv == n; ++r)
+      if (inverse_mod(a[r * n + col], q, &pinv)) piv = r;
+    if (piv == n) return false;
+    for (size_t j = 0; j < n; ++j) { std::swap(a[piv * n + j], a[col * n + j]); std::swap(inv[piv * n + j], inv[col * n + j]); }
+    for (size_t j = 0; j < n; ++j) { a[col * n + j] = mulmod_u64(a[col * n + j], pinv, q); inv[col * n + j] = mulmod_u64(inv[col * n + j], pinv, q); }
+    for (size_t r = 0; r < n; ++r) {
+      const uint64_t f = a[r * n + col];
+      if (r == col || f == 0) continue;
+      for (size_t j = 0; j < n; ++j) {
+        a[r * n + j] = submod_u64(a[r * n + j], mulmod_u64(f, a[col * n + j], q), q);
+        inv[r * n + j] = submod_u64(inv[r * n + j], mulmod_u64(f, inv[col * n + j], q), q);
+      }
+    }
+  }
+  return true;
+}
+
+// short_basis_classical.rs:105-110
+psf_status compute_w(const psf_gadget_params& gp, const uint64_t* tag, const uint64_t* A, std::vector<int64_t>& W) {
+  const size_t n = gp.n, k = gp.k, mb = gp.m_bar, w = n * k, m = mb + w;
+  if (gadget_too_short(gp.base, gp.k, gp.q)) return PSF_ERR_MODULUS;
+  std::vector<uint64_t> tinv;
+  if (tag) {
+    std::vector<uint64_t> t(tag, tag + n * n);
+    if (!mat_inverse_mod(t, n, gp.q, tinv)) return PSF_ERR_PARAM;
+  }
+  W.assign(w * mb, 0);
+  std::vector<int64_t> dg(k);
+  for (size_t col = 0; col < mb; ++col)
+    for (size_t row = 0; row < n; ++row) {
+      uint64_t v;
+      if (tag) {
+        u128 acc = 0;
+        for (size_t t = 0; t < n; ++t) acc = (acc + (u128)tinv[row * n + t] * (A[t * m + col] % gp.q)) % gp.q;
+        v = (uint64_t)acc;
+      } else v = A[row * m + col] % gp.q;
+      digits_of(v ? gp.q - v : 0, gp.q, k, gp.base, dg.data());
+      for (size_t t = 0; t < k; ++t) W[(row * k + t) * mb + col] = dg[t];
+    }
+  return PSF_OK;
+}
+
+// short_basis_classical.rs:54-102.  sa_r = [0 I; S' W], S' = S with columns reversed iff base^k == q;
+// sa_l = [I R; 0 I]; the product is formed blockwise: top = [R S' | I + R W], bottom = [S' | W].
+psf_status gen_short_basis_for_trapdoor(const psf_gadget_params& gp, const uint64_t* tag, const uint64_t* A,
+                                        const int8_t* R, std::vector<int64_t>& out) {
+  const size_t n = gp.n, k = gp.k, mb = gp.m_bar, w = n * k, m = mb + w;
+  std::vector<int64_t> W;
+  const psf_status rc = compute_w(gp, tag, A, W);
+  if (rc != PSF_OK) return rc;
+  const auto sk = short_basis_gadget_block(gp);
+  const bool reversed = is_power_of_base(gp.base, gp.k, gp.q);
+  out.assign(m * m, 0);
+  // bottom block rows: [S' | W]
+  for (size_t r = 0; r < w; ++r) {
+    int64_t* row = out.data() + (mb + r) * m;
+    const size_t blk = r / k, rr = r % k;
+    for (size_t cc = 0; cc < k; ++cc) {
+      const size_t scol = blk * k + cc;                       // column of S = I_n (x) S_k
+      const size_t dst = reversed ? (w - 1 - scol) : scol;    // reverse_columns (:80-82)
+      row[dst] = sk[rr * k + cc];
+    }
+    std::copy(W.begin() + r * mb, W.begin() + (r + 1) * mb, row + w);
+  }
+  // top block rows: [0 | I] + R * bottom
+  for (size_t r = 0; r < mb; ++r) {
+    int64_t* row = out.data() + r * m;
+    row[w + r] = 1;
+    for (size_t t = 0; t < w; ++t) {
+      const int64_t rv = R[r * w + t];
+      if (!rv) continue;
+      const int64_t* brow = out.data() + (mb + t) * m;
+      for (size_t j = 0; j < m; ++j) row[j] += rv * brow[j];
+    }
+  }
+  return PSF_OK;
+}
+
+// rotation_matrix.rs:41-63: column j of rot^-(v) is v multiplied by X^j in Z[X]/(X^n+1)
+void rot_minus(const int64_t* vec, size_t n, int64_t* out, size_t ld, size_t col_off) {
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < n; ++j) {
+      const size_t pos = i + j;
+      if (pos >= n) out[(pos - n) * ld + col_off + j] = -vec[i];
+      else out[pos * ld + col_off + j] = vec[i];
+    }
+}
+// rotation_matrix.rs:85-96: [rot^-(col_0) | rot^-(col_1) | ...]
+void rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out) {
+  std::vector<int64_t> col(rows);
+  for (size_t c = 0; c < cols; ++c) {
+    for (size_t r = 0; r < rows; ++r) col[r] = mat[r * cols + c];
+    rot_minus(col.data(), rows, out, rows * cols, c * rows);
+  }
+}
+
+}  // namespace psf

@@ -1,0 +1,63 @@
+// psf_host.hpp -- host-side (C++) mirror of the reference's deterministic gadget helpers.
+// These are setup-time functions of the parameters / key only; the
+// per-preimage work is in psf_kernels.hpp.  Row-major flat vectors throughout.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+#include "../../include/psf_mi355x.h"
+
+namespace psf {
+
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+
+inline uint64_t mulmod_u64(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((u128)a * b) % q); }
+inline uint64_t submod_u64(uint64_t a, uint64_t b, uint64_t q) { return a >= b ? a - b : a + q - b; }
+
+// smallest e with base^e >= x  (Z::log_ceil as used at gadget_parameters.rs:121-123)
+inline uint64_t log_ceil_u64(uint64_t x, uint64_t base) {
+  uint64_t e = 0;
+  u128 p = 1;
+  while (p < x) { p *= base; ++e; }
+  return e;
+}
+// base^k == q ?  (gadget_classical.rs:258, short_basis_classical.rs:80)
+inline bool is_power_of_base(uint64_t base, uint64_t k, uint64_t q) {
+  u128 p = 1;
+  for (uint64_t i = 0; i < k; ++i) { p *= base; if (p > (u128)q) return false; }
+  return p == (u128)q;
+}
+// base^k < q ?  (gadget_classical.rs:170-172)
+inline bool gadget_too_short(uint64_t base, uint64_t k, uint64_t q) {
+  u128 p = 1;
+  for (uint64_t i = 0; i < k; ++i) { p *= base; if (p >= (u128)q) return false; }
+  return p < (u128)q;
+}
+
+psf_status gadget_params_default(uint64_t n, uint64_t q, psf_gadget_params* out);
+psf_status gadget_params_ring_default(uint64_t n, uint64_t q, psf_gadget_params* out);
+
+std::vector<int64_t> gen_gadget_vec(uint64_t k, uint64_t base);
+std::vector<uint64_t> gen_gadget_vec_mod(uint64_t k, uint64_t base, uint64_t q);
+std::vector<int64_t> gen_gadget_mat(uint64_t n, uint64_t k, uint64_t base);
+// S_k (gadget_classical.rs:249-272), k x k
+std::vector<int64_t> short_basis_gadget_block(const psf_gadget_params& gp);
+// I_n (x) S_k (gadget_classical.rs:273-286)
+std::vector<int64_t> short_basis_gadget(const psf_gadget_params& gp);
+// Gram-Schmidt on columns, not normalised (MatQ::gso at mp_perturbation.rs:234); also returns ||b~_i||^2
+void gso_columns(const std::vector<int64_t>& basis, size_t dim, std::vector<double>& gso, std::vector<double>& norm2);
+// digits of one value (gadget_classical.rs:174-180)
+void digits_of(uint64_t value, uint64_t q, uint64_t k, uint64_t base, int64_t* out);
+// n x n inverse over Z_q (tag.inverse(), short_basis_classical.rs:106); false if singular
+bool mat_inverse_mod(const std::vector<uint64_t>& M, size_t n, uint64_t q, std::vector<uint64_t>& inv);
+// W with G W = -H^{-1} A [I|0]^t (short_basis_classical.rs:105-110); w x m_bar
+psf_status compute_w(const psf_gadget_params& gp, const uint64_t* tag, const uint64_t* A, std::vector<int64_t>& W);
+// S_A = [I R; 0 I] [0 I; S' W] (short_basis_classical.rs:54-102); m x m
+psf_status gen_short_basis_for_trapdoor(const psf_gadget_params& gp, const uint64_t* tag, const uint64_t* A,
+                                        const int8_t* R, std::vector<int64_t>& out);
+// rotation_matrix.rs:41-63 / :85-96
+void rot_minus(const int64_t* vec, size_t n, int64_t* out /*n x n*/, size_t ld, size_t col_off);
+void rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out /*rows x rows*cols*/);
+
+}  // namespace psf

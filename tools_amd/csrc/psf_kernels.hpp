@@ -1,0 +1,685 @@
+// psf_kernels.hpp -- HIP kernels of the PSFPerturbation::samp_p hot path (gfx950 / CDNA4 only).
+//
+// Data layout in HBM (DESIGN.md "Data layout"):  every per-batch matrix is COORDINATE-major with the batch
+// index contiguous ("[coord][b]", row stride Bs = batch padded to 128): lanes of a wave walk over preimages,
+// so key material (A, R, sqrt(Sigma_2), gadget tables) is wave-uniform and batch data is coalesced.
+// The two operands of the dominant kernel (x = sqrt(Sigma_2) d) are stored in MFMA-fragment order so that a
+// 16 KiB chunk is one contiguous, fully coalesced global read and every LDS fragment read is a conflict-free
+// ds_read_b64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "psf_rng.hpp"
+
+namespace psf {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ---- geometry of the triangular product -------------------------------------------------------------
+constexpr int TR_BM = 128;      // rows of sqrt(Sigma_2) per workgroup
+constexpr int TR_BN = 128;      // preimages per workgroup
+constexpr int TR_BK = 16;       // coordinates per staged chunk (4 MFMA k-steps)
+constexpr int TR_CHUNK = TR_BM * TR_BK;            // doubles per chunk (2048 = 16 KiB)
+constexpr int TR_KB_PER_BLOCK = TR_BM / TR_BK;     // 8
+
+// first chunk of row-block bi in the packed lower-triangular tile stream: sum_{t<bi} 8 (t+1)
+__host__ __device__ inline size_t tr_rowblock_base(size_t bi) { return 4 * bi * (bi + 1); }
+__host__ __device__ inline size_t tr_total_chunks(size_t nbi) { return 4 * nbi * (nbi + 1); }
+
+// position inside a chunk of element (r in [0,128), kk in [0,16)):  [ks = kk/4][tile = r/16][lane = (kk%4)*16 + r%16]
+__host__ __device__ inline int tr_chunk_pos(int r, int kk) {
+  return ((kk >> 2) * 8 + (r >> 4)) * 64 + ((kk & 3) << 4) + (r & 15);
+}
+
+// ---- L repack: row-major lower triangle -> fragment-ordered chunk stream ------------------------------
+// PACKED: source row i starts at i(i+1)/2 (host key format); otherwise dense with leading dimension ld.
+template <bool PACKED>
+__global__ void k_repack_L(const double* __restrict__ src, size_t ld, size_t m, double* __restrict__ dst, size_t nbi) {
+  const size_t total = tr_total_chunks(nbi) * TR_CHUNK;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t chunk = g / TR_CHUNK;
+    const int pos = (int)(g % TR_CHUNK);
+    // invert chunk -> (bi, bk): bi = largest with 4 bi (bi+1) <= chunk
+    size_t bi = (size_t)((sqrt(1.0 + (double)chunk) - 1.0) * 0.5);
+    while (tr_rowblock_base(bi + 1) <= chunk) ++bi;
+    while (tr_rowblock_base(bi) > chunk) --bi;
+    const size_t bk = chunk - tr_rowblock_base(bi);
+    const int ks = pos >> 9, tile = (pos >> 6) & 7, lane = pos & 63;
+    const size_t row = bi * TR_BM + tile * 16 + (lane & 15);
+    const size_t col = bk * TR_BK + ks * 4 + (lane >> 4);
+    double v = 0.0;
+    if (row < m && col <= row) v = PACKED ? src[row * (row + 1) / 2 + col] : src[row * ld + col];
+    dst[g] = v;
+  }
+}
+
+// inverse direction (export): chunk stream -> packed rows
+__global__ void k_unpack_L(const double* __restrict__ chunks, size_t m, double* __restrict__ packed) {
+  const size_t total = m * (m + 1) / 2;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    size_t row = (size_t)((sqrt(1.0 + 8.0 * (double)g) - 1.0) * 0.5);
+    while ((row + 1) * (row + 2) / 2 <= g) ++row;
+    while (row * (row + 1) / 2 > g) --row;
+    const size_t col = g - row * (row + 1) / 2;
+    const size_t bi = row / TR_BM, bk = col / TR_BK;
+    const size_t chunk = tr_rowblock_base(bi) + bk;
+    packed[g] = chunks[chunk * TR_CHUNK + tr_chunk_pos((int)(row % TR_BM), (int)(col % TR_BK))];
+  }
+}
+
+// ---- standard normals, written straight into the B-operand chunk stream ------------------------------
+// chunk (bj, bk) at (bj * nkb + bk); element (kk, c) -> coordinate bk*16+kk of preimage bj*128+c
+__global__ void k_normals(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t nkb, size_t nbj,
+                          double* __restrict__ Dt, int* __restrict__ fail) {
+  const size_t total = nbj * nkb * TR_CHUNK;
+  int f = 0;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t chunk = g / TR_CHUNK;
+    const int pos = (int)(g % TR_CHUNK);
+    const size_t bj = chunk / nkb, bk = chunk % nkb;
+    const int ks = pos >> 9, tile = (pos >> 6) & 7, lane = pos & 63;
+    const size_t coord = bk * TR_BK + ks * 4 + (lane >> 4);
+    const size_t b = bj * TR_BN + tile * 16 + (lane & 15);
+    double v = 0.0;
+    if (coord < m && b < B) v = sample_normal(seed, first_index + b, (uint32_t)coord, &f);
+    Dt[g] = v;
+  }
+  if (f) atomicOr(fail, 1);
+}
+
+// read one normal back out of the chunk stream (stage export)
+__global__ void k_export_normals(const double* __restrict__ Dt, size_t m, size_t B, size_t nkb, double* __restrict__ out /*B x m*/) {
+  const size_t total = m * B;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g / m, coord = g % m;
+    const size_t chunk = (b / TR_BN) * nkb + coord / TR_BK;
+    out[g] = Dt[chunk * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(coord % TR_BK))];
+  }
+}
+
+// ---- X = L * D with v_mfma_f64_16x16x4_f64 -----------------------------------------------------------
+// One workgroup (4 waves, 2x2) owns a 128 x 128 tile of X; wave tile 64 x 64 = 4x4 MFMA tiles.
+// Per element the accumulation is a single fma chain in ascending coordinate order starting from +0
+// (measured on gfx950: the instruction itself is an ascending-k fma chain, profiles/r01_probe_mfma_f64.log),
+// which is the summation order of the contract.  Zero entries above the diagonal only add exact zeros.
+//
+// Workgroup order: heavy row-blocks first; blocks that share an XCD (blockIdx % 8) walk an 8 x 8 super-tile of
+// (row-block, column-block) pairs so that each staged chunk is reused from that XCD's L2.
+__device__ inline void tr_map_block(unsigned id, int nbi, int nbj, int* bi, int* bj) {
+  // super-tiles of GR x GC blocks, enumerated with row groups descending
+  constexpr int GR = 8, GC = 8;
+  const int ncg = (nbj + GC - 1) / GC, nrg = (nbi + GR - 1) / GR;
+  const unsigned xcd = id & 7u, slot = id >> 3;
+  const unsigned group = (slot / (GR * GC)) * 8u + xcd;
+  const unsigned t = slot % (GR * GC);
+  const int rg = nrg - 1 - (int)(group / ncg), cg = (int)(group % ncg);
+  *bi = rg * GR + (GR - 1 - (int)(t / GC));
+  *bj = cg * GC + (int)(t % GC);
+  if (rg < 0) *bi = -1;
+}
+__host__ inline unsigned tr_grid_size(int nbi, int nbj) {
+  const int ncg = (nbj + 7) / 8, nrg = (nbi + 7) / 8;
+  const unsigned groups = (unsigned)(ncg * nrg);
+  const unsigned rounds = (groups + 7) / 8;
+  return rounds * 8u * 64u;
+}
+
+__global__ __launch_bounds__(256, 2) void k_trmm_f64(const double* __restrict__ Lt, const double* __restrict__ Dt,
+                                                     double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // A[2][2048] | B[2][2048]
+  int bi, bj;
+  tr_map_block(blockIdx.x, nbi, nbj, &bi, &bj);
+  if (bi < 0 || bi >= nbi || bj >= nbj) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nk = TR_KB_PER_BLOCK * (bi + 1);
+  const double2* gA = reinterpret_cast<const double2*>(Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK);
+  const double2* gB = reinterpret_cast<const double2*>(Dt + (size_t)bj * nkb * TR_CHUNK);
+  double2* sA2 = reinterpret_cast<double2*>(smem);
+  double2* sB2 = reinterpret_cast<double2*>(smem + 2 * TR_CHUNK);
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  double2 ra[4], rb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ra[i] = gA[tid + 256 * i]; rb[i] = gB[tid + 256 * i]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { sA2[tid + 256 * i] = ra[i]; sB2[tid + 256 * i] = rb[i]; }
+  __syncthreads();
+
+  for (int kb = 0; kb < nk; ++kb) {
+    const int cur = kb & 1;
+    const bool more = kb + 1 < nk;
+    if (more) {
+      const size_t off = (size_t)(kb + 1) * (TR_CHUNK / 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ra[i] = gA[off + tid + 256 * i]; rb[i] = gB[off + tid + 256 * i]; }
+    }
+    const double* sA = smem + cur * TR_CHUNK;
+    const double* sB = smem + 2 * TR_CHUNK + cur * TR_CHUNK;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = sA[(ks * 8 + wr * 4 + i) * 64 + lane];
+        b[i] = sB[(ks * 8 + wc * 4 + i) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      double2* dA = sA2 + (cur ^ 1) * (TR_CHUNK / 2);
+      double2* dB = sB2 + (cur ^ 1) * (TR_CHUNK / 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { dA[tid + 256 * i] = ra[i]; dB[tid + 256 * i] = rb[i]; }
+    }
+    __syncthreads();
+  }
+  // C/D map of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const size_t row0 = (size_t)bi * TR_BM + wr * 64, col0 = (size_t)bj * TR_BN + wc * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        X[(row0 + i * 16 + (lane >> 4) + 4 * r) * ldx + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
+}
+
+// ---- p_i <- D_{Z, r, x_i} ------------------------------------------------------------------------------
+__global__ void k_perturb_round(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
+                                const double* __restrict__ X, SampleZParams sp, int32_t* __restrict__ P,
+                                int* __restrict__ fail) {
+  const size_t total = m * ld;
+  int f = 0;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / ld, b = g % ld;
+    int32_t v = 0;
+    if (b < B) {
+      const long long s = sample_z(seed, TAG_PERTURB, first_index + b, (uint32_t)i, X[g], sp, &f);
+      if (s > 0x1ffffff || s < -0x1ffffff) f = 1;
+      v = (int32_t)s;
+    }
+    P[g] = v;
+  }
+  if (f) atomicOr(fail, 1);
+}
+
+// ---- integer products over Z_q ---------------------------------------------------------------------------
+// S[i][c] = sum_t a[i][t] * p[t][c]  (a in [0,q) as u64, p small signed), reduced mod q, then an epilogue:
+//   ZQ_SYNDROME : out[i][c] = (u[c][i] - S) mod q      out n x ld   (mp_perturbation.rs:318)
+//   ZQ_FA       : out[c][i] = S mod q                   out B x n    (mp_perturbation.rs:368)
+//   ZQ_TRAPDOOR : A[i][off + c] = (G[i][c] - S) mod q   (gadget_classical.rs:66, tag = I)
+// a is split into 31-bit limbs; each 32-term tile is summed in int64 (|a_limb * p| < 2^31 * 2^25) and folded
+// into a 128-bit running total, so no intermediate ever wraps for any q < 2^62.
+enum ZqMode { ZQ_SYNDROME = 0, ZQ_FA = 1, ZQ_TRAPDOOR = 2 };
+
+struct Acc128 { uint64_t lo; int64_t hi; };
+__device__ inline void acc128_add(Acc128& t, int64_t v) {
+  const uint64_t nl = t.lo + (uint64_t)v;
+  t.hi += (v >> 63) + (nl < t.lo ? 1 : 0);
+  t.lo = nl;
+}
+// (hi * 2^64 + lo) mod q for |hi| small; two64 = 2^64 mod q
+__device__ inline uint64_t acc128_mod(Acc128 t, uint64_t q, uint64_t two64) {
+  uint64_t r = t.lo % q;
+  int64_t h = t.hi;
+  const bool neg = h < 0;
+  uint64_t hm = (uint64_t)(neg ? -h : h);
+  // hm * two64 mod q by double-and-add (hm < 2^16 in every use)
+  uint64_t term = 0, base = two64;
+  while (hm) {
+    if (hm & 1) { term += base; if (term >= q) term -= q; }
+    base += base; if (base >= q) base -= q;
+    hm >>= 1;
+  }
+  if (neg) { r = r >= term ? r - term : r + q - term; }
+  else { r += term; if (r >= q) r -= q; }
+  return r;
+}
+
+template <typename PT, bool WIDE>
+__global__ __launch_bounds__(256) void k_zq_matmul(int mode, const uint64_t* __restrict__ Amat, size_t lda, size_t a_off,
+                                                   size_t nrows, size_t K, const PT* __restrict__ Pm, size_t ldp, size_t ncols,
+                                                   uint64_t q, uint64_t two64, uint64_t two31,
+                                                   const uint64_t* __restrict__ U, uint64_t* __restrict__ out, size_t ldo,
+                                                   size_t out_off, const uint64_t* __restrict__ gvec, uint64_t gk) {
+  // tile 64 (rows i) x 64 (cols c), K tile 32; thread -> 4 x 4 outputs
+  __shared__ uint32_t sAlo[64][33];
+  __shared__ uint32_t sAhi[WIDE ? 64 : 1][33];
+  __shared__ int32_t sP[32][64];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const size_t i0 = (size_t)blockIdx.y * 64, c0 = (size_t)blockIdx.x * 64;
+  Acc128 tlo[4][4], thi[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { tlo[r][c] = Acc128{0, 0}; thi[r][c] = Acc128{0, 0}; }
+
+  for (size_t k0 = 0; k0 < K; k0 += 32) {
+    // stage A tile (64 x 32) and P tile (32 x 64)
+    for (int e = tid; e < 64 * 32; e += 256) {
+      const int r = e >> 5, kk = e & 31;
+      uint64_t a = 0;
+      if (i0 + r < nrows && k0 + kk < K) a = Amat[(i0 + r) * lda + a_off + k0 + kk];
+      sAlo[r][kk] = (uint32_t)(a & 0x7fffffffu);
+      if (WIDE) sAhi[r][kk] = (uint32_t)(a >> 31);
+    }
+    for (int e = tid; e < 32 * 64; e += 256) {
+      const int kk = e >> 6, c = e & 63;
+      int32_t p = 0;
+      if (k0 + kk < K && c0 + c < ncols) p = (int32_t)Pm[(k0 + kk) * ldp + c0 + c];
+      sP[kk][c] = p;
+    }
+    __syncthreads();
+    int64_t alo[4][4], ahi[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { alo[r][c] = 0; ahi[r][c] = 0; }
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      int32_t p[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) p[c] = sP[kk][tx * 4 + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int32_t al = (int32_t)sAlo[ty * 4 + r][kk];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) alo[r][c] += (int64_t)al * p[c];
+        if (WIDE) {
+          const int32_t ah = (int32_t)sAhi[ty * 4 + r][kk];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ahi[r][c] += (int64_t)ah * p[c];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc128_add(tlo[r][c], alo[r][c]);
+        if (WIDE) acc128_add(thi[r][c], ahi[r][c]);
+      }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t i = i0 + ty * 4 + r, cc = c0 + tx * 4 + c;
+      if (i >= nrows || cc >= ncols) continue;
+      uint64_t s = acc128_mod(tlo[r][c], q, two64);
+      if (WIDE) {
+        const uint64_t h = acc128_mod(thi[r][c], q, two64);
+        // s += h * 2^31 mod q  (h, two31 < q < 2^62): double-and-add on two31's bits is overkill; use 128-bit split
+        const uint64_t plo = h * two31, phi = __umul64hi(h, two31);
+        Acc128 t{plo, (int64_t)phi};
+        // phi < 2^60: fold with acc128_mod's double-and-add on hi (hm up to 2^60 -> 60 iterations, once per output)
+        const uint64_t hs = acc128_mod(t, q, two64);
+        s += hs; if (s >= q) s -= q;
+      }
+      if (mode == ZQ_SYNDROME) {
+        const uint64_t u = U[cc * nrows + i] % q;
+        out[i * ldo + cc] = u >= s ? u - s : u + q - s;
+      } else if (mode == ZQ_FA) {
+        out[cc * ldo + i] = s;
+      } else {
+        // G[i][cc] = base^(cc % gk) if cc / gk == i (gadget_classical.rs:91-107)
+        const uint64_t g = (cc / gk == i) ? gvec[cc % gk] : 0;  // gvec[t] = base^t mod q
+        out[i * ldo + out_off + cc] = g >= s ? g - s : g + q - s;
+      }
+    }
+}
+
+// ---- gadget: digit decomposition + randomized nearest plane on S_k ------------------------------------
+struct GadgetTables {   // device pointers, all of length k or k*k
+  const int32_t* Sk;        // k x k basis block (row-major; columns are basis vectors)
+  const double* gso;        // k x k Gram-Schmidt vectors (columns)
+  const double* norm2;      // ||b~_i||^2
+  const SampleZParams* sz;  // parameters of D_{Z, s_G/||b~_i||, .}
+};
+
+// find_solution_gadget_mat (gadget_classical.rs:219-229) as a standalone kernel: value[rows x cols] -> out[k rows x cols]
+__global__ void k_digits(const uint64_t* __restrict__ value, size_t rows, size_t cols, uint64_t q, uint32_t k,
+                         uint64_t base, int64_t* __restrict__ out) {
+  const size_t total = rows * cols;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t j = g / cols, c = g % cols;
+    uint64_t v = value[g] % q;
+    for (uint32_t t = 0; t < k; ++t) {
+      uint64_t d;
+      if (base == 2) { d = v & 1; v >>= 1; }
+      else { d = v % base; v = (v - d) / base; }
+      out[((size_t)k * j + t) * cols + c] = (int64_t)d;
+    }
+  }
+}
+
+// One thread = one (row j of v, preimage b): x = digits(v_j); c = -x; for i = k-1..0: c' = <c,b~_i>/||b~_i||^2,
+// z_i <- D_{Z,s_i,c'}, c -= z_i b_i; result -c  (mp_perturbation.rs:173-191 + GPV08 SampleD).
+// c lives in LDS ([t][thread], conflict free), the k x k tables are broadcast reads from LDS.
+// z is written as two int8 planes (z = lo + 256 hi), four coordinates per 32-bit word, for the dot4 product R z.
+__global__ __launch_bounds__(256) void k_gadget(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q,
+                                                uint64_t base, size_t B, size_t ld, const uint64_t* __restrict__ V,
+                                                GadgetTables tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
+                                                int* __restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* s_gso = reinterpret_cast<double*>(smem_raw);                   // k*k
+  double* s_norm2 = s_gso + (size_t)k * k;                               // k
+  SampleZParams* s_sz = reinterpret_cast<SampleZParams*>(s_norm2 + k);   // k
+  int32_t* s_Sk = reinterpret_cast<int32_t*>(s_sz + k);                  // k*k
+  int32_t* s_c = s_Sk + (size_t)k * k;                                   // k * 256
+  const int tid = threadIdx.x;
+  for (uint32_t e = tid; e < k * k; e += 256) { s_gso[e] = tb.gso[e]; s_Sk[e] = tb.Sk[e]; }
+  for (uint32_t e = tid; e < k; e += 256) { s_norm2[e] = tb.norm2[e]; s_sz[e] = tb.sz[e]; }
+  __syncthreads();
+  const size_t b = (size_t)blockIdx.x * 256 + tid;
+  const uint32_t j = blockIdx.y;
+  if (b >= B) return;
+  int f = 0;
+  uint64_t v = V[(size_t)j * ld + b] % q;
+  for (uint32_t t = 0; t < k; ++t) {
+    uint64_t d;
+    if (base == 2) { d = v & 1; v >>= 1; }
+    else { d = v % base; v = (v - d) / base; }
+    s_c[t * 256 + tid] = -(int32_t)d;
+  }
+  const uint64_t index = first_index + b;
+  for (int i = (int)k - 1; i >= 0; --i) {
+    double dot = 0.0;
+    for (uint32_t t = 0; t < k; ++t) dot = fma((double)s_c[t * 256 + tid], s_gso[t * k + i], dot);
+    const double c2 = dot / s_norm2[i];
+    const long long zi = sample_z(seed, TAG_GADGET, index, j * k + (uint32_t)i, c2, s_sz[i], &f);
+    const int32_t z32 = (int32_t)zi;
+    if (zi > 0x3fffff || zi < -0x3fffff) f = 1;
+    for (uint32_t t = 0; t < k; ++t) {
+      const int32_t sk = s_Sk[t * k + i];
+      if (sk) s_c[t * 256 + tid] -= z32 * sk;
+    }
+  }
+  for (uint32_t t = 0; t < k; ++t) {
+    const int32_t z = -s_c[t * 256 + tid];
+    if (z > 32767 || z < -32768) f = 1;
+    const int32_t lo = (int32_t)(int8_t)(z & 0xff);
+    const int32_t hi = (z - lo) >> 8;
+    const size_t c = (size_t)j * k + t;
+    const size_t addr = ((c >> 2) * ld + b) * 4 + (c & 3);
+    Zlo[addr] = (int8_t)lo;
+    Zhi[addr] = (int8_t)hi;
+  }
+  if (f) atomicOr(fail, 1);
+}
+
+// ---- e = p + [R; I] z, written preimage-major (B x m int64) ---------------------------------------------
+// top part: 64 (rows i of R) x 64 (preimages) per workgroup, four coordinates per v_dot4_i32_i8
+__global__ __launch_bounds__(256) void k_recombine_top(const int8_t* __restrict__ R, size_t ldr /*bytes per row, mult of 4*/,
+                                                       size_t mbar, size_t w4, const uint32_t* __restrict__ Zlo,
+                                                       const uint32_t* __restrict__ Zhi, size_t ld, const int32_t* __restrict__ P,
+                                                       size_t B, int64_t* __restrict__ E, size_t m) {
+  __shared__ uint32_t sR[64][17];
+  __shared__ uint32_t sZl[16][64];
+  __shared__ uint32_t sZh[16][64];
+  __shared__ int64_t sE[64][65];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const size_t i0 = (size_t)blockIdx.y * 64, b0 = (size_t)blockIdx.x * 64;
+  int32_t alo[4][4], ahi[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { alo[r][c] = 0; ahi[r][c] = 0; }
+  const uint32_t* R32 = reinterpret_cast<const uint32_t*>(R);
+  const size_t ldr4 = ldr / 4;
+  for (size_t q0 = 0; q0 < w4; q0 += 16) {
+    for (int e = tid; e < 64 * 16; e += 256) {
+      const int r = e >> 4, qq = e & 15;
+      uint32_t v = 0;
+      if (i0 + r < mbar && q0 + qq < w4) v = R32[(i0 + r) * ldr4 + q0 + qq];
+      sR[r][qq] = v;
+    }
+    for (int e = tid; e < 16 * 64; e += 256) {
+      const int qq = e >> 6, c = e & 63;
+      uint32_t vl = 0, vh = 0;
+      if (q0 + qq < w4) { vl = Zlo[(q0 + qq) * ld + b0 + c]; vh = Zhi[(q0 + qq) * ld + b0 + c]; }
+      sZl[qq][c] = vl; sZh[qq][c] = vh;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) {
+      uint32_t zl[4], zh[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { zl[c] = sZl[qq][tx * 4 + c]; zh[c] = sZh[qq][tx * 4 + c]; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t rv = sR[ty * 4 + r][qq];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          alo[r][c] = __builtin_amdgcn_sdot4((int)rv, (int)zl[c], alo[r][c], false);
+          ahi[r][c] = __builtin_amdgcn_sdot4((int)rv, (int)zh[c], ahi[r][c], false);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t i = i0 + ty * 4 + r, b = b0 + tx * 4 + c;
+      int64_t v = 0;
+      if (i < mbar) v = (int64_t)P[i * ld + b] + (int64_t)alo[r][c] + 256 * (int64_t)ahi[r][c];
+      sE[tx * 4 + c][ty * 4 + r] = v;
+    }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int bb = e >> 6, ii = e & 63;
+    if (b0 + bb < B && i0 + ii < mbar) E[(b0 + bb) * m + i0 + ii] = sE[bb][ii];
+  }
+}
+
+// bottom part: e[b][mbar + c] = p[mbar + c][b] + z[c][b]
+__global__ __launch_bounds__(256) void k_recombine_bottom(size_t mbar, size_t w, const int8_t* __restrict__ Zlo,
+                                                          const int8_t* __restrict__ Zhi, size_t ld, const int32_t* __restrict__ P,
+                                                          size_t B, int64_t* __restrict__ E, size_t m) {
+  __shared__ int64_t sE[64][65];
+  const int tid = threadIdx.x;
+  const size_t c0 = (size_t)blockIdx.y * 64, b0 = (size_t)blockIdx.x * 64;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int cc = e >> 6, bb = e & 63;
+    const size_t c = c0 + cc, b = b0 + bb;
+    int64_t v = 0;
+    if (c < w) {
+      const size_t addr = ((c >> 2) * ld + b) * 4 + (c & 3);
+      v = (int64_t)P[(mbar + c) * ld + b] + (int64_t)Zlo[addr] + 256 * (int64_t)Zhi[addr];
+    }
+    sE[bb][cc] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int bb = e >> 6, cc = e & 63;
+    if (b0 + bb < B && c0 + cc < w) E[(b0 + bb) * m + mbar + c0 + cc] = sE[bb][cc];
+  }
+}
+
+// ---- samp_d, check_domain, narrowing transpose for f_a --------------------------------------------------
+__global__ void k_samp_d(uint64_t seed, uint64_t first_index, size_t m, size_t B, SampleZParams sp, int64_t* __restrict__ E,
+                         int* __restrict__ fail) {
+  const size_t total = m * B;
+  int f = 0;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g / m, i = g % m;
+    E[g] = sample_z(seed, TAG_SAMPD, first_index + b, (uint32_t)i, 0.0, sp, &f);
+  }
+  if (f) atomicOr(fail, 1);
+}
+
+// ok[b] = (||e_b||^2 <= bound), exact 128-bit norm (mp_perturbation.rs:396-402)
+__global__ __launch_bounds__(256) void k_check_domain(const int64_t* __restrict__ E, size_t len, size_t m, double bound,
+                                                      uint8_t* __restrict__ ok) {
+  __shared__ uint64_t s_lo[256];
+  __shared__ uint64_t s_hi[256];
+  const size_t b = blockIdx.x;
+  uint64_t lo = 0, hi = 0;
+  for (size_t i = threadIdx.x; i < len; i += 256) {
+    const int64_t v = E[b * len + i];
+    const uint64_t a = (uint64_t)(v < 0 ? -v : v);
+    const uint64_t pl = a * a, ph = __umul64hi(a, a);
+    const uint64_t nl = lo + pl;
+    hi += ph + (nl < lo ? 1 : 0);
+    lo = nl;
+  }
+  s_lo[threadIdx.x] = lo; s_hi[threadIdx.x] = hi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const uint64_t nl = s_lo[threadIdx.x] + s_lo[threadIdx.x + s];
+      s_hi[threadIdx.x] += s_hi[threadIdx.x + s] + (nl < s_lo[threadIdx.x] ? 1 : 0);
+      s_lo[threadIdx.x] = nl;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double nn = (double)s_hi[0] * 18446744073709551616.0 + (double)s_lo[0];
+    ok[b] = (len == m && nn <= bound) ? 1 : 0;
+  }
+}
+
+// e (B x m int64) -> P layout (m x ld int32), clamped to +-2^25 (anything larger already failed check_domain)
+__global__ __launch_bounds__(256) void k_narrow_transpose(const int64_t* __restrict__ E, size_t m, size_t B, size_t ld,
+                                                          int32_t* __restrict__ P) {
+  __shared__ int32_t s[64][65];
+  const int tid = threadIdx.x;
+  const size_t i0 = (size_t)blockIdx.y * 64, b0 = (size_t)blockIdx.x * 64;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int bb = e >> 6, ii = e & 63;
+    int64_t v = 0;
+    if (b0 + bb < B && i0 + ii < m) v = E[(b0 + bb) * m + i0 + ii];
+    if (v > 0x1ffffff) v = 0x1ffffff;
+    if (v < -0x1ffffff) v = -0x1ffffff;
+    s[ii][bb] = (int32_t)v;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int ii = e >> 6, bb = e & 63;
+    if (i0 + ii < m && b0 + bb < ld) P[(i0 + ii) * ld + b0 + bb] = s[ii][bb];
+  }
+}
+
+// P (m x ld int32) -> B x m int64 (stage export)
+__global__ void k_export_P(const int32_t* __restrict__ P, size_t m, size_t B, size_t ld, int64_t* __restrict__ out) {
+  const size_t total = m * B;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g / m, i = g % m;
+    out[g] = P[i * ld + b];
+  }
+}
+template <typename T>
+__global__ void k_export_T(const T* __restrict__ S, size_t rows, size_t B, size_t ld, T* __restrict__ out) {
+  const size_t total = rows * B;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g / rows, i = g % rows;
+    out[g] = S[i * ld + b];
+  }
+}
+
+__global__ void k_uniform_targets(uint64_t seed, uint64_t first_index, size_t n, size_t B, uint64_t q, uint64_t* __restrict__ U) {
+  const size_t total = n * B;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g / n, i = g % n;
+    U[g] = uniform_mod(seed, TAG_TARGET, (uint32_t)i, (uint32_t)(first_index + b), q);
+  }
+}
+
+// ---- trap_gen pieces ---------------------------------------------------------------------------------------
+// A[i][j] = uniform(Z_q), j < m_bar  (mp_perturbation.rs:222)
+__global__ void k_sample_abar(uint64_t seed, size_t n, size_t mbar, size_t lda, uint64_t q, uint64_t* __restrict__ A) {
+  const size_t total = n * mbar;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / mbar, j = g % mbar;
+    A[i * lda + j] = uniform_mod(seed, TAG_ABAR, (uint32_t)j, (uint32_t)i, q);
+  }
+}
+// PlusMinusOneZero (trapdoor_distribution.rs:82-86): 64 entries per Philox block
+__global__ void k_sample_R(uint64_t seed, size_t mbar, size_t w, size_t ldr, int8_t* __restrict__ R) {
+  const size_t total = mbar * ldr;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / ldr, j = g % ldr;
+    int8_t v = 0;
+    if (j < w) {
+      const U4 wd = philox(seed, (uint32_t)(j >> 6), (uint32_t)i, 0, TAG_R);
+      const uint32_t sel = (uint32_t)(j & 63) >> 4;
+      const uint32_t word = sel == 0 ? wd.x : sel == 1 ? wd.y : sel == 2 ? wd.z : wd.w;
+      const uint32_t sh = 2 * (uint32_t)(j & 15);
+      v = (int8_t)((int)((word >> sh) & 1) - (int)((word >> (sh + 1)) & 1));
+    }
+    R[g] = v;
+  }
+}
+
+// Sigma_2 = (r^2/2pi) ((s^2 I - (b^2+1) T T^t) - I), T = [R; I]  (mp_perturbation.rs:111-136), lower triangle of a
+// dense row-major m x m matrix.  The R R^t block is a dot4 product of 64 x 64 row pairs.
+__global__ __launch_bounds__(256) void k_sigma2(const int8_t* __restrict__ R, size_t ldr, size_t mbar, size_t w, size_t m,
+                                                double nf_r2, double s2, double b2p1, double* __restrict__ S, size_t lds) {
+  __shared__ uint32_t sRi[64][17];
+  __shared__ uint32_t sRj[64][17];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const size_t i0 = (size_t)blockIdx.y * 64, j0 = (size_t)blockIdx.x * 64;
+  if (j0 > i0 + 63) return;  // strictly upper tile
+  int32_t acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+  if (i0 < mbar && j0 < mbar) {
+    const uint32_t* R32 = reinterpret_cast<const uint32_t*>(R);
+    const size_t ldr4 = ldr / 4, w4 = (w + 3) / 4;
+    for (size_t q0 = 0; q0 < w4; q0 += 16) {
+      for (int e = tid; e < 64 * 16; e += 256) {
+        const int r = e >> 4, qq = e & 15;
+        uint32_t vi = 0, vj = 0;
+        if (q0 + qq < w4) {
+          if (i0 + r < mbar) vi = R32[(i0 + r) * ldr4 + q0 + qq];
+          if (j0 + r < mbar) vj = R32[(j0 + r) * ldr4 + q0 + qq];
+        }
+        sRi[r][qq] = vi; sRj[r][qq] = vj;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) {
+        uint32_t rj[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rj[c] = sRj[tx * 4 + c][qq];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t ri = sRi[ty * 4 + r][qq];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_amdgcn_sdot4((int)ri, (int)rj[c], acc[r][c], false);
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t i = i0 + ty * 4 + r, j = j0 + tx * 4 + c;
+      if (i >= m || j > i) continue;
+      double tt;
+      if (i < mbar) tt = (double)acc[r][c];
+      else if (j < mbar) tt = (double)R[j * ldr + (i - mbar)];
+      else tt = (i == j) ? 1.0 : 0.0;
+      double sp = ((i == j) ? s2 : 0.0) - b2p1 * tt;
+      if (i == j) sp = sp - 1.0;
+      S[i * lds + j] = nf_r2 * sp;
+    }
+}
+
+}  // namespace psf

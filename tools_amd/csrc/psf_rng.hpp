@@ -1,0 +1,144 @@
+// psf_rng.hpp -- randomness contract of the library, device side (gfx950).
+//
+// The reference samples through qfall-math's thread-local RNG and takes no seed (psf.rs:48-80), so the
+// contract is this library's own (DESIGN.md "Randomness contract"): every random decision is a pure
+// function of (seed, stream tag, global preimage index, coordinate, attempt) through Philox4x32-10, and
+// all floating point is IEEE binary64 with explicit fma -- compiled with -ffp-contract=off -- so that any
+// evaluation order / lane assignment gives the same bits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace psf {
+
+enum StreamTag : uint32_t {
+  TAG_ABAR = 1, TAG_R = 2, TAG_NORMAL = 3, TAG_PERTURB = 4, TAG_GADGET = 5, TAG_SAMPD = 6,
+  TAG_TARGET = 7, TAG_GPV = 8, TAG_RING_R = 9, TAG_RING_E = 10, TAG_RING_A = 11
+};
+
+constexpr uint32_t kMaxAttempts = 65536u;
+
+struct U4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(a, b);
+#else
+  return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+__host__ __device__ inline uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// Philox4x32-10, key = seed, counter = (c0, c1, c2, c3)
+__host__ __device__ inline U4 philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t lo0 = 0xD2511F53u * c0, hi0 = mulhi32(0xD2511F53u, c0);
+    const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = mulhi32(0xCD9E8D57u, c2);
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+__host__ __device__ inline uint32_t tag_word(uint32_t tag, uint64_t index) {
+  return tag | ((uint32_t)(index >> 32) << 8);
+}
+
+// exp(y), y <= 0: k = floor(y log2e + 1/2); r = y - k ln2 (hi/lo); degree-13 Taylor by fma; 2^k by exponent add.
+__host__ __device__ inline double det_exp(double y) {
+  if (!(y > -708.0)) return 0.0;
+  if (y > 0.0) y = 0.0;
+  const double kf = floor(y * 1.4426950408889634 + 0.5);
+  double r = fma(kf, -6.93147180369123816490e-01, y);
+  r = fma(kf, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const long long k = (long long)kf;
+  long long bits = __builtin_bit_cast(long long, p) + (k << 52);
+  return __builtin_bit_cast(double, bits);
+}
+
+// Parameters of D_{Z,s,.} that depend only on s; computed once on the host.
+struct SampleZParams {
+  double inv_s;     // 1/s
+  long long c6;     // ceil(6 s)
+  long long f6;     // floor(6 s)
+};
+
+inline SampleZParams make_sample_z_params(double s) {
+  SampleZParams p;
+  p.inv_s = 1.0 / s;
+  p.c6 = (long long)ceil(6.0 * s);
+  p.f6 = (long long)floor(6.0 * s);
+  return p;
+}
+
+// SampleZ of GPV08 as the reference documents it (CONTRIBUTING.md:35-45): candidates uniform in
+// [c - ceil(6s), c + floor(6s)], accepted with probability exp(-pi (x-c)^2 / s^2).  Attempt t of sample
+// (tag, index, coord) always consumes Philox block (coord, index_lo, t, tag|index_hi), so the result is the
+// first accepted attempt no matter how lanes are scheduled.  *fail is OR-ed with 1 if the cap is hit.
+__device__ inline long long sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center,
+                                     const SampleZParams sp, int* fail) {
+  const long long lo = (long long)ceil(center) - sp.c6;
+  const long long hi = (long long)floor(center) + sp.f6;
+  const uint64_t N = (uint64_t)(hi - lo + 1);
+  const uint32_t tw = tag_word(tag, index);
+  for (uint32_t t = 0; t < kMaxAttempts; ++t) {
+    const U4 w = philox(seed, coord, (uint32_t)index, t, tw);
+    const long long x = lo + (long long)mulhi64(((uint64_t)w.y << 32) | w.x, N);
+    const double u = (double)((((uint64_t)w.w << 32) | w.z) >> 11) * 0x1.0p-53;
+    const double a = ((double)x - center) * sp.inv_s;
+    const double rho = det_exp(-3.14159265358979323846 * (a * a));
+    if (u < rho) return x;
+  }
+  *fail = 1;
+  return (long long)floor(center + 0.5);
+}
+
+// N(0,1) by ratio of uniforms: x = sqrt(2/e) v/u, accepted iff u <= exp(-x^2/4).
+__device__ inline double sample_normal(uint64_t seed, uint64_t index, uint32_t coord, int* fail) {
+  const uint32_t tw = tag_word(TAG_NORMAL, index);
+  for (uint32_t t = 0; t < kMaxAttempts; ++t) {
+    const U4 w = philox(seed, coord, (uint32_t)index, t, tw);
+    const double u = (double)(((((uint64_t)w.y << 32) | w.x) >> 11) + 1) * 0x1.0p-53;
+    const uint64_t vv = (((uint64_t)w.w << 32) | w.z) >> 12;
+    const double v = (double)(2 * vv + 1) * 0x1.0p-52 - 1.0;
+    const double x = (v * 0.8577638849607068) / u;
+    const double rho = det_exp(-0.25 * (x * x));
+    if (u <= rho) return x;
+  }
+  *fail = 1;
+  return 0.0;
+}
+
+__host__ __device__ inline uint64_t uniform_mod(uint64_t seed, uint32_t tag, uint32_t c0, uint32_t c1, uint64_t q) {
+  const U4 w = philox(seed, c0, c1, 0, tag);
+  return mulhi64(((uint64_t)w.y << 32) | w.x, q);
+}
+
+}  // namespace psf

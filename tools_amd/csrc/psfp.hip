@@ -1,0 +1,624 @@
+// psfp.hip -- PSFPerturbation behind the C ABI of include/psf_mi355x.h (mp_perturbation.rs:57-62, :193-403).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/psf_mi355x.h"
+#include "psf_host.hpp"
+#include "psf_kernels.hpp"
+
+using namespace psf;
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      std::fprintf(stderr, "[psf_mi355x] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return PSF_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+static inline unsigned grid_for(size_t total, unsigned block = 256, unsigned cap = 256 * 16) {
+  size_t g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  return (unsigned)(g > cap ? cap : g);
+}
+static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- Cholesky through rocSOLVER, loaded lazily (setup path only; own blocked factorisation is DESIGN.md "next") ----
+namespace {
+struct RocSolver {
+  void* h_blas = nullptr; void* h_solver = nullptr; void* handle = nullptr;
+  int (*create)(void**) = nullptr;
+  int (*destroy)(void*) = nullptr;
+  int (*set_stream)(void*, hipStream_t) = nullptr;
+  int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
+  bool ok = false;
+  bool load() {
+    if (ok) return true;
+    h_blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h_blas) h_blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    h_solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h_solver) h_solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h_blas || !h_solver) { std::fprintf(stderr, "[psf_mi355x] cannot load rocblas/rocsolver: %s\n", dlerror()); return false; }
+    create = (int (*)(void**))dlsym(h_blas, "rocblas_create_handle");
+    destroy = (int (*)(void*))dlsym(h_blas, "rocblas_destroy_handle");
+    set_stream = (int (*)(void*, hipStream_t))dlsym(h_blas, "rocblas_set_stream");
+    dpotrf = (int (*)(void*, int, int, double*, int, int*))dlsym(h_solver, "rocsolver_dpotrf");
+    if (!create || !destroy || !set_stream || !dpotrf) return false;
+    if (create(&handle) != 0) return false;
+    ok = true;
+    return true;
+  }
+};
+RocSolver g_rocsolver;
+}  // namespace
+
+struct TimingSlot { std::string name; hipEvent_t e0, e1; };
+
+struct psfp_handle {
+  psfp_params prm;
+  size_t n, k, mb, w, m;
+  uint64_t q, two64, two31;
+  bool wide;            // q >= 2^31: two 31-bit limbs
+  bool has_key = false;
+  // key material
+  uint64_t* dA = nullptr;      // n x m
+  int8_t* dR = nullptr;        // mb x ldr
+  size_t ldr = 0;
+  double* dLt = nullptr;       // chunk stream of sqrt(Sigma_2)
+  size_t M_pad = 0, nbi = 0, nkb = 0;
+  // gadget tables
+  int32_t* dSk = nullptr; double* dGso = nullptr; double* dNorm2 = nullptr; SampleZParams* dSz = nullptr;
+  uint64_t* dGvec = nullptr;
+  std::vector<int64_t> hSk; std::vector<double> hGso;
+  SampleZParams szR, szSR;
+  // batch work buffers
+  size_t Bcap = 0, ld = 0, nbj = 0;
+  double* dDt = nullptr; double* dX = nullptr; int32_t* dP = nullptr; uint64_t* dV = nullptr;
+  int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; size_t w4 = 0;
+  uint64_t* dU = nullptr; int64_t* dE = nullptr; uint8_t* dOk = nullptr;
+  int* dFail = nullptr;
+  hipStream_t last_stream = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<TimingSlot> slots;
+};
+
+static size_t gadget_lds_bytes(size_t k) { return k * k * 8 + k * 8 + k * sizeof(SampleZParams) + k * k * 4 + k * 256 * 4; }
+
+static void free_batch(psfp_handle* h) {
+  hipFree(h->dDt); hipFree(h->dX); hipFree(h->dP); hipFree(h->dV); hipFree(h->dZlo); hipFree(h->dZhi);
+  hipFree(h->dU); hipFree(h->dE); hipFree(h->dOk);
+  h->dDt = h->dX = nullptr; h->dP = nullptr; h->dV = nullptr; h->dZlo = h->dZhi = nullptr; h->dU = nullptr; h->dE = nullptr; h->dOk = nullptr;
+  h->Bcap = 0;
+}
+
+static psf_status ensure_batch(psfp_handle* h, size_t B) {
+  if (B <= h->Bcap) {
+    h->nbj = round_up(B, TR_BN) / TR_BN;
+    return PSF_OK;
+  }
+  free_batch(h);
+  const size_t ld = round_up(B, TR_BN);
+  h->ld = ld;
+  h->nbj = ld / TR_BN;
+  HIP_TRY(hipMalloc(&h->dDt, ld / TR_BN * h->nkb * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->dX, h->M_pad * ld * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->dP, h->M_pad * ld * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&h->dV, h->n * ld * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&h->dZlo, h->w4 * ld * 4));
+  HIP_TRY(hipMalloc(&h->dZhi, h->w4 * ld * 4));
+  HIP_TRY(hipMemset(h->dZlo, 0, h->w4 * ld * 4));
+  HIP_TRY(hipMemset(h->dZhi, 0, h->w4 * ld * 4));
+  HIP_TRY(hipMemset(h->dP, 0, h->M_pad * ld * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&h->dU, B * h->n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&h->dE, B * h->m * sizeof(int64_t)));
+  HIP_TRY(hipMalloc(&h->dOk, B));
+  h->Bcap = B;
+  return PSF_OK;
+}
+
+struct ScopedTimer {
+  psfp_handle* h; hipStream_t st; size_t idx; bool on;
+  ScopedTimer(psfp_handle* h_, hipStream_t st_, const char* name) : h(h_), st(st_), on(h_->timing) {
+    if (!on) return;
+    TimingSlot s; s.name = name;
+    hipEventCreate(&s.e0); hipEventCreate(&s.e1);
+    hipEventRecord(s.e0, st);
+    h->slots.push_back(s);
+    idx = h->slots.size() - 1;
+  }
+  ~ScopedTimer() { if (on) hipEventRecord(h->slots[idx].e1, st); }
+};
+static void clear_slots(psfp_handle* h) {
+  for (auto& s : h->slots) { hipEventDestroy(s.e0); hipEventDestroy(s.e1); }
+  h->slots.clear();
+}
+
+extern "C" {
+
+const char* psf_status_string(psf_status s) {
+  switch (s) {
+    case PSF_OK: return "ok";
+    case PSF_ERR_PARAM: return "invalid parameter";
+    case PSF_ERR_NOT_PD: return "Sigma_2 is not positive definite";
+    case PSF_ERR_DOMAIN: return "sigma is not in the domain";
+    case PSF_ERR_MODULUS: return "the modulus is too large, the value is potentially not representable";
+    case PSF_ERR_NO_SOLUTION: return "the linear system has no solution";
+    case PSF_ERR_NO_KEY: return "no key material installed";
+    case PSF_ERR_HIP: return "HIP runtime error";
+    case PSF_ERR_UNSUPPORTED: return "unsupported parameter combination";
+    case PSF_ERR_SAMPLER: return "rejection sampler exceeded its attempt cap or an intermediate left its range";
+    default: return "unknown status";
+  }
+}
+
+psf_status psf_device_info(int device, char* name, size_t name_len, int* compute_units) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return PSF_ERR_HIP;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (name && name_len) { std::strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  return PSF_OK;
+}
+
+psf_status psf_gadget_params_default(uint64_t n, uint64_t q, psf_gadget_params* out) { return gadget_params_default(n, q, out); }
+psf_status psf_gadget_params_ring_default(uint64_t n, uint64_t q, psf_gadget_params* out) { return gadget_params_ring_default(n, q, out); }
+
+psf_status psf_gen_gadget_vec(uint64_t k, uint64_t base, int64_t* out) {
+  if (k < 1 || !out) return PSF_ERR_PARAM;
+  const auto g = gen_gadget_vec(k, base);
+  std::memcpy(out, g.data(), k * sizeof(int64_t));
+  return PSF_OK;
+}
+psf_status psf_gen_gadget_mat(uint64_t n, uint64_t k, uint64_t base, int64_t* out) {
+  if (n < 1 || k < 1 || !out) return PSF_ERR_PARAM;
+  const auto G = gen_gadget_mat(n, k, base);
+  std::memcpy(out, G.data(), G.size() * sizeof(int64_t));
+  return PSF_OK;
+}
+psf_status psf_short_basis_gadget(const psf_gadget_params* gp, int64_t* out) {
+  if (!gp || !out || gp->n < 1 || gp->k < 1) return PSF_ERR_PARAM;
+  const auto S = short_basis_gadget(*gp);
+  std::memcpy(out, S.data(), S.size() * sizeof(int64_t));
+  return PSF_OK;
+}
+psf_status psf_gen_short_basis_for_trapdoor(const psf_gadget_params* gp, const uint64_t* tag, const uint64_t* A, const int8_t* R, int64_t* out) {
+  if (!gp || !A || !R || !out) return PSF_ERR_PARAM;
+  std::vector<int64_t> S;
+  const psf_status rc = gen_short_basis_for_trapdoor(*gp, tag, A, R, S);
+  if (rc != PSF_OK) return rc;
+  std::memcpy(out, S.data(), S.size() * sizeof(int64_t));
+  return PSF_OK;
+}
+psf_status psf_rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out) {
+  if (!mat || !out || rows < 1 || cols < 1) return PSF_ERR_PARAM;
+  rot_minus_matrix(mat, rows, cols, out);
+  return PSF_OK;
+}
+
+psf_status psf_find_solution_gadget_mat(int device, const uint64_t* value, size_t rows, size_t cols, uint64_t q, uint64_t k,
+                                        uint64_t base, int64_t* out) {
+  if (!value || !out || q <= 1 || k < 1 || base < 2) return PSF_ERR_PARAM;
+  if (gadget_too_short(base, k, q)) return PSF_ERR_MODULUS;   // gadget_classical.rs:170-172
+  if (rows * cols == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(device));
+  uint64_t* dv = nullptr; int64_t* dout = nullptr;
+  HIP_TRY(hipMalloc(&dv, rows * cols * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&dout, k * rows * cols * sizeof(int64_t)));
+  HIP_TRY(hipMemcpy(dv, value, rows * cols * sizeof(uint64_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_digits, dim3(grid_for(rows * cols)), dim3(256), 0, 0, dv, rows, cols, q, (uint32_t)k, base, dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, k * rows * cols * sizeof(int64_t), hipMemcpyDeviceToHost));
+  hipFree(dv); hipFree(dout);
+  return PSF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
+  if (!prm || !out) return PSF_ERR_PARAM;
+  const psf_gadget_params& gp = prm->gp;
+  if (gp.n < 1 || gp.k < 1 || gp.base < 2 || gp.q <= 1 || gp.q >= (1ull << 62) || gp.m_bar < 1) return PSF_ERR_PARAM;
+  if (!(prm->r > 0.0) || !(prm->s > 0.0)) return PSF_ERR_PARAM;
+  if (gp.k > 64) return PSF_ERR_UNSUPPORTED;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || prm->device < 0 || prm->device >= count) {
+    std::fprintf(stderr, "[psf_mi355x] no usable HIP device %d (found %d); this library has no CPU fallback\n", prm->device, count);
+    return PSF_ERR_HIP;
+  }
+  HIP_TRY(hipSetDevice(prm->device));
+  psfp_handle* h = new psfp_handle();
+  h->prm = *prm;
+  h->n = gp.n; h->k = gp.k; h->mb = gp.m_bar; h->w = gp.n * gp.k; h->m = h->mb + h->w; h->q = gp.q;
+  h->two64 = (uint64_t)((((u128)1) << 64) % gp.q);
+  h->two31 = (uint64_t)((1ull << 31) % gp.q);
+  h->wide = gp.q >= (1ull << 31);
+  h->M_pad = round_up(h->m, TR_BM);
+  h->nbi = h->M_pad / TR_BM;
+  h->nkb = h->M_pad / TR_BK;
+  h->ldr = round_up(h->w, 4);
+  h->w4 = h->ldr / 4;
+  h->szR = make_sample_z_params(prm->r);
+  h->szSR = make_sample_z_params(prm->s * prm->r);                    // mp_perturbation.rs:266
+  HIP_TRY(hipMalloc(&h->dA, h->n * h->m * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&h->dR, h->mb * h->ldr));
+  HIP_TRY(hipMalloc(&h->dLt, tr_total_chunks(h->nbi) * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->dFail, sizeof(int)));
+  HIP_TRY(hipMemset(h->dFail, 0, sizeof(int)));
+  // gadget part of the trapdoor: (S, S~) of mp_perturbation.rs:233-234, block form
+  h->hSk = short_basis_gadget_block(gp);
+  std::vector<double> norm2;
+  gso_columns(h->hSk, h->k, h->hGso, norm2);
+  const double sG = prm->r * std::sqrt((double)(gp.base * gp.base + 1));   // mp_perturbation.rs:180
+  std::vector<SampleZParams> sz(h->k);
+  for (size_t i = 0; i < h->k; ++i) sz[i] = make_sample_z_params(sG / std::sqrt(norm2[i]));
+  std::vector<int32_t> sk32(h->hSk.begin(), h->hSk.end());
+  const auto gvec = gen_gadget_vec_mod(h->k, gp.base, gp.q);
+  HIP_TRY(hipMalloc(&h->dSk, sk32.size() * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&h->dGso, h->hGso.size() * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->dNorm2, h->k * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->dSz, h->k * sizeof(SampleZParams)));
+  HIP_TRY(hipMalloc(&h->dGvec, h->k * sizeof(uint64_t)));
+  HIP_TRY(hipMemcpy(h->dSk, sk32.data(), sk32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->dGso, h->hGso.data(), h->hGso.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->dNorm2, norm2.data(), h->k * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->dSz, sz.data(), h->k * sizeof(SampleZParams), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->dGvec, gvec.data(), h->k * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
+  *out = h;
+  return PSF_OK;
+}
+
+void psfp_destroy(psfp_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->prm.device);
+  free_batch(h);
+  clear_slots(h);
+  hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dFail);
+  hipFree(h->dSk); hipFree(h->dGso); hipFree(h->dNorm2); hipFree(h->dSz); hipFree(h->dGvec);
+  delete h;
+}
+
+size_t psfp_m(const psfp_handle* h) { return h ? h->m : 0; }
+
+// Sigma_2 assembly (dense lower) + Cholesky + repack.  mp_perturbation.rs:111-139.
+static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov) {
+  const double TWO_PI = 6.283185307179586476925;
+  const double nf_r2 = (1.0 / TWO_PI) * (h->prm.r * h->prm.r);
+  const double s2 = s_cov * s_cov;
+  const double b2p1 = (double)(h->prm.gp.base * h->prm.gp.base + 1);
+  double* dS = nullptr;
+  const size_t m = h->m;
+  HIP_TRY(hipMalloc(&dS, m * m * sizeof(double)));
+  HIP_TRY(hipMemset(dS, 0, m * m * sizeof(double)));
+  const unsigned tiles = (unsigned)((m + 63) / 64);
+  hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, dS, m);
+  HIP_TRY(hipGetLastError());
+  if (!g_rocsolver.load()) { hipFree(dS); return PSF_ERR_HIP; }
+  int* dinfo = nullptr;
+  HIP_TRY(hipMalloc(&dinfo, sizeof(int)));
+  g_rocsolver.set_stream(g_rocsolver.handle, nullptr);
+  // our row-major lower triangle is the column-major UPPER triangle of the same symmetric matrix (rocblas_fill_upper = 121):
+  // potrf(upper) leaves U with Sigma_2 = U^t U, and U read row-major is exactly L.
+  const int rc = g_rocsolver.dpotrf(g_rocsolver.handle, 121, (int)m, dS, (int)m, dinfo);
+  int info = -1;
+  HIP_TRY(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(dinfo);
+  if (rc != 0) { hipFree(dS); return PSF_ERR_HIP; }
+  if (info != 0) { hipFree(dS); return PSF_ERR_NOT_PD; }            // mp_perturbation.rs:109-110
+  hipLaunchKernelGGL(k_repack_L<false>, dim3(grid_for(tr_total_chunks(h->nbi) * TR_CHUNK)), dim3(256), 0, 0, dS, m, m, h->dLt, h->nbi);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  hipFree(dS);
+  return PSF_OK;
+}
+
+static void launch_zq(psfp_handle* h, hipStream_t st, int mode, const uint64_t* Amat, size_t lda, size_t a_off, size_t nrows, size_t K,
+                      const void* P, bool p_is_i8, size_t ldp, size_t ncols, const uint64_t* U, uint64_t* out, size_t ldo, size_t out_off) {
+  dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)((nrows + 63) / 64));
+#define ZQ_LAUNCH(PT, W)                                                                                              \
+  hipLaunchKernelGGL((k_zq_matmul<PT, W>), grid, dim3(256), 0, st, mode, Amat, lda, a_off, nrows, K, (const PT*)P, ldp, ncols, \
+                     h->q, h->two64, h->two31, U, out, ldo, out_off, h->dGvec, (uint64_t)h->k)
+  if (p_is_i8) { if (h->wide) ZQ_LAUNCH(int8_t, true); else ZQ_LAUNCH(int8_t, false); }
+  else { if (h->wide) ZQ_LAUNCH(int32_t, true); else ZQ_LAUNCH(int32_t, false); }
+#undef ZQ_LAUNCH
+}
+
+psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
+  if (!h) return PSF_ERR_PARAM;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  if (gadget_too_short(h->prm.gp.base, h->k, h->q)) return PSF_ERR_MODULUS;
+  // mp_perturbation.rs:222 ; gadget_classical.rs:62-64
+  hipLaunchKernelGGL(k_sample_abar, dim3(grid_for(h->n * h->mb)), dim3(256), 0, 0, seed, h->n, h->mb, h->m, h->q, h->dA);
+  hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);
+  // gadget_classical.rs:66  A = [A_bar | G - A_bar R]   (tag = identity, mp_perturbation.rs:223)
+  launch_zq(h, nullptr, ZQ_TRAPDOOR, h->dA, h->m, 0, h->n, h->mb, h->dR, true, h->ldr, h->w, nullptr, h->dA, h->m, h->mb);
+  HIP_TRY(hipGetLastError());
+  const psf_status rc = build_sqrt_sigma2(h, h->prm.s);            // mp_perturbation.rs:227-231
+  if (rc != PSF_OK) { h->has_key = false; return rc; }
+  h->has_key = true;
+  return PSF_OK;
+}
+
+psf_status psfp_compute_sqrt_sigma_2(psfp_handle* h, double s_cov) {
+  if (!h || !(s_cov > 0.0)) return PSF_ERR_PARAM;
+  if (!h->has_key) return PSF_ERR_NO_KEY;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  return build_sqrt_sigma2(h, s_cov);
+}
+
+psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, const double* Lp) {
+  if (!h || !A || !R || !Lp) return PSF_ERR_PARAM;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  HIP_TRY(hipMemcpy(h->dA, A, h->n * h->m * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(h->dR, 0, h->mb * h->ldr));
+  HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
+  double* dp = nullptr;
+  const size_t np = h->m * (h->m + 1) / 2;
+  HIP_TRY(hipMalloc(&dp, np * sizeof(double)));
+  HIP_TRY(hipMemcpy(dp, Lp, np * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_repack_L<true>, dim3(grid_for(tr_total_chunks(h->nbi) * TR_CHUNK)), dim3(256), 0, 0, dp, (size_t)0, h->m, h->dLt, h->nbi);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  hipFree(dp);
+  h->has_key = true;
+  return PSF_OK;
+}
+
+psf_status psfp_export_key(const psfp_handle* h, uint64_t* A, int8_t* R, double* Lp) {
+  if (!h) return PSF_ERR_PARAM;
+  if (!h->has_key) return PSF_ERR_NO_KEY;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  if (A) HIP_TRY(hipMemcpy(A, h->dA, h->n * h->m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (R) HIP_TRY(hipMemcpy2D(R, h->w, h->dR, h->ldr, h->w, h->mb, hipMemcpyDeviceToHost));
+  if (Lp) {
+    double* dp = nullptr;
+    const size_t np = h->m * (h->m + 1) / 2;
+    HIP_TRY(hipMalloc(&dp, np * sizeof(double)));
+    hipLaunchKernelGGL(k_unpack_L, dim3(grid_for(np)), dim3(256), 0, 0, h->dLt, h->m, dp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(Lp, dp, np * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(dp);
+  }
+  return PSF_OK;
+}
+
+psf_status psfp_export_gadget_basis(const psfp_handle* h, int64_t* Sk, double* gso) {
+  if (!h) return PSF_ERR_PARAM;
+  if (Sk) std::memcpy(Sk, h->hSk.data(), h->hSk.size() * sizeof(int64_t));
+  if (gso) std::memcpy(gso, h->hGso.data(), h->hGso.size() * sizeof(double));
+  return PSF_OK;
+}
+
+// ---- the hot path -------------------------------------------------------------------------------------------
+static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, hipStream_t st) {
+  const size_t ld = h->ld, m = h->m;
+  if (h->timing) clear_slots(h);
+  hipMemsetAsync(h->dFail, 0, sizeof(int), st);
+  {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
+    ScopedTimer t(h, st, "k_normals");
+    hipLaunchKernelGGL(k_normals, dim3(grid_for(h->nbj * h->nkb * TR_CHUNK, 256, 256 * 32)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, h->nbj, h->dDt, h->dFail);
+  }
+  {  // x = sqrt(Sigma_2) d
+    ScopedTimer t(h, st, "k_trmm_f64");
+    hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbi, (int)h->nbj)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
+                       h->dLt, h->dDt, h->dX, (int)h->nbi, (int)h->nbj, h->nkb, ld);
+  }
+  {  // p_i <- D_{Z,r,x_i}
+    ScopedTimer t(h, st, "k_perturb_round");
+    hipLaunchKernelGGL(k_perturb_round, dim3(grid_for(m * ld, 256, 256 * 32)), dim3(256), 0, st, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
+  }
+  {  // mp_perturbation.rs:318 -- v = u - A p
+    ScopedTimer t(h, st, "k_zq_matmul(syndrome)");
+    launch_zq(h, st, ZQ_SYNDROME, h->dA, m, 0, h->n, m, h->dP, false, ld, B, d_u, h->dV, ld, 0);
+  }
+  {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
+    ScopedTimer t(h, st, "k_gadget");
+    const size_t k = h->k;
+    const size_t lds = gadget_lds_bytes(k);
+    GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
+    hipLaunchKernelGGL(k_gadget, dim3((unsigned)((B + 255) / 256), (unsigned)h->n), dim3(256), lds, st, seed, first_index, (uint32_t)h->n,
+                       (uint32_t)k, h->q, h->prm.gp.base, B, ld, h->dV, tb, h->dZlo, h->dZhi, h->dFail);
+  }
+  {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
+    ScopedTimer t(h, st, "k_recombine");
+    hipLaunchKernelGGL(k_recombine_top, dim3((unsigned)((B + 63) / 64), (unsigned)((h->mb + 63) / 64)), dim3(256), 0, st, h->dR, h->ldr, h->mb,
+                       h->w4, (const uint32_t*)h->dZlo, (const uint32_t*)h->dZhi, ld, h->dP, B, d_e, m);
+    hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((B + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, st, h->mb, h->w, h->dZlo,
+                       h->dZhi, ld, h->dP, B, d_e, m);
+  }
+  HIP_TRY(hipGetLastError());
+  h->last_stream = st;
+  return PSF_OK;
+}
+
+psf_status psfp_last_status(psfp_handle* h) {
+  if (!h) return PSF_ERR_PARAM;
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  int f = 0;
+  HIP_TRY(hipMemcpy(&f, h->dFail, sizeof(int), hipMemcpyDeviceToHost));
+  return f ? PSF_ERR_SAMPLER : PSF_OK;
+}
+
+psf_status psfp_samp_p_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, void* stream) {
+  if (!h || (B && (!d_u || !d_e))) return PSF_ERR_PARAM;
+  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  psf_status rc = ensure_batch(h, B);
+  if (rc != PSF_OK) return rc;
+  return run_samp_p(h, seed, first_index, B, d_u, d_e, (hipStream_t)stream);
+}
+
+psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
+  if (!h || (B && (!u || !e))) return PSF_ERR_PARAM;
+  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  psf_status rc = ensure_batch(h, B);
+  if (rc != PSF_OK) return rc;
+  HIP_TRY(hipMemcpy(h->dU, u, B * h->n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  rc = run_samp_p(h, seed, first_index, B, h->dU, h->dE, nullptr);
+  if (rc != PSF_OK) return rc;
+  rc = psfp_last_status(h);
+  HIP_TRY(hipMemcpy(e, h->dE, B * h->m * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return rc;
+}
+
+psf_status psfp_samp_p_stages(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, double* d, double* x,
+                              int64_t* p, uint64_t* v, int64_t* z, int64_t* e) {
+  if (!h || !u || B == 0) return PSF_ERR_PARAM;
+  std::vector<int64_t> etmp(B * h->m);
+  psf_status rc = psfp_samp_p(h, seed, first_index, B, u, etmp.data());
+  if (rc != PSF_OK && rc != PSF_ERR_SAMPLER) return rc;
+  const size_t m = h->m, ld = h->ld;
+  if (e) std::memcpy(e, etmp.data(), etmp.size() * sizeof(int64_t));
+  void* tmp = nullptr;
+  HIP_TRY(hipMalloc(&tmp, B * m * sizeof(double)));
+  if (d) {
+    hipLaunchKernelGGL(k_export_normals, dim3(grid_for(B * m)), dim3(256), 0, 0, h->dDt, m, B, h->nkb, (double*)tmp);
+    HIP_TRY(hipMemcpy(d, tmp, B * m * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (x) {
+    hipLaunchKernelGGL((k_export_T<double>), dim3(grid_for(B * m)), dim3(256), 0, 0, h->dX, m, B, ld, (double*)tmp);
+    HIP_TRY(hipMemcpy(x, tmp, B * m * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  std::vector<int64_t> ptmp;
+  if (p || z) {
+    ptmp.resize(B * m);
+    hipLaunchKernelGGL(k_export_P, dim3(grid_for(B * m)), dim3(256), 0, 0, h->dP, m, B, ld, (int64_t*)tmp);
+    HIP_TRY(hipMemcpy(ptmp.data(), tmp, B * m * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (p) std::memcpy(p, ptmp.data(), ptmp.size() * sizeof(int64_t));
+  }
+  if (v) {
+    hipLaunchKernelGGL((k_export_T<uint64_t>), dim3(grid_for(B * h->n)), dim3(256), 0, 0, h->dV, h->n, B, ld, (uint64_t*)tmp);
+    HIP_TRY(hipMemcpy(v, tmp, B * h->n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  if (z)  // e_bottom = p_bottom + z  (mp_perturbation.rs:335 with the identity block of [R; I])
+    for (size_t b = 0; b < B; ++b)
+      for (size_t c = 0; c < h->w; ++c) z[b * h->w + c] = etmp[b * m + h->mb + c] - ptmp[b * m + h->mb + c];
+  hipFree(tmp);
+  return rc;
+}
+
+psf_status psfp_samp_d_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, int64_t* d_e, void* stream) {
+  if (!h || (B && !d_e)) return PSF_ERR_PARAM;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(h->dFail, 0, sizeof(int), st);
+  hipLaunchKernelGGL(k_samp_d, dim3(grid_for(B * h->m, 256, 256 * 32)), dim3(256), 0, st, seed, first_index, h->m, B, h->szSR, d_e, h->dFail);
+  HIP_TRY(hipGetLastError());
+  h->last_stream = st;
+  return PSF_OK;
+}
+
+psf_status psfp_samp_d(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, int64_t* e) {
+  if (!h || (B && !e)) return PSF_ERR_PARAM;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  int64_t* de = nullptr;
+  HIP_TRY(hipMalloc(&de, B * h->m * sizeof(int64_t)));
+  psf_status rc = psfp_samp_d_dev(h, seed, first_index, B, de, nullptr);
+  if (rc == PSF_OK) rc = psfp_last_status(h);
+  HIP_TRY(hipMemcpy(e, de, B * h->m * sizeof(int64_t), hipMemcpyDeviceToHost));
+  hipFree(de);
+  return rc;
+}
+
+static double domain_bound(const psfp_handle* h) {   // s^2 * m * r^2, mp_perturbation.rs:401
+  return ((h->prm.s * h->prm.s) * (double)h->m) * (h->prm.r * h->prm.r);
+}
+
+psf_status psfp_check_domain(psfp_handle* h, size_t B, const int64_t* e, size_t len, uint8_t* ok) {
+  if (!h || (B && (!e || !ok))) return PSF_ERR_PARAM;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  if (len == 0) { std::memset(ok, 0, B); return PSF_OK; }
+  int64_t* de = nullptr; uint8_t* dok = nullptr;
+  HIP_TRY(hipMalloc(&de, B * len * sizeof(int64_t)));
+  HIP_TRY(hipMalloc(&dok, B));
+  HIP_TRY(hipMemcpy(de, e, B * len * sizeof(int64_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_check_domain, dim3((unsigned)B), dim3(256), 0, 0, de, len, h->m, domain_bound(h), dok);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(ok, dok, B, hipMemcpyDeviceToHost));
+  hipFree(de); hipFree(dok);
+  return PSF_OK;
+}
+
+psf_status psfp_f_a_dev(psfp_handle* h, size_t B, const int64_t* d_e, uint64_t* d_u, uint8_t* d_ok, void* stream) {
+  if (!h || (B && (!d_e || !d_u || !d_ok))) return PSF_ERR_PARAM;
+  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  psf_status rc = ensure_batch(h, B);
+  if (rc != PSF_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t m = h->m, ld = h->ld;
+  hipLaunchKernelGGL(k_check_domain, dim3((unsigned)B), dim3(256), 0, st, d_e, m, m, domain_bound(h), d_ok);   // :367
+  hipLaunchKernelGGL(k_narrow_transpose, dim3((unsigned)(ld / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, st, d_e, m, B, ld, h->dP);
+  launch_zq(h, st, ZQ_FA, h->dA, m, 0, h->n, m, h->dP, false, ld, B, nullptr, d_u, h->n, 0);                    // :368
+  HIP_TRY(hipGetLastError());
+  h->last_stream = st;
+  return PSF_OK;
+}
+
+psf_status psfp_f_a(psfp_handle* h, size_t B, const int64_t* e, uint64_t* u) {
+  if (!h || (B && (!e || !u))) return PSF_ERR_PARAM;
+  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  psf_status rc = ensure_batch(h, B);
+  if (rc != PSF_OK) return rc;
+  HIP_TRY(hipMemcpy(h->dE, e, B * h->m * sizeof(int64_t), hipMemcpyHostToDevice));
+  rc = psfp_f_a_dev(h, B, h->dE, h->dU, h->dOk, nullptr);
+  if (rc != PSF_OK) return rc;
+  std::vector<uint8_t> ok(B);
+  HIP_TRY(hipMemcpy(u, h->dU, B * h->n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ok.data(), h->dOk, B, hipMemcpyDeviceToHost));
+  for (uint8_t o : ok) if (!o) return PSF_ERR_DOMAIN;
+  return PSF_OK;
+}
+
+psf_status psfp_uniform_targets_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, uint64_t* d_u, void* stream) {
+  if (!h || (B && !d_u)) return PSF_ERR_PARAM;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  hipLaunchKernelGGL(k_uniform_targets, dim3(grid_for(B * h->n)), dim3(256), 0, (hipStream_t)stream, seed, first_index, h->n, B, h->q, d_u);
+  HIP_TRY(hipGetLastError());
+  h->last_stream = (hipStream_t)stream;
+  return PSF_OK;
+}
+
+psf_status psfp_enable_timing(psfp_handle* h, int on) {
+  if (!h) return PSF_ERR_PARAM;
+  h->timing = on != 0;
+  if (!on) clear_slots(h);
+  return PSF_OK;
+}
+
+psf_status psfp_get_timing(psfp_handle* h, char* names, size_t names_len, double* ms, size_t* count) {
+  if (!h || !count) return PSF_ERR_PARAM;
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  std::string joined;
+  size_t nout = 0;
+  for (auto& s : h->slots) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, s.e0, s.e1) != hipSuccess) continue;
+    if (ms && nout < *count) ms[nout] = t;
+    if (!joined.empty()) joined += ';';
+    joined += s.name;
+    ++nout;
+  }
+  if (names && names_len) { std::strncpy(names, joined.c_str(), names_len - 1); names[names_len - 1] = 0; }
+  *count = nout;
+  return PSF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+"""Gadget helpers of sample::g_trapdoor (gadget_classical.rs, short_basis_classical.rs, rotation_matrix.rs)
+through the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import GadgetParams, check, lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def gen_gadget_vec(k, base):
+    """gadget_classical.rs:128-136"""
+    out = np.zeros(k, dtype=np.int64)
+    check(lib().psf_gen_gadget_vec(C.c_uint64(k), C.c_uint64(base), _p(out, C.c_int64)), "gen_gadget_vec")
+    return out
+
+
+def gen_gadget_mat(n, k, base):
+    """gadget_classical.rs:91-107"""
+    out = np.zeros((n, n * k), dtype=np.int64)
+    check(lib().psf_gen_gadget_mat(C.c_uint64(n), C.c_uint64(k), C.c_uint64(base), _p(out, C.c_int64)), "gen_gadget_mat")
+    return out
+
+
+def find_solution_gadget_mat(value, q, k, base, device=0):
+    """gadget_classical.rs:219-229 (HIP digit-decomposition kernel)."""
+    value = np.ascontiguousarray(value, dtype=np.uint64)
+    if value.ndim == 1:
+        value = value.reshape(-1, 1)
+    rows, cols = value.shape
+    out = np.zeros((k * rows, cols), dtype=np.int64)
+    check(lib().psf_find_solution_gadget_mat(C.c_int(device), _p(value, C.c_uint64), C.c_size_t(rows), C.c_size_t(cols),
+                                             C.c_uint64(q), C.c_uint64(k), C.c_uint64(base), _p(out, C.c_int64)),
+          "find_solution_gadget_mat")
+    return out
+
+
+def find_solution_gadget_vec(value, q, k, base, device=0):
+    """gadget_classical.rs:169-182"""
+    return find_solution_gadget_mat(np.array([[value]], dtype=np.uint64), q, k, base, device).reshape(k)
+
+
+def short_basis_gadget(gp):
+    """gadget_classical.rs:248-287"""
+    c = gp.c if hasattr(gp, "c") else gp
+    w = c.n * c.k
+    out = np.zeros((w, w), dtype=np.int64)
+    check(lib().psf_short_basis_gadget(C.byref(c), _p(out, C.c_int64)), "short_basis_gadget")
+    return out
+
+
+def gen_short_basis_for_trapdoor(gp, A, R, tag=None):
+    """short_basis_classical.rs:54-63"""
+    c = gp.c if hasattr(gp, "c") else gp
+    A = np.ascontiguousarray(A, dtype=np.uint64)
+    R = np.ascontiguousarray(R, dtype=np.int8)
+    m = c.m_bar + c.n * c.k
+    out = np.zeros((m, m), dtype=np.int64)
+    tagp = None
+    if tag is not None:
+        tag = np.ascontiguousarray(tag, dtype=np.uint64)
+        tagp = _p(tag, C.c_uint64)
+    check(lib().psf_gen_short_basis_for_trapdoor(C.byref(c), tagp, _p(A, C.c_uint64), _p(R, C.c_int8), _p(out, C.c_int64)),
+          "gen_short_basis_for_trapdoor")
+    return out
+
+
+def rot_minus_matrix(mat):
+    """rotation_matrix.rs:85-96"""
+    mat = np.ascontiguousarray(mat, dtype=np.int64)
+    rows, cols = mat.shape
+    out = np.zeros((rows, rows * cols), dtype=np.int64)
+    check(lib().psf_rot_minus_matrix(_p(mat, C.c_int64), C.c_size_t(rows), C.c_size_t(cols), _p(out, C.c_int64)), "rot_minus_matrix")
+    return out
+
+
+def rot_minus(vec):
+    """rotation_matrix.rs:41-63"""
+    vec = np.ascontiguousarray(vec, dtype=np.int64).reshape(-1, 1)
+    return rot_minus_matrix(vec)

@@ -1,0 +1,166 @@
+"""PSF trait mirror (src/primitive/psf.rs:39-81) over the C ABI.
+
+Batches: every method accepts one vector (reference semantics: one call = one preimage) or a 2-D array
+with one row per call.  `seed` / `first_index` select the Philox streams (the reference has no seed).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import GadgetParams, PsfpParams, PsfError, check, lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class GadgetParameters:
+    """gadget_parameters.rs:44-52.  distribution = PlusMinusOneZero (trapdoor_distribution.rs:52-53)."""
+
+    def __init__(self, n, k, m_bar, base, q):
+        self.c = GadgetParams(n, k, m_bar, base, q)
+
+    @classmethod
+    def init_default(cls, n, q):
+        """GadgetParameters::init_default (gadget_parameters.rs:113-133)."""
+        c = GadgetParams()
+        check(lib().psf_gadget_params_default(C.c_uint64(n), C.c_uint64(q), C.byref(c)), "init_default")
+        return cls(c.n, c.k, c.m_bar, c.base, c.q)
+
+    n = property(lambda self: self.c.n)
+    k = property(lambda self: self.c.k)
+    m_bar = property(lambda self: self.c.m_bar)
+    base = property(lambda self: self.c.base)
+    q = property(lambda self: self.c.q)
+
+    def __repr__(self):
+        return f"GadgetParameters(n={self.n}, k={self.k}, m_bar={self.m_bar}, base={self.base}, q={self.q})"
+
+
+class PSFPerturbation:
+    """mp_perturbation.rs:57-62 / impl PSF :193-403 on one MI355X."""
+
+    def __init__(self, gp, r, s, device=0):
+        self.gp, self.r, self.s, self.device = gp, float(r), float(s), device
+        prm = PsfpParams(gp.c, self.r, self.s, device, 0)
+        h = C.c_void_p()
+        check(lib().psfp_create(C.byref(prm), C.byref(h)), "PSFPerturbation")
+        self._h = h
+        self.n, self.k, self.m_bar = gp.n, gp.k, gp.m_bar
+        self.w = gp.n * gp.k
+        self.m = self.m_bar + self.w
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().psfp_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- PSF trait -------------------------------------------------------------------------------
+    def trap_gen(self, seed=0):
+        """mp_perturbation.rs:221-244.  Returns (A, (R, sqrt_sigma_2_packed, (S_k, S_k_gso)))."""
+        check(lib().psfp_trap_gen(self._h, C.c_uint64(seed)), "trap_gen")
+        return self.export_key()
+
+    def samp_d(self, seed=0, B=None, first_index=0):
+        """mp_perturbation.rs:264-267"""
+        nb = 1 if B is None else B
+        e = np.zeros((nb, self.m), dtype=np.int64)
+        check(lib().psfp_samp_d(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(nb), _p(e, C.c_int64)), "samp_d")
+        return e[0] if B is None else e
+
+    def samp_p(self, u, seed=0, first_index=0):
+        """mp_perturbation.rs:304-336 with the key installed in the handle (trap_gen / load_key)."""
+        u = np.ascontiguousarray(u, dtype=np.uint64)
+        single = u.ndim == 1
+        u2 = u.reshape(-1, self.n)
+        B = u2.shape[0]
+        e = np.zeros((B, self.m), dtype=np.int64)
+        check(lib().psfp_samp_p(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64),
+                                _p(e, C.c_int64)), "samp_p")
+        return e[0] if single else e
+
+    def f_a(self, sigma):
+        """mp_perturbation.rs:366-369; raises PsfError(ERR_DOMAIN) where the reference's assert! panics."""
+        sigma = np.ascontiguousarray(sigma, dtype=np.int64)
+        single = sigma.ndim == 1
+        if sigma.ndim > 2 or sigma.shape[-1] != self.m:
+            raise PsfError(_ffi.ERR_DOMAIN, "f_a")   # not a column vector of length m (:398-399)
+        e2 = sigma.reshape(-1, self.m)
+        B = e2.shape[0]
+        u = np.zeros((B, self.n), dtype=np.uint64)
+        check(lib().psfp_f_a(self._h, C.c_size_t(B), _p(e2, C.c_int64), _p(u, C.c_uint64)), "f_a")
+        return u[0] if single else u
+
+    def check_domain(self, sigma):
+        """mp_perturbation.rs:396-402"""
+        sigma = np.ascontiguousarray(sigma, dtype=np.int64)
+        single = sigma.ndim == 1
+        e2 = sigma.reshape(1, -1) if single else sigma
+        B, ln = e2.shape
+        ok = np.zeros(B, dtype=np.uint8)
+        check(lib().psfp_check_domain(self._h, C.c_size_t(B), _p(e2, C.c_int64), C.c_size_t(ln), _p(ok, C.c_uint8)), "check_domain")
+        return bool(ok[0]) if single else ok.astype(bool)
+
+    # ---- key material ------------------------------------------------------------------------------
+    def export_key(self):
+        A = np.zeros((self.n, self.m), dtype=np.uint64)
+        R = np.zeros((self.m_bar, self.w), dtype=np.int8)
+        Lp = np.zeros(self.m * (self.m + 1) // 2, dtype=np.float64)
+        check(lib().psfp_export_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8), _p(Lp, C.c_double)), "export_key")
+        Sk = np.zeros((self.k, self.k), dtype=np.int64)
+        gso = np.zeros((self.k, self.k), dtype=np.float64)
+        check(lib().psfp_export_gadget_basis(self._h, _p(Sk, C.c_int64), _p(gso, C.c_double)), "export_gadget_basis")
+        return A, (R, Lp, (Sk, gso))
+
+    def load_key(self, A, R, sqrt_sigma2_packed):
+        A = np.ascontiguousarray(A, dtype=np.uint64)
+        R = np.ascontiguousarray(R, dtype=np.int8)
+        Lp = np.ascontiguousarray(sqrt_sigma2_packed, dtype=np.float64)
+        assert A.shape == (self.n, self.m) and R.shape == (self.m_bar, self.w) and Lp.size == self.m * (self.m + 1) // 2
+        check(lib().psfp_load_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8), _p(Lp, C.c_double)), "load_key")
+
+    def compute_sqrt_sigma_2(self, s_cov):
+        """mp_perturbation.rs:111-139 for Sigma = s_cov^2 I."""
+        check(lib().psfp_compute_sqrt_sigma_2(self._h, C.c_double(s_cov)), "compute_sqrt_sigma_2")
+
+    # ---- stage-level access (parity tests) ---------------------------------------------------------------
+    def samp_p_stages(self, u, seed=0, first_index=0):
+        u2 = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, self.n)
+        B = u2.shape[0]
+        d, x = np.zeros((B, self.m)), np.zeros((B, self.m))
+        p, e = np.zeros((B, self.m), dtype=np.int64), np.zeros((B, self.m), dtype=np.int64)
+        v, z = np.zeros((B, self.n), dtype=np.uint64), np.zeros((B, self.w), dtype=np.int64)
+        check(lib().psfp_samp_p_stages(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64),
+                                       _p(d, C.c_double), _p(x, C.c_double), _p(p, C.c_int64), _p(v, C.c_uint64),
+                                       _p(z, C.c_int64), _p(e, C.c_int64)), "samp_p_stages")
+        return dict(d=d, x=x, p=p, v=v, z=z, e=e)
+
+    # ---- device-resident API (torch tensors / raw pointers) ----------------------------------------------
+    def samp_p_dev(self, d_u_ptr, d_e_ptr, B, seed=0, first_index=0, stream=None):
+        check(lib().psfp_samp_p_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), C.c_void_p(d_u_ptr),
+                                    C.c_void_p(d_e_ptr), C.c_void_p(stream or 0)), "samp_p_dev")
+
+    def f_a_dev(self, d_e_ptr, d_u_ptr, d_ok_ptr, B, stream=None):
+        check(lib().psfp_f_a_dev(self._h, C.c_size_t(B), C.c_void_p(d_e_ptr), C.c_void_p(d_u_ptr), C.c_void_p(d_ok_ptr),
+                                 C.c_void_p(stream or 0)), "f_a_dev")
+
+    def uniform_targets_dev(self, d_u_ptr, B, seed=0, first_index=0, stream=None):
+        check(lib().psfp_uniform_targets_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B),
+                                             C.c_void_p(d_u_ptr), C.c_void_p(stream or 0)), "uniform_targets_dev")
+
+    def last_status(self):
+        return lib().psfp_last_status(self._h)
+
+    def enable_timing(self, on=True):
+        check(lib().psfp_enable_timing(self._h, C.c_int(1 if on else 0)), "enable_timing")
+
+    def get_timing(self):
+        names = C.create_string_buffer(4096)
+        ms = (C.c_double * 64)()
+        cnt = C.c_size_t(64)
+        check(lib().psfp_get_timing(self._h, names, C.c_size_t(4096), ms, C.byref(cnt)), "get_timing")
+        nm = names.value.decode().split(";") if names.value else []
+        return list(zip(nm, list(ms)[:cnt.value]))
