@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- preimages/sec of PSF::samp_p on MI355X (BASELINE.json metric), one process per GPU.
+
+A "step" is one samp_p pass over one batch of synthetic uniform syndromes (benches/psf.rs:35,60,87: uniform
+target, trapdoor generated outside the timed region).  Default workload = BASELINE.json configs[2], the one
+the metric is quoted on: PSFPerturbation (MP12) over Z_q, n=512, q=2^30, batch=4096 per GPU, r=9, s=512.
+Inputs (u) and the key are resident in HBM before the timed region; the preimages stay in HBM.  With N>1
+ranks the batch is sharded by global preimage index (weak scaling: 4096 per GPU) and the result is gathered
+to rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
+(k_trmm_f64: x = sqrt(Sigma_2) d on the f64 MFMA pipe) and `cpu_baseline` (the CPU oracle timed on this
+host's cores, rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (scheme, n, q, r, s, batch)
+    "c3": ("PSFPerturbation", 512, 2**30, 9.0, 512.0, 4096),
+    "c3prime": ("PSFPerturbation", 512, 1073741789, 9.0, 512.0, 4096),
+    "bench64": ("PSFPerturbation", 64, 128, 6.0, 100.0, 4096),     # benches/psf.rs:78-93
+    "c1": ("PSFPerturbation", 8, 64, 3.0, 25.0, 1),                 # README.md:62-66
+}
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix; measured 77.3 by tools/probe_mfma_f64.hip (profiles/r01_probe_mfma_f64.log)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="preimages per GPU per step (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="preimages timed on the CPU (default: 32 per thread)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the result (N>1)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import tools_amd as T
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("[bench] no GPU: tools_amd has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    scheme, n, q, r, s, batch = CONFIGS[args.config]
+    B = args.batch or batch
+    gp = T.GadgetParameters.init_default(n, q)
+    psf = T.PSFPerturbation(gp, r, s, device=local_rank)
+    key_seed = 3
+    t0 = time.time()
+    from tools_amd._ffi import lib, check
+    check(lib().psfp_trap_gen(psf._h, C.c_uint64(key_seed)), "trap_gen")   # every rank: same seed -> same key
+    torch.cuda.synchronize()
+    t_trapgen = time.time() - t0
+    m = psf.m
+
+    stream = torch.cuda.current_stream().cuda_stream
+    from tools_amd.shard import shard_range, gather_rows
+    first_index, _ = shard_range(rank, world, B)               # global preimage index of this rank's row 0
+    u = torch.empty((B, n), dtype=torch.int64, device=dev)
+    e = torch.empty((B, m), dtype=torch.int64, device=dev)
+    psf.uniform_targets_dev(u.data_ptr(), B, seed=7, first_index=first_index, stream=stream)
+    gather_list = None
+    do_gather = world > 1 and not args.no_gather
+    if do_gather and rank == 0:
+        gather_list = [torch.empty((B, m), dtype=torch.int64, device=dev) for _ in range(world)]
+
+    def step(i):
+        psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=1000 + i, first_index=first_index, stream=stream)
+        if do_gather:
+            gather_rows(e, dst=0, out=gather_list)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if psf.last_status() != 0:
+        raise RuntimeError("device-side sampler failure during warmup")
+    psf.enable_timing(True)
+    trmm_ms, kern_ms = [], {}
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # per-kernel HIP-event times of the last step (events were recorded on the launch stream, no host sync in the loop)
+    for nm, ms in psf.get_timing():
+        kern_ms[nm] = ms
+    psf.enable_timing(False)
+    status = psf.last_status()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # correctness gate on the last step's output: A e == u and check_domain for every row
+    u2 = torch.empty_like(u)
+    ok = torch.empty((B,), dtype=torch.uint8, device=dev)
+    psf.f_a_dev(e.data_ptr(), u2.data_ptr(), ok.data_ptr(), B, stream=stream)
+    torch.cuda.synchronize()
+    valid = bool((u2 == u).all().item()) and bool(ok.all().item()) and status == 0
+
+    total = B * world * args.steps
+    value = total / elapsed
+    out = None
+    if rank == 0:
+        trmm = kern_ms.get("k_trmm_f64")
+        flops_per_launch = float(m) * (m + 1) * B            # m(m+1)/2 fma per preimage (m^2 flop)
+        roof = None
+        if trmm:
+            ach = flops_per_launch / (trmm * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "k_trmm_f64", "achieved": round(ach, 3), "peak": PEAK_F64_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": load_traffic(args.config, B),
+                    "launch_ms": round(trmm, 3), "flops_per_launch": flops_per_launch}
+        out = {
+            "metric": "preimages/sec (whole node) + HBM-BW% for samp_p, n=512 q~2^30 batch=4096",
+            "value": round(value, 2), "unit": "preimages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64+int64", "data": "synthetic",
+            "config": {"workload": f"{scheme} samp_p n={n} q={q} k={gp.k} m={m} r={r} s={s} batch={B}/GPU ({args.config})",
+                       "global_batch": B * world, "parallelism": f"batch-sharded x{world}" + (" + RCCL gather" if do_gather else "")},
+            "valid": valid, "kernels_ms": {k: round(v, 3) for k, v in kern_ms.items()}, "trap_gen_s": round(t_trapgen, 2),
+            "roofline": roof,
+        }
+        if args.config != "c3":
+            out["metric"] = f"preimages/sec for samp_p ({args.config})"
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(psf, n, q, r, s, u, e, first_index, 1000 + args.warmup + args.steps - 1, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not valid:
+        sys.exit(4)
+
+
+def load_traffic(config, B):
+    """HBM bytes per k_trmm_f64 launch from the rocprofv3 PMC passes (profiles/*_pmc.json), or None."""
+    path = os.path.join(ROOT, "profiles", "trmm_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+        ent = rec.get(f"{config}:B{B}")
+        return ent["hbm_bytes_per_launch"] if ent else None
+    except Exception:
+        return None
+
+
+def cpu_baseline(psf, n, q, r, s, u, e, first_index, seed, sample):
+    """The CPU oracle (oracle/psf_oracle.c, a port: the Rust/FLINT reference cannot be built here) timed on this host
+    on a bounded sample of the same workload, same key, same seed; its output must equal the GPU's rows."""
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    threads = O.num_threads()
+    S = sample or min(u.shape[0], 32 * threads)
+    A, (R, Lp, _) = psf.export_key()
+    orc = O.PSFPerturbation(O.gadget_params_default(n, q), r, s)
+    orc.load_key(A, R, Lp)
+    del A, R, Lp
+    uh = u[:S].cpu().numpy().astype(np.uint64)
+    t0 = time.perf_counter()
+    e_cpu = orc.samp_p(seed, uh, first_index=first_index, nthreads=threads)
+    dt = time.perf_counter() - t0
+    same = bool((e_cpu == e[:S].cpu().numpy()).all())
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return {"value": round(S / dt, 3), "unit": "preimages/s", "cores": threads, "kind": "port",
+            "sample": f"{S} of the batch's preimages (same key, seed and targets), {dt:.1f} s wall, OpenMP over groups of 16",
+            "cpu": model, "matches_gpu_bitwise": same}
+
+
+if __name__ == "__main__":
+    main()

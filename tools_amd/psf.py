@@ -47,13 +47,14 @@ class PSFPerturbation:
         h = C.c_void_p()
         check(lib().psfp_create(C.byref(prm), C.byref(h)), "PSFPerturbation")
         self._h = h
+        self._destroy = lib().psfp_destroy        # kept so that close() works during interpreter shutdown
         self.n, self.k, self.m_bar = gp.n, gp.k, gp.m_bar
         self.w = gp.n * gp.k
         self.m = self.m_bar + self.w
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().psfp_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     __del__ = close
