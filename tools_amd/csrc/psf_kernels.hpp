@@ -124,19 +124,23 @@ __host__ inline unsigned tr_grid_size(int nbi, int nbj) {
   return rounds * 8u * 64u;
 }
 
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
 __global__ __launch_bounds__(256, 2) void k_trmm_f64(const double* __restrict__ Lt, const double* __restrict__ Dt,
                                                      double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];  // A[2][2048] | B[2][2048]
+  // LDS: 2 stages x (A chunk 2048 doubles | B chunk 2048 doubles); filled by LDS-DMA (global_load_lds_dwordx4), no
+  // staging registers: the accumulators (128 VGPRs) leave no room to hold a chunk in flight (hipcc serialised
+  // register-staged prefetch loads behind vmcnt(0) waits).
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   int bi, bj;
   tr_map_block(blockIdx.x, nbi, nbj, &bi, &bj);
   if (bi < 0 || bi >= nbi || bj >= nbj) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int nk = TR_KB_PER_BLOCK * (bi + 1);
-  const double2* gA = reinterpret_cast<const double2*>(Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK);
-  const double2* gB = reinterpret_cast<const double2*>(Dt + (size_t)bj * nkb * TR_CHUNK);
-  double2* sA2 = reinterpret_cast<double2*>(smem);
-  double2* sB2 = reinterpret_cast<double2*>(smem + 2 * TR_CHUNK);
+  const double* gA = Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK + lane * 2;
+  const double* gB = Dt + (size_t)bj * nkb * TR_CHUNK + lane * 2;
 
   d4 acc[4][4];
 #pragma unroll
@@ -144,23 +148,28 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64(const double* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
-  double2 ra[4], rb[4];
+  // each wave moves pieces 4*wave .. 4*wave+3 (1 KiB each) of both chunks: LDS address = wave-uniform base + lane*16
+  auto stage_load = [&](int kb, int buf) {
+    const double* ga = gA + (size_t)kb * TR_CHUNK;
+    const double* gb = gB + (size_t)kb * TR_CHUNK;
+    double* la = smem + buf * (2 * TR_CHUNK);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { ra[i] = gA[tid + 256 * i]; rb[i] = gB[tid + 256 * i]; }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { sA2[tid + 256 * i] = ra[i]; sB2[tid + 256 * i] = rb[i]; }
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wave * 4 + i;
+      __builtin_amdgcn_global_load_lds(ga + piece * 128, (lds_void_ptr)(la + piece * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gb + piece * 128, (lds_void_ptr)(la + TR_CHUNK + piece * 128), 16, 0, 0);
+    }
+  };
+
+  stage_load(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kb = 0; kb < nk; ++kb) {
     const int cur = kb & 1;
-    const bool more = kb + 1 < nk;
-    if (more) {
-      const size_t off = (size_t)(kb + 1) * (TR_CHUNK / 2);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { ra[i] = gA[off + tid + 256 * i]; rb[i] = gB[off + tid + 256 * i]; }
-    }
-    const double* sA = smem + cur * TR_CHUNK;
-    const double* sB = smem + 2 * TR_CHUNK + cur * TR_CHUNK;
+    if (kb + 1 < nk) stage_load(kb + 1, cur ^ 1);
+    const double* sA = smem + cur * (2 * TR_CHUNK);
+    const double* sB = sA + TR_CHUNK;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       double a[4], b[4];
@@ -174,12 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64(const double* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) {
-      double2* dA = sA2 + (cur ^ 1) * (TR_CHUNK / 2);
-      double2* dB = sB2 + (cur ^ 1) * (TR_CHUNK / 2);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { dA[tid + 256 * i] = ra[i]; dB[tid + 256 * i] = rb[i]; }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   // C/D map of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
