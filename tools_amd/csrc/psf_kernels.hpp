@@ -216,6 +216,77 @@ __global__ void k_perturb_round(uint64_t seed, uint64_t first_index, size_t m, s
   if (f) atomicOr(fail, 1);
 }
 
+// Wave-compacted form of the same rounding: a wave owns SEG consecutive samples of the flattened valid index space
+// g = coord * B + b.  Every iteration all 64 lanes evaluate one attempt of THEIR current sample; the lanes that
+// accepted store the result and take the next unassigned sample ids (ballot + mbcnt prefix), whose centres are
+// fetched from a register window of the next 192 centres by cross-lane reads.  Which lane evaluates which
+// (sample, attempt) changes nothing: the value is the first accepted attempt of the sample's own Philox stream.
+constexpr int PR_SEG = 4096;
+
+__device__ inline int lane_rank(uint64_t mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+__global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
+                                                            const double* __restrict__ X, SampleZParams sp, int32_t* __restrict__ P,
+                                                            int* __restrict__ fail) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave_id = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t total = m * B;
+  const size_t seg0 = wave_id * PR_SEG;
+  if (seg0 >= total) return;
+  const size_t seg1 = seg0 + PR_SEG < total ? seg0 + PR_SEG : total;
+  auto centre_of = [&](size_t g) -> double { return g < seg1 ? X[(g / B) * ld + (g % B)] : 0.0; };
+  // window of prefetched centres: w0 = [base, base+64), w1 = [base+64, base+128), w2 = [base+128, base+192)
+  size_t base = seg0 + 64;
+  double w0 = centre_of(base + lane), w1 = centre_of(base + 64 + lane), w2 = centre_of(base + 128 + lane);
+  size_t my = seg0 + lane, next_free = seg0 + 64;
+  bool active = my < seg1;
+  double c = centre_of(my);
+  uint32_t t = 0;
+  int f = 0;
+  const double NEG_PI = -3.14159265358979323846;
+  while (__ballot(active)) {
+    bool accept = false;
+    long long x = 0;
+    if (active) {
+      const size_t coord = my / B, b = my % B;
+      const uint64_t index = first_index + b;
+      const long long lo = (long long)ceil(c) - sp.c6;
+      const uint64_t N = (uint64_t)((long long)floor(c) + sp.f6 - lo + 1);
+      const U4 w = philox(seed, (uint32_t)coord, (uint32_t)index, t, tag_word(TAG_PERTURB, index));
+      x = lo + (long long)mulhi64(((uint64_t)w.y << 32) | w.x, N);
+      const double u = (double)((((uint64_t)w.w << 32) | w.z) >> 11) * 0x1.0p-53;
+      const double a = ((double)x - c) * sp.inv_s;
+      accept = u < det_exp(NEG_PI * (a * a));
+      if (!accept && ++t >= kMaxAttempts) { accept = true; f = 1; x = (long long)floor(c + 0.5); }
+      if (accept) {
+        if (x > 0x1ffffff || x < -0x1ffffff) f = 1;
+        P[coord * ld + b] = (int32_t)x;
+      }
+    }
+    const uint64_t mask = __ballot(accept);
+    if (mask) {
+      const size_t nid = next_free + (size_t)lane_rank(mask);
+      const int off = (int)(nid - base);                     // in [0, 128) for accepting lanes
+      const double v0 = __shfl(w0, off & 63), v1 = __shfl(w1, off & 63);
+      if (accept) {
+        my = nid;
+        active = nid < seg1;
+        c = off < 64 ? v0 : v1;
+        t = 0;
+      }
+      next_free += (size_t)__popcll(mask);
+      if (next_free >= base + 64) {                           // slide the window
+        base += 64;
+        w0 = w1; w1 = w2;
+        w2 = centre_of(base + 128 + lane);
+      }
+    }
+  }
+  if (f) atomicOr(fail, 1);
+}
+
 // ---- integer products over Z_q ---------------------------------------------------------------------------
 // S[i][c] = sum_t a[i][t] * p[t][c]  (a in [0,q) as u64, p small signed), reduced mod q, then an epilogue:
 //   ZQ_SYNDROME : out[i][c] = (u[c][i] - S) mod q      out n x ld   (mp_perturbation.rs:318)

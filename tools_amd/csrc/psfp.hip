@@ -412,7 +412,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   }
   {  // p_i <- D_{Z,r,x_i}
     ScopedTimer t(h, st, "k_perturb_round");
-    hipLaunchKernelGGL(k_perturb_round, dim3(grid_for(m * ld, 256, 256 * 32)), dim3(256), 0, st, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
+    const size_t waves = (m * B + PR_SEG - 1) / PR_SEG;
+    hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
   }
   {  // mp_perturbation.rs:318 -- v = u - A p
     ScopedTimer t(h, st, "k_zq_matmul(syndrome)");
