@@ -441,7 +441,8 @@ __global__ void k_digits(const uint64_t* __restrict__ value, size_t rows, size_t
 // One thread = one (row j of v, preimage b): x = digits(v_j); c = -x; for i = k-1..0: c' = <c,b~_i>/||b~_i||^2,
 // z_i <- D_{Z,s_i,c'}, c -= z_i b_i; result -c  (mp_perturbation.rs:173-191 + GPV08 SampleD).
 // c lives in LDS ([t][thread], conflict free), the k x k tables are broadcast reads from LDS.
-// z is written as two int8 planes (z = lo + 256 hi), four coordinates per 32-bit word, for the dot4 product R z.
+// z is written as two int8 planes (z = lo + 256 hi) in the MFMA operand layout [c/16][b][16] (sixteen consecutive
+// coordinates of one preimage = one 16-byte fragment element); fail[1] is set when any hi byte is non-zero.
 __global__ __launch_bounds__(256) void k_gadget(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q,
                                                 uint64_t base, size_t B, size_t ld, const uint64_t* __restrict__ V,
                                                 GadgetTables tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256) void k_gadget(uint64_t seed, uint64_t first_in
   const size_t b = (size_t)blockIdx.x * 256 + tid;
   const uint32_t j = blockIdx.y;
   if (b >= B) return;
-  int f = 0;
+  int f = 0, anyhi = 0;
   uint64_t v = V[(size_t)j * ld + b] % q;
   for (uint32_t t = 0; t < k; ++t) {
     uint64_t d;
@@ -486,77 +487,106 @@ __global__ __launch_bounds__(256) void k_gadget(uint64_t seed, uint64_t first_in
     const int32_t lo = (int32_t)(int8_t)(z & 0xff);
     const int32_t hi = (z - lo) >> 8;
     const size_t c = (size_t)j * k + t;
-    const size_t addr = ((c >> 2) * ld + b) * 4 + (c & 3);
+    const size_t addr = ((c >> 4) * ld + b) * 16 + (c & 15);
     Zlo[addr] = (int8_t)lo;
     Zhi[addr] = (int8_t)hi;
+    if (hi) anyhi = 1;
   }
   if (f) atomicOr(fail, 1);
+  if (anyhi) atomicOr(fail + 1, 1);
 }
 
 // ---- e = p + [R; I] z, written preimage-major (B x m int64) ---------------------------------------------
-// top part: 64 (rows i of R) x 64 (preimages) per workgroup, four coordinates per v_dot4_i32_i8
-__global__ __launch_bounds__(256) void k_recombine_top(const int8_t* __restrict__ R, size_t ldr /*bytes per row, mult of 4*/,
-                                                       size_t mbar, size_t w4, const uint32_t* __restrict__ Zlo,
-                                                       const uint32_t* __restrict__ Zhi, size_t ld, const int32_t* __restrict__ P,
-                                                       size_t B, int64_t* __restrict__ E, size_t m) {
-  __shared__ uint32_t sR[64][17];
-  __shared__ uint32_t sZl[16][64];
-  __shared__ uint32_t sZh[16][64];
-  __shared__ int64_t sE[64][65];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const size_t i0 = (size_t)blockIdx.y * 64, b0 = (size_t)blockIdx.x * 64;
-  int32_t alo[4][4], ahi[4][4];
+// top part on the int8 matrix cores: C[b][i] = sum_c Z[c][b] R[i][c] with v_mfma_i32_16x16x64_i8, Z as the A operand
+// (rows = preimages) and R as the B operand (columns = coordinates i), so that 16 lanes hold 16 consecutive i of one
+// preimage and the int64 stores of e[b][i] are 128-byte runs.  Both operands use the same (lane group, byte) -> c map,
+// which is all the dot product needs.  Workgroup tile 128 (b) x 128 (i), wave tile 64 x 64, K step 64, LDS-DMA staging
+// (2 stages x (R tile 8 KiB | Zlo 8 KiB | Zhi 8 KiB)).  The hi plane is skipped when the gadget kernel saw no |z| > 127.
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr int RC_STAGE = 3 * 8192;
+
+__global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int nks,
+                                                           const int8_t* __restrict__ Zlo, const int8_t* __restrict__ Zhi, size_t ld,
+                                                           const int* __restrict__ flags, const int32_t* __restrict__ P, size_t B,
+                                                           int64_t* __restrict__ E, size_t m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const size_t b0 = (size_t)blockIdx.x * 128, i0 = (size_t)blockIdx.y * 128;
+  const bool use_hi = flags[1] != 0;
+
+  v4i alo[4][4], ahi[4][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { alo[r][c] = 0; ahi[r][c] = 0; }
-  const uint32_t* R32 = reinterpret_cast<const uint32_t*>(R);
-  const size_t ldr4 = ldr / 4;
-  for (size_t q0 = 0; q0 < w4; q0 += 16) {
-    for (int e = tid; e < 64 * 16; e += 256) {
-      const int r = e >> 4, qq = e & 15;
-      uint32_t v = 0;
-      if (i0 + r < mbar && q0 + qq < w4) v = R32[(i0 + r) * ldr4 + q0 + qq];
-      sR[r][qq] = v;
+    for (int y = 0; y < 4; ++y) { alo[x][y] = v4i{0, 0, 0, 0}; ahi[x][y] = v4i{0, 0, 0, 0}; }
+
+  // per-lane global sources of the two 1 KiB pieces each wave moves per array and stage
+  const int8_t* srcR[2]; const int8_t* srcL[2]; const int8_t* srcH[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = (wave * 2 + j) * 64 + lane;                 // 16-byte piece index, 0..511
+    srcR[j] = R + (i0 + (size_t)(p >> 2)) * ldr + (size_t)(p & 3) * 16;
+    const size_t zoff = ((size_t)(p >> 7) * ld + b0 + (size_t)(p & 127)) * 16;
+    srcL[j] = Zlo + zoff;
+    srcH[j] = Zhi + zoff;
+  }
+  auto stage_load = [&](int ks, int buf) {
+    unsigned char* base = rc_smem + buf * RC_STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int piece0 = (wave * 2 + j) * 64;
+      __builtin_amdgcn_global_load_lds(srcR[j] + (size_t)ks * 64, (lds_void_ptr)(base + piece0 * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(srcL[j] + (size_t)ks * 4 * ld * 16, (lds_void_ptr)(base + 8192 + piece0 * 16), 16, 0, 0);
+      if (use_hi)
+        __builtin_amdgcn_global_load_lds(srcH[j] + (size_t)ks * 4 * ld * 16, (lds_void_ptr)(base + 16384 + piece0 * 16), 16, 0, 0);
     }
-    for (int e = tid; e < 16 * 64; e += 256) {
-      const int qq = e >> 6, c = e & 63;
-      uint32_t vl = 0, vh = 0;
-      if (q0 + qq < w4) { vl = Zlo[(q0 + qq) * ld + b0 + c]; vh = Zhi[(q0 + qq) * ld + b0 + c]; }
-      sZl[qq][c] = vl; sZh[qq][c] = vh;
+  };
+  stage_load(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int r16 = lane & 15, g = lane >> 4;
+  for (int ks = 0; ks < nks; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nks) stage_load(ks + 1, cur ^ 1);
+    const unsigned char* sR = rc_smem + cur * RC_STAGE;
+    const unsigned char* sL = sR + 8192;
+    const unsigned char* sH = sR + 16384;
+    v4i fr[4], fl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fr[t] = *reinterpret_cast<const v4i*>(sR + ((wc * 64 + t * 16 + r16) * 64 + g * 16));
+      fl[t] = *reinterpret_cast<const v4i*>(sL + ((g * 128 + wr * 64 + t * 16 + r16) * 16));
     }
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) alo[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fl[bt], fr[it], alo[bt][it], 0, 0, 0);
+    if (use_hi) {
+      v4i fh[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fh[t] = *reinterpret_cast<const v4i*>(sH + ((g * 128 + wr * 64 + t * 16 + r16) * 16));
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) ahi[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fh[bt], fr[it], ahi[bt][it], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  // C/D map: column (here i) = lane & 15, row (here b) = 4 * (lane >> 4) + reg
 #pragma unroll
-    for (int qq = 0; qq < 16; ++qq) {
-      uint32_t zl[4], zh[4];
+  for (int bt = 0; bt < 4; ++bt)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { zl[c] = sZl[qq][tx * 4 + c]; zh[c] = sZh[qq][tx * 4 + c]; }
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const uint32_t rv = sR[ty * 4 + r][qq];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          alo[r][c] = __builtin_amdgcn_sdot4((int)rv, (int)zl[c], alo[r][c], false);
-          ahi[r][c] = __builtin_amdgcn_sdot4((int)rv, (int)zh[c], ahi[r][c], false);
-        }
+        const size_t bb = b0 + wr * 64 + bt * 16 + 4 * g + r;
+        const size_t ii = i0 + wc * 64 + it * 16 + r16;
+        if (bb < B && ii < mbar)
+          E[bb * m + ii] = (int64_t)P[ii * ld + bb] + (int64_t)alo[bt][it][r] + 256 * (int64_t)ahi[bt][it][r];
       }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const size_t i = i0 + ty * 4 + r, b = b0 + tx * 4 + c;
-      int64_t v = 0;
-      if (i < mbar) v = (int64_t)P[i * ld + b] + (int64_t)alo[r][c] + 256 * (int64_t)ahi[r][c];
-      sE[tx * 4 + c][ty * 4 + r] = v;
-    }
-  __syncthreads();
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int bb = e >> 6, ii = e & 63;
-    if (b0 + bb < B && i0 + ii < mbar) E[(b0 + bb) * m + i0 + ii] = sE[bb][ii];
-  }
 }
 
 // bottom part: e[b][mbar + c] = p[mbar + c][b] + z[c][b]
@@ -571,7 +601,7 @@ __global__ __launch_bounds__(256) void k_recombine_bottom(size_t mbar, size_t w,
     const size_t c = c0 + cc, b = b0 + bb;
     int64_t v = 0;
     if (c < w) {
-      const size_t addr = ((c >> 2) * ld + b) * 4 + (c & 3);
+      const size_t addr = ((c >> 4) * ld + b) * 16 + (c & 15);
       v = (int64_t)P[(mbar + c) * ld + b] + (int64_t)Zlo[addr] + 256 * (int64_t)Zhi[addr];
     }
     sE[bb][cc] = v;

@@ -79,7 +79,7 @@ struct psfp_handle {
   // batch work buffers
   size_t Bcap = 0, ld = 0, nbj = 0;
   double* dDt = nullptr; double* dX = nullptr; int32_t* dP = nullptr; uint64_t* dV = nullptr;
-  int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; size_t w4 = 0;
+  int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; size_t mb_pad = 0;
   uint64_t* dU = nullptr; int64_t* dE = nullptr; uint8_t* dOk = nullptr;
   int* dFail = nullptr;
   hipStream_t last_stream = nullptr;
@@ -110,10 +110,10 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
   HIP_TRY(hipMalloc(&h->dX, h->M_pad * ld * sizeof(double)));
   HIP_TRY(hipMalloc(&h->dP, h->M_pad * ld * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&h->dV, h->n * ld * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc(&h->dZlo, h->w4 * ld * 4));
-  HIP_TRY(hipMalloc(&h->dZhi, h->w4 * ld * 4));
-  HIP_TRY(hipMemset(h->dZlo, 0, h->w4 * ld * 4));
-  HIP_TRY(hipMemset(h->dZhi, 0, h->w4 * ld * 4));
+  HIP_TRY(hipMalloc(&h->dZlo, h->ldr * ld));      // [ldr/16][ld][16]
+  HIP_TRY(hipMalloc(&h->dZhi, h->ldr * ld));
+  HIP_TRY(hipMemset(h->dZlo, 0, h->ldr * ld));
+  HIP_TRY(hipMemset(h->dZhi, 0, h->ldr * ld));
   HIP_TRY(hipMemset(h->dP, 0, h->M_pad * ld * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&h->dU, B * h->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dE, B * h->m * sizeof(int64_t)));
@@ -241,15 +241,16 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   h->M_pad = round_up(h->m, TR_BM);
   h->nbi = h->M_pad / TR_BM;
   h->nkb = h->M_pad / TR_BK;
-  h->ldr = round_up(h->w, 4);
-  h->w4 = h->ldr / 4;
+  h->ldr = round_up(h->w, 64);          // K of the int8 MFMA product, zero padded
+  h->mb_pad = round_up(h->mb, 128);
   h->szR = make_sample_z_params(prm->r);
   h->szSR = make_sample_z_params(prm->s * prm->r);                    // mp_perturbation.rs:266
   HIP_TRY(hipMalloc(&h->dA, h->n * h->m * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc(&h->dR, h->mb * h->ldr));
+  HIP_TRY(hipMalloc(&h->dR, h->mb_pad * h->ldr));
+  HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   HIP_TRY(hipMalloc(&h->dLt, tr_total_chunks(h->nbi) * TR_CHUNK * sizeof(double)));
-  HIP_TRY(hipMalloc(&h->dFail, sizeof(int)));
-  HIP_TRY(hipMemset(h->dFail, 0, sizeof(int)));
+  HIP_TRY(hipMalloc(&h->dFail, 2 * sizeof(int)));      // [0] sampler failure, [1] some |z| > 127
+  HIP_TRY(hipMemset(h->dFail, 0, 2 * sizeof(int)));
   // gadget part of the trapdoor: (S, S~) of mp_perturbation.rs:233-234, block form
   h->hSk = short_basis_gadget_block(gp);
   std::vector<double> norm2;
@@ -357,7 +358,7 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
   if (!h || !A || !R || !Lp) return PSF_ERR_PARAM;
   HIP_TRY(hipSetDevice(h->prm.device));
   HIP_TRY(hipMemcpy(h->dA, A, h->n * h->m * sizeof(uint64_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(h->dR, 0, h->mb * h->ldr));
+  HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
   double* dp = nullptr;
   const size_t np = h->m * (h->m + 1) / 2;
@@ -400,7 +401,7 @@ psf_status psfp_export_gadget_basis(const psfp_handle* h, int64_t* Sk, double* g
 static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, hipStream_t st) {
   const size_t ld = h->ld, m = h->m;
   if (h->timing) clear_slots(h);
-  hipMemsetAsync(h->dFail, 0, sizeof(int), st);
+  hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
   {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
     ScopedTimer t(h, st, "k_normals");
     hipLaunchKernelGGL(k_normals, dim3(grid_for(h->nbj * h->nkb * TR_CHUNK, 256, 256 * 32)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, h->nbj, h->dDt, h->dFail);
@@ -429,8 +430,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   }
   {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
     ScopedTimer t(h, st, "k_recombine");
-    hipLaunchKernelGGL(k_recombine_top, dim3((unsigned)((B + 63) / 64), (unsigned)((h->mb + 63) / 64)), dim3(256), 0, st, h->dR, h->ldr, h->mb,
-                       h->w4, (const uint32_t*)h->dZlo, (const uint32_t*)h->dZhi, ld, h->dP, B, d_e, m);
+    hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((B + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), 2 * RC_STAGE, st, h->dR,
+                       h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo, h->dZhi, ld, h->dFail, h->dP, B, d_e, m);
     hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((B + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, st, h->mb, h->w, h->dZlo,
                        h->dZhi, ld, h->dP, B, d_e, m);
   }
