@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -83,6 +84,9 @@ struct psfp_handle {
   uint64_t* dU = nullptr; int64_t* dE = nullptr; uint8_t* dOk = nullptr;
   int* dFail = nullptr;
   hipStream_t last_stream = nullptr;
+  hipStream_t aux = nullptr;                 // second stream for the per-slice sampling stages
+  std::vector<hipEvent_t> slice_events;
+  size_t slices = 0;                         // 0 = default (1); PSF_SLICES overrides
   // timing
   bool timing = false;
   std::vector<TimingSlot> slots;
@@ -270,6 +274,8 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   HIP_TRY(hipMemcpy(h->dNorm2, norm2.data(), h->k * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dSz, sz.data(), h->k * sizeof(SampleZParams), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dGvec, gvec.data(), h->k * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  if (const char* env = std::getenv("PSF_SLICES")) h->slices = (size_t)std::atoi(env);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   *out = h;
@@ -281,6 +287,8 @@ void psfp_destroy(psfp_handle* h) {
   hipSetDevice(h->prm.device);
   free_batch(h);
   clear_slots(h);
+  for (auto ev : h->slice_events) hipEventDestroy(ev);
+  if (h->aux) hipStreamDestroy(h->aux);
   hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dFail);
   hipFree(h->dSk); hipFree(h->dGso); hipFree(h->dNorm2); hipFree(h->dSz); hipFree(h->dGvec);
   delete h;
@@ -398,42 +406,73 @@ psf_status psfp_export_gadget_basis(const psfp_handle* h, int64_t* Sk, double* g
 }
 
 // ---- the hot path -------------------------------------------------------------------------------------------
+// One samp_p pass.  The batch is cut into `slices` groups of 128-preimage column blocks: the FP64-MFMA product of
+// slice s+1 runs on the caller's stream while the VALU / int8-MFMA stages of slice s (rounding, syndrome, gadget,
+// recombination) run on the handle's auxiliary stream, so the sampling work hides under the matrix pipe.
 static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, hipStream_t st) {
   const size_t ld = h->ld, m = h->m;
   if (h->timing) clear_slots(h);
   hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
-  {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
-    ScopedTimer t(h, st, "k_normals");
-    hipLaunchKernelGGL(k_normals, dim3(grid_for(h->nbj * h->nkb * TR_CHUNK, 256, 256 * 32)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, h->nbj, h->dDt, h->dFail);
+  const size_t nbj_total = h->nbj;
+  size_t S = h->slices ? h->slices : 1;   // measured at C3: >1 slices lose (small per-slice grids), see profiles/r01_notes.md
+  if (S > nbj_total) S = nbj_total;
+  const size_t per = (nbj_total + S - 1) / S;
+  while (h->slice_events.size() < S + 1) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    h->slice_events.push_back(ev);
   }
-  {  // x = sqrt(Sigma_2) d
-    ScopedTimer t(h, st, "k_trmm_f64");
-    hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbi, (int)h->nbj)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
-                       h->dLt, h->dDt, h->dX, (int)h->nbi, (int)h->nbj, h->nkb, ld);
+  for (size_t sl = 0; sl < S; ++sl) {
+    const size_t bj0 = sl * per;
+    if (bj0 >= nbj_total) break;
+    const size_t nbj = (bj0 + per <= nbj_total) ? per : nbj_total - bj0;
+    const size_t boff = bj0 * TR_BN;
+    const size_t Bs = (boff + nbj * TR_BN <= B) ? nbj * TR_BN : B - boff;
+    const uint64_t fi = first_index + boff;
+    double* Dt = h->dDt + bj0 * h->nkb * TR_CHUNK;
+    {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
+      ScopedTimer t(h, st, "k_normals");
+      hipLaunchKernelGGL(k_normals, dim3(grid_for(nbj * h->nkb * TR_CHUNK, 256, 256 * 32)), dim3(256), 0, st, seed, fi, m, Bs, h->nkb, nbj, Dt, h->dFail);
+    }
+    {  // x = sqrt(Sigma_2) d
+      ScopedTimer t(h, st, "k_trmm_f64");
+      hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbi, (int)nbj)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
+                         h->dLt, Dt, h->dX + boff, (int)h->nbi, (int)nbj, h->nkb, ld);
+    }
+    hipStream_t s2 = st;
+    if (S > 1) {
+      s2 = h->aux;
+      HIP_TRY(hipEventRecord(h->slice_events[sl], st));
+      HIP_TRY(hipStreamWaitEvent(s2, h->slice_events[sl], 0));
+    }
+    {  // p_i <- D_{Z,r,x_i}
+      ScopedTimer t(h, s2, "k_perturb_round");
+      const size_t waves = (m * Bs + PR_SEG - 1) / PR_SEG;
+      hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, seed, fi, m, Bs, ld, h->dX + boff, h->szR,
+                         h->dP + boff, h->dFail);
+    }
+    {  // mp_perturbation.rs:318 -- v = u - A p
+      ScopedTimer t(h, s2, "k_zq_matmul(syndrome)");
+      launch_zq(h, s2, ZQ_SYNDROME, h->dA, m, 0, h->n, m, h->dP + boff, false, ld, Bs, d_u + boff * h->n, h->dV + boff, ld, 0);
+    }
+    {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
+      ScopedTimer t(h, s2, "k_gadget");
+      const size_t k = h->k;
+      GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
+      hipLaunchKernelGGL(k_gadget, dim3((unsigned)((Bs + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(k), s2, seed, fi, (uint32_t)h->n,
+                         (uint32_t)k, h->q, h->prm.gp.base, Bs, ld, h->dV + boff, tb, h->dZlo + boff * 16, h->dZhi + boff * 16, h->dFail);
+    }
+    {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
+      ScopedTimer t(h, s2, "k_recombine");
+      hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bs + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), 2 * RC_STAGE, s2, h->dR,
+                         h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo + boff * 16, h->dZhi + boff * 16, ld, h->dFail, h->dP + boff, Bs, d_e + boff * m, m);
+      hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bs + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, s2, h->mb, h->w,
+                         h->dZlo + boff * 16, h->dZhi + boff * 16, ld, h->dP + boff, Bs, d_e + boff * m, m);
+    }
   }
-  {  // p_i <- D_{Z,r,x_i}
-    ScopedTimer t(h, st, "k_perturb_round");
-    const size_t waves = (m * B + PR_SEG - 1) / PR_SEG;
-    hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
-  }
-  {  // mp_perturbation.rs:318 -- v = u - A p
-    ScopedTimer t(h, st, "k_zq_matmul(syndrome)");
-    launch_zq(h, st, ZQ_SYNDROME, h->dA, m, 0, h->n, m, h->dP, false, ld, B, d_u, h->dV, ld, 0);
-  }
-  {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
-    ScopedTimer t(h, st, "k_gadget");
-    const size_t k = h->k;
-    const size_t lds = gadget_lds_bytes(k);
-    GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
-    hipLaunchKernelGGL(k_gadget, dim3((unsigned)((B + 255) / 256), (unsigned)h->n), dim3(256), lds, st, seed, first_index, (uint32_t)h->n,
-                       (uint32_t)k, h->q, h->prm.gp.base, B, ld, h->dV, tb, h->dZlo, h->dZhi, h->dFail);
-  }
-  {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
-    ScopedTimer t(h, st, "k_recombine");
-    hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((B + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), 2 * RC_STAGE, st, h->dR,
-                       h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo, h->dZhi, ld, h->dFail, h->dP, B, d_e, m);
-    hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((B + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, st, h->mb, h->w, h->dZlo,
-                       h->dZhi, ld, h->dP, B, d_e, m);
+  if (S > 1) {
+    HIP_TRY(hipEventRecord(h->slice_events[S], h->aux));
+    HIP_TRY(hipStreamWaitEvent(st, h->slice_events[S], 0));
   }
   HIP_TRY(hipGetLastError());
   h->last_stream = st;
@@ -608,14 +647,23 @@ psf_status psfp_enable_timing(psfp_handle* h, int on) {
 psf_status psfp_get_timing(psfp_handle* h, char* names, size_t names_len, double* ms, size_t* count) {
   if (!h || !count) return PSF_ERR_PARAM;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
+  HIP_TRY(hipStreamSynchronize(h->aux));
   std::string joined;
-  size_t nout = 0;
-  for (auto& s : h->slots) {
+  std::vector<std::string> names_v;
+  std::vector<double> sums;
+  for (auto& s : h->slots) {          // launches of the same kernel (one per slice) are summed
     float t = 0.f;
     if (hipEventElapsedTime(&t, s.e0, s.e1) != hipSuccess) continue;
-    if (ms && nout < *count) ms[nout] = t;
+    size_t j = 0;
+    while (j < names_v.size() && names_v[j] != s.name) ++j;
+    if (j == names_v.size()) { names_v.push_back(s.name); sums.push_back(0.0); }
+    sums[j] += t;
+  }
+  size_t nout = 0;
+  for (size_t j = 0; j < names_v.size(); ++j) {
+    if (ms && nout < *count) ms[nout] = sums[j];
     if (!joined.empty()) joined += ';';
-    joined += s.name;
+    joined += names_v[j];
     ++nout;
   }
   if (names && names_len) { std::strncpy(names, joined.c_str(), names_len - 1); names[names_len - 1] = 0; }
