@@ -15,7 +15,7 @@ CONFIGS = [  # (n, q, r, s) -- reference test / doc sizes: mp_perturbation.rs:43
     (10, 128, np.log2(10), 40.0),
     (15, 157, np.log2(15), 40.0),   # prime modulus: S_k carries the digit column of q
     (8, 128, 3.0, 30.0),
-    (8, 64, 40.0, 25.0),            # wide gadget Gaussian: |z| > 127 occurs, exercising the hi byte plane of z
+    (8, 64, 100.0, 25.0),           # wide gadget Gaussian: |z| > 127 occurs, exercising the hi byte plane of z
 ]
 
 
@@ -66,12 +66,12 @@ def test_samp_p_stage_parity(T, oracle, n, q, r, s):
         assert (st["v"][b] == tr["v"]).all(), "syndrome v = u - A p differs"
         assert (st["z"][b] == tr["z"]).all(), "gadget preimage differs"
         assert (st["e"][b] == tr["e"]).all(), "preimage differs"
-    if r >= 40:
+    if r >= 100:
         assert np.abs(st["z"]).max() > 127, "this configuration is meant to exercise the hi plane"
 
 
 @pytest.mark.parametrize("n,q,r,s,B", [(8, 64, 3.0, 25.0, 1), (8, 64, 3.0, 25.0, 300), (15, 157, np.log2(15), 40.0, 130),
-                                       (8, 64, 40.0, 25.0, 140)])
+                                       (8, 64, 100.0, 25.0, 140)])
 def test_samp_p_batch_parity_and_invariants(T, oracle, n, q, r, s, B):
     psf, orc, (A, R, Lp, Sk, gso) = make_pair(T, oracle, n, q, r, s)
     orc.load_key(A, R, Lp)

@@ -14,6 +14,8 @@
 namespace psf {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 // ---- geometry of the triangular product -------------------------------------------------------------
 constexpr int TR_BM = 128;      // rows of sqrt(Sigma_2) per workgroup
@@ -123,8 +125,6 @@ __host__ inline unsigned tr_grid_size(int nbi, int nbj) {
   const unsigned rounds = (groups + 7) / 8;
   return rounds * 8u * 64u;
 }
-
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 __global__ __launch_bounds__(256, 2) void k_trmm_f64(const double* __restrict__ Lt, const double* __restrict__ Dt,
                                                      double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx) {
@@ -414,6 +414,180 @@ __global__ __launch_bounds__(256) void k_zq_matmul(int mode, const uint64_t* __r
     }
 }
 
+// ---- v = u - A p and u = A e on the int8 matrix cores ----------------------------------------------------
+// a in [0,q) is written in balanced base-256 digits d_0..d_{NA-1} (d_i in [-128,127]), p (|p| < 2^23) in three.
+// sum_k a_k p_k = sum_c 256^c T_c,  T_c = sum_{i+j=c} sum_k d_i[k] e_j[k]: each (i,j) pair is one int8 MFMA product
+// accumulated exactly in int32 (<= 16384 terms of |d e| <= 2^14 per pair, <= 3 pairs per class before the fold), and
+// every 16384 coordinates the classes are folded into a running residue mod q.  Integer arithmetic: exact.
+__global__ void k_split_A(const uint64_t* __restrict__ A, size_t lda, size_t n, size_t K, size_t n_pad, size_t K_pad, int NA,
+                          int8_t* __restrict__ A8) {
+  const size_t total = n_pad * K_pad;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / K_pad, kk = g % K_pad;
+    int64_t a = (i < n && kk < K) ? (int64_t)A[i * lda + kk] : 0;
+    for (int d = 0; d < NA; ++d) {
+      int64_t dig = (d + 1 < NA) ? (int64_t)(int8_t)(a & 0xff) : a;
+      A8[(size_t)d * total + g] = (int8_t)dig;
+      a = (a - dig) >> 8;
+    }
+  }
+}
+
+// P (K x ld int32) -> three digit planes [K_pad/16][ld][16]; thread = (16-coordinate group, preimage)
+__global__ void k_split_P(const int32_t* __restrict__ P, size_t K, size_t ld, size_t ngroups, int8_t* __restrict__ P8, int* __restrict__ fail) {
+  const size_t total = ngroups * ld;
+  const size_t plane = total * 16;
+  int f = 0;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t kg = g / ld, b = g % ld;
+    v4i o0, o1, o2;
+    int32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const size_t kk = kg * 16 + j;
+      const int32_t p = kk < K ? P[kk * ld + b] : 0;
+      const int32_t e0 = (int32_t)(int8_t)(p & 0xff);
+      const int32_t p1 = (p - e0) >> 8;
+      const int32_t e1 = (int32_t)(int8_t)(p1 & 0xff);
+      const int32_t e2 = (p1 - e1) >> 8;
+      if (e2 > 127 || e2 < -128) f = 1;
+      w0[j >> 2] |= (e0 & 0xff) << (8 * (j & 3));
+      w1[j >> 2] |= (e1 & 0xff) << (8 * (j & 3));
+      w2[j >> 2] |= (e2 & 0xff) << (8 * (j & 3));
+    }
+    o0 = v4i{w0[0], w0[1], w0[2], w0[3]}; o1 = v4i{w1[0], w1[1], w1[2], w1[3]}; o2 = v4i{w2[0], w2[1], w2[2], w2[3]};
+    *reinterpret_cast<v4i*>(P8 + g * 16) = o0;
+    *reinterpret_cast<v4i*>(P8 + plane + g * 16) = o1;
+    *reinterpret_cast<v4i*>(P8 + 2 * plane + g * 16) = o2;
+  }
+  if (f) atomicOr(fail, 1);
+}
+
+struct ZqConsts { uint64_t q, two64; uint64_t pw[12]; };   // pw[c] = 256^c mod q
+
+// (T mod q) * pw mod q for |T| < 2^31
+__device__ inline uint64_t zq_term(int32_t T, uint64_t pw, uint64_t q, uint64_t two64, bool wide) {
+  if (!wide) {
+    int64_t t = (int64_t)T % (int64_t)q;
+    if (t < 0) t += (int64_t)q;
+    return ((uint64_t)t * pw) % q;
+  }
+  const uint64_t a = (uint64_t)(T < 0 ? -(int64_t)T : (int64_t)T);
+  Acc128 t{a * pw, (int64_t)__umul64hi(a, pw)};
+  const uint64_t r = acc128_mod(t, q, two64);
+  return (T < 0 && r) ? q - r : r;
+}
+
+template <int NA>
+__global__ __launch_bounds__(256) void k_zq_mfma(int mode, const int8_t* __restrict__ A8, size_t n, size_t n_pad, size_t K_pad,
+                                                 const int8_t* __restrict__ P8, size_t ld, size_t ncols, ZqConsts zc, int wide,
+                                                 const uint64_t* __restrict__ U, uint64_t* __restrict__ out, size_t ldo) {
+  constexpr int STAGE = (NA + 3) * 4096;
+  constexpr int NC = NA + 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char zq_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const size_t b0 = (size_t)blockIdx.x * 64, i0 = (size_t)blockIdx.y * 64;
+  const size_t planeA = n_pad * K_pad, planeP = (K_pad / 16) * ld * 16;
+  const int nks = (int)(K_pad / 64);
+
+  v4i acc[NC][2][2];
+  uint64_t tot[2][2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c][x][y] = v4i{0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[x][y][r] = 0;
+    }
+  const int pA = wave * 64 + lane;   // 16-byte piece of a 4 KiB tile
+  const int8_t* srcA = A8 + (i0 + (size_t)(pA >> 2)) * K_pad + (size_t)(pA & 3) * 16;
+  const int8_t* srcP = P8 + ((size_t)(pA >> 6) * ld + b0 + (size_t)(pA & 63)) * 16;
+  auto stage_load = [&](int ks, int buf) {
+    unsigned char* base = zq_smem + buf * STAGE + wave * 1024;
+#pragma unroll
+    for (int d = 0; d < NA; ++d)
+      __builtin_amdgcn_global_load_lds(srcA + (size_t)d * planeA + (size_t)ks * 64, (lds_void_ptr)(base + d * 4096), 16, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+      __builtin_amdgcn_global_load_lds(srcP + (size_t)e * planeP + (size_t)ks * 4 * ld * 16, (lds_void_ptr)(base + (NA + e) * 4096), 16, 0, 0);
+  };
+  auto fold = [&]() {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          uint64_t t = tot[x][y][r];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            t += zq_term(acc[c][x][y][r], zc.pw[c], zc.q, zc.two64, wide != 0);
+            if (t >= zc.q) t -= zc.q;
+          }
+          tot[x][y][r] = t;
+        }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[c][x][y] = v4i{0, 0, 0, 0};
+  };
+
+  stage_load(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int r16 = lane & 15, g = lane >> 4;
+  for (int ks = 0; ks < nks; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nks) stage_load(ks + 1, cur ^ 1);
+    const unsigned char* sb = zq_smem + cur * STAGE;
+    v4i fa[NA][2], fp[3][2];
+#pragma unroll
+    for (int d = 0; d < NA; ++d)
+#pragma unroll
+      for (int x = 0; x < 2; ++x) fa[d][x] = *reinterpret_cast<const v4i*>(sb + d * 4096 + ((wr * 32 + x * 16 + r16) * 64 + g * 16));
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) fp[e][y] = *reinterpret_cast<const v4i*>(sb + (NA + e) * 4096 + ((g * 64 + wc * 32 + y * 16 + r16) * 16));
+#pragma unroll
+    for (int d = 0; d < NA; ++d)
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+            acc[d + e][x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[d][x], fp[e][y], acc[d + e][x][y], 0, 0, 0);
+    if ((ks & 255) == 255) fold();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  fold();
+  // C/D map: column (preimage) = lane & 15, row (i) = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t i = i0 + wr * 32 + x * 16 + 4 * g + r, cc = b0 + wc * 32 + y * 16 + r16;
+        if (i >= n || cc >= ncols) continue;
+        const uint64_t s = tot[x][y][r];
+        if (mode == ZQ_SYNDROME) {
+          const uint64_t u = U[cc * n + i] % zc.q;
+          out[i * ldo + cc] = u >= s ? u - s : u + zc.q - s;
+        } else {
+          out[cc * ldo + i] = s;
+        }
+      }
+}
+
 // ---- gadget: digit decomposition + randomized nearest plane on S_k ------------------------------------
 struct GadgetTables {   // device pointers, all of length k or k*k
   const int32_t* Sk;        // k x k basis block (row-major; columns are basis vectors)
@@ -502,7 +676,6 @@ __global__ __launch_bounds__(256) void k_gadget(uint64_t seed, uint64_t first_in
 // preimage and the int64 stores of e[b][i] are 128-byte runs.  Both operands use the same (lane group, byte) -> c map,
 // which is all the dot product needs.  Workgroup tile 128 (b) x 128 (i), wave tile 64 x 64, K step 64, LDS-DMA staging
 // (2 stages x (R tile 8 KiB | Zlo 8 KiB | Zhi 8 KiB)).  The hi plane is skipped when the gadget kernel saw no |z| > 127.
-typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int RC_STAGE = 3 * 8192;
 
 __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int nks,

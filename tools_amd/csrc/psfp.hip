@@ -75,12 +75,15 @@ struct psfp_handle {
   // gadget tables
   int32_t* dSk = nullptr; double* dGso = nullptr; double* dNorm2 = nullptr; SampleZParams* dSz = nullptr;
   uint64_t* dGvec = nullptr;
+  int8_t* dA8 = nullptr; int NA = 0; size_t n_pad = 0, K_pad = 0;   // balanced base-256 digit planes of A
+  ZqConsts zc;
   std::vector<int64_t> hSk; std::vector<double> hGso;
   SampleZParams szR, szSR;
   // batch work buffers
   size_t Bcap = 0, ld = 0, nbj = 0;
   double* dDt = nullptr; double* dX = nullptr; int32_t* dP = nullptr; uint64_t* dV = nullptr;
   int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; size_t mb_pad = 0;
+  int8_t* dP8 = nullptr;                      // three digit planes of P, [K_pad/16][ld][16] each
   uint64_t* dU = nullptr; int64_t* dE = nullptr; uint8_t* dOk = nullptr;
   int* dFail = nullptr;
   hipStream_t last_stream = nullptr;
@@ -95,9 +98,9 @@ struct psfp_handle {
 static size_t gadget_lds_bytes(size_t k) { return k * k * 8 + k * 8 + k * sizeof(SampleZParams) + k * k * 4 + k * 256 * 4; }
 
 static void free_batch(psfp_handle* h) {
-  hipFree(h->dDt); hipFree(h->dX); hipFree(h->dP); hipFree(h->dV); hipFree(h->dZlo); hipFree(h->dZhi);
+  hipFree(h->dDt); hipFree(h->dX); hipFree(h->dP); hipFree(h->dV); hipFree(h->dZlo); hipFree(h->dZhi); hipFree(h->dP8);
   hipFree(h->dU); hipFree(h->dE); hipFree(h->dOk);
-  h->dDt = h->dX = nullptr; h->dP = nullptr; h->dV = nullptr; h->dZlo = h->dZhi = nullptr; h->dU = nullptr; h->dE = nullptr; h->dOk = nullptr;
+  h->dDt = h->dX = nullptr; h->dP = nullptr; h->dV = nullptr; h->dZlo = h->dZhi = nullptr; h->dP8 = nullptr; h->dU = nullptr; h->dE = nullptr; h->dOk = nullptr;
   h->Bcap = 0;
 }
 
@@ -119,6 +122,7 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
   HIP_TRY(hipMemset(h->dZlo, 0, h->ldr * ld));
   HIP_TRY(hipMemset(h->dZhi, 0, h->ldr * ld));
   HIP_TRY(hipMemset(h->dP, 0, h->M_pad * ld * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&h->dP8, 3 * h->K_pad * ld));
   HIP_TRY(hipMalloc(&h->dU, B * h->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dE, B * h->m * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&h->dOk, B));
@@ -247,6 +251,17 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   h->nkb = h->M_pad / TR_BK;
   h->ldr = round_up(h->w, 64);          // K of the int8 MFMA product, zero padded
   h->mb_pad = round_up(h->mb, 128);
+  h->n_pad = round_up(h->n, 64);
+  h->K_pad = round_up(h->m, 64);
+  {  // number of balanced base-256 digits so that the top digit of any a < q fits an int8
+    uint64_t bound = gp.q - 1;
+    h->NA = 1;
+    while (bound > 127) { bound = (bound + 128) >> 8; ++h->NA; }
+    h->zc.q = gp.q; h->zc.two64 = h->two64;
+    uint64_t pw = 1 % gp.q;
+    for (int c = 0; c < 12; ++c) { h->zc.pw[c] = pw; pw = mulmod_u64(pw, 256 % gp.q, gp.q); }
+  }
+  HIP_TRY(hipMalloc(&h->dA8, (size_t)h->NA * h->n_pad * h->K_pad));
   h->szR = make_sample_z_params(prm->r);
   h->szSR = make_sample_z_params(prm->s * prm->r);                    // mp_perturbation.rs:266
   HIP_TRY(hipMalloc(&h->dA, h->n * h->m * sizeof(uint64_t)));
@@ -290,6 +305,7 @@ void psfp_destroy(psfp_handle* h) {
   for (auto ev : h->slice_events) hipEventDestroy(ev);
   if (h->aux) hipStreamDestroy(h->aux);
   hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dFail);
+  hipFree(h->dA8);
   hipFree(h->dSk); hipFree(h->dGso); hipFree(h->dNorm2); hipFree(h->dSz); hipFree(h->dGvec);
   delete h;
 }
@@ -339,6 +355,24 @@ static void launch_zq(psfp_handle* h, hipStream_t st, int mode, const uint64_t* 
 #undef ZQ_LAUNCH
 }
 
+static void split_A(psfp_handle* h) {
+  hipLaunchKernelGGL(k_split_A, dim3(grid_for(h->n_pad * h->K_pad)), dim3(256), 0, 0, h->dA, h->m, h->n, h->m, h->n_pad, h->K_pad, h->NA, h->dA8);
+}
+
+// out = (mode syndrome) U - A P  or  (mode f_a) A P, with P (K x ld int32) first cut into digit planes
+static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32_t* P, size_t ncols, const uint64_t* U, uint64_t* out, size_t ldo) {
+  const size_t ld = h->ld;
+  hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * ld, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, h->dP8, h->dFail);
+  dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64));
+#define ZQM(NA_)                                                                                                        \
+  case NA_:                                                                                                             \
+    hipLaunchKernelGGL((k_zq_mfma<NA_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, mode, h->dA8, h->n, h->n_pad, h->K_pad, h->dP8, ld, ncols, \
+                       h->zc, (int)h->wide, U, out, ldo);                                                               \
+    break;
+  switch (h->NA) { ZQM(1) ZQM(2) ZQM(3) ZQM(4) ZQM(5) ZQM(6) ZQM(7) ZQM(8) default: break; }
+#undef ZQM
+}
+
 psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
   if (!h) return PSF_ERR_PARAM;
   HIP_TRY(hipSetDevice(h->prm.device));
@@ -349,6 +383,7 @@ psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
   // gadget_classical.rs:66  A = [A_bar | G - A_bar R]   (tag = identity, mp_perturbation.rs:223)
   launch_zq(h, nullptr, ZQ_TRAPDOOR, h->dA, h->m, 0, h->n, h->mb, h->dR, true, h->ldr, h->w, nullptr, h->dA, h->m, h->mb);
   HIP_TRY(hipGetLastError());
+  split_A(h);
   const psf_status rc = build_sqrt_sigma2(h, h->prm.s);            // mp_perturbation.rs:227-231
   if (rc != PSF_OK) { h->has_key = false; return rc; }
   h->has_key = true;
@@ -368,6 +403,7 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
   HIP_TRY(hipMemcpy(h->dA, A, h->n * h->m * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
+  split_A(h);
   double* dp = nullptr;
   const size_t np = h->m * (h->m + 1) / 2;
   HIP_TRY(hipMalloc(&dp, np * sizeof(double)));
@@ -453,7 +489,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
     {  // mp_perturbation.rs:318 -- v = u - A p
       ScopedTimer t(h, s2, "k_zq_matmul(syndrome)");
-      launch_zq(h, s2, ZQ_SYNDROME, h->dA, m, 0, h->n, m, h->dP + boff, false, ld, Bs, d_u + boff * h->n, h->dV + boff, ld, 0);
+      if (S == 1) launch_zq_mfma(h, s2, ZQ_SYNDROME, h->dP, Bs, d_u, h->dV, ld);
+      else launch_zq(h, s2, ZQ_SYNDROME, h->dA, m, 0, h->n, m, h->dP + boff, false, ld, Bs, d_u + boff * h->n, h->dV + boff, ld, 0);
     }
     {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
       ScopedTimer t(h, s2, "k_gadget");
@@ -604,7 +641,7 @@ psf_status psfp_f_a_dev(psfp_handle* h, size_t B, const int64_t* d_e, uint64_t* 
   const size_t m = h->m, ld = h->ld;
   hipLaunchKernelGGL(k_check_domain, dim3((unsigned)B), dim3(256), 0, st, d_e, m, m, domain_bound(h), d_ok);   // :367
   hipLaunchKernelGGL(k_narrow_transpose, dim3((unsigned)(ld / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, st, d_e, m, B, ld, h->dP);
-  launch_zq(h, st, ZQ_FA, h->dA, m, 0, h->n, m, h->dP, false, ld, B, nullptr, d_u, h->n, 0);                    // :368
+  launch_zq_mfma(h, st, ZQ_FA, h->dP, B, nullptr, d_u, h->n);                                                    // :368
   HIP_TRY(hipGetLastError());
   h->last_stream = st;
   return PSF_OK;
