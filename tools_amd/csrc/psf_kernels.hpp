@@ -236,13 +236,28 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
   const size_t seg0 = wave_id * PR_SEG;
   if (seg0 >= total) return;
   const size_t seg1 = seg0 + PR_SEG < total ? seg0 + PR_SEG : total;
-  auto centre_of = [&](size_t g) -> double { return g < seg1 ? X[(g / B) * ld + (g % B)] : 0.0; };
+  // sample id g = seg0 + off  ->  (coordinate, preimage) by 32-bit arithmetic relative to the segment start
+  const size_t coord0 = seg0 / B;
+  const uint32_t b00 = (uint32_t)(seg0 % B), B32 = (uint32_t)B;
+  auto locate = [&](size_t g, size_t* coord, uint32_t* bb) {
+    const uint32_t o = b00 + (uint32_t)(g - seg0);
+    *coord = coord0 + o / B32;
+    *bb = o % B32;
+  };
+  auto centre_of = [&](size_t g) -> double {
+    if (g >= seg1) return 0.0;
+    size_t cc; uint32_t bb;
+    locate(g, &cc, &bb);
+    return X[cc * ld + bb];
+  };
   // window of prefetched centres: w0 = [base, base+64), w1 = [base+64, base+128), w2 = [base+128, base+192)
   size_t base = seg0 + 64;
   double w0 = centre_of(base + lane), w1 = centre_of(base + 64 + lane), w2 = centre_of(base + 128 + lane);
   size_t my = seg0 + lane, next_free = seg0 + 64;
   bool active = my < seg1;
   double c = centre_of(my);
+  size_t coord = 0; uint32_t b = 0;
+  locate(active ? my : seg0, &coord, &b);
   uint32_t t = 0;
   int f = 0;
   const double NEG_PI = -3.14159265358979323846;
@@ -250,7 +265,6 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
     bool accept = false;
     long long x = 0;
     if (active) {
-      const size_t coord = my / B, b = my % B;
       const uint64_t index = first_index + b;
       const long long lo = (long long)ceil(c) - sp.c6;
       const uint64_t N = (uint64_t)((long long)floor(c) + sp.f6 - lo + 1);
@@ -275,6 +289,7 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
         active = nid < seg1;
         c = off < 64 ? v0 : v1;
         t = 0;
+        if (active) locate(nid, &coord, &b);
       }
       next_free += (size_t)__popcll(mask);
       if (next_free >= base + 64) {                           // slide the window
