@@ -166,6 +166,44 @@ psf_status psfp_samp_p_stages(psfp_handle*, uint64_t seed, uint64_t first_index,
 psf_status psfp_enable_timing(psfp_handle*, int on);
 psf_status psfp_get_timing(psfp_handle*, char* names, size_t names_len, double* ms, size_t* count);
 
+/* ------------------------------------------------------------------------------------------------
+ * PSFGPV (gpv.rs:53-57, impl PSF :59-225)
+ *   A        = MatZq n x m
+ *   Trapdoor = (short_base, short_base_gso) (gpv.rs:61): both m x m.  They cross this ABI TRANSPOSED: row i of
+ *              `basis_t` / `gso_t` is basis vector i, i.e. column i of the reference's MatZ / MatQ
+ *              (gen_short_basis_for_trapdoor, short_basis_classical.rs:54-63; MatQ::gso, gpv.rs:91).
+ *   samp_p (gpv.rs:152-161): sol = A.solve_gaussian_elimination(u); e = sol + SampleD(basis, gso, -sol, s).
+ *   The elimination is factored once per key (pivot columns + n x n operator); it returns the same particular
+ *   solution as eliminating [A | u] per call with unit pivots and free variables 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct psfgpv_handle psfgpv_handle;
+typedef struct {
+  psf_gadget_params gp;
+  double s;        /* Gaussian parameter (gpv.rs:56) */
+  int32_t device;
+  uint32_t flags;  /* reserved, 0 */
+} psfgpv_params;
+
+psf_status psfgpv_create(const psfgpv_params* params, psfgpv_handle** out);
+void       psfgpv_destroy(psfgpv_handle*);
+size_t     psfgpv_m(const psfgpv_handle*);
+/* PSF::trap_gen (gpv.rs:83-94): A, R as for PSFPerturbation; short basis and its GSO built on device.
+ * PSF_ERR_NO_SOLUTION if A has fewer than n unit pivots mod q. */
+psf_status psfgpv_trap_gen(psfgpv_handle*, uint64_t seed);
+psf_status psfgpv_load_key(psfgpv_handle*, const uint64_t* A, const int32_t* basis_t, const double* gso_t);
+psf_status psfgpv_export_key(const psfgpv_handle*, uint64_t* A, int8_t* R, int32_t* basis_t, double* gso_t);
+psf_status psfgpv_samp_d(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, int64_t* e);         /* gpv.rs:113-116 */
+psf_status psfgpv_samp_p(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
+psf_status psfgpv_samp_p_dev(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, void* stream);
+psf_status psfgpv_f_a(psfgpv_handle*, size_t B, const int64_t* e, uint64_t* u);                               /* gpv.rs:190-193 */
+psf_status psfgpv_f_a_dev(psfgpv_handle*, size_t B, const int64_t* d_e, uint64_t* d_u, uint8_t* d_ok, void* stream);
+psf_status psfgpv_check_domain(psfgpv_handle*, size_t B, const int64_t* e, size_t len, uint8_t* ok);         /* gpv.rs:219-224 */
+psf_status psfgpv_uniform_targets_dev(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, uint64_t* d_u, void* stream);
+psf_status psfgpv_last_status(psfgpv_handle*);
+/* HIP-event duration (ms) of the nearest-plane kernel of the last samp_p call (0 if timing was off) */
+psf_status psfgpv_enable_timing(psfgpv_handle*, int on);
+psf_status psfgpv_get_timing(psfgpv_handle*, double* solve_ms, double* nearest_plane_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -341,5 +341,111 @@ class PSFPerturbation:
         return z
 
 
+# ---------------------------------------------------------------- PSFGPV
+def solve_gaussian_elimination(A, q, u):
+    A = _u64(A)
+    n, m = A.shape
+    u = _u64(u).reshape(n)
+    sol = np.zeros(m, dtype=np.uint64)
+    rc = lib().orc_solve_gaussian_elimination(_p(A, C.c_uint64), C.c_size_t(n), C.c_size_t(m), C.c_uint64(q),
+                                              _p(u, C.c_uint64), _p(sol, C.c_uint64))
+    return rc, sol
+
+
+def dot256(c, g):
+    c, g = _i64(c), np.ascontiguousarray(g, dtype=np.float64)
+    lib().orc_dot256.restype = C.c_double
+    return lib().orc_dot256(_p(c, C.c_int64), _p(g, C.c_double), C.c_size_t(c.size))
+
+
+def rot_minus_matrix(mat):
+    mat = _i64(mat)
+    rows, cols = mat.shape
+    out = np.zeros((rows, rows * cols), dtype=np.int64)
+    lib().orc_rot_minus_matrix(_p(mat, C.c_int64), C.c_size_t(rows), C.c_size_t(cols), _p(out, C.c_int64))
+    return out
+
+
+class PSFGPV:
+    """Oracle mirror of gpv.rs:53-57 / :59-225."""
+
+    def __init__(self, gp, s):
+        L = lib()
+        L.orc_gpv_new.restype = C.c_void_p
+        L.orc_gpv_new.argtypes = [C.POINTER(GadgetParams), C.c_double]
+        for nm, rt in (("orc_gpv_A", C.POINTER(C.c_uint64)), ("orc_gpv_R", C.POINTER(C.c_int8)),
+                       ("orc_gpv_basis_t", C.POINTER(C.c_int32)), ("orc_gpv_gso_t", C.POINTER(C.c_double))):
+            getattr(L, nm).restype = rt
+            getattr(L, nm).argtypes = [C.c_void_p]
+        L.orc_gpv_free.argtypes = [C.c_void_p]
+        self.gp, self.s = gp, float(s)
+        self._h = C.c_void_p(L.orc_gpv_new(C.byref(gp), C.c_double(s)))
+        if not self._h:
+            raise ValueError("bad parameters")
+        self.n, self.k, self.m_bar = gp.n, gp.k, gp.m_bar
+        self.w = gp.n * gp.k
+        self.m = self.m_bar + self.w
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_gpv_free(self._h)
+            self._h = None
+
+    @property
+    def A(self):
+        return np.ctypeslib.as_array(lib().orc_gpv_A(self._h), shape=(self.n, self.m)).copy()
+
+    @property
+    def R(self):
+        return np.ctypeslib.as_array(lib().orc_gpv_R(self._h), shape=(self.m_bar, self.w)).copy()
+
+    @property
+    def basis_t(self):
+        return np.ctypeslib.as_array(lib().orc_gpv_basis_t(self._h), shape=(self.m, self.m)).copy()
+
+    @property
+    def gso_t(self):
+        return np.ctypeslib.as_array(lib().orc_gpv_gso_t(self._h), shape=(self.m, self.m)).copy()
+
+    def trap_gen(self, seed):
+        return lib().orc_gpv_trap_gen(self._h, C.c_uint64(seed))
+
+    def load_key(self, A, basis_t, gso_t):
+        A = _u64(A)
+        bt = np.ascontiguousarray(basis_t, dtype=np.int32)
+        gt = np.ascontiguousarray(gso_t, dtype=np.float64)
+        assert A.shape == (self.n, self.m) and bt.shape == (self.m, self.m) and gt.shape == (self.m, self.m)
+        return lib().orc_gpv_load_key(self._h, _p(A, C.c_uint64), _p(bt, C.c_int32), _p(gt, C.c_double))
+
+    def samp_p(self, seed, u, first_index=0, percall=False, nthreads=0):
+        u = _u64(u).reshape(-1, self.n)
+        B = u.shape[0]
+        e = np.zeros((B, self.m), dtype=np.int64)
+        _check(lib().orc_gpv_samp_p(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u, C.c_uint64),
+                                    _p(e, C.c_int64), C.c_int(1 if percall else 0), C.c_int(nthreads)))
+        return e
+
+    def samp_d(self, seed, B=1, first_index=0):
+        e = np.zeros((B, self.m), dtype=np.int64)
+        _check(lib().orc_gpv_samp_d(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(e, C.c_int64)))
+        return e
+
+    def f_a(self, e):
+        e = _i64(e).reshape(-1, self.m)
+        u = np.zeros((e.shape[0], self.n), dtype=np.uint64)
+        rc = lib().orc_gpv_f_a(self._h, C.c_size_t(e.shape[0]), _p(e, C.c_int64), _p(u, C.c_uint64))
+        if rc == ERR_DOMAIN:
+            raise AssertionError("sigma not in domain (gpv.rs:191)")
+        return u
+
+    def check_domain(self, e):
+        e = _i64(e)
+        if e.ndim == 1:
+            e = e.reshape(1, -1)
+        ok = np.zeros(e.shape[0], dtype=np.uint8)
+        _check(lib().orc_gpv_check_domain(self._h, C.c_size_t(e.shape[0]), _p(e, C.c_int64), C.c_size_t(e.shape[1]), _p(ok, C.c_uint8)))
+        return ok.astype(bool)
+
+
 def num_threads():
     return lib().orc_num_threads()

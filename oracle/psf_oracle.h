@@ -114,6 +114,31 @@ int orc_randomized_nearest_plane_gadget(const orc_psfp*, uint64_t seed, uint64_t
 
 int orc_num_threads(void);
 
+/* ---- PSFGPV (gpv.rs) and shared pieces: see psf_oracle_gpv.c ---- */
+int orc_solve_gaussian_elimination(const uint64_t* A, size_t n, size_t m, uint64_t q, const uint64_t* u, uint64_t* sol);
+int orc_solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, size_t* piv, uint64_t* T);
+double orc_dot256(const int64_t* c, const double* g, size_t dim);
+void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double* norm2, size_t dim, double s,
+                       uint64_t seed, uint32_t tag, uint64_t index, int64_t* c);
+typedef struct orc_gpv_s orc_gpv_opaque;
+void* orc_gpv_new(const orc_gadget_params* gp, double s);
+void orc_gpv_free(void*);
+size_t orc_gpv_m(const void*);
+uint64_t* orc_gpv_A(void*);
+int8_t* orc_gpv_R(void*);
+int32_t* orc_gpv_basis_t(void*);       /* m x m, row i = basis vector i (column i of S_A) */
+double* orc_gpv_gso_t(void*);          /* m x m, row i = b~_i */
+int orc_gpv_trap_gen(void*, uint64_t seed);                                               /* gpv.rs:83-94 */
+int orc_gpv_load_key(void*, const uint64_t* A, const int32_t* basis_t, const double* gso_t);
+int orc_gpv_samp_p(const void*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e,
+                   int percall_elimination, int nthreads);                               /* gpv.rs:152-161 */
+int orc_gpv_samp_d(const void*, uint64_t seed, uint64_t first_index, size_t B, int64_t* e);  /* gpv.rs:113-116 */
+int orc_gpv_f_a(const void*, size_t B, const int64_t* e, uint64_t* u);                     /* gpv.rs:190-193 */
+int orc_gpv_check_domain(const void*, size_t B, const int64_t* e, size_t len, uint8_t* ok); /* gpv.rs:219-224 */
+/* rotation_matrix.rs:41-63 / :85-96 */
+void orc_rot_minus(const int64_t* vec, size_t n, int64_t* out, size_t ld, size_t col_off);
+void orc_rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

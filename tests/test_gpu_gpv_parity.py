@@ -1,0 +1,83 @@
+"""GPU parity of PSFGPV (gpv.rs) against the CPU oracle: A, R and the short basis bit-exact; the Gram-Schmidt vectors
+within tolerance (different summation order on the device); samp_p bit-exact once both sides hold the same key."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [(5, 256, 10.0), (6, 128, 10.0), (8, 128, 90.0), (4, 23, 12.0), (10, 157, 30.0)]   # gpv.rs:239,255 ; benches/psf.rs:27-33
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tools_amd
+    return tools_amd
+
+
+@pytest.mark.parametrize("n,q,s", CONFIGS)
+def test_trap_gen_parity(T, oracle, n, q, s):
+    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+    A, R, (bt, gt) = (lambda t: (t[0], t[1], t[2]))(psf.trap_gen(5, export=False) or psf.export_key(with_R=True))
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    assert orc.trap_gen(5) == 0
+    assert (A == orc.A).all() and (R == orc.R).all()
+    assert (bt == orc.basis_t).all(), "short basis S_A differs"
+    # the basis also equals the host-side restatement of gen_short_basis_for_trapdoor (columns = basis vectors)
+    S_host = T.gadget.gen_short_basis_for_trapdoor(psf.gp, A, R)
+    assert (bt == S_host.T).all()
+    assert ((A.astype(object) @ bt.astype(object).T) % q == 0).all()          # short_basis_classical.rs:128-188
+    scale = np.abs(orc.gso_t).max()
+    np.testing.assert_allclose(gt, orc.gso_t, rtol=0, atol=1e-9 * scale)
+
+
+@pytest.mark.parametrize("n,q,s", CONFIGS)
+def test_samp_p_parity_and_invariants(T, oracle, n, q, s):
+    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+    A, (bt, gt) = psf.trap_gen(5)
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    assert orc.load_key(A, bt, gt) == 0
+    B = 9
+    u = oracle.uniform_targets(2, B, n, q)
+    e = psf.samp_p(u, seed=31, first_index=4)
+    assert (e == orc.samp_p(31, u, first_index=4)).all()
+    assert (e[:3] == orc.samp_p(31, u[:3], first_index=4, percall=True)).all()     # per-call elimination, gpv.rs:153-156
+    assert (psf.f_a(e) == u).all() if psf.check_domain(e).all() else True
+    assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
+    # sharding independence
+    assert (psf.samp_p(u[5:8], seed=31, first_index=9) == e[5:8]).all()
+    # single call
+    assert (psf.samp_p(u[0], seed=31, first_index=4) == e[0]).all()
+
+
+def test_reference_flow(T):
+    # gpv.rs:40-51 doc example and :253-268
+    for n, q in [(8, 64), (5, 256), (6, 128)]:
+        psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), 12 if q == 64 else 10)
+        psf.trap_gen(1, export=False)
+        domain_sample = psf.samp_d(seed=2)
+        assert psf.check_domain(domain_sample)
+        range_fa = psf.f_a(domain_sample)
+        preimage = psf.samp_p(range_fa, seed=3)
+        assert psf.check_domain(preimage)
+        assert (psf.f_a(preimage) == range_fa).all()
+
+
+def test_samp_d_f_a_domain(T, oracle):
+    n, q, s = 6, 128, 10.0
+    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+    A, (bt, gt) = psf.trap_gen(7)
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    orc.load_key(A, bt, gt)
+    e = psf.samp_d(seed=3, B=6, first_index=2)
+    assert (e == orc.samp_d(3, B=6, first_index=2)).all()
+    assert psf.check_domain(e).all()
+    assert (psf.f_a(e) == orc.f_a(e)).all()
+    m = psf.m
+    with pytest.raises(T.PsfError):                      # gpv.rs:290-340 should_panic cases
+        psf.f_a(np.zeros(m - 1, dtype=np.int64))
+    big = np.zeros(m, dtype=np.int64)
+    big[0] = 10 * m
+    with pytest.raises(T.PsfError):
+        psf.f_a(big)
+    assert not psf.check_domain(big) and not psf.check_domain(np.zeros(m + 1, dtype=np.int64))
+    assert psf.check_domain(np.full(m, 10, dtype=np.int64))

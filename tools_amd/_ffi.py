@@ -51,6 +51,8 @@ def lib():
         L.psfp_m.argtypes = [C.c_void_p]
         L.psfp_destroy.restype = None
         L.psfp_destroy.argtypes = [C.c_void_p]
+        L.psfgpv_destroy.restype = None
+        L.psfgpv_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 

@@ -1,0 +1,268 @@
+// psf_gpv_kernels.hpp -- HIP kernels of PSFGPV / PSFGPVRing (gpv.rs, gpv_ring.rs): short-basis assembly, Gram-Schmidt,
+// solve operator application and the batched randomized nearest plane (MatZ::sample_d_precomputed_gso, GPV08 SampleD).
+//
+// Layout: the short basis and its Gram-Schmidt vectors are stored TRANSPOSED -- row i is basis vector i (column i of the
+// reference's matrices) -- so that step i of the nearest-plane walk streams two contiguous rows.
+#pragma once
+#include "psf_kernels.hpp"
+
+namespace psf {
+
+// ---- [0 I; S' W] transposed: row c = column c of the bottom block [S' | W] (short_basis_classical.rs:77-110) ----------
+// rows 0..w-1: columns of S' = I_n (x) S_k, column order reversed iff base^k == q (:80-82)
+// rows w..m-1: columns of W, W[jk+t][c] = t-th digit of -A[j][c] mod q (:105-110, tag = identity)
+__global__ void k_gpv_bottom_t(const uint64_t* __restrict__ A, size_t lda, uint32_t n, uint32_t k, size_t mbar, size_t w, uint64_t q,
+                               uint64_t base, const int32_t* __restrict__ Sk, int reversed, int8_t* __restrict__ BT, size_t ldw) {
+  const size_t m = mbar + w, total = m * ldw;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / ldw, t = g % ldw;
+    int32_t v = 0;
+    if (t < w) {
+      const uint32_t blk = (uint32_t)(t / k), tt = (uint32_t)(t % k);
+      if (i < w) {
+        const size_t src = reversed ? (w - 1 - i) : i;
+        if (src / k == blk) v = Sk[tt * k + (uint32_t)(src % k)];
+      } else {
+        const uint64_t a = A[(size_t)blk * lda + (i - w)] % q;
+        uint64_t x = a ? q - a : 0;
+        for (uint32_t d = 0; d < tt; ++d) x /= base;
+        v = (int32_t)(x % base);
+      }
+    }
+    BT[g] = (int8_t)v;
+  }
+}
+
+// S_A^t = [ (R S')^t ; (I + R W)^t | bottom^t ]:  St[i][r] = sum_t BT[i][t] R[r][t] + [i >= w and i - w == r]  (r < mbar),
+// St[i][mbar + t] = BT[i][t].  64 x 64 tiles, four coordinates per v_dot4_i32_i8.
+__global__ __launch_bounds__(256) void k_gpv_basis_t(const int8_t* __restrict__ BT, size_t ldw, const int8_t* __restrict__ R, size_t ldr,
+                                                     size_t m, size_t mbar, size_t w, int32_t* __restrict__ St) {
+  __shared__ uint32_t sB[64][17];
+  __shared__ uint32_t sR[64][17];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const size_t i0 = (size_t)blockIdx.y * 64, r0 = (size_t)blockIdx.x * 64;
+  int32_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0;
+  const uint32_t* B32 = reinterpret_cast<const uint32_t*>(BT);
+  const uint32_t* R32 = reinterpret_cast<const uint32_t*>(R);
+  const size_t w4 = (w + 3) / 4;
+  for (size_t q0 = 0; q0 < w4; q0 += 16) {
+    for (int e = tid; e < 64 * 16; e += 256) {
+      const int rr = e >> 4, qq = e & 15;
+      uint32_t vb = 0, vr = 0;
+      if (q0 + qq < w4) {
+        if (i0 + rr < m) vb = B32[(i0 + rr) * (ldw / 4) + q0 + qq];
+        if (r0 + rr < mbar) vr = R32[(r0 + rr) * (ldr / 4) + q0 + qq];
+      }
+      sB[rr][qq] = vb; sR[rr][qq] = vr;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) {
+      uint32_t rv[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rv[b] = sR[tx * 4 + b][qq];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const uint32_t bv = sB[ty * 4 + a][qq];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_sdot4((int)bv, (int)rv[b], acc[a][b], false);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const size_t i = i0 + ty * 4 + a, r = r0 + tx * 4 + b;
+      if (i < m && r < mbar) St[i * m + r] = acc[a][b] + ((i >= w && i - w == r) ? 1 : 0);
+    }
+}
+__global__ void k_gpv_basis_t_tail(const int8_t* __restrict__ BT, size_t ldw, size_t m, size_t mbar, size_t w, int32_t* __restrict__ St) {
+  const size_t total = m * w;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / w, t = g % w;
+    St[i * m + mbar + t] = BT[i * ldw + t];
+  }
+}
+
+// ---- Gram-Schmidt (MatQ::gso, gpv.rs:91) on the rows of St, right-looking: after b~_i is final, its component is removed
+// from every later row, so row t receives its subtractions in ascending i -- the oracle's order.
+__global__ void k_i32_to_f64(const int32_t* __restrict__ s, double* __restrict__ d, size_t total) {
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) d[g] = (double)s[g];
+}
+__device__ inline double block_sum_256(double v, double* scratch) {
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double r = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(256) void k_gs_norm(const double* __restrict__ Gt, size_t m, size_t i, double* __restrict__ norm2) {
+  __shared__ double scratch[4];
+  double acc = 0.0;
+  for (size_t j = threadIdx.x; j < m; j += 256) acc = fma(Gt[i * m + j], Gt[i * m + j], acc);
+  const double s = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) norm2[i] = s;
+}
+// mu[t] = <b_t, b~_i> / ||b~_i||^2 for t > i; one wave per row t
+__global__ __launch_bounds__(256) void k_gs_project(const int32_t* __restrict__ St, const double* __restrict__ Gt, const double* __restrict__ norm2,
+                                                    size_t m, size_t i, double* __restrict__ mu) {
+  const size_t t = i + 1 + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= m) return;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (size_t j = lane; j < m; j += 64) acc = fma((double)St[t * m + j], Gt[i * m + j], acc);
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) mu[t] = acc / norm2[i];
+}
+// Gt[t][j] -= mu[t] Gt[i][j] for t > i
+__global__ __launch_bounds__(256) void k_gs_update(double* __restrict__ Gt, const double* __restrict__ mu, size_t m, size_t i) {
+  const size_t t = i + 1 + blockIdx.y;
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= m || j >= m) return;
+  Gt[t * m + j] = fma(-mu[t], Gt[i * m + j], Gt[t * m + j]);
+}
+
+// ||b~_i||^2 as the contract's ascending fma chain (one thread per row; setup only)
+__global__ void k_row_norm2_chain(const double* __restrict__ Gt, size_t m, double* __restrict__ norm2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  double acc = 0.0;
+  for (size_t j = 0; j < m; ++j) acc = fma(Gt[i * m + j], Gt[i * m + j], acc);
+  norm2[i] = acc;
+}
+
+// ---- solve operator: c0[b][piv[r]] = -(T u_b)[r] mod q (gpv.rs:153-158: sol = A^{-1}(u), centre = -sol) -------------------
+__device__ inline uint64_t mulmod_dev(uint64_t a, uint64_t b, uint64_t q) {
+  if (q <= 0xffffffffull) return (a * b) % q;
+  uint64_t r = 0;
+  while (b) {
+    if (b & 1) { r += a; if (r >= q) r -= q; }
+    a += a; if (a >= q) a -= q;
+    b >>= 1;
+  }
+  return r;
+}
+__global__ void k_gpv_solve(const uint64_t* __restrict__ T, const uint32_t* __restrict__ piv, size_t n, size_t m, uint64_t q,
+                            const uint64_t* __restrict__ U, size_t B, int64_t* __restrict__ C0) {
+  const size_t total = n * B;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g / n, r = g % n;
+    uint64_t acc = 0;
+    for (size_t t = 0; t < n; ++t) {
+      acc += mulmod_dev(T[r * n + t], U[b * n + t] % q, q);
+      if (acc >= q) acc -= q;
+    }
+    C0[b * m + piv[r]] = -(int64_t)acc;
+  }
+}
+
+// ---- randomized nearest plane (MatZ::sample_d_precomputed_gso, gpv.rs:160) -----------------------------------------------------
+// One workgroup (256 threads = 4 waves, one per SIMD, so each thread may use up to 512 VGPRs) walks i = dim-1..0 for PB
+// preimages whose integer vectors c live in registers: thread t holds coordinates j = t + 256 r.  Per step:
+//   partial fma chains over r (ascending) -> xor butterfly per wave -> ((w0+w1)+(w2+w3))   [the contract's orc_dot256 order]
+//   c' = dot / ||b~_i||^2 ; wave p draws z for preimage p with all 64 lanes evaluating attempts t = lane, lane+64, ... and
+//   taking the first accepted one (= the sequential first-accept) ; c -= z b_i.
+// Rows i-1 of both matrices are prefetched into registers while step i samples.
+template <int JR, int PB>
+__global__ __launch_bounds__(256, 1) void k_gpv_nearest_plane(const int32_t* __restrict__ St, const double* __restrict__ Gt,
+                                                              const double* __restrict__ norm2, const SampleZParams* __restrict__ sz,
+                                                              size_t dim, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B,
+                                                              const int64_t* __restrict__ C0, int64_t* __restrict__ E, int* __restrict__ fail) {
+  __shared__ double s_w[PB][4];
+  __shared__ long long s_z[PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t b0 = (size_t)blockIdx.x * PB;
+  long long c[PB][JR];
+#pragma unroll
+  for (int p = 0; p < PB; ++p)
+#pragma unroll
+    for (int r = 0; r < JR; ++r) {
+      const size_t j = (size_t)tid + 256 * r;
+      c[p][r] = (b0 + p < B && j < dim) ? C0[(b0 + p) * dim + j] : 0;
+    }
+  double g[JR]; int32_t s[JR];
+  auto load_rows = [&](size_t i) {
+#pragma unroll
+    for (int r = 0; r < JR; ++r) {
+      const size_t j = (size_t)tid + 256 * r;
+      g[r] = j < dim ? Gt[i * dim + j] : 0.0;
+      s[r] = j < dim ? St[i * dim + j] : 0;
+    }
+  };
+  load_rows(dim - 1);
+  int f = 0;
+  for (size_t ii = dim; ii-- > 0;) {
+    double part[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < JR; ++r) acc = fma((double)c[p][r], g[r], acc);
+      for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+      part[p] = acc;
+    }
+    int32_t sc[JR];
+#pragma unroll
+    for (int r = 0; r < JR; ++r) sc[r] = s[r];
+    if (lane == 0) {
+#pragma unroll
+      for (int p = 0; p < PB; ++p) s_w[p][wave] = part[p];
+    }
+    const double n2 = norm2[ii];
+    const SampleZParams sp = sz[ii];
+    if (ii > 0) load_rows(ii - 1);                 // prefetch the next step's rows
+    __syncthreads();
+    if (wave < PB && b0 + wave >= B && lane == 0) s_z[wave] = 0;
+    if (wave < PB && b0 + wave < B) {
+      const int p = wave;
+      const double dot = (s_w[p][0] + s_w[p][1]) + (s_w[p][2] + s_w[p][3]);
+      const double cen = dot / n2;
+      const uint64_t index = first_index + b0 + p;
+      const long long lo = (long long)ceil(cen) - sp.c6;
+      const uint64_t N = (uint64_t)((long long)floor(cen) + sp.f6 - lo + 1);
+      long long z = 0;
+      bool got = false;
+      for (uint32_t t0 = 0; t0 < kMaxAttempts && !got; t0 += 64) {
+        const U4 w = philox(seed, (uint32_t)ii, (uint32_t)index, t0 + lane, tag_word(tag, index));
+        const long long x = lo + (long long)mulhi64(((uint64_t)w.y << 32) | w.x, N);
+        const double u = (double)((((uint64_t)w.w << 32) | w.z) >> 11) * 0x1.0p-53;
+        const double a = ((double)x - cen) * sp.inv_s;
+        const bool acc = u < det_exp(-3.14159265358979323846 * (a * a));
+        const uint64_t mask = __ballot(acc);
+        if (mask) {
+          const int first = __ffsll((long long)mask) - 1;
+          z = __shfl(x, first);
+          got = true;
+        }
+      }
+      if (!got) { f = 1; z = (long long)floor(cen + 0.5); }
+      if (lane == 0) s_z[p] = z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const long long z = s_z[p];
+      if (z != 0) {
+#pragma unroll
+        for (int r = 0; r < JR; ++r) c[p][r] -= z * (long long)sc[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PB; ++p)
+#pragma unroll
+    for (int r = 0; r < JR; ++r) {
+      const size_t j = (size_t)tid + 256 * r;
+      if (b0 + p < B && j < dim) E[(b0 + p) * dim + j] = -c[p][r];
+    }
+  if (f) atomicOr(fail, 1);
+}
+
+}  // namespace psf

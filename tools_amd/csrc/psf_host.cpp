@@ -193,6 +193,38 @@ psf_status gen_short_basis_for_trapdoor(const psf_gadget_params& gp, const uint6
   return PSF_OK;
 }
 
+psf_status solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, std::vector<uint32_t>& piv, std::vector<uint64_t>& T) {
+  T.assign(n * n, 0);
+  for (size_t d = 0; d < n; ++d) T[d * n + d] = 1 % q;
+  piv.clear();
+  std::vector<uint64_t> col(n);
+  for (size_t c = 0; c < m && piv.size() < n; ++c) {
+    const size_t rank = piv.size();
+    for (size_t r = 0; r < n; ++r) {                      // column c of T * A
+      u128 acc = 0;
+      for (size_t t = 0; t < n; ++t) acc = (acc + (u128)T[r * n + t] * (A[t * m + c] % q)) % q;
+      col[r] = (uint64_t)acc;
+    }
+    size_t p = n;
+    uint64_t pinv = 0;
+    for (size_t r = rank; r < n && p == n; ++r)
+      if (inverse_mod(col[r], q, &pinv)) p = r;
+    if (p == n) continue;                                 // no unit in this column: free variable
+    if (p != rank) {
+      for (size_t j = 0; j < n; ++j) std::swap(T[p * n + j], T[rank * n + j]);
+      std::swap(col[p], col[rank]);
+    }
+    for (size_t j = 0; j < n; ++j) T[rank * n + j] = mulmod_u64(T[rank * n + j], pinv, q);
+    for (size_t r = 0; r < n; ++r) {
+      if (r == rank || col[r] == 0) continue;
+      const uint64_t f = col[r];
+      for (size_t j = 0; j < n; ++j) T[r * n + j] = submod_u64(T[r * n + j], mulmod_u64(f, T[rank * n + j], q), q);
+    }
+    piv.push_back((uint32_t)c);
+  }
+  return piv.size() == n ? PSF_OK : PSF_ERR_NO_SOLUTION;
+}
+
 // rotation_matrix.rs:41-63: column j of rot^-(v) is v multiplied by X^j in Z[X]/(X^n+1)
 void rot_minus(const int64_t* vec, size_t n, int64_t* out, size_t ld, size_t col_off) {
   for (size_t i = 0; i < n; ++i)

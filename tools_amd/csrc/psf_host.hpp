@@ -56,6 +56,9 @@ psf_status compute_w(const psf_gadget_params& gp, const uint64_t* tag, const uin
 // S_A = [I R; 0 I] [0 I; S' W] (short_basis_classical.rs:54-102); m x m
 psf_status gen_short_basis_for_trapdoor(const psf_gadget_params& gp, const uint64_t* tag, const uint64_t* A,
                                         const int8_t* R, std::vector<int64_t>& out);
+// MatZq::solve_gaussian_elimination (gpv.rs:153-156) factored once per key: Gauss-Jordan with unit pivots, columns scanned
+// left to right, free variables 0.  piv[r] = r-th pivot column, T (n x n) with sol[piv[r]] = (T u)[r].
+psf_status solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, std::vector<uint32_t>& piv, std::vector<uint64_t>& T);
 // rotation_matrix.rs:41-63 / :85-96
 void rot_minus(const int64_t* vec, size_t n, int64_t* out /*n x n*/, size_t ld, size_t col_off);
 void rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out /*rows x rows*cols*/);

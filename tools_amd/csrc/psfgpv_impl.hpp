@@ -1,0 +1,261 @@
+// psfgpv_impl.hpp -- PSFGPV behind the C ABI (gpv.rs:53-57, impl PSF :59-225).  Included at the end of psfp.hip:
+// the Z_q machinery (A, its digit planes, f_a, check_domain, samp_d) is shared with PSFPerturbation through an inner
+// psfp_handle created with r = 1 (then s*r = s and the domain bound s^2 m r^2 = s^2 m, gpv.rs:113-116, :219-224).
+
+struct psfgpv_handle {
+  psfp_handle* base = nullptr;
+  double s = 0;
+  size_t n = 0, m = 0, dim = 0;       // dim = lattice dimension walked by the nearest plane (= m here)
+  int32_t* dSt = nullptr;             // dim x dim, row i = basis vector i
+  double* dGt = nullptr;              // dim x dim, row i = b~_i
+  double* dNorm2 = nullptr;
+  SampleZParams* dSz = nullptr;
+  uint64_t* dT = nullptr;             // n x n solve operator
+  uint32_t* dPiv = nullptr;           // n pivot columns
+  int64_t* dC0 = nullptr; size_t c0cap = 0;
+  bool has_key = false;
+  bool timing = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipStream_t last_stream = nullptr;
+};
+
+// Gram-Schmidt of the rows of dSt into dGt (MatQ::gso, gpv.rs:91), then ||b~_i||^2 and the per-step sampler tables
+static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
+  const size_t d = g->dim;
+  if (compute_gso) {
+    hipLaunchKernelGGL(k_i32_to_f64, dim3(grid_for(d * d)), dim3(256), 0, 0, g->dSt, g->dGt, d * d);
+    double* dmu = nullptr;
+    HIP_TRY(hipMalloc(&dmu, d * sizeof(double)));
+    for (size_t i = 0; i + 1 < d; ++i) {
+      const size_t rest = d - 1 - i;
+      hipLaunchKernelGGL(k_gs_norm, dim3(1), dim3(256), 0, 0, g->dGt, d, i, g->dNorm2);
+      hipLaunchKernelGGL(k_gs_project, dim3((unsigned)((rest + 3) / 4)), dim3(256), 0, 0, g->dSt, g->dGt, g->dNorm2, d, i, dmu);
+      hipLaunchKernelGGL(k_gs_update, dim3((unsigned)((d + 255) / 256), (unsigned)rest), dim3(256), 0, 0, g->dGt, dmu, d, i);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree(dmu);
+  }
+  hipLaunchKernelGGL(k_row_norm2_chain, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, 0, g->dGt, d, g->dNorm2);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> norm2(d);
+  HIP_TRY(hipMemcpy(norm2.data(), g->dNorm2, d * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<SampleZParams> sz(d);
+  for (size_t i = 0; i < d; ++i) {
+    if (!(norm2[i] > 0.0)) return PSF_ERR_PARAM;                       // linearly dependent "basis"
+    sz[i] = make_sample_z_params(g->s / std::sqrt(norm2[i]));
+  }
+  HIP_TRY(hipMemcpy(g->dSz, sz.data(), d * sizeof(SampleZParams), hipMemcpyHostToDevice));
+  return PSF_OK;
+}
+
+static psf_status gpv_build_solver(psfgpv_handle* g) {
+  psfp_handle* b = g->base;
+  std::vector<uint64_t> A(b->n * b->m);
+  HIP_TRY(hipMemcpy(A.data(), b->dA, A.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> piv;
+  std::vector<uint64_t> T;
+  const psf_status rc = solve_precompute(A.data(), b->n, b->m, b->q, piv, T);
+  if (rc != PSF_OK) return rc;                                         // gpv.rs:153-155: solve(...).unwrap() would panic
+  HIP_TRY(hipMemcpy(g->dT, T.data(), T.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->dPiv, piv.data(), piv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return PSF_OK;
+}
+
+template <int JR, int PB>
+static void launch_np(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e) {
+  hipLaunchKernelGGL((k_gpv_nearest_plane<JR, PB>), dim3((unsigned)((B + PB - 1) / PB)), dim3(256), 0, st, g->dSt, g->dGt, g->dNorm2, g->dSz,
+                     g->dim, seed, tag, first_index, B, g->dC0, d_e, g->base->dFail);
+}
+static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e) {
+  const size_t jr = (g->dim + 255) / 256;
+  if (jr <= 1) launch_np<1, 4>(g, st, seed, tag, first_index, B, d_e);
+  else if (jr <= 2) launch_np<2, 4>(g, st, seed, tag, first_index, B, d_e);
+  else if (jr <= 4) launch_np<4, 4>(g, st, seed, tag, first_index, B, d_e);
+  else if (jr <= 8) launch_np<8, 4>(g, st, seed, tag, first_index, B, d_e);
+  else if (jr <= 14) launch_np<14, 4>(g, st, seed, tag, first_index, B, d_e);
+  else if (jr <= 16) launch_np<16, 4>(g, st, seed, tag, first_index, B, d_e);
+  else if (jr <= 25) launch_np<25, 4>(g, st, seed, tag, first_index, B, d_e);
+  else if (jr <= 32) launch_np<32, 2>(g, st, seed, tag, first_index, B, d_e);
+  else return PSF_ERR_UNSUPPORTED;                                     // lattice dimension > 8192
+  return PSF_OK;
+}
+
+extern "C" {
+
+psf_status psfgpv_create(const psfgpv_params* prm, psfgpv_handle** out) {
+  if (!prm || !out || !(prm->s > 0.0)) return PSF_ERR_PARAM;
+  psfp_params bp;
+  bp.gp = prm->gp; bp.r = 1.0; bp.s = prm->s; bp.device = prm->device; bp.flags = PSFP_FLAG_NO_PERTURB;
+  psfp_handle* b = nullptr;
+  const psf_status rc = psfp_create(&bp, &b);
+  if (rc != PSF_OK) return rc;
+  if (b->m > 8192) { psfp_destroy(b); return PSF_ERR_UNSUPPORTED; }
+  psfgpv_handle* g = new psfgpv_handle();
+  g->base = b; g->s = prm->s; g->n = b->n; g->m = b->m; g->dim = b->m;
+  const size_t d = g->dim;
+  HIP_TRY(hipMalloc(&g->dSt, d * d * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&g->dGt, d * d * sizeof(double)));
+  HIP_TRY(hipMalloc(&g->dNorm2, d * sizeof(double)));
+  HIP_TRY(hipMalloc(&g->dSz, d * sizeof(SampleZParams)));
+  HIP_TRY(hipMalloc(&g->dT, g->n * g->n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&g->dPiv, g->n * sizeof(uint32_t)));
+  for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
+  *out = g;
+  return PSF_OK;
+}
+
+void psfgpv_destroy(psfgpv_handle* g) {
+  if (!g) return;
+  hipSetDevice(g->base->prm.device);
+  hipFree(g->dSt); hipFree(g->dGt); hipFree(g->dNorm2); hipFree(g->dSz); hipFree(g->dT); hipFree(g->dPiv); hipFree(g->dC0);
+  for (auto& e : g->ev) if (e) hipEventDestroy(e);
+  psfp_destroy(g->base);
+  delete g;
+}
+
+size_t psfgpv_m(const psfgpv_handle* g) { return g ? g->m : 0; }
+
+// gpv.rs:83-94
+psf_status psfgpv_trap_gen(psfgpv_handle* g, uint64_t seed) {
+  if (!g) return PSF_ERR_PARAM;
+  psfp_handle* b = g->base;
+  HIP_TRY(hipSetDevice(b->prm.device));
+  g->has_key = false;
+  psf_status rc = gen_A_R(b, seed);                                          // :84-88
+  if (rc != PSF_OK) return rc;
+  // gen_short_basis_for_trapdoor (:90, short_basis_classical.rs:54-110), assembled transposed on the device
+  int8_t* dBT = nullptr;
+  const size_t ldw = b->ldr;
+  HIP_TRY(hipMalloc(&dBT, b->m * ldw));
+  const int reversed = is_power_of_base(b->prm.gp.base, b->k, b->q) ? 1 : 0;
+  hipLaunchKernelGGL(k_gpv_bottom_t, dim3(grid_for(b->m * ldw, 256, 256 * 64)), dim3(256), 0, 0, b->dA, b->m, (uint32_t)b->n, (uint32_t)b->k, b->mb, b->w,
+                     b->q, b->prm.gp.base, b->dSk, reversed, dBT, ldw);
+  hipLaunchKernelGGL(k_gpv_basis_t, dim3((unsigned)((b->mb + 63) / 64), (unsigned)((b->m + 63) / 64)), dim3(256), 0, 0, dBT, ldw, b->dR, b->ldr, b->m,
+                     b->mb, b->w, g->dSt);
+  hipLaunchKernelGGL(k_gpv_basis_t_tail, dim3(grid_for(b->m * b->w, 256, 256 * 64)), dim3(256), 0, 0, dBT, ldw, b->m, b->mb, b->w, g->dSt);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  hipFree(dBT);
+  rc = gpv_finish_basis(g, true);                                             // :91 gso
+  if (rc != PSF_OK) return rc;
+  rc = gpv_build_solver(g);
+  if (rc != PSF_OK) return rc;
+  b->has_key = true;
+  g->has_key = true;
+  return PSF_OK;
+}
+
+psf_status psfgpv_load_key(psfgpv_handle* g, const uint64_t* A, const int32_t* basis_t, const double* gso_t) {
+  if (!g || !A || !basis_t || !gso_t) return PSF_ERR_PARAM;
+  psfp_handle* b = g->base;
+  HIP_TRY(hipSetDevice(b->prm.device));
+  g->has_key = false;
+  HIP_TRY(hipMemcpy(b->dA, A, b->n * b->m * sizeof(uint64_t), hipMemcpyHostToDevice));
+  split_A(b);
+  HIP_TRY(hipMemcpy(g->dSt, basis_t, g->dim * g->dim * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->dGt, gso_t, g->dim * g->dim * sizeof(double), hipMemcpyHostToDevice));
+  psf_status rc = gpv_finish_basis(g, false);
+  if (rc != PSF_OK) return rc;
+  rc = gpv_build_solver(g);
+  if (rc != PSF_OK) return rc;
+  b->has_key = true;
+  g->has_key = true;
+  return PSF_OK;
+}
+
+psf_status psfgpv_export_key(const psfgpv_handle* g, uint64_t* A, int8_t* R, int32_t* basis_t, double* gso_t) {
+  if (!g) return PSF_ERR_PARAM;
+  if (!g->has_key) return PSF_ERR_NO_KEY;
+  const psfp_handle* b = g->base;
+  HIP_TRY(hipSetDevice(b->prm.device));
+  if (A) HIP_TRY(hipMemcpy(A, b->dA, b->n * b->m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (R) HIP_TRY(hipMemcpy2D(R, b->w, b->dR, b->ldr, b->w, b->mb, hipMemcpyDeviceToHost));
+  if (basis_t) HIP_TRY(hipMemcpy(basis_t, g->dSt, g->dim * g->dim * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (gso_t) HIP_TRY(hipMemcpy(gso_t, g->dGt, g->dim * g->dim * sizeof(double), hipMemcpyDeviceToHost));
+  return PSF_OK;
+}
+
+// gpv.rs:152-161
+psf_status psfgpv_samp_p_dev(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, void* stream) {
+  if (!g || (B && (!d_u || !d_e))) return PSF_ERR_PARAM;
+  if (!g->has_key) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  psfp_handle* b = g->base;
+  HIP_TRY(hipSetDevice(b->prm.device));
+  hipStream_t st = (hipStream_t)stream;
+  if (B > g->c0cap) {
+    hipFree(g->dC0);
+    g->dC0 = nullptr;
+    HIP_TRY(hipMalloc(&g->dC0, B * g->dim * sizeof(int64_t)));
+    g->c0cap = B;
+  }
+  HIP_TRY(hipMemsetAsync(b->dFail, 0, 2 * sizeof(int), st));
+  HIP_TRY(hipMemsetAsync(g->dC0, 0, B * g->dim * sizeof(int64_t), st));
+  if (g->timing) hipEventRecord(g->ev[0], st);
+  // :153-158  sol = A.solve(u), centre = -sol
+  hipLaunchKernelGGL(k_gpv_solve, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dT, g->dPiv, g->n, g->dim, b->q, d_u, B, g->dC0);
+  if (g->timing) hipEventRecord(g->ev[1], st);
+  // :160  sol + sample_d_precomputed_gso(basis, gso, centre, s)
+  const psf_status rc = launch_nearest_plane(g, st, seed, TAG_GPV, first_index, B, d_e);
+  if (g->timing) hipEventRecord(g->ev[2], st);
+  if (rc != PSF_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  g->last_stream = st;
+  b->last_stream = st;
+  return PSF_OK;
+}
+
+psf_status psfgpv_last_status(psfgpv_handle* g) { return g ? psfp_last_status(g->base) : PSF_ERR_PARAM; }
+
+psf_status psfgpv_samp_p(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
+  if (!g || (B && (!u || !e))) return PSF_ERR_PARAM;
+  if (!g->has_key) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(g->base->prm.device));
+  uint64_t* du = nullptr; int64_t* de = nullptr;
+  HIP_TRY(hipMalloc(&du, B * g->n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&de, B * g->m * sizeof(int64_t)));
+  HIP_TRY(hipMemcpy(du, u, B * g->n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  psf_status rc = psfgpv_samp_p_dev(g, seed, first_index, B, du, de, nullptr);
+  if (rc == PSF_OK) rc = psfgpv_last_status(g);
+  HIP_TRY(hipMemcpy(e, de, B * g->m * sizeof(int64_t), hipMemcpyDeviceToHost));
+  hipFree(du); hipFree(de);
+  return rc;
+}
+
+psf_status psfgpv_samp_d(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, int64_t* e) {
+  return g ? psfp_samp_d(g->base, seed, first_index, B, e) : PSF_ERR_PARAM;
+}
+psf_status psfgpv_f_a(psfgpv_handle* g, size_t B, const int64_t* e, uint64_t* u) {
+  if (!g) return PSF_ERR_PARAM;
+  if (!g->has_key) return PSF_ERR_NO_KEY;
+  return psfp_f_a(g->base, B, e, u);
+}
+psf_status psfgpv_f_a_dev(psfgpv_handle* g, size_t B, const int64_t* d_e, uint64_t* d_u, uint8_t* d_ok, void* stream) {
+  if (!g) return PSF_ERR_PARAM;
+  if (!g->has_key) return PSF_ERR_NO_KEY;
+  return psfp_f_a_dev(g->base, B, d_e, d_u, d_ok, stream);
+}
+psf_status psfgpv_check_domain(psfgpv_handle* g, size_t B, const int64_t* e, size_t len, uint8_t* ok) {
+  return g ? psfp_check_domain(g->base, B, e, len, ok) : PSF_ERR_PARAM;
+}
+psf_status psfgpv_uniform_targets_dev(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, uint64_t* d_u, void* stream) {
+  return g ? psfp_uniform_targets_dev(g->base, seed, first_index, B, d_u, stream) : PSF_ERR_PARAM;
+}
+psf_status psfgpv_enable_timing(psfgpv_handle* g, int on) {
+  if (!g) return PSF_ERR_PARAM;
+  g->timing = on != 0;
+  return PSF_OK;
+}
+psf_status psfgpv_get_timing(psfgpv_handle* g, double* solve_ms, double* nearest_plane_ms) {
+  if (!g) return PSF_ERR_PARAM;
+  HIP_TRY(hipStreamSynchronize(g->last_stream));
+  float a = 0.f, c = 0.f;
+  if (g->timing) { hipEventElapsedTime(&a, g->ev[0], g->ev[1]); hipEventElapsedTime(&c, g->ev[1], g->ev[2]); }
+  if (solve_ms) *solve_ms = a;
+  if (nearest_plane_ms) *nearest_plane_ms = c;
+  return PSF_OK;
+}
+
+}  // extern "C"

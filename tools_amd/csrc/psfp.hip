@@ -10,6 +10,9 @@
 #include "../../include/psf_mi355x.h"
 #include "psf_host.hpp"
 #include "psf_kernels.hpp"
+#include "psf_gpv_kernels.hpp"
+
+#define PSFP_FLAG_NO_PERTURB 1u   // internal: handle used as the Z_q / f_a engine of PSFGPV(Ring); no sqrt(Sigma_2) buffers
 
 using namespace psf;
 
@@ -113,8 +116,10 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
   const size_t ld = round_up(B, TR_BN);
   h->ld = ld;
   h->nbj = ld / TR_BN;
-  HIP_TRY(hipMalloc(&h->dDt, ld / TR_BN * h->nkb * TR_CHUNK * sizeof(double)));
-  HIP_TRY(hipMalloc(&h->dX, h->M_pad * ld * sizeof(double)));
+  if (!(h->prm.flags & PSFP_FLAG_NO_PERTURB)) {
+    HIP_TRY(hipMalloc(&h->dDt, ld / TR_BN * h->nkb * TR_CHUNK * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->dX, h->M_pad * ld * sizeof(double)));
+  }
   HIP_TRY(hipMalloc(&h->dP, h->M_pad * ld * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&h->dV, h->n * ld * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dZlo, h->ldr * ld));      // [ldr/16][ld][16]
@@ -267,7 +272,7 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   HIP_TRY(hipMalloc(&h->dA, h->n * h->m * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dR, h->mb_pad * h->ldr));
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
-  HIP_TRY(hipMalloc(&h->dLt, tr_total_chunks(h->nbi) * TR_CHUNK * sizeof(double)));
+  if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dLt, tr_total_chunks(h->nbi) * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipMalloc(&h->dFail, 2 * sizeof(int)));      // [0] sampler failure, [1] some |z| > 127
   HIP_TRY(hipMemset(h->dFail, 0, 2 * sizeof(int)));
   // gadget part of the trapdoor: (S, S~) of mp_perturbation.rs:233-234, block form
@@ -373,17 +378,25 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
 #undef ZQM
 }
 
-psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
-  if (!h) return PSF_ERR_PARAM;
-  HIP_TRY(hipSetDevice(h->prm.device));
+// A_bar <- U(Z_q^{n x m_bar}), R <- PlusMinusOneZero, A = [A_bar | G - A_bar R] (gen_trapdoor, gadget_classical.rs:56-68, tag = I)
+static psf_status gen_A_R(psfp_handle* h, uint64_t seed) {
   if (gadget_too_short(h->prm.gp.base, h->k, h->q)) return PSF_ERR_MODULUS;
-  // mp_perturbation.rs:222 ; gadget_classical.rs:62-64
+  // mp_perturbation.rs:222 / gpv.rs:84 ; gadget_classical.rs:62-64
   hipLaunchKernelGGL(k_sample_abar, dim3(grid_for(h->n * h->mb)), dim3(256), 0, 0, seed, h->n, h->mb, h->m, h->q, h->dA);
   hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);
-  // gadget_classical.rs:66  A = [A_bar | G - A_bar R]   (tag = identity, mp_perturbation.rs:223)
+  // gadget_classical.rs:66
   launch_zq(h, nullptr, ZQ_TRAPDOOR, h->dA, h->m, 0, h->n, h->mb, h->dR, true, h->ldr, h->w, nullptr, h->dA, h->m, h->mb);
   HIP_TRY(hipGetLastError());
   split_A(h);
+  return PSF_OK;
+}
+
+psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
+  if (!h) return PSF_ERR_PARAM;
+  if (h->prm.flags & PSFP_FLAG_NO_PERTURB) return PSF_ERR_UNSUPPORTED;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  const psf_status rcg = gen_A_R(h, seed);
+  if (rcg != PSF_OK) return rcg;
   const psf_status rc = build_sqrt_sigma2(h, h->prm.s);            // mp_perturbation.rs:227-231
   if (rc != PSF_OK) { h->has_key = false; return rc; }
   h->has_key = true;
@@ -709,3 +722,5 @@ psf_status psfp_get_timing(psfp_handle* h, char* names, size_t names_len, double
 }
 
 }  // extern "C"
+
+#include "psfgpv_impl.hpp"

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import GadgetParams, PsfpParams, PsfError, check, lib
+from ._ffi import GadgetParams, GpvParams, PsfpParams, PsfError, check, lib
 
 
 def _p(a, t):
@@ -165,3 +165,111 @@ class PSFPerturbation:
         check(lib().psfp_get_timing(self._h, names, C.c_size_t(4096), ms, C.byref(cnt)), "get_timing")
         nm = names.value.decode().split(";") if names.value else []
         return list(zip(nm, list(ms)[:cnt.value]))
+
+
+class PSFGPV:
+    """gpv.rs:53-57 / impl PSF :59-225 on one MI355X.  The trapdoor (short basis, GSO) is exchanged TRANSPOSED:
+    row i = basis vector i = column i of the reference's matrices."""
+
+    def __init__(self, gp, s, device=0):
+        self.gp, self.s, self.device = gp, float(s), device
+        prm = GpvParams(gp.c, self.s, device, 0)
+        h = C.c_void_p()
+        check(lib().psfgpv_create(C.byref(prm), C.byref(h)), "PSFGPV")
+        self._h = h
+        self._destroy = lib().psfgpv_destroy
+        self._destroy.argtypes = [C.c_void_p]
+        self.n, self.k, self.m_bar = gp.n, gp.k, gp.m_bar
+        self.w = gp.n * gp.k
+        self.m = self.m_bar + self.w
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def trap_gen(self, seed=0, export=True):
+        """gpv.rs:83-94.  Returns (A, (basis_t, gso_t)) unless export=False."""
+        check(lib().psfgpv_trap_gen(self._h, C.c_uint64(seed)), "trap_gen")
+        return self.export_key() if export else None
+
+    def export_key(self, with_R=False):
+        A = np.zeros((self.n, self.m), dtype=np.uint64)
+        bt = np.zeros((self.m, self.m), dtype=np.int32)
+        gt = np.zeros((self.m, self.m), dtype=np.float64)
+        R = np.zeros((self.m_bar, self.w), dtype=np.int8) if with_R else None
+        check(lib().psfgpv_export_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8) if with_R else None, _p(bt, C.c_int32),
+                                      _p(gt, C.c_double)), "export_key")
+        return (A, (bt, gt)) if not with_R else (A, R, (bt, gt))
+
+    def load_key(self, A, basis_t, gso_t):
+        A = np.ascontiguousarray(A, dtype=np.uint64)
+        bt = np.ascontiguousarray(basis_t, dtype=np.int32)
+        gt = np.ascontiguousarray(gso_t, dtype=np.float64)
+        assert A.shape == (self.n, self.m) and bt.shape == (self.m, self.m) and gt.shape == (self.m, self.m)
+        check(lib().psfgpv_load_key(self._h, _p(A, C.c_uint64), _p(bt, C.c_int32), _p(gt, C.c_double)), "load_key")
+
+    def samp_d(self, seed=0, B=None, first_index=0):
+        """gpv.rs:113-116"""
+        nb = 1 if B is None else B
+        e = np.zeros((nb, self.m), dtype=np.int64)
+        check(lib().psfgpv_samp_d(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(nb), _p(e, C.c_int64)), "samp_d")
+        return e[0] if B is None else e
+
+    def samp_p(self, u, seed=0, first_index=0):
+        """gpv.rs:152-161"""
+        u = np.ascontiguousarray(u, dtype=np.uint64)
+        single = u.ndim == 1
+        u2 = u.reshape(-1, self.n)
+        B = u2.shape[0]
+        e = np.zeros((B, self.m), dtype=np.int64)
+        check(lib().psfgpv_samp_p(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64),
+                                  _p(e, C.c_int64)), "samp_p")
+        return e[0] if single else e
+
+    def f_a(self, sigma):
+        """gpv.rs:190-193"""
+        sigma = np.ascontiguousarray(sigma, dtype=np.int64)
+        single = sigma.ndim == 1
+        if sigma.ndim > 2 or sigma.shape[-1] != self.m:
+            raise PsfError(_ffi.ERR_DOMAIN, "f_a")
+        e2 = sigma.reshape(-1, self.m)
+        u = np.zeros((e2.shape[0], self.n), dtype=np.uint64)
+        check(lib().psfgpv_f_a(self._h, C.c_size_t(e2.shape[0]), _p(e2, C.c_int64), _p(u, C.c_uint64)), "f_a")
+        return u[0] if single else u
+
+    def check_domain(self, sigma):
+        """gpv.rs:219-224"""
+        sigma = np.ascontiguousarray(sigma, dtype=np.int64)
+        single = sigma.ndim == 1
+        e2 = sigma.reshape(1, -1) if single else sigma
+        ok = np.zeros(e2.shape[0], dtype=np.uint8)
+        check(lib().psfgpv_check_domain(self._h, C.c_size_t(e2.shape[0]), _p(e2, C.c_int64), C.c_size_t(e2.shape[1]),
+                                        _p(ok, C.c_uint8)), "check_domain")
+        return bool(ok[0]) if single else ok.astype(bool)
+
+    # device-resident API
+    def samp_p_dev(self, d_u_ptr, d_e_ptr, B, seed=0, first_index=0, stream=None):
+        check(lib().psfgpv_samp_p_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), C.c_void_p(d_u_ptr),
+                                      C.c_void_p(d_e_ptr), C.c_void_p(stream or 0)), "samp_p_dev")
+
+    def f_a_dev(self, d_e_ptr, d_u_ptr, d_ok_ptr, B, stream=None):
+        check(lib().psfgpv_f_a_dev(self._h, C.c_size_t(B), C.c_void_p(d_e_ptr), C.c_void_p(d_u_ptr), C.c_void_p(d_ok_ptr),
+                                   C.c_void_p(stream or 0)), "f_a_dev")
+
+    def uniform_targets_dev(self, d_u_ptr, B, seed=0, first_index=0, stream=None):
+        check(lib().psfgpv_uniform_targets_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B),
+                                               C.c_void_p(d_u_ptr), C.c_void_p(stream or 0)), "uniform_targets_dev")
+
+    def last_status(self):
+        return lib().psfgpv_last_status(self._h)
+
+    def enable_timing(self, on=True):
+        check(lib().psfgpv_enable_timing(self._h, C.c_int(1 if on else 0)), "enable_timing")
+
+    def get_timing(self):
+        a, b = C.c_double(0), C.c_double(0)
+        check(lib().psfgpv_get_timing(self._h, C.byref(a), C.byref(b)), "get_timing")
+        return {"k_gpv_solve": a.value, "k_gpv_nearest_plane": b.value}
