@@ -447,5 +447,113 @@ class PSFGPV:
         return ok.astype(bool)
 
 
+# ---------------------------------------------------------------- ring variant
+def gso_rows(basis_t):
+    bt = np.ascontiguousarray(basis_t, dtype=np.int32)
+    d = bt.shape[0]
+    out = np.zeros((d, d), dtype=np.float64)
+    lib().orc_gso_rows(_p(bt, C.c_int32), C.c_size_t(d), _p(out, C.c_double))
+    return out
+
+
+def ring_trap_gen(gp, s_td, seed):
+    n, k = gp.n, gp.k
+    a = np.zeros((k + 2, n), dtype=np.uint64)
+    r = np.zeros((k, n), dtype=np.int64)
+    e = np.zeros((k, n), dtype=np.int64)
+    _check(lib().orc_ring_trap_gen(C.byref(gp), C.c_double(s_td), C.c_uint64(seed), _p(a, C.c_uint64), _p(r, C.c_int64), _p(e, C.c_int64)))
+    return a, r, e
+
+
+def ring_compute_s(gp):
+    out = np.zeros((gp.k, gp.k), dtype=np.int64)
+    _check(lib().orc_ring_compute_s(C.byref(gp), _p(out, C.c_int64)))
+    return out
+
+
+def find_solution_gadget_ring(u, q, k, base):
+    u = _u64(u)
+    out = np.zeros((k, u.size), dtype=np.int64)
+    _check(lib().orc_find_solution_gadget_ring(_p(u, C.c_uint64), C.c_size_t(u.size), C.c_uint64(q), C.c_uint64(k), C.c_uint64(base), _p(out, C.c_int64)))
+    return out
+
+
+def ring_gen_sa_l(first, second):
+    first, second = _i64(first), _i64(second)
+    k, n = first.shape
+    out = np.zeros((k + 2, k + 2, n), dtype=np.int64)
+    lib().orc_ring_gen_sa_l(_p(first, C.c_int64), _p(second, C.c_int64), C.c_size_t(n), C.c_size_t(k), _p(out, C.c_int64))
+    return out
+
+
+def ring_gen_sa_r(gp, a):
+    a = _u64(a)
+    K, n = gp.k + 2, gp.n
+    out = np.zeros((K, n * K, n), dtype=np.int64)
+    _check(lib().orc_ring_gen_sa_r(C.byref(gp), _p(a, C.c_uint64), _p(out, C.c_int64)))
+    return out
+
+
+def ring_short_basis_t(gp, a, r, e):
+    a, r, e = _u64(a), _i64(r), _i64(e)
+    d = gp.n * (gp.k + 2)
+    out = np.zeros((d, d), dtype=np.int32)
+    _check(lib().orc_ring_short_basis_t(C.byref(gp), _p(a, C.c_uint64), _p(r, C.c_int64), _p(e, C.c_int64), _p(out, C.c_int32)))
+    return out
+
+
+def ring_embed_a(a, q):
+    a = _u64(a)
+    K, n = a.shape
+    out = np.zeros((n, n * K), dtype=np.uint64)
+    lib().orc_ring_embed_a(_p(a, C.c_uint64), C.c_size_t(n), C.c_size_t(K), C.c_uint64(q), _p(out, C.c_uint64))
+    return out
+
+
+def poly_matrix_embedding(P):
+    """coefficient embedding of a (rows x cols x n) polynomial matrix: (rows*n) x cols (short_basis_ring.rs:443)."""
+    rows, cols, n = P.shape
+    return P.transpose(0, 2, 1).reshape(rows * n, cols)
+
+
+class PSFGPVRing:
+    """Oracle mirror of gpv_ring.rs:62-67 / :69-284: ring key generation + the embedded PSFGPV machinery."""
+
+    def __init__(self, gp, s, s_td):
+        self.gp, self.s, self.s_td = gp, float(s), float(s_td)
+        self.n, self.k = gp.n, gp.k
+        self.K = gp.k + 2
+        self.d = self.n * self.K
+        egp = GadgetParams(gp.n, gp.k, 2 * gp.n, gp.base, gp.q)       # n x d system: d = 2n + nk
+        self._gpv = PSFGPV(egp, s)
+        self.a = self.r = self.e = None
+
+    def trap_gen(self, seed):
+        self.a, self.r, self.e = ring_trap_gen(self.gp, self.s_td, seed)     # gpv_ring.rs:91-98
+        return self.load_key(self.a, self.r, self.e)
+
+    def load_key(self, a, r, e, gso_t=None):
+        self.a, self.r, self.e = _u64(a), _i64(r), _i64(e)
+        self.basis_t = ring_short_basis_t(self.gp, self.a, self.r, self.e)   # gpv_ring.rs:169 (per call in the reference)
+        self.A_emb = ring_embed_a(self.a, self.gp.q)                         # gpv_ring.rs:172-178
+        self.gso_t = gso_rows(self.basis_t) if gso_t is None else gso_t
+        return self._gpv.load_key(self.A_emb, self.basis_t, self.gso_t)
+
+    def samp_p(self, seed, u, first_index=0, percall=False, nthreads=0):
+        """u: B x n coefficient vectors of the syndromes; returns B x (k+2) x n."""
+        e = self._gpv.samp_p(seed, _u64(u).reshape(-1, self.n), first_index=first_index, percall=percall, nthreads=nthreads)
+        return e.reshape(-1, self.K, self.n)
+
+    def samp_d(self, seed, B=1, first_index=0):
+        return self._gpv.samp_d(seed, B=B, first_index=first_index).reshape(-1, self.K, self.n)
+
+    def f_a(self, sigma):
+        return self._gpv.f_a(_i64(sigma).reshape(-1, self.d))
+
+    def check_domain(self, sigma):
+        sigma = _i64(sigma)
+        return self._gpv.check_domain(sigma.reshape(-1, self.d) if sigma.size % self.d == 0 and sigma.size else sigma.reshape(1, -1))
+
+
 def num_threads():
     return lib().orc_num_threads()

@@ -120,7 +120,8 @@ int orc_solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, size
 double orc_dot256(const int64_t* c, const double* g, size_t dim);
 void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double* norm2, size_t dim, double s,
                        uint64_t seed, uint32_t tag, uint64_t index, int64_t* c);
-typedef struct orc_gpv_s orc_gpv_opaque;
+/* Gram-Schmidt on the ROWS of St (MatQ::gso on the columns of the reference's matrix) */
+void orc_gso_rows(const int32_t* St, size_t m, double* Gt);
 void* orc_gpv_new(const orc_gadget_params* gp, double s);
 void orc_gpv_free(void*);
 size_t orc_gpv_m(const void*);
@@ -135,6 +136,14 @@ int orc_gpv_samp_p(const void*, uint64_t seed, uint64_t first_index, size_t B, c
 int orc_gpv_samp_d(const void*, uint64_t seed, uint64_t first_index, size_t B, int64_t* e);  /* gpv.rs:113-116 */
 int orc_gpv_f_a(const void*, size_t B, const int64_t* e, uint64_t* u);                     /* gpv.rs:190-193 */
 int orc_gpv_check_domain(const void*, size_t B, const int64_t* e, size_t len, uint8_t* ok); /* gpv.rs:219-224 */
+/* ---- ring variant (gadget_ring.rs, short_basis_ring.rs, gpv_ring.rs); polynomials = n int64/uint64 coefficients ---- */
+int orc_ring_trap_gen(const orc_gadget_params* gp, double s_td, uint64_t seed, uint64_t* a /*(k+2) x n*/, int64_t* r /*k x n*/, int64_t* e /*k x n*/);
+int orc_ring_compute_s(const orc_gadget_params* gp, int64_t* sk /*k x k*/);
+int orc_find_solution_gadget_ring(const uint64_t* u, size_t n, uint64_t q, uint64_t k, uint64_t base, int64_t* out /*k x n*/);
+void orc_ring_gen_sa_l(const int64_t* first, const int64_t* second, size_t n, size_t k, int64_t* out /*(k+2)^2 x n*/);
+int orc_ring_gen_sa_r(const orc_gadget_params* gp, const uint64_t* a, int64_t* out /*(k+2) x n(k+2) x n*/);
+int orc_ring_short_basis_t(const orc_gadget_params* gp, const uint64_t* a, const int64_t* r, const int64_t* e, int32_t* basis_t /*d x d*/);
+void orc_ring_embed_a(const uint64_t* a, size_t n, size_t K, uint64_t q, uint64_t* A_emb /*n x nK*/);
 /* rotation_matrix.rs:41-63 / :85-96 */
 void orc_rot_minus(const int64_t* vec, size_t n, int64_t* out, size_t ld, size_t col_off);
 void orc_rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out);

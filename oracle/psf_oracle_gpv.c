@@ -222,6 +222,8 @@ static void gso_rows(const int32_t* St, size_t m, double* Gt) {
   free(norm2);
 }
 
+void orc_gso_rows(const int32_t* St, size_t m, double* Gt) { gso_rows(St, m, Gt); }
+
 /* gpv.rs:83-94 */
 int orc_gpv_trap_gen(void* hv, uint64_t seed) {
   orc_gpv* h = (orc_gpv*)hv;
@@ -346,4 +348,180 @@ void orc_rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t*
     orc_rot_minus(col, rows, out, rows * cols, c * rows);
   }
   free(col);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Ring variant: gadget_ring.rs, short_basis_ring.rs, gpv_ring.rs.  Polynomials are int64 coefficient arrays of
+ * length n (degree < n), arithmetic in Z[X]/(X^n + 1) (common_moduli.rs:41-48) unless stated otherwise.
+ * ---------------------------------------------------------------------------------------- */
+/* out = a * b in Z[X]/(X^n+1) (PolyOverZ product followed by reduce_by_poly, short_basis_ring.rs:72-77) */
+static void poly_mul_negacyclic(const int64_t* a, const int64_t* b, size_t n, int64_t* out) {
+  int64_t* t = (int64_t*)calloc(n, sizeof(int64_t));
+  for (size_t i = 0; i < n; ++i) {
+    if (!a[i]) continue;
+    for (size_t j = 0; j < n; ++j) {
+      size_t d = i + j;
+      if (d >= n) t[d - n] -= a[i] * b[j];
+      else t[d] += a[i] * b[j];
+    }
+  }
+  memcpy(out, t, n * sizeof(int64_t));
+  free(t);
+}
+
+/* gen_trapdoor_ring_lwe (gadget_ring.rs:62-81) with a_bar, r, e drawn from the Philox streams:
+ *   a_bar uniform in Z_q^n (gpv_ring.rs:92-94), r_j, e_j <- D_{Z,s_td}^n (SampleZ, trapdoor_distribution.rs:112-122)
+ *   A = [1 | a_bar | g_j - (a_bar r_j + e_j)] mod (X^n+1, q);  a: (k+2) x n, r, e: k x n */
+int orc_ring_trap_gen(const orc_gadget_params* gp, double s_td, uint64_t seed, uint64_t* a, int64_t* r, int64_t* e) {
+  size_t n = gp->n, k = gp->k;
+  uint64_t q = gp->q;
+  for (size_t j = 0; j < k; ++j)
+    for (size_t c = 0; c < n; ++c) {
+      r[j * n + c] = orc_sample_z(seed, ORC_TAG_RING_R, 0, (uint32_t)(j * n + c), 0.0, s_td);
+      e[j * n + c] = orc_sample_z(seed, ORC_TAG_RING_E, 0, (uint32_t)(j * n + c), 0.0, s_td);
+    }
+  memset(a, 0, (k + 2) * n * sizeof(uint64_t));
+  a[0] = 1 % q;
+  int64_t* abar = (int64_t*)malloc(n * sizeof(int64_t));
+  for (size_t c = 0; c < n; ++c) { a[n + c] = orc_uniform_mod(seed, ORC_TAG_RING_A, (uint32_t)c, 0, q); abar[c] = (int64_t)a[n + c]; }
+  int64_t* prod = (int64_t*)malloc(n * sizeof(int64_t));
+  uint64_t g = 1 % q;
+  for (size_t j = 0; j < k; ++j) {
+    /* a_bar * r_j in Z[X]/(X^n+1): entries up to n q |r| < 2^63 for the supported q < 2^31 */
+    i128* acc = (i128*)calloc(n, sizeof(i128));
+    for (size_t x = 0; x < n; ++x)
+      for (size_t y = 0; y < n; ++y) {
+        size_t d = x + y;
+        i128 p = (i128)abar[x] * r[j * n + y];
+        if (d >= n) acc[d - n] -= p; else acc[d] += p;
+      }
+    for (size_t c = 0; c < n; ++c) {
+      i128 v = (c == 0 ? (i128)g : 0) - (acc[c] + e[j * n + c]);
+      i128 m = v % (i128)q;
+      if (m < 0) m += q;
+      a[(2 + j) * n + c] = (uint64_t)m;
+    }
+    free(acc);
+    g = g_mulmod(g, gp->base % q, q);
+  }
+  free(abar); free(prod);
+  return ORC_OK;
+}
+
+/* compute_s (short_basis_ring.rs:142-166): k x k integers (constant polynomials) */
+int orc_ring_compute_s(const orc_gadget_params* gp, int64_t* sk) { return orc_short_basis_gadget_block(gp, sk); }
+
+/* find_solution_gadget_ring (gadget_ring.rs:145-166): digits of every coefficient; out: k x n (poly i = digit i) */
+int orc_find_solution_gadget_ring(const uint64_t* u, size_t n, uint64_t q, uint64_t k, uint64_t base, int64_t* out) {
+  int64_t* d = (int64_t*)malloc(k * sizeof(int64_t));
+  for (size_t j = 0; j < n; ++j) {
+    int rc = orc_find_solution_gadget_vec(u[j], q, k, base, d);
+    if (rc) { free(d); return rc; }
+    for (size_t i = 0; i < k; ++i) out[i * n + j] = d[i];           /* index i + j*k of the classical solution (:160) */
+  }
+  free(d);
+  return ORC_OK;
+}
+
+/* gen_sa_l (short_basis_ring.rs:82-91): (k+2) x (k+2) matrix of polynomials [1 0 first ; 0 1 second ; 0 0 I_k];
+ * the caller passes (e, r) as gen_short_basis_for_trapdoor_ring does (:70).  out[(row*(k+2)+col)*n + coeff]. */
+void orc_ring_gen_sa_l(const int64_t* first, const int64_t* second, size_t n, size_t k, int64_t* out) {
+  size_t K = k + 2;
+  memset(out, 0, K * K * n * sizeof(int64_t));
+  for (size_t d = 0; d < K; ++d) out[(d * K + d) * n] = 1;
+  for (size_t j = 0; j < k; ++j)
+    for (size_t c = 0; c < n; ++c) {
+      out[(0 * K + 2 + j) * n + c] = first[j * n + c];
+      out[(1 * K + 2 + j) * n + c] = second[j * n + c];
+    }
+}
+
+/* gen_sa_r (short_basis_ring.rs:96-124): (k+2) x n(k+2) polynomials, [pd (x) [0; S'] | pd (x) [I_2; W]], pd = [X^0..X^{n-1}].
+ * a: (k+2) x n residues.  out[(row*cols + col)*n + coeff], cols = n(k+2); entries already reduced mod X^n+1. */
+int orc_ring_gen_sa_r(const orc_gadget_params* gp, const uint64_t* a, int64_t* out) {
+  size_t n = gp->n, k = gp->k, K = k + 2, cols = n * K;
+  uint64_t q = gp->q;
+  int64_t* sk = (int64_t*)malloc(k * k * sizeof(int64_t));
+  orc_ring_compute_s(gp, sk);
+  u128 bk = 1; int pw = 1;
+  for (uint64_t i = 0; i < k; ++i) { bk *= gp->base; if (bk > q) { pw = 0; break; } }
+  int reversed = pw && bk == q;                                                    /* :110-112 */
+  /* W = [w_0 | w_1], w_c = digits of -a_c (compute_w, :128-139) */
+  int64_t* W = (int64_t*)malloc(2 * k * n * sizeof(int64_t));
+  uint64_t* neg = (uint64_t*)malloc(n * sizeof(uint64_t));
+  for (int c = 0; c < 2; ++c) {
+    for (size_t j = 0; j < n; ++j) { uint64_t v = a[c * n + j] % q; neg[j] = v ? q - v : 0; }
+    int rc = orc_find_solution_gadget_ring(neg, n, q, k, gp->base, W + (size_t)c * k * n);
+    if (rc) { free(sk); free(W); free(neg); return rc; }
+  }
+  memset(out, 0, K * cols * n * sizeof(int64_t));
+  int64_t* tmp = (int64_t*)malloc(n * sizeof(int64_t));
+  for (size_t i = 0; i < n; ++i) {
+    /* X^i * S' block: columns i*k + c, rows 2..k+1 */
+    for (size_t c = 0; c < k; ++c)
+      for (size_t t = 0; t < k; ++t) {
+        int64_t v = sk[t * k + (reversed ? (k - 1 - c) : c)];
+        if (v) out[((2 + t) * cols + i * k + c) * n + i] = v;                     /* v * X^i, i < n: no wrap */
+      }
+    /* X^i * [I_2; W]: columns kn + 2i + c */
+    for (int c = 0; c < 2; ++c) {
+      size_t col = k * n + 2 * i + c;
+      out[((size_t)c * cols + col) * n + i] = 1;
+      for (size_t t = 0; t < k; ++t) {
+        const int64_t* wp = W + ((size_t)c * k + t) * n;
+        memset(tmp, 0, n * sizeof(int64_t));
+        for (size_t j = 0; j < n; ++j) {                                          /* X^i * w mod X^n+1 */
+          size_t d = i + j;
+          if (d >= n) tmp[d - n] -= wp[j]; else tmp[d] += wp[j];
+        }
+        memcpy(out + ((2 + t) * cols + col) * n, tmp, n * sizeof(int64_t));
+      }
+    }
+  }
+  free(sk); free(W); free(neg); free(tmp);
+  return ORC_OK;
+}
+
+/* gen_short_basis_for_trapdoor_ring (short_basis_ring.rs:64-79) followed by the coefficient embedding used by
+ * MatPolyOverZ::sample_d (gpv_ring.rs:204-210): basis_t is d x d (d = n(k+2)), row c = embedding of column c of
+ * sa_l * sa_r mod X^n+1, entry index polyrow*n + coeff. */
+int orc_ring_short_basis_t(const orc_gadget_params* gp, const uint64_t* a, const int64_t* r, const int64_t* e, int32_t* basis_t) {
+  size_t n = gp->n, k = gp->k, K = k + 2, d = n * K;
+  int64_t* sal = (int64_t*)malloc(K * K * n * sizeof(int64_t));
+  int64_t* sar = (int64_t*)malloc(K * d * n * sizeof(int64_t));
+  orc_ring_gen_sa_l(e, r, n, k, sal);                                              /* :70 gen_sa_l(e, r) */
+  int rc = orc_ring_gen_sa_r(gp, a, sar);                                          /* :71 */
+  if (rc) { free(sal); free(sar); return rc; }
+  int64_t* acc = (int64_t*)malloc(n * sizeof(int64_t));
+  int64_t* prod = (int64_t*)malloc(n * sizeof(int64_t));
+  for (size_t col = 0; col < d; ++col)
+    for (size_t row = 0; row < K; ++row) {
+      memset(acc, 0, n * sizeof(int64_t));
+      for (size_t t = 0; t < K; ++t) {
+        const int64_t* x = sal + (row * K + t) * n;
+        const int64_t* y = sar + (t * d + col) * n;
+        int zero = 1;
+        for (size_t c = 0; c < n && zero; ++c) if (x[c]) zero = 0;
+        if (zero) continue;
+        poly_mul_negacyclic(x, y, n, prod);                                        /* :72-77 product then reduce_by_poly */
+        for (size_t c = 0; c < n; ++c) acc[c] += prod[c];
+      }
+      for (size_t c = 0; c < n; ++c) basis_t[col * d + row * n + c] = (int32_t)acc[c];
+    }
+  free(sal); free(sar); free(acc); free(prod);
+  return ORC_OK;
+}
+
+/* rot^-(iota(a)) (gpv_ring.rs:172-178): n x n(k+2), block j = rot_minus(coefficients of a_j) */
+void orc_ring_embed_a(const uint64_t* a, size_t n, size_t K, uint64_t q, uint64_t* A_emb) {
+  size_t d = n * K;
+  for (size_t j = 0; j < K; ++j)
+    for (size_t i = 0; i < n; ++i) {
+      uint64_t v = a[j * n + i] % q;
+      for (size_t l = 0; l < n; ++l) {
+        size_t row = i + l;
+        if (row >= n) A_emb[(row - n) * d + j * n + l] = v ? q - v : 0;
+        else A_emb[row * d + j * n + l] = v;
+      }
+    }
 }
