@@ -204,6 +204,44 @@ psf_status psfgpv_last_status(psfgpv_handle*);
 psf_status psfgpv_enable_timing(psfgpv_handle*, int on);
 psf_status psfgpv_get_timing(psfgpv_handle*, double* solve_ms, double* nearest_plane_ms);
 
+/* ------------------------------------------------------------------------------------------------
+ * PSFGPVRing (gpv_ring.rs:62-67, impl PSF :69-284) over R_q = Z_q[X]/(X^n + 1)
+ *   A        = MatPolynomialRingZq 1 x (k+2)  -> uint64_t[(k+2) * n], polynomial j at a + j*n, constant term first
+ *   Trapdoor = (r, e), two 1 x k MatPolyOverZ  -> int64_t[k * n] each (gadget_ring.rs:62-81)
+ *   Domain   = MatPolyOverZ (k+2) x 1          -> int64_t[(k+2) * n] per call
+ *   Range    = one element of R_q               -> uint64_t[n] per call
+ * samp_p (gpv_ring.rs:160-212) works on the coefficient embedding: the short basis
+ * (gen_short_basis_for_trapdoor_ring, short_basis_ring.rs:64-79), rot^-(iota(a)) (rotation_matrix.rs:85-96), the
+ * elimination and the Gram-Schmidt vectors are built ONCE per key here, where the reference rebuilds them per call.
+ * f_a (gpv_ring.rs:243-247) is the R_q product a * sigma, evaluated as rot^-(iota(a)) iota(sigma) on the int8 matrix cores.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct psfring_handle psfring_handle;
+typedef struct {
+  psf_gadget_params gp;   /* from psf_gadget_params_ring_default: m_bar = k + 2 */
+  double s;               /* gpv_ring.rs:65 */
+  double s_td;            /* gpv_ring.rs:66 */
+  int32_t device;
+  uint32_t flags;
+} psfring_params;
+
+psf_status psfring_create(const psfring_params* params, psfring_handle** out);
+void       psfring_destroy(psfring_handle*);
+/* PSF::trap_gen (gpv_ring.rs:91-98) */
+psf_status psfring_trap_gen(psfring_handle*, uint64_t seed);
+psf_status psfring_load_key(psfring_handle*, const uint64_t* a, const int64_t* r, const int64_t* e);
+/* a, r, e as above; basis_t / gso_t: d x d with d = n(k+2), row c = embedded basis vector c (any may be NULL) */
+psf_status psfring_export_key(const psfring_handle*, uint64_t* a, int64_t* r, int64_t* e, int32_t* basis_t, double* gso_t);
+psf_status psfring_samp_d(psfring_handle*, uint64_t seed, uint64_t first_index, size_t B, int64_t* sigma);            /* :118-122 */
+psf_status psfring_samp_p(psfring_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* sigma);
+psf_status psfring_samp_p_dev(psfring_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_sigma, void* stream);
+psf_status psfring_f_a(psfring_handle*, size_t B, const int64_t* sigma, uint64_t* u);                                  /* :243-247 */
+psf_status psfring_f_a_dev(psfring_handle*, size_t B, const int64_t* d_sigma, uint64_t* d_u, uint8_t* d_ok, void* stream);
+psf_status psfring_check_domain(psfring_handle*, size_t B, const int64_t* sigma, size_t len, uint8_t* ok);            /* :274-283 */
+psf_status psfring_uniform_targets_dev(psfring_handle*, uint64_t seed, uint64_t first_index, size_t B, uint64_t* d_u, void* stream);
+psf_status psfring_last_status(psfring_handle*);
+psf_status psfring_enable_timing(psfring_handle*, int on);
+psf_status psfring_get_timing(psfring_handle*, double* solve_ms, double* nearest_plane_ms);
+
 #ifdef __cplusplus
 }
 #endif

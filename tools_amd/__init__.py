@@ -5,5 +5,5 @@ GadgetParameters.init_default, PSFPerturbation / PSFGPV / PSFGPVRing with
 trap_gen / samp_d / samp_p / f_a / check_domain.  Everything computes on the GPU through the C ABI.
 """
 from ._ffi import PsfError, LIB_PATH  # noqa: F401
-from .psf import GadgetParameters, PSFPerturbation, PSFGPV  # noqa: F401
+from .psf import GadgetParameters, GadgetParametersRing, PSFPerturbation, PSFGPV, PSFGPVRing  # noqa: F401
 from . import gadget  # noqa: F401

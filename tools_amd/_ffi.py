@@ -34,6 +34,10 @@ class GpvParams(C.Structure):
     _fields_ = [("gp", GadgetParams), ("s", C.c_double), ("device", C.c_int32), ("flags", C.c_uint32)]
 
 
+class RingParams(C.Structure):
+    _fields_ = [("gp", GadgetParams), ("s", C.c_double), ("s_td", C.c_double), ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -53,6 +57,8 @@ def lib():
         L.psfp_destroy.argtypes = [C.c_void_p]
         L.psfgpv_destroy.restype = None
         L.psfgpv_destroy.argtypes = [C.c_void_p]
+        L.psfring_destroy.restype = None
+        L.psfring_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 

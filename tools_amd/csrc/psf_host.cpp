@@ -243,4 +243,126 @@ void rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ring variant
+// ---------------------------------------------------------------------------------------------------------------------
+void poly_mul_negacyclic(const int64_t* a, const int64_t* b, size_t n, int64_t* out) {
+  std::vector<int64_t> t(n, 0);
+  for (size_t i = 0; i < n; ++i) {
+    if (a[i] == 0) continue;
+    for (size_t j = 0; j < n; ++j) {
+      const size_t d = i + j;
+      if (d >= n) t[d - n] -= a[i] * b[j];
+      else t[d] += a[i] * b[j];
+    }
+  }
+  std::copy(t.begin(), t.end(), out);
+}
+
+// x * X^shift in Z[X]/(X^n+1)
+static void poly_shift_negacyclic(const int64_t* x, size_t n, size_t shift, int64_t* out) {
+  for (size_t j = 0; j < n; ++j) {
+    const size_t d = j + shift;
+    if (d >= n) out[d - n] = -x[j];
+    else out[d] = x[j];
+  }
+}
+
+// gadget_ring.rs:62-81
+void ring_assemble_a(const psf_gadget_params& gp, const uint64_t* a_bar, const int64_t* r, const int64_t* e, uint64_t* a) {
+  const size_t n = gp.n, k = gp.k;
+  const uint64_t q = gp.q;
+  std::fill(a, a + (k + 2) * n, 0);
+  a[0] = 1 % q;                                                          // :74
+  for (size_t c = 0; c < n; ++c) a[n + c] = a_bar[c] % q;                // :75
+  uint64_t g = 1 % q;
+  std::vector<i128> acc(n);
+  for (size_t j = 0; j < k; ++j) {                                       // :76-78  g^t - (a_bar r + e)
+    std::fill(acc.begin(), acc.end(), (i128)0);
+    for (size_t x = 0; x < n; ++x)
+      for (size_t y = 0; y < n; ++y) {
+        const i128 p = (i128)(int64_t)(a_bar[x] % q) * r[j * n + y];
+        const size_t d = x + y;
+        if (d >= n) acc[d - n] -= p;
+        else acc[d] += p;
+      }
+    for (size_t c = 0; c < n; ++c) {
+      i128 v = (c == 0 ? (i128)g : (i128)0) - (acc[c] + e[j * n + c]);
+      v %= (i128)q;
+      if (v < 0) v += q;
+      a[(2 + j) * n + c] = (uint64_t)v;
+    }
+    g = mulmod_u64(g, gp.base % q, q);
+  }
+}
+
+// short_basis_ring.rs:64-166 in closed form.  With pd = [X^0 .. X^{n-1}], sa_l = [1 0 e; 0 1 r; 0 0 I_k] and
+// sa_r = [pd (x) [0; S'] | pd (x) [I_2; W]], column (i, c) of the product is X^i times
+//   left  block (c < k)  : ( sum_t S'[t][c] e_t , sum_t S'[t][c] r_t , S'[:, c] )
+//   right block (c in 0,1): ( [c=0] + sum_t e_t W[t][c] , [c=1] + sum_t r_t W[t][c] , W[:, c] )
+// reduced mod X^n+1 (:72-77).  W[:, c] = digits of -a_c per coefficient (compute_w :128-139, gadget_ring.rs:145-166).
+psf_status ring_short_basis_t(const psf_gadget_params& gp, const uint64_t* a, const int64_t* r, const int64_t* e, std::vector<int32_t>& basis_t) {
+  const size_t n = gp.n, k = gp.k, K = k + 2, d = n * K;
+  const uint64_t q = gp.q;
+  if (gadget_too_short(gp.base, gp.k, gp.q)) return PSF_ERR_MODULUS;
+  const auto sk = short_basis_gadget_block(gp);                          // compute_s, :142-166
+  const bool reversed = is_power_of_base(gp.base, gp.k, gp.q);           // :110-112
+  // columns before the X^i shift: K polynomials each
+  std::vector<int64_t> W(2 * k * n), dg(k);
+  for (size_t c = 0; c < 2; ++c)
+    for (size_t j = 0; j < n; ++j) {
+      const uint64_t v = a[c * n + j] % q;
+      digits_of(v ? q - v : 0, q, k, gp.base, dg.data());
+      for (size_t t = 0; t < k; ++t) W[(c * k + t) * n + j] = dg[t];
+    }
+  basis_t.assign(d * d, 0);
+  std::vector<int64_t> col(K * n), prod(n), shifted(n);
+  auto emit = [&](size_t column, size_t shift) {
+    for (size_t row = 0; row < K; ++row) {
+      poly_shift_negacyclic(col.data() + row * n, n, shift, shifted.data());
+      for (size_t c = 0; c < n; ++c) basis_t[column * d + row * n + c] = (int32_t)shifted[c];
+    }
+  };
+  for (size_t c = 0; c < k; ++c) {                                       // left block
+    std::fill(col.begin(), col.end(), 0);
+    const size_t sc = reversed ? (k - 1 - c) : c;
+    for (size_t t = 0; t < k; ++t) {
+      const int64_t v = sk[t * k + sc];
+      if (v == 0) continue;
+      for (size_t x = 0; x < n; ++x) { col[x] += v * e[t * n + x]; col[n + x] += v * r[t * n + x]; }
+      col[(2 + t) * n] = v;
+    }
+    for (size_t i = 0; i < n; ++i) emit(i * k + c, i);
+  }
+  for (size_t c = 0; c < 2; ++c) {                                       // right block
+    std::fill(col.begin(), col.end(), 0);
+    col[c * n] = 1;
+    for (size_t t = 0; t < k; ++t) {
+      const int64_t* w = W.data() + (c * k + t) * n;
+      poly_mul_negacyclic(e + t * n, w, n, prod.data());
+      for (size_t x = 0; x < n; ++x) col[x] += prod[x];
+      poly_mul_negacyclic(r + t * n, w, n, prod.data());
+      for (size_t x = 0; x < n; ++x) col[n + x] += prod[x];
+      std::copy(w, w + n, col.begin() + (2 + t) * n);
+    }
+    for (size_t i = 0; i < n; ++i) emit(k * n + 2 * i + c, i);
+  }
+  return PSF_OK;
+}
+
+// gpv_ring.rs:172-178
+void ring_embed_a(const uint64_t* a, size_t n, size_t K, uint64_t q, std::vector<uint64_t>& A_emb) {
+  const size_t d = n * K;
+  A_emb.assign(n * d, 0);
+  for (size_t j = 0; j < K; ++j)
+    for (size_t i = 0; i < n; ++i) {
+      const uint64_t v = a[j * n + i] % q;
+      for (size_t l = 0; l < n; ++l) {
+        const size_t row = i + l;
+        if (row >= n) A_emb[(row - n) * d + j * n + l] = v ? q - v : 0;
+        else A_emb[row * d + j * n + l] = v;
+      }
+    }
+}
+
 }  // namespace psf

@@ -63,4 +63,14 @@ psf_status solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, s
 void rot_minus(const int64_t* vec, size_t n, int64_t* out /*n x n*/, size_t ld, size_t col_off);
 void rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out /*rows x rows*cols*/);
 
+// ---- ring variant (gadget_ring.rs, short_basis_ring.rs, gpv_ring.rs); polynomials = n coefficients, constant term first ----
+// out = a * b in Z[X]/(X^n+1)
+void poly_mul_negacyclic(const int64_t* a, const int64_t* b, size_t n, int64_t* out);
+// gen_trapdoor_ring_lwe (gadget_ring.rs:62-81): a = [1 | a_bar | g_j - (a_bar r_j + e_j)] mod (X^n+1, q); a: (k+2) x n
+void ring_assemble_a(const psf_gadget_params& gp, const uint64_t* a_bar, const int64_t* r, const int64_t* e, uint64_t* a);
+// coefficient embedding of gen_short_basis_for_trapdoor_ring (short_basis_ring.rs:64-166), transposed: row c = column c
+psf_status ring_short_basis_t(const psf_gadget_params& gp, const uint64_t* a, const int64_t* r, const int64_t* e, std::vector<int32_t>& basis_t);
+// rot^-(iota(a)) (gpv_ring.rs:172-178, rotation_matrix.rs:85-96): n x n(k+2) over Z_q
+void ring_embed_a(const uint64_t* a, size_t n, size_t K, uint64_t q, std::vector<uint64_t>& A_emb);
+
 }  // namespace psf

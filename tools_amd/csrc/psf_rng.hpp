@@ -102,7 +102,7 @@ inline SampleZParams make_sample_z_params(double s) {
 // [c - ceil(6s), c + floor(6s)], accepted with probability exp(-pi (x-c)^2 / s^2).  Attempt t of sample
 // (tag, index, coord) always consumes Philox block (coord, index_lo, t, tag|index_hi), so the result is the
 // first accepted attempt no matter how lanes are scheduled.  *fail is OR-ed with 1 if the cap is hit.
-__device__ inline long long sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center,
+__host__ __device__ inline long long sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center,
                                      const SampleZParams sp, int* fail) {
   const long long lo = (long long)ceil(center) - sp.c6;
   const long long hi = (long long)floor(center) + sp.f6;

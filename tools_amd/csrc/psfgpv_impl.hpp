@@ -259,3 +259,125 @@ psf_status psfgpv_get_timing(psfgpv_handle* g, double* solve_ms, double* nearest
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PSFGPVRing (gpv_ring.rs:62-67, impl PSF :69-284): ring key material on the host, then the embedded PSFGPV machinery.
+// ---------------------------------------------------------------------------------------------------------------------
+struct psfring_handle {
+  psfgpv_handle* g = nullptr;          // n x d system with d = n(k+2) (gadget parameters n, k, m_bar' = 2n)
+  psf_gadget_params gp;                // ring parameters (m_bar = k + 2)
+  double s_td = 0;
+  std::vector<uint64_t> a;             // (k+2) x n
+  std::vector<int64_t> r, e;           // k x n
+};
+
+static psf_status ring_install(psfring_handle* h) {
+  const size_t n = h->gp.n, K = h->gp.k + 2;
+  std::vector<int32_t> bt;
+  const psf_status rc = ring_short_basis_t(h->gp, h->a.data(), h->r.data(), h->e.data(), bt);   // gpv_ring.rs:169
+  if (rc != PSF_OK) return rc;
+  std::vector<uint64_t> A_emb;
+  ring_embed_a(h->a.data(), n, K, h->gp.q, A_emb);                                               // gpv_ring.rs:172-178
+  psfgpv_handle* g = h->g;
+  psfp_handle* b = g->base;
+  HIP_TRY(hipSetDevice(b->prm.device));
+  g->has_key = false;
+  HIP_TRY(hipMemcpy(b->dA, A_emb.data(), A_emb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  split_A(b);
+  HIP_TRY(hipMemcpy(g->dSt, bt.data(), bt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  psf_status rc2 = gpv_finish_basis(g, true);           // GSO of the embedded basis (inside MatPolyOverZ::sample_d, gpv_ring.rs:205)
+  if (rc2 != PSF_OK) return rc2;
+  rc2 = gpv_build_solver(g);                            // gpv_ring.rs:180-185
+  if (rc2 != PSF_OK) return rc2;
+  b->has_key = true;
+  g->has_key = true;
+  return PSF_OK;
+}
+
+extern "C" {
+
+psf_status psfring_create(const psfring_params* prm, psfring_handle** out) {
+  if (!prm || !out || !(prm->s > 0.0) || !(prm->s_td > 0.0)) return PSF_ERR_PARAM;
+  const psf_gadget_params& gp = prm->gp;
+  if (gp.n < 1 || gp.k < 1 || gp.q <= 1 || gp.q >= (1ull << 31)) return gp.q >= (1ull << 31) ? PSF_ERR_UNSUPPORTED : PSF_ERR_PARAM;
+  psfgpv_params gpvp;
+  gpvp.gp = psf_gadget_params{gp.n, gp.k, 2 * gp.n, gp.base, gp.q};
+  gpvp.s = prm->s; gpvp.device = prm->device; gpvp.flags = 0;
+  psfgpv_handle* g = nullptr;
+  const psf_status rc = psfgpv_create(&gpvp, &g);
+  if (rc != PSF_OK) return rc;
+  psfring_handle* h = new psfring_handle();
+  h->g = g; h->gp = gp; h->s_td = prm->s_td;
+  *out = h;
+  return PSF_OK;
+}
+
+void psfring_destroy(psfring_handle* h) {
+  if (!h) return;
+  psfgpv_destroy(h->g);
+  delete h;
+}
+
+// gpv_ring.rs:91-98 + gen_trapdoor_ring_lwe (gadget_ring.rs:62-81); r, e <- SampleZ(s_td) (trapdoor_distribution.rs:112-122)
+psf_status psfring_trap_gen(psfring_handle* h, uint64_t seed) {
+  if (!h) return PSF_ERR_PARAM;
+  const size_t n = h->gp.n, k = h->gp.k;
+  const SampleZParams sp = make_sample_z_params(h->s_td);
+  h->r.assign(k * n, 0); h->e.assign(k * n, 0); h->a.assign((k + 2) * n, 0);
+  int fail = 0;
+  for (size_t j = 0; j < k; ++j)
+    for (size_t c = 0; c < n; ++c) {
+      h->r[j * n + c] = sample_z(seed, TAG_RING_R, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);
+      h->e[j * n + c] = sample_z(seed, TAG_RING_E, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);
+    }
+  if (fail) return PSF_ERR_SAMPLER;
+  std::vector<uint64_t> a_bar(n);
+  for (size_t c = 0; c < n; ++c) a_bar[c] = uniform_mod(seed, TAG_RING_A, (uint32_t)c, 0, h->gp.q);   // gpv_ring.rs:92-94
+  ring_assemble_a(h->gp, a_bar.data(), h->r.data(), h->e.data(), h->a.data());
+  return ring_install(h);
+}
+
+psf_status psfring_load_key(psfring_handle* h, const uint64_t* a, const int64_t* r, const int64_t* e) {
+  if (!h || !a || !r || !e) return PSF_ERR_PARAM;
+  const size_t n = h->gp.n, k = h->gp.k;
+  h->a.assign(a, a + (k + 2) * n);
+  h->r.assign(r, r + k * n);
+  h->e.assign(e, e + k * n);
+  return ring_install(h);
+}
+
+psf_status psfring_export_key(const psfring_handle* h, uint64_t* a, int64_t* r, int64_t* e, int32_t* basis_t, double* gso_t) {
+  if (!h) return PSF_ERR_PARAM;
+  if (!h->g->has_key) return PSF_ERR_NO_KEY;
+  if (a) std::memcpy(a, h->a.data(), h->a.size() * sizeof(uint64_t));
+  if (r) std::memcpy(r, h->r.data(), h->r.size() * sizeof(int64_t));
+  if (e) std::memcpy(e, h->e.data(), h->e.size() * sizeof(int64_t));
+  return psfgpv_export_key(h->g, nullptr, nullptr, basis_t, gso_t);
+}
+
+psf_status psfring_samp_d(psfring_handle* h, uint64_t seed, uint64_t first_index, size_t B, int64_t* sigma) {
+  return h ? psfgpv_samp_d(h->g, seed, first_index, B, sigma) : PSF_ERR_PARAM;
+}
+psf_status psfring_samp_p(psfring_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* sigma) {
+  return h ? psfgpv_samp_p(h->g, seed, first_index, B, u, sigma) : PSF_ERR_PARAM;
+}
+psf_status psfring_samp_p_dev(psfring_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_sigma, void* stream) {
+  return h ? psfgpv_samp_p_dev(h->g, seed, first_index, B, d_u, d_sigma, stream) : PSF_ERR_PARAM;
+}
+psf_status psfring_f_a(psfring_handle* h, size_t B, const int64_t* sigma, uint64_t* u) {
+  return h ? psfgpv_f_a(h->g, B, sigma, u) : PSF_ERR_PARAM;
+}
+psf_status psfring_f_a_dev(psfring_handle* h, size_t B, const int64_t* d_sigma, uint64_t* d_u, uint8_t* d_ok, void* stream) {
+  return h ? psfgpv_f_a_dev(h->g, B, d_sigma, d_u, d_ok, stream) : PSF_ERR_PARAM;
+}
+psf_status psfring_check_domain(psfring_handle* h, size_t B, const int64_t* sigma, size_t len, uint8_t* ok) {
+  return h ? psfgpv_check_domain(h->g, B, sigma, len, ok) : PSF_ERR_PARAM;
+}
+psf_status psfring_uniform_targets_dev(psfring_handle* h, uint64_t seed, uint64_t first_index, size_t B, uint64_t* d_u, void* stream) {
+  return h ? psfgpv_uniform_targets_dev(h->g, seed, first_index, B, d_u, stream) : PSF_ERR_PARAM;
+}
+psf_status psfring_last_status(psfring_handle* h) { return h ? psfgpv_last_status(h->g) : PSF_ERR_PARAM; }
+psf_status psfring_enable_timing(psfring_handle* h, int on) { return h ? psfgpv_enable_timing(h->g, on) : PSF_ERR_PARAM; }
+psf_status psfring_get_timing(psfring_handle* h, double* a, double* b) { return h ? psfgpv_get_timing(h->g, a, b) : PSF_ERR_PARAM; }
+
+}  // extern "C"

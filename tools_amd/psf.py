@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import GadgetParams, GpvParams, PsfpParams, PsfError, check, lib
+from ._ffi import GadgetParams, GpvParams, PsfpParams, RingParams, PsfError, check, lib
 
 
 def _p(a, t):
@@ -36,6 +36,17 @@ class GadgetParameters:
 
     def __repr__(self):
         return f"GadgetParameters(n={self.n}, k={self.k}, m_bar={self.m_bar}, base={self.base}, q={self.q})"
+
+
+class GadgetParametersRing(GadgetParameters):
+    """gadget_parameters.rs:73-81; modulus polynomial X^n + 1 (common_moduli.rs:41-48), distribution SampleZ."""
+
+    @classmethod
+    def init_default(cls, n, q):
+        """GadgetParametersRing::init_default (gadget_parameters.rs:165-185)."""
+        c = GadgetParams()
+        check(lib().psf_gadget_params_ring_default(C.c_uint64(n), C.c_uint64(q), C.byref(c)), "init_default")
+        return cls(c.n, c.k, c.m_bar, c.base, c.q)
 
 
 class PSFPerturbation:
@@ -272,4 +283,118 @@ class PSFGPV:
     def get_timing(self):
         a, b = C.c_double(0), C.c_double(0)
         check(lib().psfgpv_get_timing(self._h, C.byref(a), C.byref(b)), "get_timing")
+        return {"k_gpv_solve": a.value, "k_gpv_nearest_plane": b.value}
+
+
+class PSFGPVRing:
+    """gpv_ring.rs:62-67 / impl PSF :69-284 on one MI355X.  Polynomials are coefficient rows (constant term first):
+    a: (k+2) x n, r / e: k x n, domain elements: (k+2) x n, range elements: n."""
+
+    def __init__(self, gp, s, s_td, device=0):
+        self.gp, self.s, self.s_td, self.device = gp, float(s), float(s_td), device
+        prm = RingParams(gp.c, self.s, self.s_td, device, 0)
+        h = C.c_void_p()
+        check(lib().psfring_create(C.byref(prm), C.byref(h)), "PSFGPVRing")
+        self._h = h
+        self._destroy = lib().psfring_destroy
+        self.n, self.k = gp.n, gp.k
+        self.K = gp.k + 2
+        self.d = self.n * self.K
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def trap_gen(self, seed=0):
+        """gpv_ring.rs:91-98.  Returns (a, (r, e))."""
+        check(lib().psfring_trap_gen(self._h, C.c_uint64(seed)), "trap_gen")
+        a, r, e, _, _ = self.export_key(basis=False)
+        return a, (r, e)
+
+    def load_key(self, a, r, e):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        r = np.ascontiguousarray(r, dtype=np.int64)
+        e = np.ascontiguousarray(e, dtype=np.int64)
+        assert a.shape == (self.K, self.n) and r.shape == (self.k, self.n) and e.shape == (self.k, self.n)
+        check(lib().psfring_load_key(self._h, _p(a, C.c_uint64), _p(r, C.c_int64), _p(e, C.c_int64)), "load_key")
+
+    def export_key(self, basis=True):
+        a = np.zeros((self.K, self.n), dtype=np.uint64)
+        r = np.zeros((self.k, self.n), dtype=np.int64)
+        e = np.zeros((self.k, self.n), dtype=np.int64)
+        bt = np.zeros((self.d, self.d), dtype=np.int32) if basis else None
+        gt = np.zeros((self.d, self.d), dtype=np.float64) if basis else None
+        check(lib().psfring_export_key(self._h, _p(a, C.c_uint64), _p(r, C.c_int64), _p(e, C.c_int64),
+                                       _p(bt, C.c_int32) if basis else None, _p(gt, C.c_double) if basis else None), "export_key")
+        return a, r, e, bt, gt
+
+    def samp_d(self, seed=0, B=None, first_index=0):
+        """gpv_ring.rs:118-122"""
+        nb = 1 if B is None else B
+        sg = np.zeros((nb, self.K, self.n), dtype=np.int64)
+        check(lib().psfring_samp_d(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(nb), _p(sg, C.c_int64)), "samp_d")
+        return sg[0] if B is None else sg
+
+    def samp_p(self, u, seed=0, first_index=0):
+        """gpv_ring.rs:160-212; u: n coefficients (or B x n)."""
+        u = np.ascontiguousarray(u, dtype=np.uint64)
+        single = u.ndim == 1
+        u2 = u.reshape(-1, self.n)
+        B = u2.shape[0]
+        sg = np.zeros((B, self.K, self.n), dtype=np.int64)
+        check(lib().psfring_samp_p(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64),
+                                   _p(sg, C.c_int64)), "samp_p")
+        return sg[0] if single else sg
+
+    def f_a(self, sigma):
+        """gpv_ring.rs:243-247"""
+        sigma = np.ascontiguousarray(sigma, dtype=np.int64)
+        if sigma.shape[-2:] != (self.K, self.n) or sigma.ndim > 3:
+            raise PsfError(_ffi.ERR_DOMAIN, "f_a")
+        single = sigma.ndim == 2
+        s2 = sigma.reshape(-1, self.d)
+        u = np.zeros((s2.shape[0], self.n), dtype=np.uint64)
+        check(lib().psfring_f_a(self._h, C.c_size_t(s2.shape[0]), _p(s2, C.c_int64), _p(u, C.c_uint64)), "f_a")
+        return u[0] if single else u
+
+    def check_domain(self, sigma):
+        """gpv_ring.rs:274-283: column vector of k+2 polynomials with |iota(sigma)|^2 <= s^2 n (k+2)."""
+        sigma = np.ascontiguousarray(sigma, dtype=np.int64)
+        if sigma.ndim == 2:
+            if sigma.shape[1] != self.n:
+                return False
+            s2 = sigma.reshape(1, -1)
+            single = True
+        else:
+            s2 = sigma.reshape(sigma.shape[0], -1)
+            single = False
+        ok = np.zeros(s2.shape[0], dtype=np.uint8)
+        check(lib().psfring_check_domain(self._h, C.c_size_t(s2.shape[0]), _p(s2, C.c_int64), C.c_size_t(s2.shape[1]),
+                                         _p(ok, C.c_uint8)), "check_domain")
+        return bool(ok[0]) if single else ok.astype(bool)
+
+    def samp_p_dev(self, d_u_ptr, d_sigma_ptr, B, seed=0, first_index=0, stream=None):
+        check(lib().psfring_samp_p_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), C.c_void_p(d_u_ptr),
+                                       C.c_void_p(d_sigma_ptr), C.c_void_p(stream or 0)), "samp_p_dev")
+
+    def f_a_dev(self, d_sigma_ptr, d_u_ptr, d_ok_ptr, B, stream=None):
+        check(lib().psfring_f_a_dev(self._h, C.c_size_t(B), C.c_void_p(d_sigma_ptr), C.c_void_p(d_u_ptr), C.c_void_p(d_ok_ptr),
+                                    C.c_void_p(stream or 0)), "f_a_dev")
+
+    def uniform_targets_dev(self, d_u_ptr, B, seed=0, first_index=0, stream=None):
+        check(lib().psfring_uniform_targets_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B),
+                                                C.c_void_p(d_u_ptr), C.c_void_p(stream or 0)), "uniform_targets_dev")
+
+    def last_status(self):
+        return lib().psfring_last_status(self._h)
+
+    def enable_timing(self, on=True):
+        check(lib().psfring_enable_timing(self._h, C.c_int(1 if on else 0)), "enable_timing")
+
+    def get_timing(self):
+        a, b = C.c_double(0), C.c_double(0)
+        check(lib().psfring_get_timing(self._h, C.byref(a), C.byref(b)), "get_timing")
         return {"k_gpv_solve": a.value, "k_gpv_nearest_plane": b.value}
