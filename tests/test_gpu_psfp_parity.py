@@ -15,6 +15,9 @@ CONFIGS = [  # (n, q, r, s) -- reference test / doc sizes: mp_perturbation.rs:43
     (10, 128, np.log2(10), 40.0),
     (15, 157, np.log2(15), 40.0),   # prime modulus: S_k carries the digit column of q
     (8, 128, 3.0, 30.0),
+    (4, 2**60, 2.0, 70.0),          # C5's modulus: two-limb / 8-digit Z_q arithmetic, k = 60 gadget
+    (3, 2**61 - 1, 2.0, 70.0),      # large prime modulus: digit column in S_k, wide non-power-of-two reduction
+    (4, 1073741789, 2.0, 50.0),     # C3's prime alternative
     (8, 64, 100.0, 25.0),           # wide gadget Gaussian: |z| > 127 occurs, exercising the hi byte plane of z
 ]
 

@@ -1,6 +1,5 @@
 // psfp.hip -- PSFPerturbation behind the C ABI of include/psf_mi355x.h (mp_perturbation.rs:57-62, :193-403).
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +10,7 @@
 #include "psf_host.hpp"
 #include "psf_kernels.hpp"
 #include "psf_gpv_kernels.hpp"
+#include "psf_chol_kernels.hpp"
 
 #define PSFP_FLAG_NO_PERTURB 1u   // internal: handle used as the Z_q / f_a engine of PSFGPV(Ring); no sqrt(Sigma_2) buffers
 
@@ -31,35 +31,6 @@ static inline unsigned grid_for(size_t total, unsigned block = 256, unsigned cap
   return (unsigned)(g > cap ? cap : g);
 }
 static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-// ---- Cholesky through rocSOLVER, loaded lazily (setup path only; own blocked factorisation is DESIGN.md "next") ----
-namespace {
-struct RocSolver {
-  void* h_blas = nullptr; void* h_solver = nullptr; void* handle = nullptr;
-  int (*create)(void**) = nullptr;
-  int (*destroy)(void*) = nullptr;
-  int (*set_stream)(void*, hipStream_t) = nullptr;
-  int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
-  bool ok = false;
-  bool load() {
-    if (ok) return true;
-    h_blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h_blas) h_blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    h_solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h_solver) h_solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h_blas || !h_solver) { std::fprintf(stderr, "[psf_mi355x] cannot load rocblas/rocsolver: %s\n", dlerror()); return false; }
-    create = (int (*)(void**))dlsym(h_blas, "rocblas_create_handle");
-    destroy = (int (*)(void*))dlsym(h_blas, "rocblas_destroy_handle");
-    set_stream = (int (*)(void*, hipStream_t))dlsym(h_blas, "rocblas_set_stream");
-    dpotrf = (int (*)(void*, int, int, double*, int, int*))dlsym(h_solver, "rocsolver_dpotrf");
-    if (!create || !destroy || !set_stream || !dpotrf) return false;
-    if (create(&handle) != 0) return false;
-    ok = true;
-    return true;
-  }
-};
-RocSolver g_rocsolver;
-}  // namespace
 
 struct TimingSlot { std::string name; hipEvent_t e0, e1; };
 
@@ -296,6 +267,8 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   HIP_TRY(hipMemcpy(h->dGvec, gvec.data(), h->k * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
   if (const char* env = std::getenv("PSF_SLICES")) h->slices = (size_t)std::atoi(env);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, CH_NB * (CH_NB + 1) * 8));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB * (CH_NB + 1) / 2 + CH_NB * 64) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   *out = h;
@@ -330,17 +303,24 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov) {
   const unsigned tiles = (unsigned)((m + 63) / 64);
   hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, dS, m);
   HIP_TRY(hipGetLastError());
-  if (!g_rocsolver.load()) { hipFree(dS); return PSF_ERR_HIP; }
+  // blocked right-looking Cholesky of the lower triangle, panel width 128 (psf_chol_kernels.hpp)
   int* dinfo = nullptr;
   HIP_TRY(hipMalloc(&dinfo, sizeof(int)));
-  g_rocsolver.set_stream(g_rocsolver.handle, nullptr);
-  // our row-major lower triangle is the column-major UPPER triangle of the same symmetric matrix (rocblas_fill_upper = 121):
-  // potrf(upper) leaves U with Sigma_2 = U^t U, and U read row-major is exactly L.
-  const int rc = g_rocsolver.dpotrf(g_rocsolver.handle, 121, (int)m, dS, (int)m, dinfo);
+  HIP_TRY(hipMemset(dinfo, 0, sizeof(int)));
+  for (size_t off = 0; off < m; off += CH_NB) {
+    const int nb = (int)(m - off < (size_t)CH_NB ? m - off : (size_t)CH_NB);
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), (size_t)nb * (CH_NB + 1) * sizeof(double), 0, dS, m, off, nb, dinfo);
+    const size_t rest = m - off - nb;
+    if (rest == 0) break;
+    const size_t trsm_lds = ((size_t)nb * (nb + 1) / 2 + (size_t)nb * 64) * sizeof(double);
+    hipLaunchKernelGGL(k_chol_trsm, dim3((unsigned)((rest + 63) / 64)), dim3(64), trsm_lds, 0, dS, m, off, nb, m, dinfo);
+    const size_t nt = (rest + 127) / 128;
+    hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 2 * 4096 * sizeof(double), 0, dS, m, off, m, (int)nt, dinfo);
+  }
+  HIP_TRY(hipGetLastError());
   int info = -1;
   HIP_TRY(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));
   hipFree(dinfo);
-  if (rc != 0) { hipFree(dS); return PSF_ERR_HIP; }
   if (info != 0) { hipFree(dS); return PSF_ERR_NOT_PD; }            // mp_perturbation.rs:109-110
   hipLaunchKernelGGL(k_repack_L<false>, dim3(grid_for(tr_total_chunks(h->nbi) * TR_CHUNK)), dim3(256), 0, 0, dS, m, m, h->dLt, h->nbi);
   HIP_TRY(hipGetLastError());
