@@ -28,6 +28,8 @@ CONFIGS = {
     "c3prime": ("PSFPerturbation", 512, 1073741789, 9.0, 512.0, 4096),
     "bench64": ("PSFPerturbation", 64, 128, 6.0, 100.0, 4096),     # benches/psf.rs:78-93
     "c1": ("PSFPerturbation", 8, 64, 3.0, 25.0, 1),                 # README.md:62-66
+    "c2": ("PSFGPV", 256, 3329, None, 1024.0, 1024),                # BASELINE.json configs[1]
+    "c4": ("PSFGPVRing", 256, 3329, None, 0.0, 4096),               # BASELINE.json configs[3]; s = compute_s(256), gpv_ring.rs:296-298
 }
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix; measured 77.3 by tools/probe_mfma_f64.hip (profiles/r01_probe_mfma_f64.log)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
@@ -69,15 +71,28 @@ def main():
 
     scheme, n, q, r, s, batch = CONFIGS[args.config]
     B = args.batch or batch
-    gp = T.GadgetParameters.init_default(n, q)
-    psf = T.PSFPerturbation(gp, r, s, device=local_rank)
     key_seed = 3
     t0 = time.time()
     from tools_amd._ffi import lib, check
-    check(lib().psfp_trap_gen(psf._h, C.c_uint64(key_seed)), "trap_gen")   # every rank: same seed -> same key
+    if scheme == "PSFPerturbation":
+        gp = T.GadgetParameters.init_default(n, q)
+        psf = T.PSFPerturbation(gp, r, s, device=local_rank)
+        check(lib().psfp_trap_gen(psf._h, C.c_uint64(key_seed)), "trap_gen")   # every rank: same seed -> same key
+        m = psf.m
+    elif scheme == "PSFGPV":
+        gp = T.GadgetParameters.init_default(n, q)
+        psf = T.PSFGPV(gp, s, device=local_rank)
+        psf.trap_gen(key_seed, export=False)
+        m = psf.m
+    else:
+        import math
+        s = s or ((2 * 2 * 1.005 * math.sqrt(n) + 1) * 2) * 4               # compute_s, gpv_ring.rs:296-298
+        gp = T.GadgetParametersRing.init_default(n, q)
+        psf = T.PSFGPVRing(gp, s, 1.005, device=local_rank)
+        check(lib().psfring_trap_gen(psf._h, C.c_uint64(key_seed)), "trap_gen")
+        m = psf.d
     torch.cuda.synchronize()
     t_trapgen = time.time() - t0
-    m = psf.m
 
     stream = torch.cuda.current_stream().cuda_stream
     from tools_amd.shard import shard_range, gather_rows
@@ -114,7 +129,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     # per-kernel HIP-event times of the last step (events were recorded on the launch stream, no host sync in the loop)
-    for nm, ms in psf.get_timing():
+    tm = psf.get_timing()
+    for nm, ms in (tm.items() if isinstance(tm, dict) else tm):
         kern_ms[nm] = ms
     psf.enable_timing(False)
     status = psf.last_status()
@@ -155,7 +171,7 @@ def main():
         if args.config != "c3":
             out["metric"] = f"preimages/sec for samp_p ({args.config})"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(psf, n, q, r, s, u, e, first_index, 1000 + args.warmup + args.steps - 1, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, 1000 + args.warmup + args.steps - 1, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -175,23 +191,38 @@ def load_traffic(config, B):
         return None
 
 
-def cpu_baseline(psf, n, q, r, s, u, e, first_index, seed, sample):
+def cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, seed, sample):
     """The CPU oracle (oracle/psf_oracle.c, a port: the Rust/FLINT reference cannot be built here) timed on this host
     on a bounded sample of the same workload, same key, same seed; its output must equal the GPU's rows."""
     import numpy as np
     from oracle import oracle as O
     O.build()
     threads = O.num_threads()
-    S = sample or min(u.shape[0], 32 * threads)
-    A, (R, Lp, _) = psf.export_key()
-    orc = O.PSFPerturbation(O.gadget_params_default(n, q), r, s)
-    orc.load_key(A, R, Lp)
-    del A, R, Lp
+    if scheme == "PSFPerturbation":
+        S = sample or min(u.shape[0], 16 * threads)
+        A, (R, Lp, _) = psf.export_key()
+        orc = O.PSFPerturbation(O.gadget_params_default(n, q), r, s)
+        orc.load_key(A, R, Lp)
+        del A, R, Lp
+        how = "OpenMP over groups of 16"
+    elif scheme == "PSFGPV":
+        S = sample or min(u.shape[0], 8 * threads)
+        A, (bt, gt) = psf.export_key()
+        orc = O.PSFGPV(O.gadget_params_default(n, q), s)
+        orc.load_key(A, bt, gt)
+        del A, bt, gt
+        how = "OpenMP over preimages, elimination factored once per key"
+    else:
+        S = sample or min(u.shape[0], 8 * threads)
+        a, rr, ee, bt, gt = psf.export_key()
+        orc = O.PSFGPVRing(O.gadget_params_ring_default(n, q), s, 1.005)
+        orc.load_key(a, rr, ee, gso_t=gt)
+        how = "OpenMP over preimages, basis / elimination / GSO once per key"
     uh = u[:S].cpu().numpy().astype(np.uint64)
     t0 = time.perf_counter()
     e_cpu = orc.samp_p(seed, uh, first_index=first_index, nthreads=threads)
     dt = time.perf_counter() - t0
-    same = bool((e_cpu == e[:S].cpu().numpy()).all())
+    same = bool((e_cpu.reshape(S, -1) == e[:S].cpu().numpy()).all())
     model = ""
     try:
         with open("/proc/cpuinfo") as fh:
@@ -202,7 +233,7 @@ def cpu_baseline(psf, n, q, r, s, u, e, first_index, seed, sample):
     except Exception:
         pass
     return {"value": round(S / dt, 3), "unit": "preimages/s", "cores": threads, "kind": "port",
-            "sample": f"{S} of the batch's preimages (same key, seed and targets), {dt:.1f} s wall, OpenMP over groups of 16",
+            "sample": f"{S} of the batch's preimages (same key, seed and targets), {dt:.1f} s wall, {how}",
             "cpu": model, "matches_gpu_bitwise": same}
 
 
