@@ -107,9 +107,8 @@ __global__ void k_export_normals(const double* __restrict__ Dt, size_t m, size_t
 //
 // Workgroup order: heavy row-blocks first; blocks that share an XCD (blockIdx % 8) walk an 8 x 8 super-tile of
 // (row-block, column-block) pairs so that each staged chunk is reused from that XCD's L2.
-__device__ inline void tr_map_block(unsigned id, int nbi, int nbj, int* bi, int* bj) {
-  // super-tiles of GR x GC blocks, enumerated with row groups descending
-  constexpr int GR = 8, GC = 8;
+__device__ inline void tr_map_block(unsigned id, int nbi, int nbj, int GR, int GC, int* bi, int* bj) {
+  // super-tiles of GR x GC blocks (GR * GC = 64), enumerated with row groups descending
   const int ncg = (nbj + GC - 1) / GC, nrg = (nbi + GR - 1) / GR;
   const unsigned xcd = id & 7u, slot = id >> 3;
   const unsigned group = (slot / (GR * GC)) * 8u + xcd;
@@ -119,21 +118,21 @@ __device__ inline void tr_map_block(unsigned id, int nbi, int nbj, int* bi, int*
   *bj = cg * GC + (int)(t % GC);
   if (rg < 0) *bi = -1;
 }
-__host__ inline unsigned tr_grid_size(int nbi, int nbj) {
-  const int ncg = (nbj + 7) / 8, nrg = (nbi + 7) / 8;
+__host__ inline unsigned tr_grid_size(int nbi, int nbj, int GR = 8, int GC = 8) {
+  const int ncg = (nbj + GC - 1) / GC, nrg = (nbi + GR - 1) / GR;
   const unsigned groups = (unsigned)(ncg * nrg);
   const unsigned rounds = (groups + 7) / 8;
   return rounds * 8u * 64u;
 }
 
 __global__ __launch_bounds__(256, 2) void k_trmm_f64(const double* __restrict__ Lt, const double* __restrict__ Dt,
-                                                     double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx) {
+                                                     double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx, int GR, int GC) {
   // LDS: 2 stages x (A chunk 2048 doubles | B chunk 2048 doubles); filled by LDS-DMA (global_load_lds_dwordx4), no
   // staging registers: the accumulators (128 VGPRs) leave no room to hold a chunk in flight (hipcc serialised
   // register-staged prefetch loads behind vmcnt(0) waits).
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int bi, bj;
-  tr_map_block(blockIdx.x, nbi, nbj, &bi, &bj);
+  tr_map_block(blockIdx.x, nbi, nbj, GR, GC, &bi, &bj);
   if (bi < 0 || bi >= nbi || bj >= nbj) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

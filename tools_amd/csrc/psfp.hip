@@ -465,8 +465,10 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
     {  // x = sqrt(Sigma_2) d
       ScopedTimer t(h, st, "k_trmm_f64");
-      hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbi, (int)nbj)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
-                         h->dLt, Dt, h->dX + boff, (int)h->nbi, (int)nbj, h->nkb, ld);
+      int GR = 8, GC = 8;
+      if (const char* env = std::getenv("PSF_TRMM_GROUP")) { GR = std::atoi(env); if (GR < 1 || 64 % GR) GR = 8; GC = 64 / GR; }
+      hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbi, (int)nbj, GR, GC)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
+                         h->dLt, Dt, h->dX + boff, (int)h->nbi, (int)nbj, h->nkb, ld, GR, GC);
     }
     hipStream_t s2 = st;
     if (S > 1) {
