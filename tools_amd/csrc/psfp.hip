@@ -60,6 +60,15 @@ struct psfp_handle {
   int8_t* dP8 = nullptr;                      // three digit planes of P, [K_pad/16][ld][16] each
   uint64_t* dU = nullptr; int64_t* dE = nullptr; uint8_t* dOk = nullptr;
   int* dFail = nullptr;
+  // Two sets of the per-batch intermediates: consecutive samp_p calls alternate between them so that the sampling
+  // stages of call i (stream aux) overlap the normals + FP64 product of call i+1 (stream s1).
+  struct BatchSet { double* dDt = nullptr; double* dX = nullptr; int32_t* dP = nullptr; int8_t* dP8 = nullptr; uint64_t* dV = nullptr;
+                    int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; int* dFail = nullptr; } sets[2];
+  int32_t* dPf = nullptr; int8_t* dP8f = nullptr;   // scratch of f_a (kept apart from the pipelined sets)
+  bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
+  size_t ncall = 0;
+  hipStream_t s1 = nullptr;
+  hipEvent_t evT[2] = {nullptr, nullptr}, evP[2] = {nullptr, nullptr}, evIn = nullptr;
   hipStream_t last_stream = nullptr;
   hipStream_t aux = nullptr;                 // second stream for the per-slice sampling stages
   std::vector<hipEvent_t> slice_events;
@@ -71,10 +80,19 @@ struct psfp_handle {
 
 static size_t gadget_lds_bytes(size_t k) { return k * k * 8 + k * 8 + k * sizeof(SampleZParams) + k * k * 4 + k * 256 * 4; }
 
+static void select_set(psfp_handle* h, int i) {
+  const auto& t = h->sets[i];
+  h->dDt = t.dDt; h->dX = t.dX; h->dP = t.dP; h->dP8 = t.dP8; h->dV = t.dV; h->dZlo = t.dZlo; h->dZhi = t.dZhi; h->dFail = t.dFail;
+}
+
 static void free_batch(psfp_handle* h) {
-  hipFree(h->dDt); hipFree(h->dX); hipFree(h->dP); hipFree(h->dV); hipFree(h->dZlo); hipFree(h->dZhi); hipFree(h->dP8);
-  hipFree(h->dU); hipFree(h->dE); hipFree(h->dOk);
-  h->dDt = h->dX = nullptr; h->dP = nullptr; h->dV = nullptr; h->dZlo = h->dZhi = nullptr; h->dP8 = nullptr; h->dU = nullptr; h->dE = nullptr; h->dOk = nullptr;
+  for (auto& t : h->sets) {
+    hipFree(t.dDt); hipFree(t.dX); hipFree(t.dP); hipFree(t.dP8); hipFree(t.dV); hipFree(t.dZlo); hipFree(t.dZhi);
+    t.dDt = t.dX = nullptr; t.dP = nullptr; t.dP8 = nullptr; t.dV = nullptr; t.dZlo = t.dZhi = nullptr;
+  }
+  hipFree(h->dPf); hipFree(h->dP8f); hipFree(h->dU); hipFree(h->dE); hipFree(h->dOk);
+  h->dPf = nullptr; h->dP8f = nullptr; h->dU = nullptr; h->dE = nullptr; h->dOk = nullptr;
+  select_set(h, 0);
   h->Bcap = 0;
 }
 
@@ -83,25 +101,34 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
     h->nbj = round_up(B, TR_BN) / TR_BN;
     return PSF_OK;
   }
+  HIP_TRY(hipDeviceSynchronize());
   free_batch(h);
   const size_t ld = round_up(B, TR_BN);
   h->ld = ld;
   h->nbj = ld / TR_BN;
-  if (!(h->prm.flags & PSFP_FLAG_NO_PERTURB)) {
-    HIP_TRY(hipMalloc(&h->dDt, ld / TR_BN * h->nkb * TR_CHUNK * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->dX, h->M_pad * ld * sizeof(double)));
+  const bool perturb = !(h->prm.flags & PSFP_FLAG_NO_PERTURB);
+  const int nsets = (perturb && h->pipeline) ? 2 : 1;
+  for (int i = 0; i < nsets; ++i) {
+    auto& t = h->sets[i];
+    if (perturb) {
+      HIP_TRY(hipMalloc(&t.dDt, ld / TR_BN * h->nkb * TR_CHUNK * sizeof(double)));
+      HIP_TRY(hipMalloc(&t.dX, h->M_pad * ld * sizeof(double)));
+      HIP_TRY(hipMalloc(&t.dP, h->M_pad * ld * sizeof(int32_t)));
+      HIP_TRY(hipMalloc(&t.dP8, 3 * h->K_pad * ld));
+      HIP_TRY(hipMalloc(&t.dV, h->n * ld * sizeof(uint64_t)));
+      HIP_TRY(hipMalloc(&t.dZlo, h->ldr * ld));      // [ldr/16][ld][16]
+      HIP_TRY(hipMalloc(&t.dZhi, h->ldr * ld));
+      HIP_TRY(hipMemset(t.dZlo, 0, h->ldr * ld));
+      HIP_TRY(hipMemset(t.dZhi, 0, h->ldr * ld));
+      HIP_TRY(hipMemset(t.dP, 0, h->M_pad * ld * sizeof(int32_t)));
+    }
   }
-  HIP_TRY(hipMalloc(&h->dP, h->M_pad * ld * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&h->dV, h->n * ld * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc(&h->dZlo, h->ldr * ld));      // [ldr/16][ld][16]
-  HIP_TRY(hipMalloc(&h->dZhi, h->ldr * ld));
-  HIP_TRY(hipMemset(h->dZlo, 0, h->ldr * ld));
-  HIP_TRY(hipMemset(h->dZhi, 0, h->ldr * ld));
-  HIP_TRY(hipMemset(h->dP, 0, h->M_pad * ld * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&h->dP8, 3 * h->K_pad * ld));
+  HIP_TRY(hipMalloc(&h->dPf, h->M_pad * ld * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&h->dP8f, 3 * h->K_pad * ld));
   HIP_TRY(hipMalloc(&h->dU, B * h->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dE, B * h->m * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&h->dOk, B));
+  select_set(h, 0);
   h->Bcap = B;
   return PSF_OK;
 }
@@ -244,8 +271,23 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   HIP_TRY(hipMalloc(&h->dR, h->mb_pad * h->ldr));
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dLt, tr_total_chunks(h->nbi) * TR_CHUNK * sizeof(double)));
-  HIP_TRY(hipMalloc(&h->dFail, 2 * sizeof(int)));      // [0] sampler failure, [1] some |z| > 127
-  HIP_TRY(hipMemset(h->dFail, 0, 2 * sizeof(int)));
+  for (auto& t : h->sets) {                             // [0] sampler failure, [1] some |z| > 127
+    HIP_TRY(hipMalloc(&t.dFail, 2 * sizeof(int)));
+    HIP_TRY(hipMemset(t.dFail, 0, 2 * sizeof(int)));
+  }
+  h->dFail = h->sets[0].dFail;
+  {  // the FP64 product gets the high-priority queue, the sampling stages the low one
+    int lo_prio = 0, hi_prio = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+    HIP_TRY(hipStreamCreateWithPriority(&h->s1, hipStreamNonBlocking, hi_prio));
+    HIP_TRY(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, lo_prio));
+  }
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&h->evT[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->evP[i], hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming));
+  if (const char* env = std::getenv("PSF_PIPELINE")) h->pipeline = std::atoi(env) != 0;
   // gadget part of the trapdoor: (S, S~) of mp_perturbation.rs:233-234, block form
   h->hSk = short_basis_gadget_block(gp);
   std::vector<double> norm2;
@@ -265,7 +307,6 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   HIP_TRY(hipMemcpy(h->dNorm2, norm2.data(), h->k * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dSz, sz.data(), h->k * sizeof(SampleZParams), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dGvec, gvec.data(), h->k * sizeof(uint64_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
   if (const char* env = std::getenv("PSF_SLICES")) h->slices = (size_t)std::atoi(env);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, CH_NB * (CH_NB + 1) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB * (CH_NB + 1) / 2 + CH_NB * 64) * 8));
@@ -282,7 +323,11 @@ void psfp_destroy(psfp_handle* h) {
   clear_slots(h);
   for (auto ev : h->slice_events) hipEventDestroy(ev);
   if (h->aux) hipStreamDestroy(h->aux);
-  hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dFail);
+  hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt);
+  for (auto& t : h->sets) hipFree(t.dFail);
+  if (h->s1) hipStreamDestroy(h->s1);
+  for (int i = 0; i < 2; ++i) { if (h->evT[i]) hipEventDestroy(h->evT[i]); if (h->evP[i]) hipEventDestroy(h->evP[i]); }
+  if (h->evIn) hipEventDestroy(h->evIn);
   hipFree(h->dA8);
   hipFree(h->dSk); hipFree(h->dGso); hipFree(h->dNorm2); hipFree(h->dSz); hipFree(h->dGvec);
   delete h;
@@ -345,13 +390,13 @@ static void split_A(psfp_handle* h) {
 }
 
 // out = (mode syndrome) U - A P  or  (mode f_a) A P, with P (K x ld int32) first cut into digit planes
-static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32_t* P, size_t ncols, const uint64_t* U, uint64_t* out, size_t ldo) {
+static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32_t* P, int8_t* P8, size_t ncols, const uint64_t* U, uint64_t* out, size_t ldo) {
   const size_t ld = h->ld;
-  hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * ld, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, h->dP8, h->dFail);
+  hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * ld, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, P8, h->dFail);
   dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64));
 #define ZQM(NA_)                                                                                                        \
   case NA_:                                                                                                             \
-    hipLaunchKernelGGL((k_zq_mfma<NA_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, mode, h->dA8, h->n, h->n_pad, h->K_pad, h->dP8, ld, ncols, \
+    hipLaunchKernelGGL((k_zq_mfma<NA_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, mode, h->dA8, h->n, h->n_pad, h->K_pad, P8, ld, ncols, \
                        h->zc, (int)h->wide, U, out, ldo);                                                               \
     break;
   switch (h->NA) { ZQM(1) ZQM(2) ZQM(3) ZQM(4) ZQM(5) ZQM(6) ZQM(7) ZQM(8) default: break; }
@@ -441,9 +486,20 @@ psf_status psfp_export_gadget_basis(const psfp_handle* h, int64_t* Sk, double* g
 static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, hipStream_t st) {
   const size_t ld = h->ld, m = h->m;
   if (h->timing) clear_slots(h);
-  hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
   const size_t nbj_total = h->nbj;
   size_t S = h->slices ? h->slices : 1;   // measured at C3: >1 slices lose (small per-slice grids), see profiles/r01_notes.md
+  // Pipelining across calls: normals + FP64 product on s1, sampling stages on aux, caller's stream joins at the end.
+  const bool pipe = h->pipeline && S == 1;
+  hipStream_t user_st = st;
+  int cur = 0;
+  if (pipe) {
+    cur = (int)(h->ncall++ & 1);
+    select_set(h, cur);
+    HIP_TRY(hipEventRecord(h->evIn, user_st));            // u is ready on the caller's stream from here on
+    HIP_TRY(hipStreamWaitEvent(h->s1, h->evP[cur], 0));   // the previous user of this buffer set has finished
+    st = h->s1;
+  }
+  hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
   if (S > nbj_total) S = nbj_total;
   const size_t per = (nbj_total + S - 1) / S;
   while (h->slice_events.size() < S + 1) {
@@ -475,26 +531,32 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       s2 = h->aux;
       HIP_TRY(hipEventRecord(h->slice_events[sl], st));
       HIP_TRY(hipStreamWaitEvent(s2, h->slice_events[sl], 0));
+    } else if (pipe) {
+      s2 = h->aux;
+      HIP_TRY(hipEventRecord(h->evT[cur], st));
+      HIP_TRY(hipStreamWaitEvent(s2, h->evT[cur], 0));
+      HIP_TRY(hipStreamWaitEvent(s2, h->evIn, 0));
     }
-    {  // p_i <- D_{Z,r,x_i}
+    static const int post_mask = std::getenv("PSF_POST_MASK") ? std::atoi(std::getenv("PSF_POST_MASK")) : 15;   // timing experiments only
+    if (post_mask & 1) {  // p_i <- D_{Z,r,x_i}
       ScopedTimer t(h, s2, "k_perturb_round");
       const size_t waves = (m * Bs + PR_SEG - 1) / PR_SEG;
       hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, seed, fi, m, Bs, ld, h->dX + boff, h->szR,
                          h->dP + boff, h->dFail);
     }
-    {  // mp_perturbation.rs:318 -- v = u - A p
+    if (post_mask & 2) {  // mp_perturbation.rs:318 -- v = u - A p
       ScopedTimer t(h, s2, "k_zq_matmul(syndrome)");
-      if (S == 1) launch_zq_mfma(h, s2, ZQ_SYNDROME, h->dP, Bs, d_u, h->dV, ld);
+      if (S == 1) launch_zq_mfma(h, s2, ZQ_SYNDROME, h->dP, h->dP8, Bs, d_u, h->dV, ld);
       else launch_zq(h, s2, ZQ_SYNDROME, h->dA, m, 0, h->n, m, h->dP + boff, false, ld, Bs, d_u + boff * h->n, h->dV + boff, ld, 0);
     }
-    {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
+    if (post_mask & 4) {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
       ScopedTimer t(h, s2, "k_gadget");
       const size_t k = h->k;
       GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
       hipLaunchKernelGGL(k_gadget, dim3((unsigned)((Bs + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(k), s2, seed, fi, (uint32_t)h->n,
                          (uint32_t)k, h->q, h->prm.gp.base, Bs, ld, h->dV + boff, tb, h->dZlo + boff * 16, h->dZhi + boff * 16, h->dFail);
     }
-    {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
+    if (post_mask & 8) {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
       ScopedTimer t(h, s2, "k_recombine");
       hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bs + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), 2 * RC_STAGE, s2, h->dR,
                          h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo + boff * 16, h->dZhi + boff * 16, ld, h->dFail, h->dP + boff, Bs, d_e + boff * m, m);
@@ -506,6 +568,11 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     HIP_TRY(hipEventRecord(h->slice_events[S], h->aux));
     HIP_TRY(hipStreamWaitEvent(st, h->slice_events[S], 0));
   }
+  if (pipe) {
+    HIP_TRY(hipEventRecord(h->evP[cur], h->aux));
+    HIP_TRY(hipStreamWaitEvent(user_st, h->evP[cur], 0));   // results of this call are ordered before later work on the caller's stream
+    st = user_st;
+  }
   HIP_TRY(hipGetLastError());
   h->last_stream = st;
   return PSF_OK;
@@ -514,9 +581,10 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
 psf_status psfp_last_status(psfp_handle* h) {
   if (!h) return PSF_ERR_PARAM;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
-  int f = 0;
-  HIP_TRY(hipMemcpy(&f, h->dFail, sizeof(int), hipMemcpyDeviceToHost));
-  return f ? PSF_ERR_SAMPLER : PSF_OK;
+  int f = 0, f2 = 0;
+  HIP_TRY(hipMemcpy(&f, h->sets[0].dFail, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&f2, h->sets[1].dFail, sizeof(int), hipMemcpyDeviceToHost));
+  return (f | f2) ? PSF_ERR_SAMPLER : PSF_OK;
 }
 
 psf_status psfp_samp_p_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, void* stream) {
@@ -635,8 +703,8 @@ psf_status psfp_f_a_dev(psfp_handle* h, size_t B, const int64_t* d_e, uint64_t* 
   hipStream_t st = (hipStream_t)stream;
   const size_t m = h->m, ld = h->ld;
   hipLaunchKernelGGL(k_check_domain, dim3((unsigned)B), dim3(256), 0, st, d_e, m, m, domain_bound(h), d_ok);   // :367
-  hipLaunchKernelGGL(k_narrow_transpose, dim3((unsigned)(ld / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, st, d_e, m, B, ld, h->dP);
-  launch_zq_mfma(h, st, ZQ_FA, h->dP, B, nullptr, d_u, h->n);                                                    // :368
+  hipLaunchKernelGGL(k_narrow_transpose, dim3((unsigned)(ld / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, st, d_e, m, B, ld, h->dPf);
+  launch_zq_mfma(h, st, ZQ_FA, h->dPf, h->dP8f, B, nullptr, d_u, h->n);                                                    // :368
   HIP_TRY(hipGetLastError());
   h->last_stream = st;
   return PSF_OK;
@@ -680,6 +748,7 @@ psf_status psfp_get_timing(psfp_handle* h, char* names, size_t names_len, double
   if (!h || !count) return PSF_ERR_PARAM;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   HIP_TRY(hipStreamSynchronize(h->aux));
+  HIP_TRY(hipStreamSynchronize(h->s1));
   std::string joined;
   std::vector<std::string> names_v;
   std::vector<double> sums;
