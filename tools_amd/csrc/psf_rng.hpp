@@ -41,8 +41,10 @@ __host__ __device__ inline U4 philox(uint64_t seed, uint32_t c0, uint32_t c1, ui
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    const uint32_t lo0 = 0xD2511F53u * c0, hi0 = mulhi32(0xD2511F53u, c0);
-    const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = mulhi32(0xCD9E8D57u, c2);
+    // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32) instead of a mul_hi / mul_lo pair
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t lo0 = (uint32_t)p0, hi0 = (uint32_t)(p0 >> 32);
+    const uint32_t lo1 = (uint32_t)p1, hi1 = (uint32_t)(p1 >> 32);
     c0 = hi1 ^ c1 ^ k0;
     c1 = lo1;
     c2 = hi0 ^ c3 ^ k1;
