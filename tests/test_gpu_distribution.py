@@ -1,0 +1,74 @@
+"""End-to-end distribution checks of samp_p on the GPU (the reference has none).
+
+MP12's perturbation method must output a SPHERICAL discrete Gaussian of parameter s*r over the coset
+{e : A e = u}: every coordinate has standard deviation s r / sqrt(2 pi) and distinct coordinates are uncorrelated --
+which only holds if Sigma_2, its Cholesky factor, the perturbation, the gadget sampler (parameter r sqrt(b^2+1)) and
+the recombination e = p + [R; I] z all fit together (mp_perturbation.rs:111-139, :304-336)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_perturbation_preimages_are_spherical():
+    import tools_amd as T
+    n, q, r, s, B = 8, 64, 3.0, 25.0, 24000
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+    A, (R, _, _) = psf.trap_gen(3)
+    u = np.tile(np.array([[5, 60, 0, 17, 33, 1, 2, 63]], dtype=np.uint64), (B, 1))     # one fixed syndrome
+    e = psf.samp_p(u, seed=11).astype(np.float64)
+    sigma = s * r / math.sqrt(2 * math.pi)
+    std = e.std(axis=0)
+    assert np.abs(std / sigma - 1).max() < 0.05, (std.min(), std.max(), sigma)
+    assert np.abs(e.mean(axis=0)).max() < 5 * sigma / math.sqrt(B) + 1.0
+    # the two halves of e (the A_bar part that receives R z, and the gadget part) must not differ in scale
+    mb = psf.m_bar
+    assert abs(std[:mb].mean() / std[mb:].mean() - 1) < 0.01
+    corr = np.corrcoef(e.T)
+    np.fill_diagonal(corr, 0)
+    assert np.abs(corr).max() < 6 / math.sqrt(B)
+    # squared norm concentrates around m sigma^2
+    nrm2 = (e**2).sum(axis=1)
+    assert abs(nrm2.mean() / (psf.m * sigma**2) - 1) < 0.02
+
+
+def test_gpv_preimages_have_the_right_scale():
+    import tools_amd as T
+    n, q, s, B = 6, 128, 60.0, 12000      # s above the smoothing parameter of the short basis so the output is ~ spherical
+    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+    psf.trap_gen(2, export=False)
+    u = np.tile(np.array([[1, 100, 7, 64, 0, 127]], dtype=np.uint64), (B, 1))
+    e = psf.samp_p(u, seed=5).astype(np.float64)
+    sigma = s / math.sqrt(2 * math.pi)
+    std = e.std(axis=0)
+    assert np.abs(std / sigma - 1).max() < 0.06, (std.min(), std.max(), sigma)
+    corr = np.corrcoef(e.T)
+    np.fill_diagonal(corr, 0)
+    assert np.abs(corr).max() < 6 / math.sqrt(B)
+
+
+def test_samp_d_marginals():
+    import tools_amd as T
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(5, 32), 2.0, 20.0)
+    e = psf.samp_d(seed=1, B=20000).astype(np.float64)        # D_{Z^m, s r}, mp_perturbation.rs:264-267
+    sigma = 40.0 / math.sqrt(2 * math.pi)
+    assert np.abs(e.std(axis=0) / sigma - 1).max() < 0.04
+    assert np.abs(e).max() <= 6 * 40.0 + 1
+
+
+def test_empty_and_ragged_batches():
+    import tools_amd as T
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(5, 32), 2.0, 25.0)
+    psf.trap_gen(1)
+    assert psf.samp_p(np.zeros((0, 5), dtype=np.uint64)).shape == (0, psf.m)
+    assert psf.samp_d(B=0).shape == (0, psf.m)
+    u = np.arange(5 * 129, dtype=np.uint64).reshape(129, 5) % 32        # 129 = one column block + 1
+    e = psf.samp_p(u, seed=9)
+    assert (psf.f_a(e) == u).all() and psf.check_domain(e).all()
+    for b in (0, 127, 128):                                              # rows do not depend on the batch they ride in
+        assert (psf.samp_p(u[b], seed=9, first_index=b) == e[b]).all()
+    # index beyond 2^32 selects a different (but still valid) stream
+    e_hi = psf.samp_p(u[:3], seed=9, first_index=2**33)
+    assert (psf.f_a(e_hi) == u[:3]).all() and not (e_hi == e[:3]).all()
