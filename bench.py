@@ -95,20 +95,18 @@ def main():
     t_trapgen = time.time() - t0
 
     stream = torch.cuda.current_stream().cuda_stream
-    from tools_amd.shard import shard_range, gather_rows
+    from tools_amd.shard import shard_range, AsyncRowGather
     first_index, _ = shard_range(rank, world, B)               # global preimage index of this rank's row 0
     u = torch.empty((B, n), dtype=torch.int64, device=dev)
     e = torch.empty((B, m), dtype=torch.int64, device=dev)
     psf.uniform_targets_dev(u.data_ptr(), B, seed=7, first_index=first_index, stream=stream)
-    gather_list = None
     do_gather = world > 1 and not args.no_gather
-    if do_gather and rank == 0:
-        gather_list = [torch.empty((B, m), dtype=torch.int64, device=dev) for _ in range(world)]
+    gatherer = AsyncRowGather(B, m, dev, dst=0) if do_gather else None     # step i's rows travel while step i+1 computes
 
     def step(i):
         psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=1000 + i, first_index=first_index, stream=stream)
         if do_gather:
-            gather_rows(e, dst=0, out=gather_list)
+            gatherer.submit(e)
 
     def fence():
         torch.cuda.synchronize()
@@ -118,6 +116,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if do_gather:
+        gatherer.finish()
     if psf.last_status() != 0:
         raise RuntimeError("device-side sampler failure during warmup")
     psf.enable_timing(True)
@@ -126,6 +126,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    if do_gather:
+        gatherer.finish()                  # every step's rows have reached rank 0 inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     # per-kernel HIP-event times of the last step (events were recorded on the launch stream, no host sync in the loop)
@@ -164,7 +166,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64+int64", "data": "synthetic",
             "config": {"workload": f"{scheme} samp_p n={n} q={q} k={gp.k} m={m} r={r} s={s} batch={B}/GPU ({args.config})",
-                       "global_batch": B * world, "parallelism": f"batch-sharded x{world}" + (" + RCCL gather" if do_gather else "")},
+                       "global_batch": B * world, "parallelism": f"batch-sharded x{world}" + (" + overlapped RCCL gather of int32 rows to rank 0" if do_gather else "")},
             "valid": valid, "kernels_ms": {k: round(v, 3) for k, v in kern_ms.items()}, "trap_gen_s": round(t_trapgen, 2),
             "roofline": roof,
         }

@@ -28,7 +28,7 @@ def _worker(rank, world, port, per_rank, q, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
-    from tools_amd.shard import shard_range, gather_rows
+    from tools_amd.shard import shard_range, gather_rows, AsyncRowGather
     n = 5
     psf = O.PSFPerturbation(O.gadget_params_default(n, q), 2.5, 25.0)
     assert psf.trap_gen(8) == 0                         # same key seed on every rank -> same key
@@ -36,10 +36,16 @@ def _worker(rank, world, port, per_rank, q, out_path):
     u = O.uniform_targets(1, count, n, q, first_index=first)
     e = psf.samp_p(77, u, first_index=first, nthreads=1)
     got = gather_rows(torch.from_numpy(e), dst=0)
+    # the overlapped int32 gather used by bench.py: three "steps" in flight over two staging buffers
+    ag = AsyncRowGather(count, psf.m, torch.device("cpu"), dst=0)
+    for step in range(3):
+        ag.submit(torch.from_numpy(e) + step)
+    last = ag.finish()
     if rank == 0:
         np.save(out_path, torch.cat(got).numpy())
+        assert (torch.cat(last).to(torch.int64) == torch.cat(got) + 2).all()
     else:
-        assert got is None
+        assert got is None and last is None
     dist.barrier()
     dist.destroy_process_group()
 
