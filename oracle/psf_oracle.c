@@ -79,22 +79,43 @@ double orc_det_exp(double y) {
 
 /* Z::sample_discrete_gauss / SampleZ of GPV08 as documented at CONTRIBUTING.md:35-45:
  * candidates uniform in [center - ceil(6s), center + floor(6s)], accepted with probability
- * rho_s(x - c) = exp(-pi (x-c)^2 / s^2)  (s = sigma*sqrt(2 pi)). */
-int64_t orc_sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center, double s) {
+ * rho_s(x - c) = exp(-pi (x-c)^2 / s^2)  (s = sigma*sqrt(2 pi)).
+ * Randomness: one Philox block serves two attempts, attempt t = 2*block + half uses words (x,y) / (z,w).
+ *   candidate : index = (wa * N) >> 32 with Lemire's rejection of the 2^32 mod N lowest fractions (exactly uniform);
+ *   acceptance: a 64-bit uniform U = wb * 2^32 + ext is compared with floor(rho * 2^64); the low word `ext` is drawn
+ *               lazily from block (0x80000000 | t) only when wb equals the high word of the threshold. */
+static int sz_attempt(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t t, uint32_t wa, uint32_t wb,
+                      int64_t lo, uint32_t N, uint32_t thr, double center, double inv_s, int64_t* x_out) {
   const double NEG_PI = -3.14159265358979323846;
+  uint64_t prod = (uint64_t)wa * N;
+  if ((uint32_t)prod < thr) return 0;
+  int64_t x = lo + (int64_t)(prod >> 32);
+  double a = ((double)x - center) * inv_s;
+  double rs = orc_det_exp(NEG_PI * (a * a)) * 4294967296.0;      /* rho * 2^32, exact scaling */
+  double r32 = floor(rs);
+  uint64_t r32u = (uint64_t)r32;
+  *x_out = x;
+  if ((uint64_t)wb < r32u) return 1;
+  if ((uint64_t)wb > r32u) return 0;
+  uint32_t w2[4];
+  orc_philox4x32(seed, coord, idx_lo, 0x80000000u | t, tw, w2);
+  double rfrac = floor((rs - r32) * 4294967296.0);
+  return (double)w2[0] < rfrac;
+}
+
+int64_t orc_sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center, double s) {
   double inv_s = 1.0 / s;
   int64_t lo = (int64_t)ceil(center) - (int64_t)ceil(6.0 * s);
   int64_t hi = (int64_t)floor(center) + (int64_t)floor(6.0 * s);
-  uint64_t N = (uint64_t)(hi - lo + 1);
+  uint32_t N = (uint32_t)(hi - lo + 1);
+  uint32_t thr = (uint32_t)(0u - N) % N;
+  uint32_t tw = tag_word(tag, index);
   uint32_t w[4];
-  for (uint32_t t = 0; t < ORC_MAX_ATTEMPTS; ++t) {
-    orc_philox4x32(seed, coord, (uint32_t)index, t, tag_word(tag, index), w);
-    uint64_t r64 = ((uint64_t)w[1] << 32) | w[0];
-    int64_t x = lo + (int64_t)mulhi64(r64, N);
-    double u = (double)((((uint64_t)w[3] << 32) | w[2]) >> 11) * 0x1.0p-53;
-    double a = ((double)x - center) * inv_s;
-    double rho = orc_det_exp(NEG_PI * (a * a));
-    if (u < rho) return x;
+  int64_t x;
+  for (uint32_t tb = 0; tb < ORC_MAX_ATTEMPTS / 2; ++tb) {
+    orc_philox4x32(seed, coord, (uint32_t)index, tb, tw, w);
+    if (sz_attempt(seed, coord, (uint32_t)index, tw, 2 * tb, w[0], w[1], lo, N, thr, center, inv_s, &x)) return x;
+    if (sz_attempt(seed, coord, (uint32_t)index, tw, 2 * tb + 1, w[2], w[3], lo, N, thr, center, inv_s, &x)) return x;
   }
   return (int64_t)floor(center + 0.5);
 }

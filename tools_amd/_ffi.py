@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpsf_mi355x.so")
+LIB_PATH = os.environ.get("PSF_LIB") or os.path.join(_HERE, "lib", "libpsf_mi355x.so")   # PSF_LIB: A/B builds of the same ABI
 
 OK, ERR_PARAM, ERR_NOT_PD, ERR_DOMAIN, ERR_MODULUS, ERR_NO_SOLUTION, ERR_NO_KEY, ERR_HIP, ERR_UNSUPPORTED, ERR_SAMPLER = range(10)
 

@@ -225,16 +225,15 @@ __global__ __launch_bounds__(256, 1) void k_gpv_nearest_plane(const int32_t* __r
       const double dot = (s_w[p][0] + s_w[p][1]) + (s_w[p][2] + s_w[p][3]);
       const double cen = dot / n2;
       const uint64_t index = first_index + b0 + p;
-      const long long lo = (long long)ceil(cen) - sp.c6;
-      const uint64_t N = (uint64_t)((long long)floor(cen) + sp.f6 - lo + 1);
+      const uint32_t tw = tag_word(tag, index);
+      const SzRange rg = sz_range(cen, sp);
       long long z = 0;
       bool got = false;
       for (uint32_t t0 = 0; t0 < kMaxAttempts && !got; t0 += 64) {
-        const U4 w = philox(seed, (uint32_t)ii, (uint32_t)index, t0 + lane, tag_word(tag, index));
-        const long long x = lo + (long long)mulhi64(((uint64_t)w.y << 32) | w.x, N);
-        const double u = (double)((((uint64_t)w.w << 32) | w.z) >> 11) * 0x1.0p-53;
-        const double a = ((double)x - cen) * sp.inv_s;
-        const bool acc = u < det_exp(-3.14159265358979323846 * (a * a));
+        const uint32_t t = t0 + lane;                       // lanes 2j, 2j+1 share Philox block t >> 1
+        const U4 w = philox(seed, (uint32_t)ii, (uint32_t)index, t >> 1, tw);
+        long long x = 0;
+        const bool acc = sz_attempt(seed, (uint32_t)ii, (uint32_t)index, tw, t, (t & 1) ? w.z : w.x, (t & 1) ? w.w : w.y, rg, cen, sp.inv_s, &x);
         const uint64_t mask = __ballot(acc);
         if (mask) {
           const int first = __ffsll((long long)mask) - 1;

@@ -20,13 +20,16 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 // ---- geometry of the triangular product -------------------------------------------------------------
 constexpr int TR_BM = 128;      // rows of sqrt(Sigma_2) per workgroup
 constexpr int TR_BN = 128;      // preimages per workgroup
-constexpr int TR_BK = 16;       // coordinates per staged chunk (4 MFMA k-steps)
+#ifndef PSF_TR_BK
+#define PSF_TR_BK 16
+#endif
+constexpr int TR_BK = PSF_TR_BK;  // coordinates per staged chunk (TR_BK / 4 MFMA k-steps)
 constexpr int TR_CHUNK = TR_BM * TR_BK;            // doubles per chunk (2048 = 16 KiB)
 constexpr int TR_KB_PER_BLOCK = TR_BM / TR_BK;     // 8
 
 // first chunk of row-block bi in the packed lower-triangular tile stream: sum_{t<bi} 8 (t+1)
-__host__ __device__ inline size_t tr_rowblock_base(size_t bi) { return 4 * bi * (bi + 1); }
-__host__ __device__ inline size_t tr_total_chunks(size_t nbi) { return 4 * nbi * (nbi + 1); }
+__host__ __device__ inline size_t tr_rowblock_base(size_t bi) { return (size_t)TR_KB_PER_BLOCK * bi * (bi + 1) / 2; }
+__host__ __device__ inline size_t tr_total_chunks(size_t nbi) { return (size_t)TR_KB_PER_BLOCK * nbi * (nbi + 1) / 2; }
 
 // position inside a chunk of element (r in [0,128), kk in [0,16)):  [ks = kk/4][tile = r/16][lane = (kk%4)*16 + r%16]
 __host__ __device__ inline int tr_chunk_pos(int r, int kk) {
@@ -42,7 +45,7 @@ __global__ void k_repack_L(const double* __restrict__ src, size_t ld, size_t m, 
     const size_t chunk = g / TR_CHUNK;
     const int pos = (int)(g % TR_CHUNK);
     // invert chunk -> (bi, bk): bi = largest with 4 bi (bi+1) <= chunk
-    size_t bi = (size_t)((sqrt(1.0 + (double)chunk) - 1.0) * 0.5);
+    size_t bi = (size_t)((sqrt(1.0 + 8.0 * (double)chunk / TR_KB_PER_BLOCK) - 1.0) * 0.5);
     while (tr_rowblock_base(bi + 1) <= chunk) ++bi;
     while (tr_rowblock_base(bi) > chunk) --bi;
     const size_t bk = chunk - tr_rowblock_base(bi);
@@ -125,7 +128,7 @@ __host__ inline unsigned tr_grid_size(int nbi, int nbj, int GR = 8, int GC = 8) 
   return rounds * 8u * 64u;
 }
 
-__global__ __launch_bounds__(256, 2) void k_trmm_f64(const double* __restrict__ Lt, const double* __restrict__ Dt,
+__global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const double* __restrict__ Lt, const double* __restrict__ Dt,
                                                      double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx, int GR, int GC) {
   // LDS: 2 stages x (A chunk 2048 doubles | B chunk 2048 doubles); filled by LDS-DMA (global_load_lds_dwordx4), no
   // staging registers: the accumulators (128 VGPRs) leave no room to hold a chunk in flight (hipcc serialised
@@ -153,8 +156,8 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64(const double* __restrict__ 
     const double* gb = gB + (size_t)kb * TR_CHUNK;
     double* la = smem + buf * (2 * TR_CHUNK);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = wave * 4 + i;
+    for (int i = 0; i < TR_CHUNK / 512; ++i) {
+      const int piece = wave * (TR_CHUNK / 512) + i;
       __builtin_amdgcn_global_load_lds(ga + piece * 128, (lds_void_ptr)(la + piece * 128), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(gb + piece * 128, (lds_void_ptr)(la + TR_CHUNK + piece * 128), 16, 0, 0);
     }
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64(const double* __restrict__ 
     const double* sA = smem + cur * (2 * TR_CHUNK);
     const double* sB = sA + TR_CHUNK;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < TR_BK / 4; ++ks) {
       double a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -259,20 +262,18 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
   locate(active ? my : seg0, &coord, &b);
   uint32_t t = 0;
   int f = 0;
-  const double NEG_PI = -3.14159265358979323846;
   while (__ballot(active)) {
     bool accept = false;
     long long x = 0;
     if (active) {
+      // one Philox block = two attempts of this lane's sample
       const uint64_t index = first_index + b;
-      const long long lo = (long long)ceil(c) - sp.c6;
-      const uint64_t N = (uint64_t)((long long)floor(c) + sp.f6 - lo + 1);
-      const U4 w = philox(seed, (uint32_t)coord, (uint32_t)index, t, tag_word(TAG_PERTURB, index));
-      x = lo + (long long)mulhi64(((uint64_t)w.y << 32) | w.x, N);
-      const double u = (double)((((uint64_t)w.w << 32) | w.z) >> 11) * 0x1.0p-53;
-      const double a = ((double)x - c) * sp.inv_s;
-      accept = u < det_exp(NEG_PI * (a * a));
-      if (!accept && ++t >= kMaxAttempts) { accept = true; f = 1; x = (long long)floor(c + 0.5); }
+      const uint32_t tw = tag_word(TAG_PERTURB, index);
+      const SzRange rg = sz_range(c, sp);
+      const U4 w = philox(seed, (uint32_t)coord, (uint32_t)index, t, tw);
+      accept = sz_attempt(seed, (uint32_t)coord, (uint32_t)index, tw, 2 * t, w.x, w.y, rg, c, sp.inv_s, &x);
+      if (!accept) accept = sz_attempt(seed, (uint32_t)coord, (uint32_t)index, tw, 2 * t + 1, w.z, w.w, rg, c, sp.inv_s, &x);
+      if (!accept && ++t >= kMaxAttempts / 2) { accept = true; f = 1; x = (long long)floor(c + 0.5); }
       if (accept) {
         if (x > 0x1ffffff || x < -0x1ffffff) f = 1;
         P[coord * ld + b] = (int32_t)x;

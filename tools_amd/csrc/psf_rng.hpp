@@ -101,22 +101,44 @@ inline SampleZParams make_sample_z_params(double s) {
 }
 
 // SampleZ of GPV08 as the reference documents it (CONTRIBUTING.md:35-45): candidates uniform in
-// [c - ceil(6s), c + floor(6s)], accepted with probability exp(-pi (x-c)^2 / s^2).  Attempt t of sample
-// (tag, index, coord) always consumes Philox block (coord, index_lo, t, tag|index_hi), so the result is the
-// first accepted attempt no matter how lanes are scheduled.  *fail is OR-ed with 1 if the cap is hit.
+// [c - ceil(6s), c + floor(6s)], accepted with probability exp(-pi (x-c)^2 / s^2).
+// One Philox block (coord, index_lo, block, tag|index_hi) serves attempts 2*block (words x,y) and 2*block+1 (words z,w):
+//   candidate : index = (wa * N) >> 32, attempt void if the low product word is below 2^32 mod N (Lemire: exactly uniform);
+//   acceptance: U = wb * 2^32 + ext against floor(rho * 2^64); ext comes from block (0x80000000 | attempt), drawn only on a tie.
+// The value of a sample is its first accepted attempt, whatever lane or order evaluates the attempts.
+struct SzRange { long long lo; uint32_t N, thr; };
+__host__ __device__ inline SzRange sz_range(double center, const SampleZParams sp) {
+  SzRange r;
+  r.lo = (long long)ceil(center) - sp.c6;
+  r.N = (uint32_t)((long long)floor(center) + sp.f6 - r.lo + 1);
+  r.thr = (uint32_t)(0u - r.N) % r.N;
+  return r;
+}
+__host__ __device__ inline bool sz_attempt(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t t, uint32_t wa, uint32_t wb,
+                                           const SzRange rg, double center, double inv_s, long long* x_out) {
+  const uint64_t prod = (uint64_t)wa * rg.N;
+  if ((uint32_t)prod < rg.thr) return false;
+  const long long x = rg.lo + (long long)(prod >> 32);
+  const double a = ((double)x - center) * inv_s;
+  const double rs = det_exp(-3.14159265358979323846 * (a * a)) * 4294967296.0;
+  const double r32 = floor(rs);
+  const uint64_t r32u = (uint64_t)r32;
+  *x_out = x;
+  if ((uint64_t)wb < r32u) return true;
+  if ((uint64_t)wb > r32u) return false;
+  const U4 w2 = philox(seed, coord, idx_lo, 0x80000000u | t, tw);
+  return (double)w2.x < floor((rs - r32) * 4294967296.0);
+}
+
 __host__ __device__ inline long long sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center,
-                                     const SampleZParams sp, int* fail) {
-  const long long lo = (long long)ceil(center) - sp.c6;
-  const long long hi = (long long)floor(center) + sp.f6;
-  const uint64_t N = (uint64_t)(hi - lo + 1);
+                                              const SampleZParams sp, int* fail) {
+  const SzRange rg = sz_range(center, sp);
   const uint32_t tw = tag_word(tag, index);
-  for (uint32_t t = 0; t < kMaxAttempts; ++t) {
-    const U4 w = philox(seed, coord, (uint32_t)index, t, tw);
-    const long long x = lo + (long long)mulhi64(((uint64_t)w.y << 32) | w.x, N);
-    const double u = (double)((((uint64_t)w.w << 32) | w.z) >> 11) * 0x1.0p-53;
-    const double a = ((double)x - center) * sp.inv_s;
-    const double rho = det_exp(-3.14159265358979323846 * (a * a));
-    if (u < rho) return x;
+  long long x = 0;
+  for (uint32_t tb = 0; tb < kMaxAttempts / 2; ++tb) {
+    const U4 w = philox(seed, coord, (uint32_t)index, tb, tw);
+    if (sz_attempt(seed, coord, (uint32_t)index, tw, 2 * tb, w.x, w.y, rg, center, sp.inv_s, &x)) return x;
+    if (sz_attempt(seed, coord, (uint32_t)index, tw, 2 * tb + 1, w.z, w.w, rg, center, sp.inv_s, &x)) return x;
   }
   *fail = 1;
   return (long long)floor(center + 0.5);
