@@ -200,25 +200,7 @@ __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const
 }
 
 // ---- p_i <- D_{Z, r, x_i} ------------------------------------------------------------------------------
-__global__ void k_perturb_round(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
-                                const double* __restrict__ X, SampleZParams sp, int32_t* __restrict__ P,
-                                int* __restrict__ fail) {
-  const size_t total = m * ld;
-  int f = 0;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t i = g / ld, b = g % ld;
-    int32_t v = 0;
-    if (b < B) {
-      const long long s = sample_z(seed, TAG_PERTURB, first_index + b, (uint32_t)i, X[g], sp, &f);
-      if (s > 0x1ffffff || s < -0x1ffffff) f = 1;
-      v = (int32_t)s;
-    }
-    P[g] = v;
-  }
-  if (f) atomicOr(fail, 1);
-}
-
-// Wave-compacted form of the same rounding: a wave owns SEG consecutive samples of the flattened valid index space
+// Wave-compacted rounding: a wave owns SEG consecutive samples of the flattened valid index space
 // g = coord * B + b.  Every iteration all 64 lanes evaluate one attempt of THEIR current sample; the lanes that
 // accepted store the result and take the next unassigned sample ids (ballot + mbcnt prefix), whose centres are
 // fetched from a register window of the next 192 centres by cross-lane reads.  Which lane evaluates which

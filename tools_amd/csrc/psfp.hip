@@ -70,9 +70,7 @@ struct psfp_handle {
   hipStream_t s1 = nullptr;
   hipEvent_t evT[2] = {nullptr, nullptr}, evP[2] = {nullptr, nullptr}, evIn = nullptr;
   hipStream_t last_stream = nullptr;
-  hipStream_t aux = nullptr;                 // second stream for the per-slice sampling stages
-  std::vector<hipEvent_t> slice_events;
-  size_t slices = 0;                         // 0 = default (1); PSF_SLICES overrides
+  hipStream_t aux = nullptr;                 // low-priority stream of the sampling stages in pipelined mode
   // timing
   bool timing = false;
   std::vector<TimingSlot> slots;
@@ -307,7 +305,6 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   HIP_TRY(hipMemcpy(h->dNorm2, norm2.data(), h->k * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dSz, sz.data(), h->k * sizeof(SampleZParams), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dGvec, gvec.data(), h->k * sizeof(uint64_t), hipMemcpyHostToDevice));
-  if (const char* env = std::getenv("PSF_SLICES")) h->slices = (size_t)std::atoi(env);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, CH_NB * (CH_NB + 1) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB * (CH_NB + 1) / 2 + CH_NB * 64) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
@@ -321,7 +318,6 @@ void psfp_destroy(psfp_handle* h) {
   hipSetDevice(h->prm.device);
   free_batch(h);
   clear_slots(h);
-  for (auto ev : h->slice_events) hipEventDestroy(ev);
   if (h->aux) hipStreamDestroy(h->aux);
   hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt);
   for (auto& t : h->sets) hipFree(t.dFail);
@@ -480,17 +476,16 @@ psf_status psfp_export_gadget_basis(const psfp_handle* h, int64_t* Sk, double* g
 }
 
 // ---- the hot path -------------------------------------------------------------------------------------------
-// One samp_p pass.  The batch is cut into `slices` groups of 128-preimage column blocks: the FP64-MFMA product of
-// slice s+1 runs on the caller's stream while the VALU / int8-MFMA stages of slice s (rounding, syndrome, gadget,
-// recombination) run on the handle's auxiliary stream, so the sampling work hides under the matrix pipe.
+// One samp_p pass over B rows (mp_perturbation.rs:304-336).  By default everything runs in order on the caller's stream.
+// With PSF_PIPELINE=1 consecutive calls alternate between two sets of intermediates: normals + FP64 product of call i+1 on
+// stream s1, sampling stages of call i on stream aux, the caller's stream joins at the end (measured zero-sum on MI355X,
+// profiles/r01_notes.md, hence off by default; covered by tests/test_gpu_pipeline_mode.py).
 static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, hipStream_t st) {
   const size_t ld = h->ld, m = h->m;
   if (h->timing) clear_slots(h);
-  const size_t nbj_total = h->nbj;
-  size_t S = h->slices ? h->slices : 1;   // measured at C3: >1 slices lose (small per-slice grids), see profiles/r01_notes.md
-  // Pipelining across calls: normals + FP64 product on s1, sampling stages on aux, caller's stream joins at the end.
-  const bool pipe = h->pipeline && S == 1;
-  hipStream_t user_st = st;
+  const size_t nbj = h->nbj;
+  const bool pipe = h->pipeline;
+  hipStream_t user_st = st, s2 = st;
   int cur = 0;
   if (pipe) {
     cur = (int)(h->ncall++ & 1);
@@ -498,83 +493,51 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     HIP_TRY(hipEventRecord(h->evIn, user_st));            // u is ready on the caller's stream from here on
     HIP_TRY(hipStreamWaitEvent(h->s1, h->evP[cur], 0));   // the previous user of this buffer set has finished
     st = h->s1;
+    s2 = h->aux;
   }
   hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
-  if (S > nbj_total) S = nbj_total;
-  const size_t per = (nbj_total + S - 1) / S;
-  while (h->slice_events.size() < S + 1) {
-    hipEvent_t ev;
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    h->slice_events.push_back(ev);
+  {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
+    ScopedTimer t(h, st, "k_normals");
+    hipLaunchKernelGGL(k_normals, dim3(grid_for(nbj * h->nkb * TR_CHUNK, 256, 256 * 32)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail);
   }
-  for (size_t sl = 0; sl < S; ++sl) {
-    const size_t bj0 = sl * per;
-    if (bj0 >= nbj_total) break;
-    const size_t nbj = (bj0 + per <= nbj_total) ? per : nbj_total - bj0;
-    const size_t boff = bj0 * TR_BN;
-    const size_t Bs = (boff + nbj * TR_BN <= B) ? nbj * TR_BN : B - boff;
-    const uint64_t fi = first_index + boff;
-    double* Dt = h->dDt + bj0 * h->nkb * TR_CHUNK;
-    {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
-      ScopedTimer t(h, st, "k_normals");
-      hipLaunchKernelGGL(k_normals, dim3(grid_for(nbj * h->nkb * TR_CHUNK, 256, 256 * 32)), dim3(256), 0, st, seed, fi, m, Bs, h->nkb, nbj, Dt, h->dFail);
-    }
-    {  // x = sqrt(Sigma_2) d
-      ScopedTimer t(h, st, "k_trmm_f64");
-      int GR = 8, GC = 8;
-      if (const char* env = std::getenv("PSF_TRMM_GROUP")) { GR = std::atoi(env); if (GR < 1 || 64 % GR) GR = 8; GC = 64 / GR; }
-      hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbi, (int)nbj, GR, GC)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
-                         h->dLt, Dt, h->dX + boff, (int)h->nbi, (int)nbj, h->nkb, ld, GR, GC);
-    }
-    hipStream_t s2 = st;
-    if (S > 1) {
-      s2 = h->aux;
-      HIP_TRY(hipEventRecord(h->slice_events[sl], st));
-      HIP_TRY(hipStreamWaitEvent(s2, h->slice_events[sl], 0));
-    } else if (pipe) {
-      s2 = h->aux;
-      HIP_TRY(hipEventRecord(h->evT[cur], st));
-      HIP_TRY(hipStreamWaitEvent(s2, h->evT[cur], 0));
-      HIP_TRY(hipStreamWaitEvent(s2, h->evIn, 0));
-    }
-    static const int post_mask = std::getenv("PSF_POST_MASK") ? std::atoi(std::getenv("PSF_POST_MASK")) : 15;   // timing experiments only
-    if (post_mask & 1) {  // p_i <- D_{Z,r,x_i}
-      ScopedTimer t(h, s2, "k_perturb_round");
-      const size_t waves = (m * Bs + PR_SEG - 1) / PR_SEG;
-      hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, seed, fi, m, Bs, ld, h->dX + boff, h->szR,
-                         h->dP + boff, h->dFail);
-    }
-    if (post_mask & 2) {  // mp_perturbation.rs:318 -- v = u - A p
-      ScopedTimer t(h, s2, "k_zq_matmul(syndrome)");
-      if (S == 1) launch_zq_mfma(h, s2, ZQ_SYNDROME, h->dP, h->dP8, Bs, d_u, h->dV, ld);
-      else launch_zq(h, s2, ZQ_SYNDROME, h->dA, m, 0, h->n, m, h->dP + boff, false, ld, Bs, d_u + boff * h->n, h->dV + boff, ld, 0);
-    }
-    if (post_mask & 4) {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
-      ScopedTimer t(h, s2, "k_gadget");
-      const size_t k = h->k;
-      GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
-      hipLaunchKernelGGL(k_gadget, dim3((unsigned)((Bs + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(k), s2, seed, fi, (uint32_t)h->n,
-                         (uint32_t)k, h->q, h->prm.gp.base, Bs, ld, h->dV + boff, tb, h->dZlo + boff * 16, h->dZhi + boff * 16, h->dFail);
-    }
-    if (post_mask & 8) {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
-      ScopedTimer t(h, s2, "k_recombine");
-      hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bs + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), 2 * RC_STAGE, s2, h->dR,
-                         h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo + boff * 16, h->dZhi + boff * 16, ld, h->dFail, h->dP + boff, Bs, d_e + boff * m, m);
-      hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bs + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, s2, h->mb, h->w,
-                         h->dZlo + boff * 16, h->dZhi + boff * 16, ld, h->dP + boff, Bs, d_e + boff * m, m);
-    }
+  {  // x = sqrt(Sigma_2) d
+    ScopedTimer t(h, st, "k_trmm_f64");
+    hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbi, (int)nbj, 8, 8)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
+                       h->dLt, h->dDt, h->dX, (int)h->nbi, (int)nbj, h->nkb, ld, 8, 8);
   }
-  if (S > 1) {
-    HIP_TRY(hipEventRecord(h->slice_events[S], h->aux));
-    HIP_TRY(hipStreamWaitEvent(st, h->slice_events[S], 0));
+  if (pipe) {
+    HIP_TRY(hipEventRecord(h->evT[cur], st));
+    HIP_TRY(hipStreamWaitEvent(s2, h->evT[cur], 0));
+    HIP_TRY(hipStreamWaitEvent(s2, h->evIn, 0));
+  }
+  {  // p_i <- D_{Z,r,x_i}
+    ScopedTimer t(h, s2, "k_perturb_round");
+    const size_t waves = (m * B + PR_SEG - 1) / PR_SEG;
+    hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
+  }
+  {  // mp_perturbation.rs:318 -- v = u - A p
+    ScopedTimer t(h, s2, "k_zq_matmul(syndrome)");
+    launch_zq_mfma(h, s2, ZQ_SYNDROME, h->dP, h->dP8, B, d_u, h->dV, ld);
+  }
+  {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
+    ScopedTimer t(h, s2, "k_gadget");
+    GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
+    hipLaunchKernelGGL(k_gadget, dim3((unsigned)((B + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(h->k), s2, seed, first_index,
+                       (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, B, ld, h->dV, tb, h->dZlo, h->dZhi, h->dFail);
+  }
+  {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
+    ScopedTimer t(h, s2, "k_recombine");
+    hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((B + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), 2 * RC_STAGE, s2, h->dR,
+                       h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo, h->dZhi, ld, h->dFail, h->dP, B, d_e, m);
+    hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((B + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, s2, h->mb, h->w,
+                       h->dZlo, h->dZhi, ld, h->dP, B, d_e, m);
   }
   if (pipe) {
     HIP_TRY(hipEventRecord(h->evP[cur], h->aux));
     HIP_TRY(hipStreamWaitEvent(user_st, h->evP[cur], 0));   // results of this call are ordered before later work on the caller's stream
-    st = user_st;
   }
   HIP_TRY(hipGetLastError());
-  h->last_stream = st;
+  h->last_stream = user_st;
   return PSF_OK;
 }
 
