@@ -424,7 +424,9 @@ __global__ void k_split_A(const uint64_t* __restrict__ A, size_t lda, size_t n, 
     int64_t a = (i < n && kk < K) ? (int64_t)A[i * lda + kk] : 0;
     for (int d = 0; d < NA; ++d) {
       int64_t dig = (d + 1 < NA) ? (int64_t)(int8_t)(a & 0xff) : a;
-      A8[(size_t)d * total + g] = (int8_t)dig;
+      // tile-packed: [digit][row tile of 64][k step of 64][row in tile][64 bytes] -- one 4 KiB tile is one contiguous read
+      const size_t off = (((size_t)d * (n_pad / 64) + i / 64) * (K_pad / 64) + kk / 64) * 4096 + (i % 64) * 64 + (kk % 64);
+      A8[off] = (int8_t)dig;
       a = (a - dig) >> 8;
     }
   }
@@ -475,10 +477,12 @@ __device__ inline uint64_t zq_term(int32_t T, uint64_t pw, uint64_t q, uint64_t 
   return (T < 0 && r) ? q - r : r;
 }
 
+// grid = (column tiles, row tiles, K splits).  A split covers at most 256 K-steps (16384 coordinates), so its int32 class
+// accumulators never overflow and are folded into a residue exactly once, after the loop; the per-split residues go to
+// `part[split][i][c]` and k_zq_combine adds them.  (Folding inside the K loop made hipcc spill accumulators to scratch.)
 template <int NA>
-__global__ __launch_bounds__(256) void k_zq_mfma(int mode, const int8_t* __restrict__ A8, size_t n, size_t n_pad, size_t K_pad,
-                                                 const int8_t* __restrict__ P8, size_t ld, size_t ncols, ZqConsts zc, int wide,
-                                                 const uint64_t* __restrict__ U, uint64_t* __restrict__ out, size_t ldo) {
+__global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, size_t n_pad, size_t K_pad, const int8_t* __restrict__ P8, size_t ld,
+                                                 int ks_per_split, ZqConsts zc, int wide, uint64_t* __restrict__ part) {
   constexpr int STAGE = (NA + 3) * 4096;
   constexpr int NC = NA + 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char zq_smem[];
@@ -487,61 +491,38 @@ __global__ __launch_bounds__(256) void k_zq_mfma(int mode, const int8_t* __restr
   const int wr = wave >> 1, wc = wave & 1;
   const size_t b0 = (size_t)blockIdx.x * 64, i0 = (size_t)blockIdx.y * 64;
   const size_t planeA = n_pad * K_pad, planeP = (K_pad / 16) * ld * 16;
-  const int nks = (int)(K_pad / 64);
+  const int nks_all = (int)(K_pad / 64);
+  const int ks0 = (int)blockIdx.z * ks_per_split;
+  const int ks1 = ks0 + ks_per_split < nks_all ? ks0 + ks_per_split : nks_all;
 
   v4i acc[NC][2][2];
-  uint64_t tot[2][2][4];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c][x][y] = v4i{0, 0, 0, 0};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tot[x][y][r] = 0;
-    }
+      for (int y = 0; y < 2; ++y) acc[c][x][y] = v4i{0, 0, 0, 0};
   const int pA = wave * 64 + lane;   // 16-byte piece of a 4 KiB tile
-  const int8_t* srcA = A8 + (i0 + (size_t)(pA >> 2)) * K_pad + (size_t)(pA & 3) * 16;
+  const int8_t* srcA = A8 + (size_t)blockIdx.y * (K_pad / 64) * 4096 + (size_t)pA * 16;   // tile-packed planes, see k_split_A
   const int8_t* srcP = P8 + ((size_t)(pA >> 6) * ld + b0 + (size_t)(pA & 63)) * 16;
   auto stage_load = [&](int ks, int buf) {
     unsigned char* base = zq_smem + buf * STAGE + wave * 1024;
 #pragma unroll
     for (int d = 0; d < NA; ++d)
-      __builtin_amdgcn_global_load_lds(srcA + (size_t)d * planeA + (size_t)ks * 64, (lds_void_ptr)(base + d * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(srcA + (size_t)d * planeA + (size_t)ks * 4096, (lds_void_ptr)(base + d * 4096), 16, 0, 0);
 #pragma unroll
     for (int e = 0; e < 3; ++e)
       __builtin_amdgcn_global_load_lds(srcP + (size_t)e * planeP + (size_t)ks * 4 * ld * 16, (lds_void_ptr)(base + (NA + e) * 4096), 16, 0, 0);
   };
-  auto fold = [&]() {
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          uint64_t t = tot[x][y][r];
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            t += zq_term(acc[c][x][y][r], zc.pw[c], zc.q, zc.two64, wide != 0);
-            if (t >= zc.q) t -= zc.q;
-          }
-          tot[x][y][r] = t;
-        }
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[c][x][y] = v4i{0, 0, 0, 0};
-  };
-
-  stage_load(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (ks0 < ks1) {
+    stage_load(ks0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   const int r16 = lane & 15, g = lane >> 4;
-  for (int ks = 0; ks < nks; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nks) stage_load(ks + 1, cur ^ 1);
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int cur = (ks - ks0) & 1;
+    if (ks + 1 < ks1) stage_load(ks + 1, cur ^ 1);
     const unsigned char* sb = zq_smem + cur * STAGE;
     v4i fa[NA][2], fp[3][2];
 #pragma unroll
@@ -561,28 +542,59 @@ __global__ __launch_bounds__(256) void k_zq_mfma(int mode, const int8_t* __restr
 #pragma unroll
           for (int y = 0; y < 2; ++y)
             acc[d + e][x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[d][x], fp[e][y], acc[d + e][x][y], 0, 0, 0);
-    if ((ks & 255) == 255) fold();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  fold();
-  // C/D map: column (preimage) = lane & 15, row (i) = 4 * (lane >> 4) + reg
+  // fold the classes: residue = sum_c (T_c mod q) 256^c mod q.  C/D map: column (preimage) = lane & 15, row (i) = 4 * (lane >> 4) + reg
+  uint64_t* dst = part + (size_t)blockIdx.z * n_pad * ld;
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const size_t i = i0 + wr * 32 + x * 16 + 4 * g + r, cc = b0 + wc * 32 + y * 16 + r16;
-        if (i >= n || cc >= ncols) continue;
-        const uint64_t s = tot[x][y][r];
-        if (mode == ZQ_SYNDROME) {
-          const uint64_t u = U[cc * n + i] % zc.q;
-          out[i * ldo + cc] = u >= s ? u - s : u + zc.q - s;
-        } else {
-          out[cc * ldo + i] = s;
+        uint64_t t = 0;
+        for (int c = 0; c < NC; ++c) {
+          int32_t T;
+          switch (c) {   // static register indices
+            case 0: T = acc[0][x][y][r]; break;
+            case 1: T = acc[1][x][y][r]; break;
+            case 2: T = acc[2 < NC ? 2 : 0][x][y][r]; break;
+            case 3: T = acc[3 < NC ? 3 : 0][x][y][r]; break;
+            case 4: T = acc[4 < NC ? 4 : 0][x][y][r]; break;
+            case 5: T = acc[5 < NC ? 5 : 0][x][y][r]; break;
+            case 6: T = acc[6 < NC ? 6 : 0][x][y][r]; break;
+            case 7: T = acc[7 < NC ? 7 : 0][x][y][r]; break;
+            case 8: T = acc[8 < NC ? 8 : 0][x][y][r]; break;
+            default: T = acc[9 < NC ? 9 : 0][x][y][r]; break;
+          }
+          t += zq_term(T, zc.pw[c], zc.q, zc.two64, wide != 0);
+          if (t >= zc.q) t -= zc.q;
         }
+        const size_t i = i0 + wr * 32 + x * 16 + 4 * g + r, cc = b0 + wc * 32 + y * 16 + r16;
+        dst[i * ld + cc] = t;
       }
+}
+
+// out = (u - sum_z part[z]) mod q  (syndrome, mp_perturbation.rs:318)  or  sum_z part[z] mod q written row-per-preimage (f_a, :368)
+__global__ void k_zq_combine(int mode, const uint64_t* __restrict__ part, int splits, size_t n, size_t n_pad, size_t ld, size_t ncols, uint64_t q,
+                             const uint64_t* __restrict__ U, uint64_t* __restrict__ out, size_t ldo) {
+  const size_t total = n * ld;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / ld, cc = g % ld;
+    if (cc >= ncols) continue;
+    uint64_t s = 0;
+    for (int z = 0; z < splits; ++z) {
+      s += part[(size_t)z * n_pad * ld + g];
+      if (s >= q) s -= q;
+    }
+    if (mode == ZQ_SYNDROME) {
+      const uint64_t u = U[cc * n + i] % q;
+      out[i * ldo + cc] = u >= s ? u - s : u + q - s;
+    } else {
+      out[cc * ldo + i] = s;
+    }
+  }
 }
 
 // ---- gadget: digit decomposition + randomized nearest plane on S_k ------------------------------------

@@ -65,6 +65,7 @@ struct psfp_handle {
   struct BatchSet { double* dDt = nullptr; double* dX = nullptr; int32_t* dP = nullptr; int8_t* dP8 = nullptr; uint64_t* dV = nullptr;
                     int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; int* dFail = nullptr; } sets[2];
   int32_t* dPf = nullptr; int8_t* dP8f = nullptr;   // scratch of f_a (kept apart from the pipelined sets)
+  uint64_t* dPart = nullptr; int zq_splits = 1, zq_ks = 0;   // per-split residues of the int8-MFMA Z_q product
   bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
   size_t ncall = 0;
   hipStream_t s1 = nullptr;
@@ -88,8 +89,8 @@ static void free_batch(psfp_handle* h) {
     hipFree(t.dDt); hipFree(t.dX); hipFree(t.dP); hipFree(t.dP8); hipFree(t.dV); hipFree(t.dZlo); hipFree(t.dZhi);
     t.dDt = t.dX = nullptr; t.dP = nullptr; t.dP8 = nullptr; t.dV = nullptr; t.dZlo = t.dZhi = nullptr;
   }
-  hipFree(h->dPf); hipFree(h->dP8f); hipFree(h->dU); hipFree(h->dE); hipFree(h->dOk);
-  h->dPf = nullptr; h->dP8f = nullptr; h->dU = nullptr; h->dE = nullptr; h->dOk = nullptr;
+  hipFree(h->dPf); hipFree(h->dP8f); hipFree(h->dPart); hipFree(h->dU); hipFree(h->dE); hipFree(h->dOk);
+  h->dPf = nullptr; h->dP8f = nullptr; h->dPart = nullptr; h->dU = nullptr; h->dE = nullptr; h->dOk = nullptr;
   select_set(h, 0);
   h->Bcap = 0;
 }
@@ -123,6 +124,15 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
   }
   HIP_TRY(hipMalloc(&h->dPf, h->M_pad * ld * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&h->dP8f, 3 * h->K_pad * ld));
+  {  // K splits of the Z_q product: at most 256 K-steps each (int32 exactness), and enough workgroups to fill the chip
+    const int nks = (int)(h->K_pad / 64);
+    int splits = (nks + 255) / 256;
+    const size_t tiles = (ld / 64) * (h->n_pad / 64);
+    while (splits < 8 && tiles * splits < 2048 && nks / (splits + 1) >= 16) ++splits;
+    h->zq_splits = splits;
+    h->zq_ks = (nks + splits - 1) / splits;
+    HIP_TRY(hipMalloc(&h->dPart, (size_t)splits * h->n_pad * ld * sizeof(uint64_t)));
+  }
   HIP_TRY(hipMalloc(&h->dU, B * h->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dE, B * h->m * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&h->dOk, B));
@@ -389,13 +399,15 @@ static void split_A(psfp_handle* h) {
 static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32_t* P, int8_t* P8, size_t ncols, const uint64_t* U, uint64_t* out, size_t ldo) {
   const size_t ld = h->ld;
   hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * ld, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, P8, h->dFail);
-  dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64));
+  dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64), (unsigned)h->zq_splits);
 #define ZQM(NA_)                                                                                                        \
   case NA_:                                                                                                             \
-    hipLaunchKernelGGL((k_zq_mfma<NA_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, mode, h->dA8, h->n, h->n_pad, h->K_pad, P8, ld, ncols, \
-                       h->zc, (int)h->wide, U, out, ldo);                                                               \
+    hipLaunchKernelGGL((k_zq_mfma<NA_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, h->zq_ks, h->zc,  \
+                       (int)h->wide, h->dPart);                                                                         \
     break;
   switch (h->NA) { ZQM(1) ZQM(2) ZQM(3) ZQM(4) ZQM(5) ZQM(6) ZQM(7) ZQM(8) default: break; }
+  hipLaunchKernelGGL(k_zq_combine, dim3(grid_for(h->n * ld, 256, 256 * 32)), dim3(256), 0, st, mode, h->dPart, h->zq_splits, h->n, h->n_pad, ld, ncols,
+                     h->q, U, out, ldo);
 #undef ZQM
 }
 
