@@ -679,6 +679,198 @@ __global__ __launch_bounds__(256) void k_gadget(uint64_t seed, uint64_t first_in
   if (anyhi) atomicOr(fail + 1, 1);
 }
 
+// ---- the same sampler with task queues: no lane waits for another lane's rejection loop ---------------------------------
+// A wave owns GQ_P problems (a problem = one (row j of v, preimage b) pair, k sequential steps).  Its state lives in LDS:
+// c (int16, [row][problem]), the current step and centre, the drawn z.  Each problem is in exactly one place:
+//   READY queue (centre known, waiting for a lane) -> held by a lane (rejection attempts, two per iteration)
+//   -> PENDING queue (z drawn) -> advance pass (64 pending problems at once: c -= z b_i, next centre) -> READY ... -> done.
+// Lanes that accept push their problem to PENDING and take the next READY one (ballot + mbcnt), so all 64 lanes attempt
+// every iteration, and the sequential part (update + projection) always runs with a full wave.  Results are those of the
+// lock-step kernel: each draw is the first accepted attempt of its own Philox stream, each projection the same fma chain.
+struct GadgetTablesQ {
+  const int32_t* Sk; const double* gso; const double* norm2; const SampleZParams* sz;
+  const int32_t* rng;        // 4k: first / last non-zero row of b~_i, first / last non-zero row of b_i
+};
+constexpr int GQ_WAVES = 4;
+
+__host__ __device__ inline int gq_problems_per_wave(uint32_t k) { (void)k; return 128; }
+__host__ inline size_t gadget_queue_lds_bytes(size_t k) {
+  const size_t P = (size_t)gq_problems_per_wave((uint32_t)k);
+  const size_t tables = k * k * 8 + k * 8 + k * sizeof(SampleZParams) + k * k * 4 + 4 * k * 4;
+  const size_t per_wave = k * P * 2 + P * 8 + P * 4 + P * 4 + P * 2 + P * 2;
+  return tables + GQ_WAVES * per_wave + 64;
+}
+
+__global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q,
+                                                      uint64_t base, size_t B, size_t ld, const uint64_t* __restrict__ V,
+                                                      GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
+                                                      int* __restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gq_raw[];
+  const int P = gq_problems_per_wave(k);
+  double* s_gso = reinterpret_cast<double*>(gq_raw);                       // k*k
+  double* s_norm2 = s_gso + (size_t)k * k;                                 // k
+  SampleZParams* s_sz = reinterpret_cast<SampleZParams*>(s_norm2 + k);     // k
+  int32_t* s_Sk = reinterpret_cast<int32_t*>(s_sz + k);                    // k*k
+  int32_t* s_rng = s_Sk + (size_t)k * k;                                   // 4k
+  unsigned char* wave_base = reinterpret_cast<unsigned char*>(s_rng + 4 * k);
+  wave_base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(wave_base) + 7) & ~(uintptr_t)7);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t per_wave = (size_t)k * P * 2 + (size_t)P * 8 + P * 4 + P * 4 + P * 2 + P * 2;
+  unsigned char* wb = wave_base + (size_t)wave * per_wave;
+  double* s_cen = reinterpret_cast<double*>(wb);                           // P
+  int32_t* s_z = reinterpret_cast<int32_t*>(s_cen + P);                    // P
+  int32_t* s_step = s_z + P;                                               // P
+  uint16_t* s_ready = reinterpret_cast<uint16_t*>(s_step + P);             // P (ring)
+  uint16_t* s_pend = s_ready + P;                                          // P (ring)
+  int16_t* s_c = reinterpret_cast<int16_t*>(s_pend + P);                   // k * P, [row][problem]
+
+  for (uint32_t e = tid; e < k * k; e += 256) { s_gso[e] = tb.gso[e]; s_Sk[e] = tb.Sk[e]; }
+  for (uint32_t e = tid; e < k; e += 256) { s_norm2[e] = tb.norm2[e]; s_sz[e] = tb.sz[e]; }
+  for (uint32_t e = tid; e < 4 * k; e += 256) s_rng[e] = tb.rng[e];
+  __syncthreads();
+
+  const size_t total = (size_t)n * B;
+  const size_t seg0 = ((size_t)blockIdx.x * GQ_WAVES + wave) * (size_t)P;
+  if (seg0 >= total) return;
+  const int nprob = (int)(total - seg0 < (size_t)P ? total - seg0 : (size_t)P);
+  int f = 0, anyhi = 0;
+#define GQ_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+
+  auto centre = [&](int p, int col) -> double {     // <c, b~_col> / ||b~_col||^2 over the non-zero rows (ascending fma chain)
+    double dot = 0.0;
+    const int hi = s_rng[k + col];
+    for (int r = s_rng[col]; r <= hi; ++r) dot = fma((double)s_c[r * P + p], s_gso[r * k + col], dot);
+    return dot / s_norm2[col];
+  };
+
+  // ---- init: digits, first centre, everything READY
+  for (int p = lane; p < nprob; p += 64) {
+    const size_t pid = seg0 + p;
+    const uint32_t j = (uint32_t)(pid / B);
+    const size_t b = pid % B;
+    uint64_t v = V[(size_t)j * ld + b] % q;
+    for (uint32_t r = 0; r < k; ++r) {
+      uint64_t d;
+      if (base == 2) { d = v & 1; v >>= 1; }
+      else { d = v % base; v = (v - d) / base; }
+      s_c[r * P + p] = (int16_t)(-(int)d);
+    }
+    s_step[p] = (int)k - 1;
+    s_cen[p] = centre(p, (int)k - 1);
+    s_ready[p] = (uint16_t)p;
+  }
+  GQ_FENCE();
+  int rhead = 0, rcount = nprob;          // READY ring (wave-uniform bookkeeping)
+  int phead = 0, pcount = 0;              // PENDING ring
+  int done = 0;
+
+  bool has = false;
+  int myp = 0, mystep = 0;
+  uint32_t t = 0, myj = 0;
+  size_t myb = 0;
+  double cen = 0.0;
+  SampleZParams sp = s_sz[0];
+
+  while (done < nprob) {
+    // ---- idle lanes take READY problems
+    {
+      const uint64_t need = __ballot(!has);
+      const int want = __popcll(need);
+      const int take = want < rcount ? want : rcount;
+      if (!has) {
+        const int rk = lane_rank(need);
+        if (rk < take) {
+          myp = s_ready[(rhead + rk) % P];
+          mystep = s_step[myp];
+          cen = s_cen[myp];
+          sp = s_sz[mystep];
+          const size_t pid = seg0 + myp;
+          myj = (uint32_t)(pid / B);
+          myb = pid % B;
+          t = 0;
+          has = true;
+        }
+      }
+      rhead = (rhead + take) % P;
+      rcount -= take;
+    }
+    // ---- one Philox block = two attempts
+    bool accept = false;
+    long long x = 0;
+    if (has) {
+      const uint64_t index = first_index + myb;
+      const uint32_t tw = tag_word(TAG_GADGET, index);
+      const uint32_t coord = myj * k + (uint32_t)mystep;
+      const SzRange rg = sz_range(cen, sp);
+      const U4 w = philox(seed, coord, (uint32_t)index, t, tw);
+      accept = sz_attempt(seed, coord, (uint32_t)index, tw, 2 * t, w.x, w.y, rg, cen, sp.inv_s, &x);
+      if (!accept) accept = sz_attempt(seed, coord, (uint32_t)index, tw, 2 * t + 1, w.z, w.w, rg, cen, sp.inv_s, &x);
+      if (!accept && ++t >= kMaxAttempts / 2) { accept = true; f = 1; x = (long long)floor(cen + 0.5); }
+    }
+    {
+      const uint64_t mask = __ballot(accept);
+      if (accept) {
+        if (x > 16000 || x < -16000) f = 1;
+        s_z[myp] = (int32_t)x;
+        s_pend[(phead + pcount + lane_rank(mask)) % P] = (uint16_t)myp;
+        has = false;
+      }
+      pcount += __popcll(mask);
+    }
+    GQ_FENCE();
+    // ---- advance a full wave of PENDING problems (or whatever is left once nothing else can run)
+    const bool starving = !__ballot(has) && rcount == 0;
+    while (pcount >= 64 || (starving && pcount > 0)) {
+      const int cnt = pcount < 64 ? pcount : 64;
+      bool to_ready = false;
+      int p = 0;
+      if (lane < cnt) {
+        p = s_pend[(phead + lane) % P];
+        int i = s_step[p];
+        const int z = s_z[p];
+        const int shi = s_rng[3 * k + i];
+        for (int r = s_rng[2 * k + i]; r <= shi; ++r) {
+          const int nv = (int)s_c[r * P + p] - z * s_Sk[r * k + i];
+          if (nv > 32767 || nv < -32768) f = 1;
+          s_c[r * P + p] = (int16_t)nv;
+        }
+        --i;
+        s_step[p] = i;
+        if (i >= 0) {
+          s_cen[p] = centre(p, i);
+          to_ready = true;
+        } else {
+          const size_t pid = seg0 + p;
+          const uint32_t j = (uint32_t)(pid / B);
+          const size_t b = pid % B;
+          for (uint32_t r = 0; r < k; ++r) {
+            const int32_t zz = -(int32_t)s_c[r * P + p];
+            const int32_t zl = (int32_t)(int8_t)(zz & 0xff);
+            const int32_t zh = (zz - zl) >> 8;
+            const size_t c = (size_t)j * k + r;
+            const size_t addr = ((c >> 4) * ld + b) * 16 + (c & 15);
+            Zlo[addr] = (int8_t)zl;
+            Zhi[addr] = (int8_t)zh;
+            if (zh) anyhi = 1;
+          }
+        }
+      }
+      const uint64_t rmask = __ballot(to_ready);
+      if (to_ready) s_ready[(rhead + rcount + lane_rank(rmask)) % P] = (uint16_t)p;
+      const int nready = __popcll(rmask);
+      rcount += nready;
+      done += cnt - nready;
+      phead = (phead + cnt) % P;
+      pcount -= cnt;
+      GQ_FENCE();
+      if (!starving) break;                 // with lanes still sampling, one pass per iteration keeps everybody busy
+    }
+  }
+#undef GQ_FENCE
+  if (f) atomicOr(fail, 1);
+  if (anyhi) atomicOr(fail + 1, 1);
+}
+
 // ---- e = p + [R; I] z, written preimage-major (B x m int64) ---------------------------------------------
 // top part on the int8 matrix cores: C[b][i] = sum_c Z[c][b] R[i][c] with v_mfma_i32_16x16x64_i8, Z as the A operand
 // (rows = preimages) and R as the B operand (columns = coordinates i), so that 16 lanes hold 16 consecutive i of one

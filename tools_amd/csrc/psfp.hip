@@ -47,6 +47,7 @@ struct psfp_handle {
   double* dLt = nullptr;       // chunk stream of sqrt(Sigma_2)
   size_t M_pad = 0, nbi = 0, nkb = 0;
   // gadget tables
+  int32_t* dRng = nullptr;
   int32_t* dSk = nullptr; double* dGso = nullptr; double* dNorm2 = nullptr; SampleZParams* dSz = nullptr;
   uint64_t* dGvec = nullptr;
   int8_t* dA8 = nullptr; int NA = 0; size_t n_pad = 0, K_pad = 0;   // balanced base-256 digit planes of A
@@ -66,6 +67,7 @@ struct psfp_handle {
                     int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; int* dFail = nullptr; } sets[2];
   int32_t* dPf = nullptr; int8_t* dP8f = nullptr;   // scratch of f_a (kept apart from the pipelined sets)
   uint64_t* dPart = nullptr; int zq_splits = 1, zq_ks = 0;   // per-split residues of the int8-MFMA Z_q product
+  bool gadget_queue = true;   // task-queue gadget sampler (PSF_GADGET_QUEUE=0: lock-step kernel)
   bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
   size_t ncall = 0;
   hipStream_t s1 = nullptr;
@@ -304,6 +306,17 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   std::vector<SampleZParams> sz(h->k);
   for (size_t i = 0; i < h->k; ++i) sz[i] = make_sample_z_params(sG / std::sqrt(norm2[i]));
   std::vector<int32_t> sk32(h->hSk.begin(), h->hSk.end());
+  std::vector<int32_t> rng(4 * h->k);
+  for (size_t col = 0; col < h->k; ++col) {        // non-zero row ranges of b~_col and b_col (zeros are exact: they can be skipped)
+    int glo = (int)h->k, ghi = -1, slo = (int)h->k, shi = -1;
+    for (size_t r = 0; r < h->k; ++r) {
+      if (h->hGso[r * h->k + col] != 0.0) { if ((int)r < glo) glo = (int)r; ghi = (int)r; }
+      if (h->hSk[r * h->k + col] != 0) { if ((int)r < slo) slo = (int)r; shi = (int)r; }
+    }
+    rng[col] = glo; rng[h->k + col] = ghi; rng[2 * h->k + col] = slo; rng[3 * h->k + col] = shi;
+  }
+  HIP_TRY(hipMalloc(&h->dRng, rng.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(h->dRng, rng.data(), rng.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   const auto gvec = gen_gadget_vec_mod(h->k, gp.base, gp.q);
   HIP_TRY(hipMalloc(&h->dSk, sk32.size() * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&h->dGso, h->hGso.size() * sizeof(double)));
@@ -319,6 +332,8 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB * (CH_NB + 1) / 2 + CH_NB * 64) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
+  if (const char* env = std::getenv("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
   *out = h;
   return PSF_OK;
 }
@@ -335,6 +350,7 @@ void psfp_destroy(psfp_handle* h) {
   for (int i = 0; i < 2; ++i) { if (h->evT[i]) hipEventDestroy(h->evT[i]); if (h->evP[i]) hipEventDestroy(h->evP[i]); }
   if (h->evIn) hipEventDestroy(h->evIn);
   hipFree(h->dA8);
+  hipFree(h->dRng);
   hipFree(h->dSk); hipFree(h->dGso); hipFree(h->dNorm2); hipFree(h->dSz); hipFree(h->dGvec);
   delete h;
 }
@@ -533,9 +549,16 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   }
   {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
     ScopedTimer t(h, s2, "k_gadget");
-    GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
-    hipLaunchKernelGGL(k_gadget, dim3((unsigned)((B + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(h->k), s2, seed, first_index,
-                       (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, B, ld, h->dV, tb, h->dZlo, h->dZhi, h->dFail);
+    if (h->gadget_queue) {
+      GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
+      const size_t per_wg = (size_t)GQ_WAVES * gq_problems_per_wave((uint32_t)h->k);
+      hipLaunchKernelGGL(k_gadget_queue, dim3((unsigned)((h->n * B + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k), s2, seed,
+                         first_index, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, B, ld, h->dV, tq, h->dZlo, h->dZhi, h->dFail);
+    } else {
+      GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
+      hipLaunchKernelGGL(k_gadget, dim3((unsigned)((B + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(h->k), s2, seed, first_index,
+                         (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, B, ld, h->dV, tb, h->dZlo, h->dZhi, h->dFail);
+    }
   }
   {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
     ScopedTimer t(h, s2, "k_recombine");
