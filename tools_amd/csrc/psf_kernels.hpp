@@ -693,7 +693,7 @@ struct GadgetTablesQ {
 };
 constexpr int GQ_WAVES = 4;
 
-__host__ __device__ inline int gq_problems_per_wave(uint32_t k) { (void)k; return 128; }
+__host__ __device__ inline int gq_problems_per_wave(uint32_t k) { (void)k; return 128; }   // 256 measured slower (LDS limits occupancy)
 __host__ inline size_t gadget_queue_lds_bytes(size_t k) {
   const size_t P = (size_t)gq_problems_per_wave((uint32_t)k);
   const size_t tables = k * k * 8 + k * 8 + k * sizeof(SampleZParams) + k * k * 4 + 4 * k * 4;
