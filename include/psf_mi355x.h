@@ -88,6 +88,10 @@ psf_status psf_short_basis_gadget(const psf_gadget_params* gp, int64_t* out);
 psf_status psf_gen_short_basis_for_trapdoor(const psf_gadget_params* gp, const uint64_t* tag /*n x n*/,
                                             const uint64_t* A /*n x m*/, const int8_t* R /*m_bar x nk*/,
                                             int64_t* out);
+/* PolynomialRingZq product in R_q = Z_q[X]/(X^n + 1) (common_moduli.rs:41-48), the arithmetic under the MatPolynomialRingZq
+ * products at gadget_ring.rs:78 and gpv_ring.rs:245-246: out[c] = a[c] * b[c] mod (X^n + 1, q) for `count` pairs of n
+ * coefficients (constant term first); a as residues, b as signed integers (a MatPolyOverZ entry).  Runs on the device. */
+psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out);
 /* rot_minus_matrix (rotation_matrix.rs:85-96): mat[rows x cols] -> out[rows x rows*cols] */
 psf_status psf_rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out);
 

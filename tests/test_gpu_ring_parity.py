@@ -105,3 +105,26 @@ def test_ring_reference_flow(T):
         psf.f_a(big)
     assert not psf.check_domain(big)
     assert psf.check_domain(np.zeros((psf.K, psf.n), dtype=np.int64))
+
+
+def test_polynomial_ring_product_kernel(T):
+    rng = np.random.default_rng(5)
+    for n, q in [(4, 16), (5, 2**31 - 58), (256, 3329), (64, 2**40 + 15), (1, 7)]:
+        a = rng.integers(0, q, size=(3, n), dtype=np.uint64)
+        b = rng.integers(-50, 50, size=(3, n), dtype=np.int64)
+        got = T.gadget.poly_mul_negacyclic(a, b, q)
+        for c in range(3):
+            assert got[c].tolist() == polymul_negacyclic(a[c], b[c], n, q)
+    assert T.gadget.poly_mul_negacyclic(np.zeros((0, 8), dtype=np.uint64), np.zeros((0, 8), dtype=np.int64), 17).shape == (0, 8)
+
+
+def test_ring_f_a_equals_sum_of_ring_products(T):
+    """f_a (gpv_ring.rs:243-247) evaluated on the embedding must equal sum_j a_j * sigma_j computed with the R_q kernel."""
+    n, q = 16, 3329
+    psf = T.PSFGPVRing(T.GadgetParametersRing.init_default(n, q), compute_s(n), 1.005)
+    a, _ = psf.trap_gen(2)
+    sg = psf.samp_d(seed=3, B=4)
+    u = psf.f_a(sg)
+    for b in range(4):
+        prods = T.gadget.poly_mul_negacyclic(a, sg[b], q)
+        assert ((prods.astype(object).sum(axis=0)) % q == u[b].astype(object)).all()

@@ -264,4 +264,36 @@ __global__ __launch_bounds__(256, 1) void k_gpv_nearest_plane(const int32_t* __r
   if (f) atomicOr(fail, 1);
 }
 
+// ---- R_q = Z_q[X]/(X^n + 1): negacyclic product (PolynomialRingZq multiplication under gadget_ring.rs:78 and gpv_ring.rs:245-246) ----
+// One workgroup per pair; both operands in LDS; thread t owns coefficients t, t+256, ...  out[c] = sum_{i<=c} a_i b_{c-i} - sum_{i>c} a_i b_{n+c-i}.
+// Exact: positive and negative parts are accumulated in 128 bits (q < 2^31) or reduced term by term (larger q).
+__global__ __launch_bounds__(256) void k_polymul_negacyclic(uint64_t q, uint64_t two64, uint32_t n, const uint64_t* __restrict__ A, size_t a_stride,
+                                                            const int64_t* __restrict__ Bp, size_t b_stride, uint64_t* __restrict__ out, size_t o_stride) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t pm_smem[];   // a[n] | b[n]
+  uint64_t* sa = pm_smem;
+  uint64_t* sb = pm_smem + n;
+  const size_t pair = blockIdx.x;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    sa[i] = A[pair * a_stride + i] % q;
+    const int64_t v = Bp[pair * b_stride + i] % (int64_t)q;
+    sb[i] = (uint64_t)(v < 0 ? v + (int64_t)q : v);
+  }
+  __syncthreads();
+  const bool small = q <= 0x7fffffffull;
+  for (uint32_t c = threadIdx.x; c < n; c += 256) {
+    uint64_t pos = 0, neg = 0;
+    if (small) {
+      Acc128 P{0, 0}, N{0, 0};
+      for (uint32_t i = 0; i <= c; ++i) acc128_add(P, (int64_t)(sa[i] * sb[c - i]));
+      for (uint32_t i = c + 1; i < n; ++i) acc128_add(N, (int64_t)(sa[i] * sb[n + c - i]));
+      pos = acc128_mod(P, q, two64);
+      neg = acc128_mod(N, q, two64);
+    } else {
+      for (uint32_t i = 0; i <= c; ++i) { pos += mulmod_dev(sa[i], sb[c - i], q); if (pos >= q) pos -= q; }
+      for (uint32_t i = c + 1; i < n; ++i) { neg += mulmod_dev(sa[i], sb[n + c - i], q); if (neg >= q) neg -= q; }
+    }
+    out[pair * o_stride + c] = pos >= neg ? pos - neg : pos + q - neg;
+  }
+}
+
 }  // namespace psf

@@ -318,6 +318,26 @@ void psfring_destroy(psfring_handle* h) {
   delete h;
 }
 
+psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out) {
+  if (q <= 1 || q >= (1ull << 62) || n < 1 || n > 8192 || (count && (!a || !b || !out))) return PSF_ERR_PARAM;
+  if (count == 0) return PSF_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return PSF_ERR_HIP;
+  HIP_TRY(hipSetDevice(device));
+  uint64_t *da = nullptr, *dout = nullptr; int64_t* db = nullptr;
+  HIP_TRY(hipMalloc(&da, count * n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&db, count * n * sizeof(int64_t)));
+  HIP_TRY(hipMalloc(&dout, count * n * sizeof(uint64_t)));
+  HIP_TRY(hipMemcpy(da, a, count * n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, b, count * n * sizeof(int64_t), hipMemcpyHostToDevice));
+  const uint64_t two64 = (uint64_t)((((u128)1) << 64) % q);
+  hipLaunchKernelGGL(k_polymul_negacyclic, dim3((unsigned)count), dim3(256), 2 * n * sizeof(uint64_t), 0, q, two64, (uint32_t)n, da, n, db, n, dout, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, count * n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  hipFree(da); hipFree(db); hipFree(dout);
+  return PSF_OK;
+}
+
 // gpv_ring.rs:91-98 + gen_trapdoor_ring_lwe (gadget_ring.rs:62-81); r, e <- SampleZ(s_td) (trapdoor_distribution.rs:112-122)
 psf_status psfring_trap_gen(psfring_handle* h, uint64_t seed) {
   if (!h) return PSF_ERR_PARAM;
@@ -333,7 +353,26 @@ psf_status psfring_trap_gen(psfring_handle* h, uint64_t seed) {
   if (fail) return PSF_ERR_SAMPLER;
   std::vector<uint64_t> a_bar(n);
   for (size_t c = 0; c < n; ++c) a_bar[c] = uniform_mod(seed, TAG_RING_A, (uint32_t)c, 0, h->gp.q);   // gpv_ring.rs:92-94
-  ring_assemble_a(h->gp, a_bar.data(), h->r.data(), h->e.data(), h->a.data());
+  // A = [1 | a_bar | g_j - (a_bar r_j + e_j)] (gadget_ring.rs:74-78); the k products a_bar * r_j run on the device
+  {
+    const uint64_t q = h->gp.q;
+    std::vector<uint64_t> abar_rep(k * n), prod(k * n);
+    for (size_t j = 0; j < k; ++j) std::copy(a_bar.begin(), a_bar.end(), abar_rep.begin() + j * n);
+    const psf_status rc = psf_poly_mul_negacyclic(h->g->base->prm.device, q, n, k, abar_rep.data(), h->r.data(), prod.data());
+    if (rc != PSF_OK) return rc;
+    h->a[0] = 1 % q;
+    for (size_t c = 0; c < n; ++c) h->a[n + c] = a_bar[c] % q;
+    uint64_t gpow = 1 % q;
+    for (size_t j = 0; j < k; ++j) {
+      for (size_t c = 0; c < n; ++c) {
+        i128 v = (c == 0 ? (i128)gpow : (i128)0) - ((i128)prod[j * n + c] + h->e[j * n + c]);
+        v %= (i128)q;
+        if (v < 0) v += q;
+        h->a[(2 + j) * n + c] = (uint64_t)v;
+      }
+      gpow = mulmod_u64(gpow, h->gp.base % q, q);
+    }
+  }
   return ring_install(h);
 }
 
