@@ -92,6 +92,10 @@ psf_status psf_gen_short_basis_for_trapdoor(const psf_gadget_params* gp, const u
  * products at gadget_ring.rs:78 and gpv_ring.rs:245-246: out[c] = a[c] * b[c] mod (X^n + 1, q) for `count` pairs of n
  * coefficients (constant term first); a as residues, b as signed integers (a MatPolyOverZ entry).  Runs on the device. */
 psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out);
+/* the same product with the method chosen explicitly: method 0 = schoolbook kernel, 1 = (incomplete) negacyclic NTT kernel,
+ * available when q < 2^31 is a prime with 4 | q-1 and n is a power of two (q = 3329, n = 256: seven levels and degree-1
+ * leaves, as in ML-KEM); PSF_ERR_UNSUPPORTED otherwise.  psf_poly_mul_negacyclic uses the NTT whenever it is available. */
+psf_status psf_poly_mul_negacyclic_method(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out, int method);
 /* rot_minus_matrix (rotation_matrix.rs:85-96): mat[rows x cols] -> out[rows x rows*cols] */
 psf_status psf_rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out);
 

@@ -128,3 +128,21 @@ def test_ring_f_a_equals_sum_of_ring_products(T):
     for b in range(4):
         prods = T.gadget.poly_mul_negacyclic(a, sg[b], q)
         assert ((prods.astype(object).sum(axis=0)) % q == u[b].astype(object)).all()
+
+
+def test_ntt_product_equals_schoolbook(T):
+    """(incomplete) negacyclic NTT kernel == schoolbook kernel == big-integer reference, for NTT-friendly primes."""
+    rng = np.random.default_rng(9)
+    cases = [(3329, 256), (3329, 128), (3329, 512), (7681, 256), (12289, 1024), (257, 64), (17, 8), (5, 2), (2**31 - 2**27 + 1, 256),
+             (1073479681, 512)]
+    for q, n in cases:
+        a = rng.integers(0, q, size=(2, n), dtype=np.uint64)
+        b = rng.integers(-q + 1, q, size=(2, n), dtype=np.int64)
+        ntt = T.gadget.poly_mul_negacyclic(a, b, q, method=1)
+        sb = T.gadget.poly_mul_negacyclic(a, b, q, method=0)
+        assert (ntt == sb).all(), (q, n)
+        assert ntt[0].tolist() == polymul_negacyclic(a[0], b[0], n, q)
+    for q, n in [(16, 8), (3329 * 3, 8), (3329, 6), (7, 4), (2**31 + 11, 8)]:      # not prime / 4 does not divide q-1 / n not 2^a / q too large
+        with pytest.raises(T.PsfError) as ei:
+            T.gadget.poly_mul_negacyclic(np.zeros((1, n), dtype=np.uint64), np.zeros((1, n), dtype=np.int64), q, method=1)
+        assert ei.value.status == 8

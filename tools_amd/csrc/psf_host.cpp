@@ -350,6 +350,59 @@ psf_status ring_short_basis_t(const psf_gadget_params& gp, const uint64_t* a, co
   return PSF_OK;
 }
 
+static uint64_t powmod_u64(uint64_t b, uint64_t e, uint64_t q) {
+  uint64_t r = 1 % q;
+  b %= q;
+  while (e) { if (e & 1) r = mulmod_u64(r, b, q); b = mulmod_u64(b, b, q); e >>= 1; }
+  return r;
+}
+static bool is_prime_u64(uint64_t q) {
+  if (q < 2) return false;
+  for (uint64_t p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) { if (q % p == 0) return q == p; }
+  uint64_t dd = q - 1; int r = 0;
+  while ((dd & 1) == 0) { dd >>= 1; ++r; }
+  for (uint64_t a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {   // deterministic below 2^64
+    uint64_t x = powmod_u64(a, dd, q);
+    if (x == 1 || x == q - 1) continue;
+    bool comp = true;
+    for (int i = 1; i < r && comp; ++i) { x = mulmod_u64(x, x, q); if (x == q - 1) comp = false; }
+    if (comp) return false;
+  }
+  return true;
+}
+
+NttPlan make_ntt_plan(uint64_t q, uint32_t n) {
+  NttPlan pl;
+  pl.q = q; pl.n = n;
+  if (n < 2 || (n & (n - 1)) || q >= (1ull << 31) || !is_prime_u64(q)) return pl;
+  uint32_t t = 0;
+  for (uint64_t x = q - 1; (x & 1) == 0; x >>= 1) ++t;           // t = v2(q - 1): primitive 2^t-th roots of unity exist
+  if (t < 2) return pl;
+  uint32_t log_n = 0;
+  while ((1u << log_n) < n) ++log_n;
+  const uint32_t L = (t - 1 < log_n) ? t - 1 : log_n;
+  // zeta: element of order exactly 2^(L+1):  x^((q-1)/2^(L+1)) for a quadratic non-residue x
+  uint64_t zeta = 0;
+  for (uint64_t x = 2; x < q; ++x) {
+    if (powmod_u64(x, (q - 1) / 2, q) != q - 1) continue;         // need a non-residue so that the order is full
+    zeta = powmod_u64(x, (q - 1) >> (L + 1), q);
+    break;
+  }
+  if (zeta == 0) return pl;
+  pl.L = L; pl.d = n >> L;
+  const uint32_t cnt = 1u << L;
+  pl.zetas.assign(cnt, 0); pl.zetas_inv.assign(cnt, 0);
+  for (uint32_t i = 0; i < cnt; ++i) {
+    uint32_t br = 0;
+    for (uint32_t b = 0; b < L; ++b) if (i & (1u << b)) br |= 1u << (L - 1 - b);
+    pl.zetas[i] = powmod_u64(zeta, br, q);
+    pl.zetas_inv[i] = powmod_u64(pl.zetas[i], q - 2, q);
+  }
+  pl.inv_scale = powmod_u64(cnt % q, q - 2, q);                    // 2^-L
+  pl.ok = true;
+  return pl;
+}
+
 // gpv_ring.rs:172-178
 void ring_embed_a(const uint64_t* a, size_t n, size_t K, uint64_t q, std::vector<uint64_t>& A_emb) {
   const size_t d = n * K;

@@ -70,6 +70,11 @@ void poly_mul_negacyclic(const int64_t* a, const int64_t* b, size_t n, int64_t* 
 void ring_assemble_a(const psf_gadget_params& gp, const uint64_t* a_bar, const int64_t* r, const int64_t* e, uint64_t* a);
 // coefficient embedding of gen_short_basis_for_trapdoor_ring (short_basis_ring.rs:64-166), transposed: row c = column c
 psf_status ring_short_basis_t(const psf_gadget_params& gp, const uint64_t* a, const int64_t* r, const int64_t* e, std::vector<int32_t>& basis_t);
+// Plan of an (incomplete) negacyclic NTT of Z_q[X]/(X^n+1): levels L = min(v2(q-1) - 1, log2 n), leaf degree d = n >> L,
+// zetas[i] = zeta^{bitrev_L(i)} for a primitive 2^(L+1)-th root of unity zeta (Kyber's table for q = 3329, n = 256: L = 7, d = 2).
+// ok = false when q is not a prime with v2(q-1) >= 2, n is not a power of two, or q >= 2^31.
+struct NttPlan { bool ok = false; uint32_t n = 0, L = 0, d = 0; uint64_t q = 0, inv_scale = 0; std::vector<uint64_t> zetas, zetas_inv; };
+NttPlan make_ntt_plan(uint64_t q, uint32_t n);
 // rot^-(iota(a)) (gpv_ring.rs:172-178, rotation_matrix.rs:85-96): n x n(k+2) over Z_q
 void ring_embed_a(const uint64_t* a, size_t n, size_t K, uint64_t q, std::vector<uint64_t>& A_emb);
 

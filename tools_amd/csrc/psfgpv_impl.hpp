@@ -318,8 +318,13 @@ void psfring_destroy(psfring_handle* h) {
   delete h;
 }
 
-psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out) {
+psf_status psf_poly_mul_negacyclic_method(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out, int method) {
   if (q <= 1 || q >= (1ull << 62) || n < 1 || n > 8192 || (count && (!a || !b || !out))) return PSF_ERR_PARAM;
+  NttPlan plan;
+  if (method == 1) {
+    plan = make_ntt_plan(q, (uint32_t)n);
+    if (!plan.ok) return PSF_ERR_UNSUPPORTED;
+  }
   if (count == 0) return PSF_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return PSF_ERR_HIP;
@@ -330,12 +335,30 @@ psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t coun
   HIP_TRY(hipMalloc(&dout, count * n * sizeof(uint64_t)));
   HIP_TRY(hipMemcpy(da, a, count * n * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(db, b, count * n * sizeof(int64_t), hipMemcpyHostToDevice));
-  const uint64_t two64 = (uint64_t)((((u128)1) << 64) % q);
-  hipLaunchKernelGGL(k_polymul_negacyclic, dim3((unsigned)count), dim3(256), 2 * n * sizeof(uint64_t), 0, q, two64, (uint32_t)n, da, n, db, n, dout, n);
-  HIP_TRY(hipGetLastError());
+  if (method == 1) {
+    uint64_t *dz = nullptr, *dzi = nullptr;
+    HIP_TRY(hipMalloc(&dz, plan.zetas.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&dzi, plan.zetas.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(dz, plan.zetas.data(), plan.zetas.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dzi, plan.zetas_inv.data(), plan.zetas.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_polymul_ntt, dim3((unsigned)count), dim3(256), 3 * n * sizeof(uint32_t) + 16, 0, (uint32_t)q, (uint32_t)n, plan.L, plan.d, dz, dzi,
+                       plan.inv_scale, da, db, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree(dz); hipFree(dzi);
+  } else {
+    const uint64_t two64 = (uint64_t)((((u128)1) << 64) % q);
+    hipLaunchKernelGGL(k_polymul_negacyclic, dim3((unsigned)count), dim3(256), 2 * n * sizeof(uint64_t), 0, q, two64, (uint32_t)n, da, n, db, n, dout, n);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipMemcpy(out, dout, count * n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   hipFree(da); hipFree(db); hipFree(dout);
   return PSF_OK;
+}
+
+psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out) {
+  const bool ntt = q < (1ull << 31) && n >= 2 && n <= 8192 && make_ntt_plan(q, (uint32_t)n).ok;
+  return psf_poly_mul_negacyclic_method(device, q, n, count, a, b, out, ntt ? 1 : 0);
 }
 
 // gpv_ring.rs:91-98 + gen_trapdoor_ring_lwe (gadget_ring.rs:62-81); r, e <- SampleZ(s_td) (trapdoor_distribution.rs:112-122)

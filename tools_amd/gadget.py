@@ -84,15 +84,21 @@ def rot_minus(vec):
     return rot_minus_matrix(vec)
 
 
-def poly_mul_negacyclic(a, b, q, device=0):
+def poly_mul_negacyclic(a, b, q, device=0, method=None):
     """a * b in Z_q[X]/(X^n + 1) on the device (PolynomialRingZq product; gadget_ring.rs:78, gpv_ring.rs:245-246).
-    a: residues (count x n or n), b: signed integers of the same shape."""
+    a: residues (count x n or n), b: signed integers of the same shape.  method: None = automatic, 0 = schoolbook kernel,
+    1 = (incomplete) negacyclic NTT kernel (PsfError(UNSUPPORTED) when q / n do not admit one)."""
     a = np.ascontiguousarray(a, dtype=np.uint64)
     b = np.ascontiguousarray(b, dtype=np.int64)
     single = a.ndim == 1
     a2, b2 = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
     assert a2.shape == b2.shape
     out = np.zeros_like(a2)
-    check(lib().psf_poly_mul_negacyclic(C.c_int(device), C.c_uint64(q), C.c_size_t(a2.shape[1]), C.c_size_t(a2.shape[0]),
-                                        _p(a2, C.c_uint64), _p(b2, C.c_int64), _p(out, C.c_uint64)), "poly_mul_negacyclic")
+    if method is None:
+        check(lib().psf_poly_mul_negacyclic(C.c_int(device), C.c_uint64(q), C.c_size_t(a2.shape[1]), C.c_size_t(a2.shape[0]),
+                                            _p(a2, C.c_uint64), _p(b2, C.c_int64), _p(out, C.c_uint64)), "poly_mul_negacyclic")
+    else:
+        check(lib().psf_poly_mul_negacyclic_method(C.c_int(device), C.c_uint64(q), C.c_size_t(a2.shape[1]), C.c_size_t(a2.shape[0]),
+                                                   _p(a2, C.c_uint64), _p(b2, C.c_int64), _p(out, C.c_uint64), C.c_int(method)),
+              "poly_mul_negacyclic")
     return out[0] if single else out
