@@ -92,6 +92,72 @@ __global__ void k_normals(uint64_t seed, uint64_t first_index, size_t m, size_t 
   if (f) atomicOr(fail, 1);
 }
 
+// Wave-compacted form: a wave owns NR_SEG consecutive positions of the chunk stream; every iteration each lane evaluates
+// one ratio-of-uniforms attempt of its current position, accepted lanes store and take the next unassigned position
+// (ballot + mbcnt).  Same values as k_normals (first accepted attempt of each (coordinate, preimage) stream).
+constexpr int NR_SEG = 4096;   // two chunks
+__device__ inline int lane_rank(uint64_t mask);
+
+__global__ __launch_bounds__(256) void k_normals_wave(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t nkb, size_t nbj,
+                                                      double* __restrict__ Dt, int* __restrict__ fail) {
+  const int lane = threadIdx.x & 63;
+  const size_t total = nbj * nkb * TR_CHUNK;
+  const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NR_SEG;
+  if (seg0 >= total) return;
+  const size_t seg1 = seg0 + NR_SEG < total ? seg0 + NR_SEG : total;
+  const size_t chunk0 = seg0 / TR_CHUNK;
+  constexpr int NCH = NR_SEG / TR_CHUNK + 1;
+  size_t cbj[NCH], cbk[NCH];                       // (column block, K block) of the chunks this wave touches
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) { cbj[i] = (chunk0 + i) / nkb; cbk[i] = (chunk0 + i) % nkb; }
+  auto locate = [&](size_t g, size_t* coord, size_t* b) {
+    const int ci = (int)(g / TR_CHUNK - chunk0);
+    const int pos = (int)(g % TR_CHUNK);
+    size_t bj = cbj[0], bk = cbk[0];
+#pragma unroll
+    for (int i = 1; i < NCH; ++i) if (ci == i) { bj = cbj[i]; bk = cbk[i]; }
+    const int ks = pos >> 9, tile = (pos >> 6) & 7, ln = pos & 63;
+    *coord = bk * TR_BK + ks * 4 + (ln >> 4);
+    *b = bj * TR_BN + tile * 16 + (ln & 15);
+  };
+  size_t my = seg0 + lane, next_free = seg0 + 64;
+  bool active = my < seg1;
+  size_t coord = 0, b = 0;
+  uint32_t t = 0;
+  int f = 0;
+  if (active) locate(my, &coord, &b);
+  while (__ballot(active)) {
+    bool accept = false;
+    double v = 0.0;
+    if (active) {
+      if (coord >= m || b >= B) accept = true;                      // padding of the operand: exact zero, nothing to draw
+      else {
+        const uint64_t index = first_index + b;
+        const U4 w = philox(seed, (uint32_t)coord, (uint32_t)index, t, tag_word(TAG_NORMAL, index));
+        const double u = (double)(((((uint64_t)w.y << 32) | w.x) >> 11) + 1) * 0x1.0p-53;
+        const uint64_t vv = (((uint64_t)w.w << 32) | w.z) >> 12;
+        const double x = (((double)(2 * vv + 1) * 0x1.0p-52 - 1.0) * 0.8577638849607068) / u;
+        accept = u <= det_exp(-0.25 * (x * x));
+        v = x;
+        if (!accept && ++t >= kMaxAttempts) { accept = true; f = 1; v = 0.0; }
+      }
+      if (accept) Dt[my] = v;
+    }
+    const uint64_t mask = __ballot(accept);
+    if (mask) {
+      const size_t nid = next_free + (size_t)lane_rank(mask);
+      if (accept) {
+        my = nid;
+        active = nid < seg1;
+        t = 0;
+        if (active) locate(nid, &coord, &b);
+      }
+      next_free += (size_t)__popcll(mask);
+    }
+  }
+  if (f) atomicOr(fail, 1);
+}
+
 // read one normal back out of the chunk stream (stage export)
 __global__ void k_export_normals(const double* __restrict__ Dt, size_t m, size_t B, size_t nkb, double* __restrict__ out /*B x m*/) {
   const size_t total = m * B;

@@ -526,7 +526,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
   {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
     ScopedTimer t(h, st, "k_normals");
-    hipLaunchKernelGGL(k_normals, dim3(grid_for(nbj * h->nkb * TR_CHUNK, 256, 256 * 32)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail);
+    const size_t nwaves = (nbj * h->nkb * TR_CHUNK + NR_SEG - 1) / NR_SEG;
+    hipLaunchKernelGGL(k_normals_wave, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail);
   }
   {  // x = sqrt(Sigma_2) d
     ScopedTimer t(h, st, "k_trmm_f64");
