@@ -20,6 +20,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL on this driver
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
@@ -160,6 +161,9 @@ def main():
             roof = {"bound": "mfma", "kernel": "k_trmm_f64", "achieved": round(ach, 3), "peak": PEAK_F64_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": load_traffic(args.config, B),
                     "launch_ms": round(trmm, 3), "flops_per_launch": flops_per_launch}
+            if roof["traffic"]:                      # the HBM side of the same launch, for the metric's "HBM-BW%"
+                roof["hbm_GBps"] = round(roof["traffic"] / (trmm * 1e-3) / 1e9, 1)
+                roof["hbm_frac_of_peak"] = round(roof["traffic"] / (trmm * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)
         out = {
             "metric": "preimages/sec (whole node) + HBM-BW% for samp_p, n=512 q~2^30 batch=4096",
             "value": round(value, 2), "unit": "preimages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -158,6 +158,10 @@ psf_status psfp_f_a_dev(psfp_handle*, size_t B, const int64_t* d_e, uint64_t* d_
 psf_status psfp_last_status(psfp_handle*);
 /* synthetic uniform targets u <- Z_q^{B x n} (benches/psf.rs:35,60,87) written to device memory */
 psf_status psfp_uniform_targets_dev(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, uint64_t* d_u, void* stream);
+/* result rows for the inter-GPU gather: narrows count int64 preimage coordinates in device memory to
+ * int32 (|e_i| <= 6 s r sqrt(m) for every parameter set of mp_perturbation.rs / gpv.rs); *d_overflow (device int) is
+ * OR-ed with 1 if a value does not fit, so the caller can refuse to ship truncated rows */
+psf_status psf_narrow_rows_dev(const int64_t* d_src, int32_t* d_dst, size_t count, int* d_overflow, int device, void* stream);
 
 /* stage-level access for parity tests and profiling (host buffers; NULL = skip):
  * runs samp_p for B rows and copies out the intermediates of the reference's call stack

@@ -41,3 +41,70 @@ def run(mode):
 
 def test_pipelined_mode_is_bit_identical():
     assert run("0") == run("1")
+
+
+@pytest.mark.gpu
+def test_narrow_rows_for_gather():
+    """shard.narrow_rows on device tensors: values, odd count, overflow flag."""
+    import torch
+    from tools_amd.shard import narrow_rows
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    for count in (0, 1, 7, 4096 * 105 + 1):
+        src = torch.randint(-2**31, 2**31, (count,), dtype=torch.int64, generator=g).to(dev)
+        dst = torch.full((count,), 77, dtype=torch.int32, device=dev)
+        flag = torch.zeros((), dtype=torch.int32, device=dev)
+        narrow_rows(src, dst, flag)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        assert torch.equal(dst.to(torch.int64), src)
+    for bad_pos in (0, 12344, 12345):
+        src = torch.zeros((12346,), dtype=torch.int64, device=dev)
+        src[bad_pos] = 2**31
+        dst = torch.empty((12346,), dtype=torch.int32, device=dev)
+        flag = torch.zeros((), dtype=torch.int32, device=dev)
+        narrow_rows(src, dst, flag)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 1
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29641"
+import torch, torch.distributed as dist
+import tools_amd as T
+from tools_amd.shard import AsyncRowGather
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+gp = T.GadgetParameters.init_default(16, 257)
+psf = T.PSFPerturbation(gp, 4.0, 40.0, device=0)
+psf.trap_gen(seed=2)
+B, m, n = 96, psf.m, 16
+stream = torch.cuda.current_stream().cuda_stream
+u = torch.empty((B, n), dtype=torch.int64, device=dev)
+e = torch.empty((B, m), dtype=torch.int64, device=dev)
+psf.uniform_targets_dev(u.data_ptr(), B, seed=7, first_index=0, stream=stream)
+g = AsyncRowGather(B, m, dev, dst=0, force=True)
+keep = []
+for i in range(3):
+    psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=100 + i, first_index=0, stream=stream)
+    keep.append(e.clone())
+    g.submit(e)
+out = g.finish()
+torch.cuda.synchronize()
+assert len(out) == 1 and torch.equal(out[0].to(torch.int64), keep[-1]), "gathered rows differ"
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_async_row_gather_over_rccl_one_rank():
+    """The bench's N>1 result path (narrow kernel -> async RCCL gather -> wait) on a one-rank RCCL group."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -158,6 +158,24 @@ __global__ __launch_bounds__(256) void k_normals_wave(uint64_t seed, uint64_t fi
   if (f) atomicOr(fail, 1);
 }
 
+// int64 -> int32 rows for the inter-GPU gather; two values per thread-iteration, 16-byte loads
+__global__ __launch_bounds__(256) void k_narrow_rows(const int64_t* __restrict__ src, int32_t* __restrict__ dst, size_t count, int* __restrict__ overflow) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  int bad = 0;
+  const size_t pairs = count / 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride) {
+    const longlong2 v = reinterpret_cast<const longlong2*>(src)[i];
+    bad |= (v.x != (int64_t)(int32_t)v.x) | (v.y != (int64_t)(int32_t)v.y);
+    reinterpret_cast<int2*>(dst)[i] = make_int2((int32_t)v.x, (int32_t)v.y);
+  }
+  if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t v = src[count - 1];
+    bad |= v != (int64_t)(int32_t)v;
+    dst[count - 1] = (int32_t)v;
+  }
+  if (bad) atomicOr(overflow, 1);
+}
+
 // read one normal back out of the chunk stream (stage export)
 __global__ void k_export_normals(const double* __restrict__ Dt, size_t m, size_t B, size_t nkb, double* __restrict__ out /*B x m*/) {
   const size_t total = m * B;

@@ -736,6 +736,16 @@ psf_status psfp_uniform_targets_dev(psfp_handle* h, uint64_t seed, uint64_t firs
   return PSF_OK;
 }
 
+psf_status psf_narrow_rows_dev(const int64_t* d_src, int32_t* d_dst, size_t count, int* d_overflow, int device, void* stream) {
+  if (count && (!d_src || !d_dst || !d_overflow)) return PSF_ERR_PARAM;
+  if (((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 7)) return PSF_ERR_PARAM;
+  if (count == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_narrow_rows, dim3(grid_for(count / 2 + 1, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, d_src, d_dst, count, d_overflow);
+  HIP_TRY(hipGetLastError());
+  return PSF_OK;
+}
+
 psf_status psfp_enable_timing(psfp_handle* h, int on) {
   if (!h) return PSF_ERR_PARAM;
   h->timing = on != 0;

@@ -1,8 +1,26 @@
 """Batch sharding over ranks: preimages are independent, so a job of `total` rows is cut into
 contiguous index ranges, one per rank, and the only exchange is a gather of the result rows to rank 0.
 The Philox streams are keyed by the GLOBAL row index, so the gathered matrix equals the single-rank result."""
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+
+def narrow_rows(src_int64, dst_int32, overflow_flag):
+    """int64 -> int32 copy of result rows on the current stream.  Device tensors go through the library's
+    psf_narrow_rows_dev (one pass: 8 B read + 4 B written per coordinate, range check fused); host tensors
+    (the gloo tests) through torch.  overflow_flag: int32 scalar tensor on the same device, OR-ed with 1."""
+    if src_int64.is_cuda:
+        from ._ffi import lib, check
+        check(lib().psf_narrow_rows_dev(C.c_void_p(src_int64.data_ptr()), C.c_void_p(dst_int32.data_ptr()),
+                                        C.c_size_t(src_int64.numel()), C.c_void_p(overflow_flag.data_ptr()),
+                                        C.c_int(src_int64.device.index or 0),
+                                        C.c_void_p(torch.cuda.current_stream(src_int64.device).cuda_stream)), "narrow_rows")
+    else:
+        if src_int64.numel():
+            overflow_flag |= int(src_int64.abs().amax() >= 2**31)
+        dst_int32.copy_(src_int64)
 
 
 def shard_range(rank, world, per_rank):
@@ -38,8 +56,8 @@ class AsyncRowGather:
     checked on device), which halves the bytes on the links; two staging buffers alternate so that a buffer is only
     rewritten after the gather that reads it has completed."""
 
-    def __init__(self, rows, cols, device, dst=0, depth=2):
-        self.enabled = dist.is_initialized() and dist.get_world_size() > 1
+    def __init__(self, rows, cols, device, dst=0, depth=2, force=False):
+        self.enabled = dist.is_initialized() and (dist.get_world_size() > 1 or force)   # force: exercise the path on one rank
         self.dst, self.depth = dst, depth
         self.rank = dist.get_rank() if self.enabled else 0
         self.world = dist.get_world_size() if self.enabled else 1
@@ -49,7 +67,7 @@ class AsyncRowGather:
             self.recv = [[torch.empty((rows, cols), dtype=torch.int32, device=device) for _ in range(self.world)] for _ in range(depth)]
         self.work = [None] * depth
         self.step = 0
-        self.overflow = torch.zeros((), dtype=torch.bool, device=device) if self.enabled else None
+        self.overflow = torch.zeros((), dtype=torch.int32, device=device) if self.enabled else None
 
     def submit(self, e_int64):
         """Queue the gather of this step's rows; returns immediately."""
@@ -58,8 +76,7 @@ class AsyncRowGather:
         i = self.step % self.depth
         if self.work[i] is not None:
             self.work[i].wait()                      # the previous user of this staging buffer has been delivered
-        self.overflow |= (e_int64.abs().amax() >= 2**31)
-        self.stage[i].copy_(e_int64)                 # int64 -> int32 on the current stream
+        narrow_rows(e_int64, self.stage[i], self.overflow)       # int64 -> int32 on the current stream
         self.work[i] = dist.gather(self.stage[i], self.recv[i] if self.rank == self.dst else None, dst=self.dst, async_op=True)
         self.step += 1
 
