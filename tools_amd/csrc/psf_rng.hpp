@@ -114,21 +114,41 @@ __host__ __device__ inline SzRange sz_range(double center, const SampleZParams s
   r.thr = (uint32_t)(0u - r.N) % r.N;
   return r;
 }
-__host__ __device__ inline bool sz_attempt(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t t, uint32_t wa, uint32_t wb,
-                                           const SzRange rg, double center, double inv_s, long long* x_out) {
-  const uint64_t prod = (uint64_t)wa * rg.N;
-  if ((uint32_t)prod < rg.thr) return false;
-  const long long x = rg.lo + (long long)(prod >> 32);
+// exact acceptance decision for candidate x of attempt t (acceptance word wb): wb vs floor(rho 2^32), tie -> side block
+__host__ __device__ inline bool sz_decide(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t t, long long x, uint32_t wb,
+                                          double center, double inv_s) {
   const double a = ((double)x - center) * inv_s;
   const double rs = det_exp(-3.14159265358979323846 * (a * a)) * 4294967296.0;
   const double r32 = floor(rs);
   const uint64_t r32u = (uint64_t)r32;
-  *x_out = x;
   if ((uint64_t)wb < r32u) return true;
   if ((uint64_t)wb > r32u) return false;
   const U4 w2 = philox(seed, coord, idx_lo, 0x80000000u | t, tw);
   return (double)w2.x < floor((rs - r32) * 4294967296.0);
 }
+__host__ __device__ inline bool sz_attempt(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t t, uint32_t wa, uint32_t wb,
+                                           const SzRange rg, double center, double inv_s, long long* x_out) {
+  const uint64_t prod = (uint64_t)wa * rg.N;
+  if ((uint32_t)prod < rg.thr) return false;
+  const long long x = rg.lo + (long long)(prod >> 32);
+  *x_out = x;
+  return sz_decide(seed, coord, idx_lo, tw, t, x, wb, center, inv_s);
+}
+#if defined(__HIPCC__)
+// Conservative single-precision screen for one attempt: false only when sz_attempt is certainly false (index rejected, or
+// wb 2^-32 above an upper bound of rho: fp32 exp of the fp32-rounded argument is within 1e-4 relative of det_exp for
+// |arg| <= 36 pi, the factor 1.001 and the absolute slack cover that, the rounding of wb and flushed denormals).
+// A "maybe" is settled by sz_decide, so the accepted attempt and value are those of the exact sampler.
+__device__ inline bool sz_maybe(uint32_t wa, uint32_t wb, const SzRange rg, double center, double inv_s, long long* x_out) {
+  const uint64_t prod = (uint64_t)wa * rg.N;
+  if ((uint32_t)prod < rg.thr) return false;
+  const long long x = rg.lo + (long long)(prod >> 32);
+  const float a = (float)(((double)x - center) * inv_s);
+  const float rho_hi = __expf(-3.14159274f * (a * a)) * 1.001f + 1e-9f;
+  *x_out = x;
+  return (float)wb * 0x1.0p-32f <= rho_hi;
+}
+#endif
 
 __host__ __device__ inline long long sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center,
                                               const SampleZParams sp, int* fail) {
