@@ -215,6 +215,10 @@ psf_status psfgpv_last_status(psfgpv_handle*);
 /* HIP-event duration (ms) of the nearest-plane kernel of the last samp_p call (0 if timing was off) */
 psf_status psfgpv_enable_timing(psfgpv_handle*, int on);
 psf_status psfgpv_get_timing(psfgpv_handle*, double* solve_ms, double* nearest_plane_ms);
+/* diagnostic of the last samp_p call: workgroups of the nearest-plane walk (gpv.rs:160) that ran with the integer vector
+ * in doubles (0 if q >= 2^50 sent the call straight to the int64 pass) and how many of them reached the 2^52 exactness
+ * bound and were re-run by the int64 pass; the result is the same either way */
+psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle*, size_t* workgroups, size_t* handed_over);
 
 /* ------------------------------------------------------------------------------------------------
  * PSFGPVRing (gpv_ring.rs:62-67, impl PSF :69-284) over R_q = Z_q[X]/(X^n + 1)

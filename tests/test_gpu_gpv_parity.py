@@ -81,3 +81,40 @@ def test_samp_d_f_a_domain(T, oracle):
         psf.f_a(big)
     assert not psf.check_domain(big) and not psf.check_domain(np.zeros(m + 1, dtype=np.int64))
     assert psf.check_domain(np.full(m, 10, dtype=np.int64))
+
+
+@pytest.mark.parametrize("n,q,s", [(6, 128, 10.0), (10, 157, 30.0)])
+def test_nearest_plane_int64_pass_equals_fp53_pass(T, oracle, monkeypatch, n, q, s):
+    """The walk keeps c in doubles (exact below 2^52) with an int64 pass behind it; PSF_GPV_INT64=1 runs the int64 pass
+    alone.  Both must give the oracle's bits."""
+    gp = T.GadgetParameters.init_default(n, q)
+    psf = T.PSFGPV(gp, s)
+    A, (bt, gt) = psf.trap_gen(5)
+    u = oracle.uniform_targets(2, 7, n, q)
+    e = psf.samp_p(u, seed=31, first_index=4)
+    assert psf.nearest_plane_stats() == (4, 0)
+    monkeypatch.setenv("PSF_GPV_INT64", "1")
+    psf64 = T.PSFGPV(gp, s)
+    psf64.load_key(A, bt, gt)
+    assert (psf64.samp_p(u, seed=31, first_index=4) == e).all()
+    assert psf64.nearest_plane_stats() == (0, 0)
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    assert orc.load_key(A, bt, gt) == 0
+    assert (e == orc.samp_p(31, u, first_index=4)).all()
+
+
+def test_nearest_plane_hands_over_when_the_fp53_bound_trips(T, oracle):
+    """q = 2^45: c0_bound + sum |z_i| max|b_i| passes 2^52 within a few steps, so every workgroup of the FP53 pass stops and
+    the int64 pass produces the result; still the oracle's bits and A e = u."""
+    n, q, s = 3, 2**45, 60.0
+    gp = T.GadgetParameters.init_default(n, q)
+    psf = T.PSFGPV(gp, s)
+    A, (bt, gt) = psf.trap_gen(9)
+    u = oracle.uniform_targets(3, 5, n, q)
+    e = psf.samp_p(u, seed=11, first_index=0)
+    groups, handed = psf.nearest_plane_stats()
+    assert groups == 3 and handed == groups
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    assert orc.load_key(A, bt, gt) == 0
+    assert (e == orc.samp_p(11, u, first_index=0)).all()
+    assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()

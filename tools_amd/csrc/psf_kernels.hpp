@@ -291,6 +291,29 @@ __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const
 // (sample, attempt) changes nothing: the value is the first accepted attempt of the sample's own Philox stream.
 constexpr int PR_SEG = 4096;
 
+// acc += shfl_xor(acc, off) for off = 32, 16, 8, 4, 2, 1 -- the xor butterfly of the dot256 contract -- without LDS-crossbar
+// permutes: v_permlane32_swap / v_permlane16_swap (gfx950) for the two widest levels, DPP moves for the rest.  Bit-identical to
+// the __shfl_xor form (a + b = b + a); checked on hardware by tools/probe_dpp_butterfly.hip.
+__device__ inline double wave_xor_sum(double x) {
+  typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+  auto mk = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
+  uint32_t lo = (uint32_t)__double2loint(x), hi = (uint32_t)__double2hiint(x);
+  { const u2v a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    x = mk(a.x, b.x) + mk(a.y, b.y); lo = (uint32_t)__double2loint(x); hi = (uint32_t)__double2hiint(x); }
+  { const u2v a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x = mk(a.x, b.x) + mk(a.y, b.y); lo = (uint32_t)__double2loint(x); hi = (uint32_t)__double2hiint(x); }
+  { const int pl = __builtin_amdgcn_update_dpp(0, (int)lo, 0x128, 0xf, 0xf, false), ph = __builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xf, 0xf, false);   // row_ror:8
+    x = x + mk((uint32_t)pl, (uint32_t)ph); lo = (uint32_t)__double2loint(x); hi = (uint32_t)__double2hiint(x); }
+  { int pl = __builtin_amdgcn_update_dpp(0, (int)lo, 0x104, 0xf, 0x5, false); pl = __builtin_amdgcn_update_dpp(pl, (int)lo, 0x114, 0xf, 0xa, false);       // row_shl:4 | row_shr:4
+    int ph = __builtin_amdgcn_update_dpp(0, (int)hi, 0x104, 0xf, 0x5, false); ph = __builtin_amdgcn_update_dpp(ph, (int)hi, 0x114, 0xf, 0xa, false);
+    x = x + mk((uint32_t)pl, (uint32_t)ph); lo = (uint32_t)__double2loint(x); hi = (uint32_t)__double2hiint(x); }
+  { const int pl = __builtin_amdgcn_update_dpp(0, (int)lo, 0x4e, 0xf, 0xf, false), ph = __builtin_amdgcn_update_dpp(0, (int)hi, 0x4e, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+    x = x + mk((uint32_t)pl, (uint32_t)ph); lo = (uint32_t)__double2loint(x); hi = (uint32_t)__double2hiint(x); }
+  { const int pl = __builtin_amdgcn_update_dpp(0, (int)lo, 0xb1, 0xf, 0xf, false), ph = __builtin_amdgcn_update_dpp(0, (int)hi, 0xb1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+    x = x + mk((uint32_t)pl, (uint32_t)ph); }
+  return x;
+}
+
 __device__ inline int lane_rank(uint64_t mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }

@@ -90,6 +90,8 @@ struct SampleZParams {
   double inv_s;     // 1/s
   long long c6;     // ceil(6 s)
   long long f6;     // floor(6 s)
+  uint32_t n_int;   // candidates when the centre is an integer: c6 + f6 + 1 (one fewer otherwise)
+  uint32_t thr_int, thr_frac;   // 2^32 mod N for N = n_int and N = n_int - 1 (Lemire rejection thresholds)
 };
 
 inline SampleZParams make_sample_z_params(double s) {
@@ -97,6 +99,9 @@ inline SampleZParams make_sample_z_params(double s) {
   p.inv_s = 1.0 / s;
   p.c6 = (long long)ceil(6.0 * s);
   p.f6 = (long long)floor(6.0 * s);
+  p.n_int = (uint32_t)(p.c6 + p.f6 + 1);
+  p.thr_int = (uint32_t)(0u - p.n_int) % p.n_int;
+  p.thr_frac = p.n_int > 1 ? (uint32_t)(0u - (p.n_int - 1)) % (p.n_int - 1) : 0;
   return p;
 }
 
@@ -109,9 +114,11 @@ inline SampleZParams make_sample_z_params(double s) {
 struct SzRange { long long lo; uint32_t N, thr; };
 __host__ __device__ inline SzRange sz_range(double center, const SampleZParams sp) {
   SzRange r;
-  r.lo = (long long)ceil(center) - sp.c6;
-  r.N = (uint32_t)((long long)floor(center) + sp.f6 - r.lo + 1);
-  r.thr = (uint32_t)(0u - r.N) % r.N;
+  const double cc = ceil(center), cf = floor(center);
+  const bool integral = cc == cf;                 // N = floor(c) + f6 - (ceil(c) - c6) + 1
+  r.lo = (long long)cc - sp.c6;
+  r.N = integral ? sp.n_int : sp.n_int - 1;
+  r.thr = integral ? sp.thr_int : sp.thr_frac;
   return r;
 }
 // exact acceptance decision for candidate x of attempt t (acceptance word wb): wb vs floor(rho 2^32), tie -> side block

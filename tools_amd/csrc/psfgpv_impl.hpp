@@ -13,8 +13,15 @@ struct psfgpv_handle {
   uint64_t* dT = nullptr;             // n x n solve operator
   uint32_t* dPiv = nullptr;           // n pivot columns
   int64_t* dC0 = nullptr; size_t c0cap = 0;
+  int jr = 0;                         // nearest-plane template size for dim (np_template_jr)
+  int32_t* dStP = nullptr;            // packed, zero-padded copies of dSt / dGt in the nearest-plane kernel's layout (k_np_pack)
+  double* dGtP = nullptr;
+  double* dRowMax = nullptr;          // max |entry| per basis row (bound of the FP53 nearest-plane pass)
+  int* dRedo = nullptr;               // per-workgroup hand-over mask FP53 pass -> int64 pass (c0cap entries)
   bool has_key = false;
   bool timing = false;
+  unsigned last_blocks = 0;           // workgroups of the last nearest-plane launch (0 if the FP53 pass was skipped)
+  bool force_int64 = false;           // PSF_GPV_INT64=1: skip the FP53 pass (tests compare both)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   hipStream_t last_stream = nullptr;
 };
@@ -37,6 +44,8 @@ static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
     hipFree(dmu);
   }
   hipLaunchKernelGGL(k_row_norm2_chain, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, 0, g->dGt, d, g->dNorm2);
+  hipLaunchKernelGGL(k_row_absmax_i32, dim3((unsigned)d), dim3(64), 0, 0, g->dSt, d, g->dRowMax);
+  if (g->jr) hipLaunchKernelGGL(k_np_pack, dim3((unsigned)d), dim3(256), 0, 0, g->dSt, g->dGt, d, np_g2(g->jr), np_s4(g->jr), g->dStP, g->dGtP);
   HIP_TRY(hipGetLastError());
   std::vector<double> norm2(d);
   HIP_TRY(hipMemcpy(norm2.data(), g->dNorm2, d * sizeof(double), hipMemcpyDeviceToHost));
@@ -62,24 +71,48 @@ static psf_status gpv_build_solver(psfgpv_handle* g) {
   return PSF_OK;
 }
 
-template <int JR, int PB>
+// template JR (coordinates per thread) for a lattice dimension; 0 = unsupported (> 8192)
+static int np_template_jr(size_t dim) {
+  const size_t jr = (dim + 255) / 256;
+  const int sizes[] = {1, 2, 4, 8, 14, 16, 25, 32};
+  for (int v : sizes) if (jr <= (size_t)v) return v;
+  return 0;
+}
+template <int JR>
 static void launch_np(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e) {
-  hipLaunchKernelGGL((k_gpv_nearest_plane<JR, PB>), dim3((unsigned)((B + PB - 1) / PB)), dim3(256), 0, st, g->dSt, g->dGt, g->dNorm2, g->dSz,
-                     g->dim, seed, tag, first_index, B, g->dC0, d_e, g->base->dFail);
+  const unsigned blocks = (unsigned)((B + 1) / 2);
+  const uint64_t q = g->base->q;
+  const bool fp53 = q < (1ull << 50) && !g->force_int64;
+  g->last_blocks = fp53 ? blocks : 0;
+  if (fp53) {
+    hipMemsetAsync(g->dRedo, 0, blocks * sizeof(int), st);
+    hipLaunchKernelGGL((k_gpv_nearest_plane<JR, true>), dim3(blocks), dim3(256), 0, st, g->dStP, g->dGtP, g->dNorm2, g->dSz, g->dRowMax, (double)q,
+                       g->dim, seed, tag, first_index, B, g->dC0, d_e, g->base->dFail, g->dRedo);
+  }
+  hipLaunchKernelGGL((k_gpv_nearest_plane<JR, false>), dim3(blocks), dim3(256), 0, st, g->dStP, g->dGtP, g->dNorm2, g->dSz, g->dRowMax, 0.0,
+                     g->dim, seed, tag, first_index, B, g->dC0, d_e, g->base->dFail, fp53 ? g->dRedo : nullptr);
 }
 static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e) {
-  const size_t jr = (g->dim + 255) / 256;
-  if (jr <= 1) launch_np<1, 4>(g, st, seed, tag, first_index, B, d_e);
-  else if (jr <= 2) launch_np<2, 4>(g, st, seed, tag, first_index, B, d_e);
-  else if (jr <= 4) launch_np<4, 4>(g, st, seed, tag, first_index, B, d_e);
-  else if (jr <= 8) launch_np<8, 4>(g, st, seed, tag, first_index, B, d_e);
-  else if (jr <= 14) launch_np<14, 4>(g, st, seed, tag, first_index, B, d_e);
-  else if (jr <= 16) launch_np<16, 4>(g, st, seed, tag, first_index, B, d_e);
-  else if (jr <= 25) launch_np<25, 4>(g, st, seed, tag, first_index, B, d_e);
-  else if (jr <= 32) launch_np<32, 2>(g, st, seed, tag, first_index, B, d_e);
-  else return PSF_ERR_UNSUPPORTED;                                     // lattice dimension > 8192
+  switch (g->jr) {
+    case 1: launch_np<1>(g, st, seed, tag, first_index, B, d_e); break;
+    case 2: launch_np<2>(g, st, seed, tag, first_index, B, d_e); break;
+    case 4: launch_np<4>(g, st, seed, tag, first_index, B, d_e); break;
+    case 8: launch_np<8>(g, st, seed, tag, first_index, B, d_e); break;
+    case 14: launch_np<14>(g, st, seed, tag, first_index, B, d_e); break;
+    case 16: launch_np<16>(g, st, seed, tag, first_index, B, d_e); break;
+    case 25: launch_np<25>(g, st, seed, tag, first_index, B, d_e); break;
+    case 32: launch_np<32>(g, st, seed, tag, first_index, B, d_e); break;
+    default: return PSF_ERR_UNSUPPORTED;                                // lattice dimension > 8192
+  }
   return PSF_OK;
 }
+
+#ifdef NP_PROFILE
+extern "C" void psf_debug_np_prof(long long* out, int reset) {
+  if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_np_prof), sizeof(long long) * 8);
+  if (reset) { long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_np_prof), z, sizeof(z)); }
+}
+#endif
 
 extern "C" {
 
@@ -97,6 +130,13 @@ psf_status psfgpv_create(const psfgpv_params* prm, psfgpv_handle** out) {
   HIP_TRY(hipMalloc(&g->dSt, d * d * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&g->dGt, d * d * sizeof(double)));
   HIP_TRY(hipMalloc(&g->dNorm2, d * sizeof(double)));
+  HIP_TRY(hipMalloc(&g->dRowMax, d * sizeof(double)));
+  g->jr = np_template_jr(d);
+  if (g->jr) {
+    HIP_TRY(hipMalloc(&g->dGtP, d * (size_t)np_g2(g->jr) * 512 * sizeof(double)));
+    HIP_TRY(hipMalloc(&g->dStP, d * (size_t)np_s4(g->jr) * 1024 * sizeof(int32_t)));
+  }
+  { const char* ev = getenv("PSF_GPV_INT64"); g->force_int64 = ev && ev[0] == '1'; }
   HIP_TRY(hipMalloc(&g->dSz, d * sizeof(SampleZParams)));
   HIP_TRY(hipMalloc(&g->dT, g->n * g->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&g->dPiv, g->n * sizeof(uint32_t)));
@@ -108,7 +148,7 @@ psf_status psfgpv_create(const psfgpv_params* prm, psfgpv_handle** out) {
 void psfgpv_destroy(psfgpv_handle* g) {
   if (!g) return;
   hipSetDevice(g->base->prm.device);
-  hipFree(g->dSt); hipFree(g->dGt); hipFree(g->dNorm2); hipFree(g->dSz); hipFree(g->dT); hipFree(g->dPiv); hipFree(g->dC0);
+  hipFree(g->dSt); hipFree(g->dGt); hipFree(g->dNorm2); hipFree(g->dSz); hipFree(g->dT); hipFree(g->dPiv); hipFree(g->dC0); hipFree(g->dRowMax); hipFree(g->dRedo); hipFree(g->dStP); hipFree(g->dGtP);
   for (auto& e : g->ev) if (e) hipEventDestroy(e);
   psfp_destroy(g->base);
   delete g;
@@ -188,6 +228,9 @@ psf_status psfgpv_samp_p_dev(psfgpv_handle* g, uint64_t seed, uint64_t first_ind
     hipFree(g->dC0);
     g->dC0 = nullptr;
     HIP_TRY(hipMalloc(&g->dC0, B * g->dim * sizeof(int64_t)));
+    hipFree(g->dRedo);
+    g->dRedo = nullptr;
+    HIP_TRY(hipMalloc(&g->dRedo, (B + 1) * sizeof(int)));
     g->c0cap = B;
   }
   HIP_TRY(hipMemsetAsync(b->dFail, 0, 2 * sizeof(int), st));
@@ -255,6 +298,17 @@ psf_status psfgpv_get_timing(psfgpv_handle* g, double* solve_ms, double* nearest
   if (g->timing) { hipEventElapsedTime(&a, g->ev[0], g->ev[1]); hipEventElapsedTime(&c, g->ev[1], g->ev[2]); }
   if (solve_ms) *solve_ms = a;
   if (nearest_plane_ms) *nearest_plane_ms = c;
+  return PSF_OK;
+}
+psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle* g, size_t* workgroups, size_t* handed_over) {
+  if (!g) return PSF_ERR_PARAM;
+  HIP_TRY(hipStreamSynchronize(g->last_stream));
+  std::vector<int> redo(g->last_blocks);
+  if (g->last_blocks) HIP_TRY(hipMemcpy(redo.data(), g->dRedo, redo.size() * sizeof(int), hipMemcpyDeviceToHost));
+  size_t cnt = 0;
+  for (int v : redo) cnt += v != 0;
+  if (workgroups) *workgroups = g->last_blocks;
+  if (handed_over) *handed_over = cnt;
   return PSF_OK;
 }
 

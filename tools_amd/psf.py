@@ -280,6 +280,12 @@ class PSFGPV:
     def enable_timing(self, on=True):
         check(lib().psfgpv_enable_timing(self._h, C.c_int(1 if on else 0)), "enable_timing")
 
+    def nearest_plane_stats(self):
+        """(workgroups of the FP53 pass, workgroups handed over to the int64 pass) of the last samp_p call."""
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        check(lib().psfgpv_get_nearest_plane_stats(self._h, C.byref(a), C.byref(b)), "nearest_plane_stats")
+        return a.value, b.value
+
     def get_timing(self):
         a, b = C.c_double(0), C.c_double(0)
         check(lib().psfgpv_get_timing(self._h, C.byref(a), C.byref(b)), "get_timing")
