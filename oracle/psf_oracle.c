@@ -80,42 +80,58 @@ double orc_det_exp(double y) {
 /* Z::sample_discrete_gauss / SampleZ of GPV08 as documented at CONTRIBUTING.md:35-45:
  * candidates uniform in [center - ceil(6s), center + floor(6s)], accepted with probability
  * rho_s(x - c) = exp(-pi (x-c)^2 / s^2)  (s = sigma*sqrt(2 pi)).
- * Randomness: one Philox block serves two attempts, attempt t = 2*block + half uses words (x,y) / (z,w).
- *   candidate : index = (wa * N) >> 32 with Lemire's rejection of the 2^32 mod N lowest fractions (exactly uniform);
- *   acceptance: a 64-bit uniform U = wb * 2^32 + ext is compared with floor(rho * 2^64); the low word `ext` is drawn
- *               lazily from block (0x80000000 | t) only when wb equals the high word of the threshold. */
+ * Randomness: an attempt consumes a candidate word wa and an acceptance word wb of sh bits each.
+ *   narrow (sh = 16; ceil(6s) + floor(6s) + 1 <= 4096): Philox block g serves attempts 4g + j, j = 0..3, from its word j
+ *          (wa = high half, wb = low half);
+ *   wide   (sh = 32): block b serves attempts 2b (words x, y) and 2b + 1 (words z, w).
+ *   candidate : index = (wa * N) >> sh with Lemire's rejection of the 2^sh mod N lowest fractions (exactly uniform);
+ *   acceptance: U = wb * 2^32 + ext is compared with floor(rho * 2^(sh+32)); the low word `ext` is drawn
+ *               lazily from block (0x80000000 | t) only when wb equals the high part of the threshold. */
+#define ORC_NARROW_MAX_N 4096u
+
 static int sz_attempt(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t t, uint32_t wa, uint32_t wb,
-                      int64_t lo, uint32_t N, uint32_t thr, double center, double inv_s, int64_t* x_out) {
+                      int64_t lo, uint32_t N, uint32_t thr, uint32_t sh, double center, double inv_s, int64_t* x_out) {
   const double NEG_PI = -3.14159265358979323846;
   uint64_t prod = (uint64_t)wa * N;
-  if ((uint32_t)prod < thr) return 0;
-  int64_t x = lo + (int64_t)(prod >> 32);
+  if ((uint32_t)(prod & ((1ull << sh) - 1)) < thr) return 0;
+  int64_t x = lo + (int64_t)(prod >> sh);
   double a = ((double)x - center) * inv_s;
-  double rs = orc_det_exp(NEG_PI * (a * a)) * 4294967296.0;      /* rho * 2^32, exact scaling */
-  double r32 = floor(rs);
-  uint64_t r32u = (uint64_t)r32;
+  double rs = orc_det_exp(NEG_PI * (a * a)) * (sh == 16 ? 65536.0 : 4294967296.0);      /* rho * 2^sh, exact scaling */
+  double rf = floor(rs);
+  uint64_t ru = (uint64_t)rf;
   *x_out = x;
-  if ((uint64_t)wb < r32u) return 1;
-  if ((uint64_t)wb > r32u) return 0;
+  if ((uint64_t)wb < ru) return 1;
+  if ((uint64_t)wb > ru) return 0;
   uint32_t w2[4];
   orc_philox4x32(seed, coord, idx_lo, 0x80000000u | t, tw, w2);
-  double rfrac = floor((rs - r32) * 4294967296.0);
+  double rfrac = floor((rs - rf) * 4294967296.0);
   return (double)w2[0] < rfrac;
 }
 
 int64_t orc_sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center, double s) {
   double inv_s = 1.0 / s;
-  int64_t lo = (int64_t)ceil(center) - (int64_t)ceil(6.0 * s);
-  int64_t hi = (int64_t)floor(center) + (int64_t)floor(6.0 * s);
+  int64_t c6 = (int64_t)ceil(6.0 * s), f6 = (int64_t)floor(6.0 * s);
+  int64_t lo = (int64_t)ceil(center) - c6;
+  int64_t hi = (int64_t)floor(center) + f6;
   uint32_t N = (uint32_t)(hi - lo + 1);
-  uint32_t thr = (uint32_t)(0u - N) % N;
+  uint32_t sh = (uint64_t)(c6 + f6 + 1) <= ORC_NARROW_MAX_N ? 16 : 32;   /* by s alone, not by the centre */
+  uint32_t thr = (uint32_t)((1ull << sh) % N);
   uint32_t tw = tag_word(tag, index);
-  uint32_t w[4];
+  uint32_t w[4], v[4];
   int64_t x;
-  for (uint32_t tb = 0; tb < ORC_MAX_ATTEMPTS / 2; ++tb) {
-    orc_philox4x32(seed, coord, (uint32_t)index, tb, tw, w);
-    if (sz_attempt(seed, coord, (uint32_t)index, tw, 2 * tb, w[0], w[1], lo, N, thr, center, inv_s, &x)) return x;
-    if (sz_attempt(seed, coord, (uint32_t)index, tw, 2 * tb + 1, w[2], w[3], lo, N, thr, center, inv_s, &x)) return x;
+  for (uint32_t g = 0; g < ORC_MAX_ATTEMPTS / 4; ++g) {
+    uint32_t wa[4], wb[4];
+    if (sh == 16) {
+      orc_philox4x32(seed, coord, (uint32_t)index, g, tw, w);
+      for (int j = 0; j < 4; ++j) { wa[j] = w[j] >> 16; wb[j] = w[j] & 0xffffu; }
+    } else {
+      orc_philox4x32(seed, coord, (uint32_t)index, 2 * g, tw, w);
+      orc_philox4x32(seed, coord, (uint32_t)index, 2 * g + 1, tw, v);
+      wa[0] = w[0]; wb[0] = w[1]; wa[1] = w[2]; wb[1] = w[3];
+      wa[2] = v[0]; wb[2] = v[1]; wa[3] = v[2]; wb[3] = v[3];
+    }
+    for (uint32_t j = 0; j < 4; ++j)
+      if (sz_attempt(seed, coord, (uint32_t)index, tw, 4 * g + j, wa[j], wb[j], lo, N, thr, sh, center, inv_s, &x)) return x;
   }
   return (int64_t)floor(center + 0.5);
 }

@@ -278,9 +278,10 @@ __global__ __launch_bounds__(256, 2) void k_gpv_nearest_plane(const int32_t* __r
     const double n2 = norm2[ii];
     const double rmax = FP53 ? rowmax[ii] : 0.0;
     const SampleZParams sp = sz[ii];
-    if (!sampler && samp_live) {                   // attempts 0..63, two per Philox block
-      const U4 w = philox(seed, (uint32_t)ii, (uint32_t)index_s, (uint32_t)lane >> 1, tw_s);
-      s_rng[ps][lane] = (lane & 1) ? make_uint2(w.z, w.w) : make_uint2(w.x, w.y);
+    if (!sampler && samp_live) {                   // words of attempts 0..63
+      uint32_t wa, wb;
+      sz_attempt_words(seed, (uint32_t)ii, (uint32_t)index_s, tw_s, (uint32_t)lane, sp.sh, &wa, &wb);
+      s_rng[ps][lane] = make_uint2(wa, wb);
     }
     double part[2];
 #pragma unroll
@@ -308,11 +309,8 @@ __global__ __launch_bounds__(256, 2) void k_gpv_nearest_plane(const int32_t* __r
         bool got = false;
         uint2 wr = s_rng[ps][lane];
         for (uint32_t t0 = 0; t0 < kMaxAttempts && !got; t0 += 64) {
-          const uint32_t ta = t0 + (uint32_t)lane;                  // lanes 2j, 2j+1 share Philox block ta >> 1
-          if (t0) {
-            const U4 w = philox(seed, (uint32_t)ii, (uint32_t)index_s, ta >> 1, tw_s);
-            wr = (ta & 1) ? make_uint2(w.z, w.w) : make_uint2(w.x, w.y);
-          }
+          const uint32_t ta = t0 + (uint32_t)lane;
+          if (t0) sz_attempt_words(seed, (uint32_t)ii, (uint32_t)index_s, tw_s, ta, sp.sh, &wr.x, &wr.y);
           long long x = 0;
           const bool acc = sz_attempt(seed, (uint32_t)ii, (uint32_t)index_s, tw_s, ta, wr.x, wr.y, rg, cen, sp.inv_s, &x);
           const uint64_t mask = __ballot(acc);

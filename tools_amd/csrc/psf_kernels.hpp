@@ -355,28 +355,11 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
     bool accept = false;
     long long x = 0;
     if (active) {
-      // two Philox blocks = four attempts of this lane's sample, screened in fp32; only the first "maybe" pays the fp64 exp
+      // four attempts of this lane's sample (one Philox block when the range is narrow), screened in fp32: see sz_group4
       const uint64_t index = first_index + b;
       const uint32_t tw = tag_word(TAG_PERTURB, index);
       const SzRange rg = sz_range(c, sp);
-      const U4 wA = philox(seed, (uint32_t)coord, (uint32_t)index, 2 * t, tw);
-      const U4 wB = philox(seed, (uint32_t)coord, (uint32_t)index, 2 * t + 1, tw);
-      const uint32_t wa[4] = {wA.x, wA.z, wB.x, wB.z}, wb[4] = {wA.y, wA.w, wB.y, wB.w};
-      int tm = -1;
-      uint32_t wbm = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        long long xc;
-        if (tm < 0 && sz_maybe(wa[j], wb[j], rg, c, sp.inv_s, &xc)) { tm = j; wbm = wb[j]; x = xc; }
-      }
-      if (tm >= 0) {
-        accept = sz_decide(seed, (uint32_t)coord, (uint32_t)index, tw, 4 * t + tm, x, wbm, c, sp.inv_s);
-        if (!accept) {                                       // screened in but rejected exactly (rare): finish the group exactly
-#pragma unroll
-          for (int j = 1; j < 4; ++j)
-            if (!accept && j > tm) accept = sz_attempt(seed, (uint32_t)coord, (uint32_t)index, tw, 4 * t + j, wa[j], wb[j], rg, c, sp.inv_s, &x);
-        }
-      }
+      accept = sz_group4(seed, (uint32_t)coord, (uint32_t)index, tw, t, rg, c, sp.inv_s, &x);
       if (!accept && ++t >= kMaxAttempts / 4) { accept = true; f = 1; x = (long long)floor(c + 0.5); }
       if (accept) {
         if (x > 0x1ffffff || x < -0x1ffffff) f = 1;
@@ -916,7 +899,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
       rhead = (rhead + take) % P;
       rcount -= take;
     }
-    // ---- two Philox blocks = four attempts, screened in fp32; the first "maybe" is settled exactly (see sz_maybe)
+    // ---- four attempts (one Philox block when the range is narrow), screened in fp32: see sz_group4
     bool accept = false;
     long long x = 0;
     if (has) {
@@ -924,24 +907,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
       const uint32_t tw = tag_word(TAG_GADGET, index);
       const uint32_t coord = myj * k + (uint32_t)mystep;
       const SzRange rg = sz_range(cen, sp);
-      const U4 wA = philox(seed, coord, (uint32_t)index, 2 * t, tw);
-      const U4 wB = philox(seed, coord, (uint32_t)index, 2 * t + 1, tw);
-      const uint32_t wa[4] = {wA.x, wA.z, wB.x, wB.z}, wbw[4] = {wA.y, wA.w, wB.y, wB.w};
-      int tm = -1;
-      uint32_t wbm = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        long long xc;
-        if (tm < 0 && sz_maybe(wa[j], wbw[j], rg, cen, sp.inv_s, &xc)) { tm = j; wbm = wbw[j]; x = xc; }
-      }
-      if (tm >= 0) {
-        accept = sz_decide(seed, coord, (uint32_t)index, tw, 4 * t + tm, x, wbm, cen, sp.inv_s);
-        if (!accept) {
-#pragma unroll
-          for (int j = 1; j < 4; ++j)
-            if (!accept && j > tm) accept = sz_attempt(seed, coord, (uint32_t)index, tw, 4 * t + j, wa[j], wbw[j], rg, cen, sp.inv_s, &x);
-        }
-      }
+      accept = sz_group4(seed, coord, (uint32_t)index, tw, t, rg, cen, sp.inv_s, &x);
       if (!accept && ++t >= kMaxAttempts / 4) { accept = true; f = 1; x = (long long)floor(cen + 0.5); }
     }
     {

@@ -91,8 +91,11 @@ struct SampleZParams {
   long long c6;     // ceil(6 s)
   long long f6;     // floor(6 s)
   uint32_t n_int;   // candidates when the centre is an integer: c6 + f6 + 1 (one fewer otherwise)
-  uint32_t thr_int, thr_frac;   // 2^32 mod N for N = n_int and N = n_int - 1 (Lemire rejection thresholds)
+  uint32_t thr_int, thr_frac;   // 2^sh mod N for N = n_int and N = n_int - 1 (Lemire rejection thresholds)
+  uint32_t sh;      // bits per attempt word: 16 (narrow, n_int <= 4096) or 32 (wide)
 };
+
+constexpr uint32_t kNarrowMaxN = 4096;
 
 inline SampleZParams make_sample_z_params(double s) {
   SampleZParams p;
@@ -100,18 +103,23 @@ inline SampleZParams make_sample_z_params(double s) {
   p.c6 = (long long)ceil(6.0 * s);
   p.f6 = (long long)floor(6.0 * s);
   p.n_int = (uint32_t)(p.c6 + p.f6 + 1);
-  p.thr_int = (uint32_t)(0u - p.n_int) % p.n_int;
-  p.thr_frac = p.n_int > 1 ? (uint32_t)(0u - (p.n_int - 1)) % (p.n_int - 1) : 0;
+  p.sh = p.n_int <= kNarrowMaxN ? 16 : 32;
+  const uint64_t two_sh = 1ull << p.sh;
+  p.thr_int = (uint32_t)(two_sh % p.n_int);
+  p.thr_frac = p.n_int > 1 ? (uint32_t)(two_sh % (p.n_int - 1)) : 0;
   return p;
 }
 
 // SampleZ of GPV08 as the reference documents it (CONTRIBUTING.md:35-45): candidates uniform in
 // [c - ceil(6s), c + floor(6s)], accepted with probability exp(-pi (x-c)^2 / s^2).
-// One Philox block (coord, index_lo, block, tag|index_hi) serves attempts 2*block (words x,y) and 2*block+1 (words z,w):
-//   candidate : index = (wa * N) >> 32, attempt void if the low product word is below 2^32 mod N (Lemire: exactly uniform);
-//   acceptance: U = wb * 2^32 + ext against floor(rho * 2^64); ext comes from block (0x80000000 | attempt), drawn only on a tie.
+// An attempt consumes a candidate word wa and an acceptance word wb of sh bits each:
+//   narrow (sh = 16, at most 4096 candidates): Philox block g (coord, index_lo, g, tag|index_hi) serves attempts 4g + j,
+//          j = 0..3, from its word j: wa = high half, wb = low half;
+//   wide   (sh = 32): block b serves attempts 2b (words x, y) and 2b + 1 (words z, w).
+//   candidate : index = (wa * N) >> sh, attempt void if the low sh bits of the product are below 2^sh mod N (Lemire: exactly uniform);
+//   acceptance: U = wb * 2^32 + ext against floor(rho * 2^(sh+32)); ext comes from block (0x80000000 | attempt), drawn only on a tie.
 // The value of a sample is its first accepted attempt, whatever lane or order evaluates the attempts.
-struct SzRange { long long lo; uint32_t N, thr; };
+struct SzRange { long long lo; uint32_t N, thr, sh; };
 __host__ __device__ inline SzRange sz_range(double center, const SampleZParams sp) {
   SzRange r;
   const double cc = ceil(center), cf = floor(center);
@@ -119,41 +127,95 @@ __host__ __device__ inline SzRange sz_range(double center, const SampleZParams s
   r.lo = (long long)cc - sp.c6;
   r.N = integral ? sp.n_int : sp.n_int - 1;
   r.thr = integral ? sp.thr_int : sp.thr_frac;
+  r.sh = sp.sh;
   return r;
 }
-// exact acceptance decision for candidate x of attempt t (acceptance word wb): wb vs floor(rho 2^32), tie -> side block
+// the (wa, wb) words of attempts 4g .. 4g+3
+__host__ __device__ inline void sz_group_words(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t g, uint32_t sh,
+                                               uint32_t wa[4], uint32_t wb[4]) {
+  if (sh == 16) {
+    const U4 w = philox(seed, coord, idx_lo, g, tw);
+    wa[0] = w.x >> 16; wb[0] = w.x & 0xffffu;
+    wa[1] = w.y >> 16; wb[1] = w.y & 0xffffu;
+    wa[2] = w.z >> 16; wb[2] = w.z & 0xffffu;
+    wa[3] = w.w >> 16; wb[3] = w.w & 0xffffu;
+  } else {
+    const U4 u = philox(seed, coord, idx_lo, 2 * g, tw), v = philox(seed, coord, idx_lo, 2 * g + 1, tw);
+    wa[0] = u.x; wb[0] = u.y; wa[1] = u.z; wb[1] = u.w;
+    wa[2] = v.x; wb[2] = v.y; wa[3] = v.z; wb[3] = v.w;
+  }
+}
+// ... of the single attempt t
+__host__ __device__ inline void sz_attempt_words(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t t, uint32_t sh,
+                                                 uint32_t* wa, uint32_t* wb) {
+  if (sh == 16) {
+    const U4 w = philox(seed, coord, idx_lo, t >> 2, tw);
+    const uint32_t word = (t & 2) ? ((t & 1) ? w.w : w.z) : ((t & 1) ? w.y : w.x);
+    *wa = word >> 16; *wb = word & 0xffffu;
+  } else {
+    const U4 w = philox(seed, coord, idx_lo, t >> 1, tw);
+    *wa = (t & 1) ? w.z : w.x; *wb = (t & 1) ? w.w : w.y;
+  }
+}
+// exact acceptance decision for candidate x of attempt t (acceptance word wb): wb vs floor(rho 2^sh), tie -> side block
 __host__ __device__ inline bool sz_decide(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t t, long long x, uint32_t wb,
-                                          double center, double inv_s) {
+                                          double center, double inv_s, uint32_t sh) {
   const double a = ((double)x - center) * inv_s;
-  const double rs = det_exp(-3.14159265358979323846 * (a * a)) * 4294967296.0;
-  const double r32 = floor(rs);
-  const uint64_t r32u = (uint64_t)r32;
-  if ((uint64_t)wb < r32u) return true;
-  if ((uint64_t)wb > r32u) return false;
+  const double rs = det_exp(-3.14159265358979323846 * (a * a)) * (sh == 16 ? 65536.0 : 4294967296.0);
+  const double rf = floor(rs);
+  const uint64_t ru = (uint64_t)rf;
+  if ((uint64_t)wb < ru) return true;
+  if ((uint64_t)wb > ru) return false;
   const U4 w2 = philox(seed, coord, idx_lo, 0x80000000u | t, tw);
-  return (double)w2.x < floor((rs - r32) * 4294967296.0);
+  return (double)w2.x < floor((rs - rf) * 4294967296.0);
 }
 __host__ __device__ inline bool sz_attempt(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t t, uint32_t wa, uint32_t wb,
                                            const SzRange rg, double center, double inv_s, long long* x_out) {
   const uint64_t prod = (uint64_t)wa * rg.N;
-  if ((uint32_t)prod < rg.thr) return false;
-  const long long x = rg.lo + (long long)(prod >> 32);
+  if ((uint32_t)(prod & ((1ull << rg.sh) - 1)) < rg.thr) return false;
+  const long long x = rg.lo + (long long)(prod >> rg.sh);
   *x_out = x;
-  return sz_decide(seed, coord, idx_lo, tw, t, x, wb, center, inv_s);
+  return sz_decide(seed, coord, idx_lo, tw, t, x, wb, center, inv_s, rg.sh);
 }
 #if defined(__HIPCC__)
 // Conservative single-precision screen for one attempt: false only when sz_attempt is certainly false (index rejected, or
-// wb 2^-32 above an upper bound of rho: fp32 exp of the fp32-rounded argument is within 1e-4 relative of det_exp for
+// wb 2^-sh above an upper bound of rho: fp32 exp of the fp32-rounded argument is within 1e-4 relative of det_exp for
 // |arg| <= 36 pi, the factor 1.001 and the absolute slack cover that, the rounding of wb and flushed denormals).
 // A "maybe" is settled by sz_decide, so the accepted attempt and value are those of the exact sampler.
 __device__ inline bool sz_maybe(uint32_t wa, uint32_t wb, const SzRange rg, double center, double inv_s, long long* x_out) {
   const uint64_t prod = (uint64_t)wa * rg.N;
-  if ((uint32_t)prod < rg.thr) return false;
-  const long long x = rg.lo + (long long)(prod >> 32);
+  if ((uint32_t)(prod & ((1ull << rg.sh) - 1)) < rg.thr) return false;
+  const long long x = rg.lo + (long long)(prod >> rg.sh);
   const float a = (float)(((double)x - center) * inv_s);
   const float rho_hi = __expf(-3.14159274f * (a * a)) * 1.001f + 1e-9f;
   *x_out = x;
-  return (float)wb * 0x1.0p-32f <= rho_hi;
+  return (float)wb * (rg.sh == 16 ? 0x1.0p-16f : 0x1.0p-32f) <= rho_hi;
+}
+// attempts 4g .. 4g+3 of one sample: screened in fp32, the first "maybe" settled exactly; the rare screened-in-but-rejected
+// case finishes the group with exact attempts, so the outcome is that of four sequential sz_attempt calls
+__device__ inline bool sz_group4(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t g, const SzRange rg, double center,
+                                 double inv_s, long long* x_out) {
+  uint32_t wa[4], wb[4];
+  sz_group_words(seed, coord, idx_lo, tw, g, rg.sh, wa, wb);
+  int tm = -1;
+  uint32_t wbm = 0;
+  long long x = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    long long xc;
+    if (tm < 0 && sz_maybe(wa[j], wb[j], rg, center, inv_s, &xc)) { tm = j; wbm = wb[j]; x = xc; }
+  }
+  bool accept = false;
+  if (tm >= 0) {
+    accept = sz_decide(seed, coord, idx_lo, tw, 4 * g + (uint32_t)tm, x, wbm, center, inv_s, rg.sh);
+    if (!accept) {
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
+        if (!accept && j > tm) accept = sz_attempt(seed, coord, idx_lo, tw, 4 * g + (uint32_t)j, wa[j], wb[j], rg, center, inv_s, &x);
+    }
+  }
+  *x_out = x;
+  return accept;
 }
 #endif
 
@@ -162,10 +224,11 @@ __host__ __device__ inline long long sample_z(uint64_t seed, uint32_t tag, uint6
   const SzRange rg = sz_range(center, sp);
   const uint32_t tw = tag_word(tag, index);
   long long x = 0;
-  for (uint32_t tb = 0; tb < kMaxAttempts / 2; ++tb) {
-    const U4 w = philox(seed, coord, (uint32_t)index, tb, tw);
-    if (sz_attempt(seed, coord, (uint32_t)index, tw, 2 * tb, w.x, w.y, rg, center, sp.inv_s, &x)) return x;
-    if (sz_attempt(seed, coord, (uint32_t)index, tw, 2 * tb + 1, w.z, w.w, rg, center, sp.inv_s, &x)) return x;
+  for (uint32_t g = 0; g < kMaxAttempts / 4; ++g) {
+    uint32_t wa[4], wb[4];
+    sz_group_words(seed, coord, (uint32_t)index, tw, g, rg.sh, wa, wb);
+    for (int j = 0; j < 4; ++j)
+      if (sz_attempt(seed, coord, (uint32_t)index, tw, 4 * g + (uint32_t)j, wa[j], wb[j], rg, center, sp.inv_s, &x)) return x;
   }
   *fail = 1;
   return (long long)floor(center + 0.5);
