@@ -19,6 +19,7 @@ CONFIGS = [  # (n, q, r, s) -- reference test / doc sizes: mp_perturbation.rs:43
     (3, 2**61 - 1, 2.0, 70.0),      # large prime modulus: digit column in S_k, wide non-power-of-two reduction
     (4, 1073741789, 2.0, 50.0),     # C3's prime alternative
     (8, 64, 100.0, 25.0),           # wide gadget Gaussian: |z| > 127 occurs, exercising the hi byte plane of z
+    (8, 64, 400.0, 25.0),           # > 4096 candidates per SampleZ: the 32-bit attempt words ("wide")
 ]
 
 
@@ -109,7 +110,7 @@ def test_readme_flow(T, oracle):
     assert (psf.f_a(preimage) == range_fa).all()
 
 
-@pytest.mark.parametrize("n,q,r,s", CONFIGS[:3])
+@pytest.mark.parametrize("n,q,r,s", CONFIGS[:3] + [(8, 64, 9.0, 512.0)])   # last: C3's s r = 4608, wide attempt words
 def test_samp_d_f_a_check_domain_parity(T, oracle, n, q, r, s):
     psf, orc, (A, R, Lp, Sk, gso) = make_pair(T, oracle, n, q, r, s)
     orc.load_key(A, R, Lp)
