@@ -61,7 +61,7 @@ __global__ void k_divsqrt(const double* x, const double* y, double* q, double* r
 
 static uint64_t bits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d clock=%d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
   std::mt19937_64 rng(12345);
@@ -108,8 +108,8 @@ int main() {
   }
   // ---------- 2. rate ----------
   {
-    int iters = 20000;
-    for (int wpb : {256, 512}) {
+    int iters = argc > 1 ? atoi(argv[1]) : 20000;          // 250000 = about 55 ms per launch (sustained clocks)
+    for (int wpb : {256, 512, 256, 512}) {
       int blocks = prop.multiProcessorCount * (wpb == 256 ? 2 : 1);
       for (int rep = 0; rep < 2; ++rep) {
       double* out; CK(hipMalloc(&out, (size_t)blocks * wpb * 8));

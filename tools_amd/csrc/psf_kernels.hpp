@@ -236,8 +236,13 @@ __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const
 
   // each wave moves pieces 4*wave .. 4*wave+3 (1 KiB each) of both chunks: LDS address = wave-uniform base + lane*16
   auto stage_load = [&](int kb, int buf) {
+#ifdef TRMM_FAKE_L2   /* timing experiment only: every load hits the same few chunks (results are garbage) */
+    const double* ga = Lt + lane * 2 + (size_t)(kb & 7) * TR_CHUNK;
+    const double* gb = Dt + lane * 2 + (size_t)(kb & 7) * TR_CHUNK;
+#else
     const double* ga = gA + (size_t)kb * TR_CHUNK;
     const double* gb = gB + (size_t)kb * TR_CHUNK;
+#endif
     double* la = smem + buf * (2 * TR_CHUNK);
 #pragma unroll
     for (int i = 0; i < TR_CHUNK / 512; ++i) {
