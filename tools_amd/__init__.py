@@ -7,3 +7,4 @@ trap_gen / samp_d / samp_p / f_a / check_domain.  Everything computes on the GPU
 from ._ffi import PsfError, LIB_PATH  # noqa: F401
 from .psf import GadgetParameters, GadgetParametersRing, PSFPerturbation, PSFGPV, PSFGPVRing  # noqa: F401
 from . import gadget  # noqa: F401
+from . import textio  # noqa: F401
