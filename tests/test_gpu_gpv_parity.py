@@ -118,3 +118,21 @@ def test_nearest_plane_hands_over_when_the_fp53_bound_trips(T, oracle):
     assert orc.load_key(A, bt, gt) == 0
     assert (e == orc.samp_p(11, u, first_index=0)).all()
     assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
+
+
+@pytest.mark.parametrize("n,q,jr", [(32, 256, 4), (64, 256, 8), (128, 2**15, 16), (256, 2**15, 32)])
+def test_samp_p_parity_at_every_nearest_plane_template(T, oracle, n, q, jr):
+    """Lattice dimensions that select the larger k_gpv_nearest_plane<JR> instantiations (the small configs above only reach
+    JR = 1 and 2; C2 / C4 use 25 / 14).  Key from the device, three preimages (an odd count: the last workgroup is half empty)."""
+    s = 1000.0
+    gp = T.GadgetParameters.init_default(n, q)
+    psf = T.PSFGPV(gp, s)
+    assert (psf.m + 255) // 256 <= jr and ((psf.m + 255) // 256 > jr // 2 or jr == 4)
+    A, (bt, gt) = psf.trap_gen(3)
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    assert orc.load_key(A, bt, gt) == 0
+    u = oracle.uniform_targets(5, 3, n, q)
+    e = psf.samp_p(u, seed=17, first_index=2)
+    assert psf.nearest_plane_stats()[1] == 0
+    assert (e == orc.samp_p(17, u, first_index=2)).all()
+    assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
