@@ -32,8 +32,8 @@ print(h.hexdigest())
 ''' % ROOT
 
 
-def run(mode):
-    env = dict(os.environ, PSF_PIPELINE=mode)
+def run(mode, **extra):
+    env = dict(os.environ, PSF_PIPELINE=mode, **extra)
     r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout.strip().splitlines()[-1]
@@ -41,6 +41,12 @@ def run(mode):
 
 def test_pipelined_mode_is_bit_identical():
     assert run("0") == run("1")
+
+
+def test_lock_step_gadget_kernel_is_bit_identical():
+    """PSF_GADGET_QUEUE=0 selects the lock-step gadget sampler (one lane per problem, sample_z loop) instead of the
+    READY/PENDING queue kernel; same Philox streams, same bits."""
+    assert run("0") == run("0", PSF_GADGET_QUEUE="0")
 
 
 @pytest.mark.gpu
