@@ -116,6 +116,8 @@ extern "C" void psf_debug_np_prof(long long* out, int reset) {
 
 extern "C" {
 
+static psf_status psfgpv_init(psfgpv_handle* g);
+
 psf_status psfgpv_create(const psfgpv_params* prm, psfgpv_handle** out) {
   if (!prm || !out || !(prm->s > 0.0)) return PSF_ERR_PARAM;
   psfp_params bp;
@@ -126,6 +128,13 @@ psf_status psfgpv_create(const psfgpv_params* prm, psfgpv_handle** out) {
   if (b->m > 8192) { psfp_destroy(b); return PSF_ERR_UNSUPPORTED; }
   psfgpv_handle* g = new psfgpv_handle();
   g->base = b; g->s = prm->s; g->n = b->n; g->m = b->m; g->dim = b->m;
+  const psf_status rc2 = psfgpv_init(g);
+  if (rc2 != PSF_OK) { psfgpv_destroy(g); return rc2; }     // releases the partial allocations and the inner handle
+  *out = g;
+  return PSF_OK;
+}
+
+static psf_status psfgpv_init(psfgpv_handle* g) {
   const size_t d = g->dim;
   HIP_TRY(hipMalloc(&g->dSt, d * d * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&g->dGt, d * d * sizeof(double)));
@@ -141,7 +150,6 @@ psf_status psfgpv_create(const psfgpv_params* prm, psfgpv_handle** out) {
   HIP_TRY(hipMalloc(&g->dT, g->n * g->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&g->dPiv, g->n * sizeof(uint32_t)));
   for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
-  *out = g;
   return PSF_OK;
 }
 

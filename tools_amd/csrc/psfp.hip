@@ -241,6 +241,8 @@ psf_status psf_find_solution_gadget_mat(int device, const uint64_t* value, size_
 }
 
 // ------------------------------------------------------------------------------------------------------------
+static psf_status psfp_init(psfp_handle* h, const psfp_params* prm);
+
 psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   if (!prm || !out) return PSF_ERR_PARAM;
   const psf_gadget_params& gp = prm->gp;
@@ -254,6 +256,14 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   }
   HIP_TRY(hipSetDevice(prm->device));
   psfp_handle* h = new psfp_handle();
+  const psf_status rc = psfp_init(h, prm);
+  if (rc != PSF_OK) { psfp_destroy(h); return rc; }      // whatever was allocated before the failure is released
+  *out = h;
+  return PSF_OK;
+}
+
+static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
+  const psf_gadget_params& gp = prm->gp;
   h->prm = *prm;
   h->n = gp.n; h->k = gp.k; h->mb = gp.m_bar; h->w = gp.n * gp.k; h->m = h->mb + h->w; h->q = gp.q;
   h->two64 = (uint64_t)((((u128)1) << 64) % gp.q);
@@ -334,7 +344,6 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   if (const char* env = std::getenv("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
-  *out = h;
   return PSF_OK;
 }
 
@@ -396,15 +405,15 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov) {
   return PSF_OK;
 }
 
-static void launch_zq(psfp_handle* h, hipStream_t st, int mode, const uint64_t* Amat, size_t lda, size_t a_off, size_t nrows, size_t K,
-                      const void* P, bool p_is_i8, size_t ldp, size_t ncols, const uint64_t* U, uint64_t* out, size_t ldo, size_t out_off) {
-  dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)((nrows + 63) / 64));
-#define ZQ_LAUNCH(PT, W)                                                                                              \
-  hipLaunchKernelGGL((k_zq_matmul<PT, W>), grid, dim3(256), 0, st, mode, Amat, lda, a_off, nrows, K, (const PT*)P, ldp, ncols, \
-                     h->q, h->two64, h->two31, U, out, ldo, out_off, h->dGvec, (uint64_t)h->k)
-  if (p_is_i8) { if (h->wide) ZQ_LAUNCH(int8_t, true); else ZQ_LAUNCH(int8_t, false); }
-  else { if (h->wide) ZQ_LAUNCH(int32_t, true); else ZQ_LAUNCH(int32_t, false); }
-#undef ZQ_LAUNCH
+// A[:, m_bar:] = G - A_bar R  (gadget_classical.rs:66): the one product still on the limb kernel (setup path, R in int8)
+static void launch_zq_trapdoor(psfp_handle* h) {
+  dim3 grid((unsigned)((h->w + 63) / 64), (unsigned)((h->n + 63) / 64));
+  if (h->wide)
+    hipLaunchKernelGGL((k_zq_matmul<int8_t, true>), grid, dim3(256), 0, 0, (int)ZQ_TRAPDOOR, h->dA, h->m, (size_t)0, h->n, h->mb, h->dR, h->ldr, h->w,
+                       h->q, h->two64, h->two31, (const uint64_t*)nullptr, h->dA, h->m, h->mb, h->dGvec, (uint64_t)h->k);
+  else
+    hipLaunchKernelGGL((k_zq_matmul<int8_t, false>), grid, dim3(256), 0, 0, (int)ZQ_TRAPDOOR, h->dA, h->m, (size_t)0, h->n, h->mb, h->dR, h->ldr, h->w,
+                       h->q, h->two64, h->two31, (const uint64_t*)nullptr, h->dA, h->m, h->mb, h->dGvec, (uint64_t)h->k);
 }
 
 static void split_A(psfp_handle* h) {
@@ -434,7 +443,7 @@ static psf_status gen_A_R(psfp_handle* h, uint64_t seed) {
   hipLaunchKernelGGL(k_sample_abar, dim3(grid_for(h->n * h->mb)), dim3(256), 0, 0, seed, h->n, h->mb, h->m, h->q, h->dA);
   hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);
   // gadget_classical.rs:66
-  launch_zq(h, nullptr, ZQ_TRAPDOOR, h->dA, h->m, 0, h->n, h->mb, h->dR, true, h->ldr, h->w, nullptr, h->dA, h->m, h->mb);
+  launch_zq_trapdoor(h);
   HIP_TRY(hipGetLastError());
   split_A(h);
   return PSF_OK;
