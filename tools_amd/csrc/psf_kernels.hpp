@@ -335,10 +335,17 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
   // sample id g = seg0 + off  ->  (coordinate, preimage) by 32-bit arithmetic relative to the segment start
   const size_t coord0 = seg0 / B;
   const uint32_t b00 = (uint32_t)(seg0 % B), B32 = (uint32_t)B;
+  const bool one_wrap = B32 >= (uint32_t)PR_SEG;          // then o < b00 + PR_SEG < 2 B: the division is a compare (uniform choice)
   auto locate = [&](size_t g, size_t* coord, uint32_t* bb) {
     const uint32_t o = b00 + (uint32_t)(g - seg0);
-    *coord = coord0 + o / B32;
-    *bb = o % B32;
+    if (one_wrap) {
+      const bool wrap = o >= B32;
+      *coord = coord0 + (wrap ? 1 : 0);
+      *bb = wrap ? o - B32 : o;
+    } else {
+      *coord = coord0 + o / B32;
+      *bb = o % B32;
+    }
   };
   auto centre_of = [&](size_t g) -> double {
     if (g >= seg1) return 0.0;
@@ -874,6 +881,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
   int phead = 0, pcount = 0;              // PENDING ring
   int done = 0;
 
+  const uint32_t pj0 = (uint32_t)(seg0 / B), pb0 = (uint32_t)(seg0 % B), B32 = (uint32_t)B;   // one 64-bit division per wave
   bool has = false;
   int myp = 0, mystep = 0;
   uint32_t t = 0, myj = 0;
@@ -894,9 +902,9 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
           mystep = s_step[myp];
           cen = s_cen[myp];
           sp = s_sz[mystep];
-          const size_t pid = seg0 + myp;
-          myj = (uint32_t)(pid / B);
-          myb = pid % B;
+          const uint32_t o = pb0 + (uint32_t)myp;               // seg0 + myp = pj0 * B + o
+          if (B32 >= (uint32_t)P) { const bool wrap = o >= B32; myj = pj0 + (wrap ? 1u : 0u); myb = wrap ? o - B32 : o; }
+          else { myj = pj0 + o / B32; myb = o % B32; }
           t = 0;
           has = true;
         }
