@@ -211,8 +211,9 @@ __global__ __launch_bounds__(256) void k_np_pack(const int32_t* __restrict__ St,
   }
 }
 
+// workgroups per CU by register budget: c takes 4 JR VGPRs in the FP53 pass (2 preimages x JR doubles), the rows 3 JR
 template <int JR, bool FP53>
-__global__ __launch_bounds__(256, 2) void k_gpv_nearest_plane(const int32_t* __restrict__ StP, const double* __restrict__ GtP,
+__global__ __launch_bounds__(256, JR <= 8 ? 4 : JR <= 16 ? 3 : 2) void k_gpv_nearest_plane(const int32_t* __restrict__ StP, const double* __restrict__ GtP,
                                                               const double* __restrict__ norm2, const SampleZParams* __restrict__ sz,
                                                               const double* __restrict__ rowmax, double c0_bound,
                                                               size_t dim, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B,
