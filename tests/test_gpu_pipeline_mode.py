@@ -114,3 +114,15 @@ def test_async_row_gather_over_rccl_one_rank():
     env = dict(os.environ, PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("first", ["lib", "torch"])
+def test_library_and_torch_share_one_hip_runtime(first):
+    """Either load order must work: the ctypes loader maps torch's bundled HIP runtime before the library so that the process
+    never holds two runtimes (tools_amd/_ffi.py, tools/probe_load_order.py)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe_load_order.py"), first], capture_output=True, text=True, timeout=600)
+    out = r.stdout
+    assert r.returncode == 0 and "FAILED" not in out and "lib ok" in out and "torch ok" in out, out + r.stderr[-2000:]
+    last = [l for l in out.splitlines() if l.strip().startswith("[")][-1]
+    assert last.count("libamdhip64") == 1, out          # exactly one HIP runtime mapped at the end

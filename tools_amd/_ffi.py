@@ -41,6 +41,27 @@ class RingParams(C.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (SONAME
+    libamdhip64.so.7, like the system one this library is linked against).  If the system runtime initialises first, torch
+    later loads its bundled copy as a second runtime and fails with "No HIP GPUs are available"; if torch's is already in the
+    process, the loader satisfies our DT_NEEDED with it and everything shares one runtime (tools/probe_load_order.py shows
+    both orders).  So when torch is installed, map its runtime first -- by path, without importing torch.
+    PSF_SYSTEM_HIP=1 skips this (hosts that never import torch)."""
+    if os.environ.get("PSF_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass                                   # fall back to the system runtime the library was linked against
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -48,6 +69,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). tools_amd has no CPU fallback.")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.psf_status_string.restype = C.c_char_p
         L.psf_status_string.argtypes = [C.c_int]

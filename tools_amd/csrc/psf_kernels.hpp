@@ -813,7 +813,7 @@ constexpr int GQ_WAVES = 4;
 __host__ __device__ inline int gq_problems_per_wave(uint32_t k) { (void)k; return 128; }   // 256 measured slower (LDS limits occupancy)
 __host__ inline size_t gadget_queue_lds_bytes(size_t k) {
   const size_t P = (size_t)gq_problems_per_wave((uint32_t)k);
-  const size_t tables = k * k * 8 + k * 8 + k * sizeof(SampleZParams) + k * k * 4 + 4 * k * 4;
+  const size_t tables = k * k * 8 + k * 8 + k * sizeof(SampleZParams) + 4 * k * 4 + k * k * 2;
   const size_t per_wave = k * P * 2 + P * 8 + P * 4 + P * 4 + P * 2 + P * 2;
   return tables + GQ_WAVES * per_wave + 64;
 }
@@ -827,9 +827,9 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
   double* s_gso = reinterpret_cast<double*>(gq_raw);                       // k*k
   double* s_norm2 = s_gso + (size_t)k * k;                                 // k
   SampleZParams* s_sz = reinterpret_cast<SampleZParams*>(s_norm2 + k);     // k
-  int32_t* s_Sk = reinterpret_cast<int32_t*>(s_sz + k);                    // k*k
-  int32_t* s_rng = s_Sk + (size_t)k * k;                                   // 4k
-  unsigned char* wave_base = reinterpret_cast<unsigned char*>(s_rng + 4 * k);
+  int32_t* s_rng = reinterpret_cast<int32_t*>(s_sz + k);                   // 4k
+  int16_t* s_Sk = reinterpret_cast<int16_t*>(s_rng + 4 * k);               // k*k (entries of S_k are digits of q, base or -1: |.| < 2^15, checked by the host)
+  unsigned char* wave_base = reinterpret_cast<unsigned char*>(s_Sk + (size_t)k * k);
   wave_base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(wave_base) + 7) & ~(uintptr_t)7);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t per_wave = (size_t)k * P * 2 + (size_t)P * 8 + P * 4 + P * 4 + P * 2 + P * 2;
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
   uint16_t* s_pend = s_ready + P;                                          // P (ring)
   int16_t* s_c = reinterpret_cast<int16_t*>(s_pend + P);                   // k * P, [row][problem]
 
-  for (uint32_t e = tid; e < k * k; e += 256) { s_gso[e] = tb.gso[e]; s_Sk[e] = tb.Sk[e]; }
+  for (uint32_t e = tid; e < k * k; e += 256) { s_gso[e] = tb.gso[e]; s_Sk[e] = (int16_t)tb.Sk[e]; }
   for (uint32_t e = tid; e < k; e += 256) { s_norm2[e] = tb.norm2[e]; s_sz[e] = tb.sz[e]; }
   for (uint32_t e = tid; e < 4 * k; e += 256) s_rng[e] = tb.rng[e];
   __syncthreads();
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
         const int z = s_z[p];
         const int shi = s_rng[3 * k + i];
         for (int r = s_rng[2 * k + i]; r <= shi; ++r) {
-          const int nv = (int)s_c[r * P + p] - z * s_Sk[r * k + i];
+          const int nv = (int)s_c[r * P + p] - z * (int)s_Sk[r * k + i];
           if (nv > 32767 || nv < -32768) f = 1;
           s_c[r * P + p] = (int16_t)nv;
         }

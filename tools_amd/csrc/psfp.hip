@@ -344,6 +344,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   if (const char* env = std::getenv("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
+  for (int64_t v : h->hSk) if (v > 32767 || v < -32768) h->gadget_queue = false;      // the queue kernel keeps S_k in int16
   return PSF_OK;
 }
 
