@@ -41,6 +41,31 @@ __global__ void k_rate(double* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
+
+// the TRMM inner loop without global traffic: 16 accumulators (64 x 64 wave tile), per 16 MFMAs eight ds_read_b64 of fresh
+// operands from LDS (conflict-free, lane-contiguous) -- what the matrix cores deliver when fed from LDS
+__global__ __launch_bounds__(256, 2) void k_rate_lds(double* out, int iters) {
+  __shared__ double buf[8192];                       // 64 KiB
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 8192; e += 256) buf[e] = 1.0 + (e & 1023) * 1e-6;
+  __syncthreads();
+  d4 c[4][4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c[i][j] = d4{0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+    const double* p = buf + ((it & 7) * 1024) + (w & 1) * 256;
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = p[i * 64 + l]; b[i] = p[512 + i * 64 + l]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], c[i][j], 0, 0, 0);
+  }
+  double s = 0;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) s += c[i][j][0] + c[i][j][1] + c[i][j][2] + c[i][j][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void k_vfma_rate(double* out, int iters) {
   double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9;
   double c[16];
@@ -123,6 +148,22 @@ int main(int argc, char** argv) {
       double flops = (double)blocks * (wpb / 64) * iters * 4.0 * (2.0 * 16 * 16 * 4);
       printf("mfma_f64 rate: blocks=%d threads=%d  %.3f ms  %.2f TFLOP/s\n", blocks, wpb, ms, flops / ms * 1e-9);
       CK(hipFree(out));
+      }
+    }
+    {  // MFMA fed from LDS (TRMM inner loop shape), 2 workgroups of 4 waves per CU
+      int blocks = prop.multiProcessorCount * 2, wpb = 256; int it = iters / 4;
+      for (int rep = 0; rep < 2; ++rep) {
+        double* out; CK(hipMalloc(&out, (size_t)blocks * wpb * 8));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_rate_lds, dim3(blocks), dim3(wpb), 0, 0, out, 100);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_rate_lds, dim3(blocks), dim3(wpb), 0, 0, out, it);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double flops = (double)blocks * (wpb / 64) * it * 16.0 * (2.0 * 16 * 16 * 4);
+        printf("mfma_f64 fed from LDS: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms * 1e-9);
+        CK(hipFree(out));
       }
     }
     {
