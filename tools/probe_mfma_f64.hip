@@ -66,6 +66,60 @@ __global__ __launch_bounds__(256, 2) void k_rate_lds(double* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// variant: two k-steps per LDS read (ds_read_b128), 8 reads per 32 MFMAs
+__global__ __launch_bounds__(256, 2) void k_rate_lds128(double* out, int iters) {
+  __shared__ __attribute__((aligned(16))) double buf[8192];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 8192; e += 256) buf[e] = 1.0 + (e & 1023) * 1e-6;
+  __syncthreads();
+  d4 c[4][4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c[i][j] = d4{0, 0, 0, 0};
+  for (int it = 0; it < iters; it += 2) {
+    const double2* p = reinterpret_cast<const double2*>(buf + ((it & 6) * 1024)) + (w & 1) * 256;
+    double2 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = p[i * 64 + l]; b[i] = p[512 + i * 64 + l]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, c[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, c[i][j], 0, 0, 0);
+  }
+  double s = 0;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) s += c[i][j][0] + c[i][j][1] + c[i][j][2] + c[i][j][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// variant: explicit register double buffering (operands of step it+1 requested before the MFMAs of step it)
+__global__ __launch_bounds__(256, 2) void k_rate_lds_pipe(double* out, int iters) {
+  __shared__ double buf[8192];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 8192; e += 256) buf[e] = 1.0 + (e & 1023) * 1e-6;
+  __syncthreads();
+  d4 c[4][4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c[i][j] = d4{0, 0, 0, 0};
+  double a[4], b[4], an[4], bn[4];
+  { const double* p = buf + (w & 1) * 256;
+    for (int i = 0; i < 4; ++i) { a[i] = p[i * 64 + l]; b[i] = p[512 + i * 64 + l]; } }
+  for (int it = 0; it < iters; ++it) {
+    const double* p = buf + (((it + 1) & 7) * 1024) + (w & 1) * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { an[i] = p[i * 64 + l]; bn[i] = p[512 + i * 64 + l]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], c[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+  }
+  double s = 0;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) s += c[i][j][0] + c[i][j][1] + c[i][j][2] + c[i][j][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void k_vfma_rate(double* out, int iters) {
   double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9;
   double c[16];
@@ -150,19 +204,25 @@ int main(int argc, char** argv) {
       CK(hipFree(out));
       }
     }
-    {  // MFMA fed from LDS (TRMM inner loop shape), 2 workgroups of 4 waves per CU
+    {  // MFMA fed from LDS (TRMM inner loop shape), 2 workgroups of 4 waves per CU; three feeding patterns
       int blocks = prop.multiProcessorCount * 2, wpb = 256; int it = iters / 4;
+      for (int variant = 0; variant < 3; ++variant)
       for (int rep = 0; rep < 2; ++rep) {
         double* out; CK(hipMalloc(&out, (size_t)blocks * wpb * 8));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(k_rate_lds, dim3(blocks), dim3(wpb), 0, 0, out, 100);
+        auto launch = [&](int n) {
+          if (variant == 0) hipLaunchKernelGGL(k_rate_lds, dim3(blocks), dim3(wpb), 0, 0, out, n);
+          else if (variant == 1) hipLaunchKernelGGL(k_rate_lds128, dim3(blocks), dim3(wpb), 0, 0, out, n);
+          else hipLaunchKernelGGL(k_rate_lds_pipe, dim3(blocks), dim3(wpb), 0, 0, out, n);
+        };
+        launch(100);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_rate_lds, dim3(blocks), dim3(wpb), 0, 0, out, it);
+        launch(it);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         double flops = (double)blocks * (wpb / 64) * it * 16.0 * (2.0 * 16 * 16 * 4);
-        printf("mfma_f64 fed from LDS: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms * 1e-9);
+        printf("mfma_f64 fed from LDS (%s): %.3f ms  %.2f TFLOP/s\n", variant == 0 ? "ds_read_b64 per k-step" : variant == 1 ? "ds_read_b128, two k-steps" : "b64, register double buffer", ms, flops / ms * 1e-9);
         CK(hipFree(out));
       }
     }
