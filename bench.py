@@ -177,7 +177,11 @@ def main():
         }
         if args.config != "c3":
             out["metric"] = f"preimages/sec for samp_p ({args.config})"
-        if world == 1 and not args.no_cpu_baseline:
+        key_gb = (m * (m + 1) // 2) * 8 / 1e9 if scheme == "PSFPerturbation" else m * m * 12 / 1e9
+        if world == 1 and not args.no_cpu_baseline and key_gb > 16:
+            out["cpu_baseline"] = None          # the oracle would need the key twice in host memory: not timed at this size
+            print(f"[bench] cpu_baseline skipped: key of {key_gb:.0f} GB", file=sys.stderr)
+        elif world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, 1000 + args.warmup + args.steps - 1, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
