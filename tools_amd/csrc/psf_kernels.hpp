@@ -810,7 +810,9 @@ struct GadgetTablesQ {
 };
 constexpr int GQ_WAVES = 4;
 
-__host__ __device__ inline int gq_problems_per_wave(uint32_t k) { (void)k; return 128; }   // 256 measured slower (LDS limits occupancy)
+// slots per wave (a power of two).  256 measured slower at k = 30 (LDS limits occupancy); 64 at k = 60 (two workgroups per CU
+// instead of one) measured 0.155 ns per draw against 0.124 with 128
+__host__ __device__ inline int gq_problems_per_wave(uint32_t k) { (void)k; return 128; }
 __host__ inline size_t gadget_queue_lds_bytes(size_t k) {
   const size_t P = (size_t)gq_problems_per_wave((uint32_t)k);
   const size_t tables = k * k * 8 + k * 8 + k * sizeof(SampleZParams) + 4 * k * 4 + k * k * 2;
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
       if (!has) {
         const int rk = lane_rank(need);
         if (rk < take) {
-          myp = s_ready[(rhead + rk) % P];
+          myp = s_ready[(rhead + rk) & (P - 1)];
           mystep = s_step[myp];
           cen = s_cen[myp];
           sp = s_sz[mystep];
@@ -909,7 +911,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
           has = true;
         }
       }
-      rhead = (rhead + take) % P;
+      rhead = (rhead + take) & (P - 1);
       rcount -= take;
     }
     // ---- four attempts (one Philox block when the range is narrow), screened in fp32: see sz_group4
@@ -928,7 +930,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
       if (accept) {
         if (x > 16000 || x < -16000) f = 1;
         s_z[myp] = (int32_t)x;
-        s_pend[(phead + pcount + lane_rank(mask)) % P] = (uint16_t)myp;
+        s_pend[(phead + pcount + lane_rank(mask)) & (P - 1)] = (uint16_t)myp;
         has = false;
       }
       pcount += __popcll(mask);
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
       bool to_ready = false;
       int p = 0;
       if (lane < cnt) {
-        p = s_pend[(phead + lane) % P];
+        p = s_pend[(phead + lane) & (P - 1)];
         int i = s_step[p];
         const int z = s_z[p];
         const int shi = s_rng[3 * k + i];
@@ -972,11 +974,11 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
         }
       }
       const uint64_t rmask = __ballot(to_ready);
-      if (to_ready) s_ready[(rhead + rcount + lane_rank(rmask)) % P] = (uint16_t)p;
+      if (to_ready) s_ready[(rhead + rcount + lane_rank(rmask)) & (P - 1)] = (uint16_t)p;
       const int nready = __popcll(rmask);
       rcount += nready;
       done += cnt - nready;
-      phead = (phead + cnt) % P;
+      phead = (phead + cnt) & (P - 1);
       pcount -= cnt;
       GQ_FENCE();
       if (!starving) break;                 // with lanes still sampling, one pass per iteration keeps everybody busy
