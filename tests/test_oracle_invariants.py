@@ -82,21 +82,30 @@ def test_check_domain_cases(oracle):
         psf.f_a(big)
 
 
-def test_sample_z_distribution(oracle):
-    # chi-square of D_{Z,s,c} against rho_s(x-c) -- the reference has no such test
-    s, c, N = 4.5, 0.3, 60000
+@pytest.mark.parametrize("s,c", [(4.5, 0.3),          # narrow words, fractional centre
+                                 (4.5, 2.0),          # integer centre: one more candidate
+                                 (300.0, -7.25),      # narrow words near the 4096-candidate limit (Lemire rejections ~1 %)
+                                 (400.0, 0.5)])       # wide (32-bit) words
+def test_sample_z_distribution(oracle, s, c):
+    # chi-square of D_{Z,s,c} against rho_s(x-c), binned so that every cell expects >= 8 draws -- the reference has no such
+    # test
+    N = 60000
     xs = np.array([oracle.sample_z(99, oracle.TAG_PERTURB, i, 5, c, s) for i in range(N)])
     lo, hi = math.ceil(c) - math.ceil(6 * s), math.floor(c) + math.floor(6 * s)
     assert xs.min() >= lo and xs.max() <= hi
     support = np.arange(lo, hi + 1)
     prob = np.exp(-math.pi * (support - c) ** 2 / s**2)
     prob /= prob.sum()
-    keep = prob * N >= 8
-    obs = np.array([(xs == v).sum() for v in support[keep]])
-    exp = prob[keep] * N
-    chi2 = ((obs - exp) ** 2 / exp).sum()
+    width = max(1, int(s / 6))
+    edges = np.arange(lo, hi + 1 + width, width)
+    obs, _ = np.histogram(xs, bins=edges)
+    exp = np.array([prob[(support >= a) & (support < b)].sum() for a, b in zip(edges[:-1], edges[1:])]) * N
+    keep = exp >= 8
+    chi2 = ((obs[keep] - exp[keep]) ** 2 / exp[keep]).sum()
     dof = keep.sum() - 1
+    assert obs[~keep].sum() <= 8 * (~keep).sum() + 30
     assert chi2 < dof + 5 * math.sqrt(2 * dof), (chi2, dof)
+    assert abs(xs.mean() - c) < 5 * s / math.sqrt(2 * math.pi * N) + 0.02
 
 
 def test_normal_distribution(oracle):
