@@ -83,13 +83,19 @@ class PSFPerturbation:
         check(lib().psfp_samp_d(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(nb), _p(e, C.c_int64)), "samp_d")
         return e[0] if B is None else e
 
-    def samp_p(self, u, seed=0, first_index=0):
-        """mp_perturbation.rs:304-336 with the key installed in the handle (trap_gen / load_key)."""
+    def samp_p(self, u, seed=0, first_index=0, out=None):
+        """mp_perturbation.rs:304-336 with the key installed in the handle (trap_gen / load_key).
+        out: optional (B, m) int64 C-contiguous array to fill -- a reused buffer avoids first-touch page faults on a gigabyte
+        of fresh memory (C3 batch: 86 ms per call into a reused buffer, 150-200 ms into a new one; tools/host_path_timing.py)."""
         u = np.ascontiguousarray(u, dtype=np.uint64)
         single = u.ndim == 1
         u2 = u.reshape(-1, self.n)
         B = u2.shape[0]
-        e = np.zeros((B, self.m), dtype=np.int64)
+        if out is None:
+            e = np.empty((B, self.m), dtype=np.int64)
+        else:
+            e = out
+            assert e.dtype == np.int64 and e.shape == (B, self.m) and e.flags.c_contiguous
         check(lib().psfp_samp_p(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64),
                                 _p(e, C.c_int64)), "samp_p")
         return e[0] if single else e
