@@ -193,17 +193,46 @@ __device__ inline bool sz_maybe(uint32_t wa, uint32_t wb, const SzRange rg, doub
 }
 // attempts 4g .. 4g+3 of one sample: screened in fp32, the first "maybe" settled exactly; the rare screened-in-but-rejected
 // case finishes the group with exact attempts, so the outcome is that of four sequential sz_attempt calls
+// The same screen for narrow words, in fp32 from the candidate word on: idx < 4096 and cand < 2^16, so the product is a 24-bit
+// multiply, idx converts exactly, and a = (idx + (lo - c)) / s is evaluated with |error| < 2e-6 (c_rel = fp32(lo - c), |lo - c| <= 6s+1),
+// which moves rho by < 1e-4 relative -- inside the same 1.001 margin.  Returns the candidate index; x = lo + idx is formed
+// only for the attempt that survives.
+__device__ inline bool sz_maybe16(uint32_t word, const SzRange rg, float c_rel, float inv_s_f, uint32_t* idx_out) {
+  const uint32_t prod = __umul24(word >> 16, rg.N);
+  if ((prod & 0xffffu) < rg.thr) return false;
+  const uint32_t idx = prod >> 16;
+  const float a = ((float)idx + c_rel) * inv_s_f;
+  const float rho_hi = __expf(-3.14159274f * (a * a)) * 1.001f + 1e-9f;
+  *idx_out = idx;
+  return (float)(word & 0xffffu) <= rho_hi * 65536.0f;
+}
+// attempts 4g .. 4g+3 of one sample: screened in fp32, the first "maybe" settled exactly; the rare screened-in-but-rejected
+// case finishes the group with exact attempts, so the outcome is that of four sequential sz_attempt calls
 __device__ inline bool sz_group4(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t g, const SzRange rg, double center,
                                  double inv_s, long long* x_out) {
   uint32_t wa[4], wb[4];
-  sz_group_words(seed, coord, idx_lo, tw, g, rg.sh, wa, wb);
   int tm = -1;
   uint32_t wbm = 0;
   long long x = 0;
+  if (rg.sh == 16 && fabs(center) < 0x1.0p40) {
+    const U4 w = philox(seed, coord, idx_lo, g, tw);
+    const uint32_t word[4] = {w.x, w.y, w.z, w.w};
+    const float c_rel = (float)((double)rg.lo - center), inv_s_f = (float)inv_s;
+    uint32_t idxm = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    long long xc;
-    if (tm < 0 && sz_maybe(wa[j], wb[j], rg, center, inv_s, &xc)) { tm = j; wbm = wb[j]; x = xc; }
+    for (int j = 0; j < 4; ++j) {
+      wa[j] = word[j] >> 16; wb[j] = word[j] & 0xffffu;
+      uint32_t idx;
+      if (tm < 0 && sz_maybe16(word[j], rg, c_rel, inv_s_f, &idx)) { tm = j; idxm = idx; }
+    }
+    if (tm >= 0) { wbm = wb[tm]; x = rg.lo + (long long)idxm; }
+  } else {
+    sz_group_words(seed, coord, idx_lo, tw, g, rg.sh, wa, wb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long long xc;
+      if (tm < 0 && sz_maybe(wa[j], wb[j], rg, center, inv_s, &xc)) { tm = j; wbm = wb[j]; x = xc; }
+    }
   }
   bool accept = false;
   if (tm >= 0) {
