@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A per-test ceiling (pytest-timeout, when installed) so that one stalled test cannot hold the whole suite."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def kats():
     with open(os.path.join(ROOT, "tests", "golden", "ref_kats.json")) as fh:

@@ -21,7 +21,7 @@ def build():
 def test_cpp_mirror_builds_and_fails_loudly_without_gpu():
     import torch
     build()
-    r = subprocess.run([BIN], capture_output=True, text=True)
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     if torch.cuda.is_available():
         assert r.returncode == 0, r.stdout + r.stderr
     else:
@@ -31,6 +31,6 @@ def test_cpp_mirror_builds_and_fails_loudly_without_gpu():
 @pytest.mark.gpu
 def test_cpp_mirror_flow_on_gpu():
     build()
-    r = subprocess.run([BIN], capture_output=True, text=True)
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PSFPerturbation ok" in r.stdout and "PSFGPV ok" in r.stdout and "PSFGPVRing ok" in r.stdout

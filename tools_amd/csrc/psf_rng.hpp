@@ -191,20 +191,22 @@ __device__ inline bool sz_maybe(uint32_t wa, uint32_t wb, const SzRange rg, doub
   *x_out = x;
   return (float)wb * (rg.sh == 16 ? 0x1.0p-16f : 0x1.0p-32f) <= rho_hi;
 }
-// attempts 4g .. 4g+3 of one sample: screened in fp32, the first "maybe" settled exactly; the rare screened-in-but-rejected
-// case finishes the group with exact attempts, so the outcome is that of four sequential sz_attempt calls
-// The same screen for narrow words, in fp32 from the candidate word on: idx < 4096 and cand < 2^16, so the product is a 24-bit
+// The screen for narrow words, in fp32 from the candidate word on: idx < 4096 and cand < 2^16, so the product is a 24-bit
 // multiply, idx converts exactly, and a = (idx + (lo - c)) / s is evaluated with |error| < 2e-6 (c_rel = fp32(lo - c), |lo - c| <= 6s+1),
-// which moves rho by < 1e-4 relative -- inside the same 1.001 margin.  Returns the candidate index; x = lo + idx is formed
-// only for the attempt that survives.
-__device__ inline bool sz_maybe16(uint32_t word, const SzRange rg, float c_rel, float inv_s_f, uint32_t* idx_out) {
+// which moves rho by < 1e-4 relative -- inside the 0.1 % margins used below.  Returns the candidate index; x = lo + idx is formed
+// only for the attempt that survives.  Outcome classes: 0 = certainly rejected; 1 = certainly accepted (wb + 1 <= 0.999 rho_f 2^16
+// < rho 2^16, so wb is below floor(rho 2^16) and no tie can occur); 2 = inside the +-0.1 % band around the threshold -- only
+// these are settled in f64.
+__device__ inline int sz_screen16(uint32_t word, const SzRange rg, float c_rel, float inv_s_f, uint32_t* idx_out) {
   const uint32_t prod = __umul24(word >> 16, rg.N);
-  if ((prod & 0xffffu) < rg.thr) return false;
+  if ((prod & 0xffffu) < rg.thr) return 0;
   const uint32_t idx = prod >> 16;
   const float a = ((float)idx + c_rel) * inv_s_f;
-  const float rho_hi = __expf(-3.14159274f * (a * a)) * 1.001f + 1e-9f;
+  const float rho = __expf(-3.14159274f * (a * a));
+  const float wbf = (float)(word & 0xffffu);
   *idx_out = idx;
-  return (float)(word & 0xffffu) <= rho_hi * 65536.0f;
+  if (wbf > (rho * 1.001f + 1e-9f) * 65536.0f) return 0;
+  return (wbf + 1.0f <= rho * 0.999f * 65536.0f) ? 1 : 2;
 }
 // attempts 4g .. 4g+3 of one sample: screened in fp32, the first "maybe" settled exactly; the rare screened-in-but-rejected
 // case finishes the group with exact attempts, so the outcome is that of four sequential sz_attempt calls
@@ -219,13 +221,16 @@ __device__ inline bool sz_group4(uint64_t seed, uint32_t coord, uint32_t idx_lo,
     const uint32_t word[4] = {w.x, w.y, w.z, w.w};
     const float c_rel = (float)((double)rg.lo - center), inv_s_f = (float)inv_s;
     uint32_t idxm = 0;
+    int cls = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       wa[j] = word[j] >> 16; wb[j] = word[j] & 0xffffu;
-      uint32_t idx;
-      if (tm < 0 && sz_maybe16(word[j], rg, c_rel, inv_s_f, &idx)) { tm = j; idxm = idx; }
+      uint32_t idx = 0;
+      const int cj = tm < 0 ? sz_screen16(word[j], rg, c_rel, inv_s_f, &idx) : 0;
+      if (tm < 0 && cj) { tm = j; idxm = idx; cls = cj; }
     }
     if (tm >= 0) { wbm = wb[tm]; x = rg.lo + (long long)idxm; }
+    if (cls == 1) { *x_out = x; return true; }     // the first surviving attempt is a certain accept: no f64 evaluation at all
   } else {
     sz_group_words(seed, coord, idx_lo, tw, g, rg.sh, wa, wb);
 #pragma unroll
