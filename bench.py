@@ -149,6 +149,10 @@ def main():
     psf.f_a_dev(e.data_ptr(), u2.data_ptr(), ok.data_ptr(), B, stream=stream)
     torch.cuda.synchronize()
     valid = bool((u2 == u).all().item()) and bool(ok.all().item()) and status == 0
+    if world > 1:                                   # every rank's rows must pass, not only rank 0's
+        vt = torch.tensor([1 if valid else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(vt, op=dist.ReduceOp.MIN)
+        valid = bool(vt.item())
 
     total = B * world * args.steps
     value = total / elapsed
