@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="preimages timed on the CPU (default: 32 per thread)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the result (N>1)")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barriers, gather, reductions) on a one-rank RCCL group")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,8 +68,10 @@ def main():
         sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     scheme, n, q, r, s, batch = CONFIGS[args.config]
@@ -102,8 +105,8 @@ def main():
     u = torch.empty((B, n), dtype=torch.int64, device=dev)
     e = torch.empty((B, m), dtype=torch.int64, device=dev)
     psf.uniform_targets_dev(u.data_ptr(), B, seed=7, first_index=first_index, stream=stream)
-    do_gather = world > 1 and not args.no_gather
-    gatherer = AsyncRowGather(B, m, dev, dst=0) if do_gather else None     # step i's rows travel while step i+1 computes
+    do_gather = multi and not args.no_gather
+    gatherer = AsyncRowGather(B, m, dev, dst=0, force=args.force_dist) if do_gather else None     # step i's rows travel while step i+1 computes
 
     def step(i):
         psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=1000 + i, first_index=first_index, stream=stream)
@@ -112,7 +115,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +141,7 @@ def main():
         kern_ms[nm] = ms
     psf.enable_timing(False)
     status = psf.last_status()
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -149,7 +152,7 @@ def main():
     psf.f_a_dev(e.data_ptr(), u2.data_ptr(), ok.data_ptr(), B, stream=stream)
     torch.cuda.synchronize()
     valid = bool((u2 == u).all().item()) and bool(ok.all().item()) and status == 0
-    if world > 1:                                   # every rank's rows must pass, not only rank 0's
+    if multi:                                       # every rank's rows must pass, not only rank 0's
         vt = torch.tensor([1 if valid else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(vt, op=dist.ReduceOp.MIN)
         valid = bool(vt.item())
@@ -187,9 +190,16 @@ def main():
             print(f"[bench] cpu_baseline skipped: key of {key_gb:.0f} GB", file=sys.stderr)
         elif world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, 1000 + args.warmup + args.steps - 1, args.cpu_sample)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; push it out first so that the JSON line is the last line of stdout
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if not valid:
         sys.exit(4)
 

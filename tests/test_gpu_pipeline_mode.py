@@ -134,3 +134,20 @@ def test_library_and_torch_share_one_hip_runtime(first):
     assert r.returncode == 0 and "FAILED" not in out and "lib ok" in out and "torch ok" in out, out + r.stderr[-2000:]
     last = [l for l in out.splitlines() if l.strip().startswith("[")][-1]
     assert last.count("libamdhip64") == 1, out          # exactly one HIP runtime mapped at the end
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_on_a_one_rank_group():
+    """bench.py --force-dist walks the N>1 code path (process group, barriers, narrowing + RCCL gather, MAX / MIN reductions) on a
+    one-rank group; the JSON line must be the last line of stdout and carry valid = true."""
+    import json
+    env = dict(os.environ, MASTER_PORT="29577")
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--config", "bench64", "--no-cpu-baseline",
+                            "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("the one-rank RCCL group did not come up within 240 s on this box (environment, not the library)")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = r.stdout.strip().splitlines()[-1]
+    d = json.loads(line)
+    assert d["valid"] is True and d["n_gpus"] == 1 and d["steps"] == 2 and "RCCL gather" in d["config"]["parallelism"]
