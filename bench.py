@@ -190,15 +190,21 @@ def main():
             print(f"[bench] cpu_baseline skipped: key of {key_gb:.0f} GB", file=sys.stderr)
         elif world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, 1000 + args.warmup + args.steps - 1, args.cpu_sample)
-    if multi:
-        dist.destroy_process_group()
-    if rank == 0:
-        # RCCL writes a version banner through C stdio; push it out first so that the JSON line is the last line of stdout
+    def flush_c_stdio():                            # RCCL writes its version banner through C stdio (NCCL_DEBUG=VERSION on the GPU boxes)
         try:
             C.CDLL(None).fflush(None)
         except Exception:
             pass
         sys.stdout.flush()
+
+    if multi:                                       # every rank empties its buffers, then the group is torn down, then rank 0 speaks last
+        flush_c_stdio()
+        dist.barrier()
+        dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        if world > 1:
+            time.sleep(0.5)                         # the other ranks have nothing buffered any more; let their last writes land
         print(json.dumps(out), flush=True)
     if not valid:
         sys.exit(4)
