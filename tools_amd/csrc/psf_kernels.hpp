@@ -74,27 +74,9 @@ __global__ void k_unpack_L(const double* __restrict__ chunks, size_t m, double* 
 
 // ---- standard normals, written straight into the B-operand chunk stream ------------------------------
 // chunk (bj, bk) at (bj * nkb + bk); element (kk, c) -> coordinate bk*16+kk of preimage bj*128+c
-__global__ void k_normals(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t nkb, size_t nbj,
-                          double* __restrict__ Dt, int* __restrict__ fail) {
-  const size_t total = nbj * nkb * TR_CHUNK;
-  int f = 0;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t chunk = g / TR_CHUNK;
-    const int pos = (int)(g % TR_CHUNK);
-    const size_t bj = chunk / nkb, bk = chunk % nkb;
-    const int ks = pos >> 9, tile = (pos >> 6) & 7, lane = pos & 63;
-    const size_t coord = bk * TR_BK + ks * 4 + (lane >> 4);
-    const size_t b = bj * TR_BN + tile * 16 + (lane & 15);
-    double v = 0.0;
-    if (coord < m && b < B) v = sample_normal(seed, first_index + b, (uint32_t)coord, &f);
-    Dt[g] = v;
-  }
-  if (f) atomicOr(fail, 1);
-}
-
-// Wave-compacted form: a wave owns NR_SEG consecutive positions of the chunk stream; every iteration each lane evaluates
+// Wave-compacted: a wave owns NR_SEG consecutive positions of the chunk stream; every iteration each lane evaluates
 // one ratio-of-uniforms attempt of its current position, accepted lanes store and take the next unassigned position
-// (ballot + mbcnt).  Same values as k_normals (first accepted attempt of each (coordinate, preimage) stream).
+// (ballot + mbcnt).  The value of a position is the first accepted attempt of its own (coordinate, preimage) Philox stream.
 constexpr int NR_SEG = 4096;   // two chunks
 __device__ inline int lane_rank(uint64_t mask);
 
