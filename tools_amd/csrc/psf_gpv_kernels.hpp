@@ -139,7 +139,7 @@ __global__ void k_row_norm2_chain(const double* __restrict__ Gt, size_t m, doubl
   norm2[i] = acc;
 }
 
-// ---- solve operator: c0[b][piv[r]] = -(T u_b)[r] mod q (gpv.rs:153-158: sol = A^{-1}(u), centre = -sol) -------------------
+// ---- solve operator: c0[b][piv[r]] = -(T u_b)[r] mod q (gpv.rs:153-158: sol = A^{-1}(u), centre = -sol); T is passed transposed ---
 __device__ inline uint64_t mulmod_dev(uint64_t a, uint64_t b, uint64_t q) {
   if (q <= 0xffffffffull) return (a * b) % q;
   uint64_t r = 0;
@@ -150,15 +150,25 @@ __device__ inline uint64_t mulmod_dev(uint64_t a, uint64_t b, uint64_t q) {
   }
   return r;
 }
-__global__ void k_gpv_solve(const uint64_t* __restrict__ T, const uint32_t* __restrict__ piv, size_t n, size_t m, uint64_t q,
+__global__ void k_gpv_solve(const uint64_t* __restrict__ Tt, const uint32_t* __restrict__ piv, size_t n, size_t m, uint64_t q, uint64_t two64,
                             const uint64_t* __restrict__ U, size_t B, int64_t* __restrict__ C0) {
   const size_t total = n * B;
   for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const size_t b = g / n, r = g % n;
     uint64_t acc = 0;
-    for (size_t t = 0; t < n; ++t) {
-      acc += mulmod_dev(T[r * n + t], U[b * n + t] % q, q);
-      if (acc >= q) acc -= q;
+    if (q <= 0x7fffffffull) {                       // products below 2^62: sum them in 128 bits, reduce once
+      Acc128 s{0, 0};
+      for (size_t t = 0; t < n; ++t) {
+        uint64_t uq = U[b * n + t];
+        if (uq >= q) uq %= q;
+        acc128_add(s, (int64_t)(Tt[t * n + r] * uq));
+      }
+      acc = acc128_mod(s, q, two64);
+    } else {
+      for (size_t t = 0; t < n; ++t) {
+        acc += mulmod_dev(Tt[t * n + r], U[b * n + t] % q, q);
+        if (acc >= q) acc -= q;
+      }
     }
     C0[b * m + piv[r]] = -(int64_t)acc;
   }

@@ -10,7 +10,7 @@ struct psfgpv_handle {
   double* dGt = nullptr;              // dim x dim, row i = b~_i
   double* dNorm2 = nullptr;
   SampleZParams* dSz = nullptr;
-  uint64_t* dT = nullptr;             // n x n solve operator
+  uint64_t* dT = nullptr;             // n x n solve operator, transposed
   uint32_t* dPiv = nullptr;           // n pivot columns
   int64_t* dC0 = nullptr; size_t c0cap = 0;
   int jr = 0;                         // nearest-plane template size for dim (np_template_jr)
@@ -66,7 +66,13 @@ static psf_status gpv_build_solver(psfgpv_handle* g) {
   std::vector<uint64_t> T;
   const psf_status rc = solve_precompute(A.data(), b->n, b->m, b->q, piv, T);
   if (rc != PSF_OK) return rc;                                         // gpv.rs:153-155: solve(...).unwrap() would panic
-  HIP_TRY(hipMemcpy(g->dT, T.data(), T.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  {  // stored transposed: lane r of the solve kernel reads Tt[t][r], consecutive lanes consecutive addresses
+    const size_t nn = b->n;
+    std::vector<uint64_t> Tt(T.size());
+    for (size_t r = 0; r < nn; ++r)
+      for (size_t t = 0; t < nn; ++t) Tt[t * nn + r] = T[r * nn + t];
+    HIP_TRY(hipMemcpy(g->dT, Tt.data(), Tt.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMemcpy(g->dPiv, piv.data(), piv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   return PSF_OK;
 }
@@ -245,7 +251,7 @@ psf_status psfgpv_samp_p_dev(psfgpv_handle* g, uint64_t seed, uint64_t first_ind
   HIP_TRY(hipMemsetAsync(g->dC0, 0, B * g->dim * sizeof(int64_t), st));
   if (g->timing) hipEventRecord(g->ev[0], st);
   // :153-158  sol = A.solve(u), centre = -sol
-  hipLaunchKernelGGL(k_gpv_solve, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dT, g->dPiv, g->n, g->dim, b->q, d_u, B, g->dC0);
+  hipLaunchKernelGGL(k_gpv_solve, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dT, g->dPiv, g->n, g->dim, b->q, b->two64, d_u, B, g->dC0);
   if (g->timing) hipEventRecord(g->ev[1], st);
   // :160  sol + sample_d_precomputed_gso(basis, gso, centre, s)
   const psf_status rc = launch_nearest_plane(g, st, seed, TAG_GPV, first_index, B, d_e);
