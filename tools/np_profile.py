@@ -34,3 +34,6 @@ tot = sum(out[:6])
 for nm, v in zip(names, out):
     print(f"{nm:32s} {v:12d} ticks  {100.0 * v / max(tot, 1):5.1f}%  per step {v / m:8.1f}")
 print("total ticks", tot, "steps", m)
+
+import struct
+print("largest FP53 exactness bound reached by a workgroup: 2^%.1f" % math.log2(max(struct.unpack("d", struct.pack("q", out[6]))[0], 1.0)))

@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256, JR <= 8 ? 4 : JR <= 16 ? 3 : 2) void k_gpv_nea
   }
 #ifdef NP_PROFILE
   if (blockIdx.x == 0 && tid == 0) for (int k = 0; k < 6; ++k) g_np_prof[k] += tacc_[k];
+  if (FP53 && tid == 0) { const double mb = bnd[0] > bnd[1] ? bnd[0] : bnd[1]; atomicMax((unsigned long long*)&g_np_prof[6], (unsigned long long)__double_as_longlong(mb)); }
 #endif
 #pragma unroll
   for (int k = 0; k < 2; ++k)
