@@ -34,3 +34,18 @@ def test_cpp_mirror_flow_on_gpu():
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PSFPerturbation ok" in r.stdout and "PSFGPV ok" in r.stdout and "PSFGPVRing ok" in r.stdout
+
+
+def test_host_logic_under_address_and_ub_sanitizers():
+    """tools_amd/csrc/psf_host.cpp (no HIP in it) built with g++ -fsanitize=address,undefined and driven through the reference's
+    invariants by tests/cpp/host_sanitize.cpp: A S_A = 0, G-digits, elimination, ring embedding, rot^-."""
+    src = os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp")
+    host = os.path.join(ROOT, "tools_amd", "csrc", "psf_host.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "host_sanitize")
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-fno-omit-frame-pointer", "-o", exe, src, host], capture_output=True, text=True, timeout=600)
+    if b.returncode != 0 and ("asan" in b.stderr.lower() or "ubsan" in b.stderr.lower() or "sanitize" in b.stderr.lower()):
+        pytest.skip("this g++ has no sanitizer runtime: " + b.stderr[-300:])
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0 and "HOST_SANITIZE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
