@@ -70,7 +70,7 @@ double orc_det_exp(double y) {
   int64_t k = (int64_t)kf;
   uint64_t bits;
   memcpy(&bits, &p, 8);
-  bits = (uint64_t)((int64_t)bits + (k << 52));
+  bits += (uint64_t)k << 52;                       /* two's-complement add of k to the exponent field (k may be negative) */
   memcpy(&p, &bits, 8);
   return p;
 }

@@ -49,3 +49,18 @@ def test_host_logic_under_address_and_ub_sanitizers():
     assert b.returncode == 0, b.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and "HOST_SANITIZE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """The checker itself: oracle/*.c built with gcc -fsanitize=address,undefined and run through one small flow per scheme
+    (tests/cpp/oracle_sanitize.c)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "oracle_sanitize")
+    srcs = [os.path.join(ROOT, "tests", "cpp", "oracle_sanitize.c"), os.path.join(ROOT, "oracle", "psf_oracle.c"),
+            os.path.join(ROOT, "oracle", "psf_oracle_gpv.c")]
+    b = subprocess.run(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+                        "-ffp-contract=off", "-fopenmp", "-o", exe] + srcs + ["-lm"], capture_output=True, text=True, timeout=600)
+    if b.returncode != 0 and "sanitize" in b.stderr.lower():
+        pytest.skip("this gcc has no sanitizer runtime: " + b.stderr[-300:])
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", OMP_NUM_THREADS="2"))
+    assert r.returncode == 0 and "ORACLE_SANITIZE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -81,7 +81,8 @@ __host__ __device__ inline double det_exp(double y) {
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
   const long long k = (long long)kf;
-  long long bits = __builtin_bit_cast(long long, p) + (k << 52);
+  const unsigned long long ubits = __builtin_bit_cast(unsigned long long, p) + ((unsigned long long)k << 52);   // k may be negative
+  long long bits = (long long)ubits;
   return __builtin_bit_cast(double, bits);
 }
 
