@@ -247,9 +247,12 @@ class PSFPerturbation:
         self.m = self.m_bar + self.w
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_psfp_free(self._h)
-            self._h = None
+        try:                                   # at interpreter shutdown module globals may already be gone
+            if getattr(self, "_h", None):
+                lib().orc_psfp_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     # key material views (copies)
     @property
@@ -387,9 +390,12 @@ class PSFGPV:
         self.m = self.m_bar + self.w
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_gpv_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_gpv_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     @property
     def A(self):
