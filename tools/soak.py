@@ -1,7 +1,7 @@
 """Soak of the full-size paths: many batches with fresh seeds; every batch is checked through A e = u and check_domain on the
 device, and a slice of it bit for bit against the CPU oracle (rare events -- acceptance ties, screened-in-but-rejected
 attempts, second sampling rounds, queue corner cases -- occur thousands of times over a run).
-   python tools/soak.py c3|c2|c4 [iterations] [oracle rows per iteration]"""
+   python tools/soak.py c3|c2|c4|psfp:n:q:r:s:B [iterations] [oracle rows per iteration]"""
 import ctypes as C, math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,8 +14,11 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 O.build()
 dev = torch.device("cuda:0")
-if cfg == "c3":
+if cfg == "c3" or cfg.startswith("psfp:"):
     n, q, r, s, B = 512, 2**30, 9.0, 512.0, 4096
+    if cfg.startswith("psfp:"):                     # psfp:n:q:r:s:B
+        f = cfg.split(":")
+        n, q, r, s, B = int(f[1]), int(f[2]), float(f[3]), float(f[4]), int(f[5])
     psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
     check(lib().psfp_trap_gen(psf._h, C.c_uint64(3)), "trap_gen")
     A, (R, Lp, _) = psf.export_key()
