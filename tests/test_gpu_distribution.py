@@ -72,3 +72,34 @@ def test_empty_and_ragged_batches():
     # index beyond 2^32 selects a different (but still valid) stream
     e_hi = psf.samp_p(u[:3], seed=9, first_index=2**33)
     assert (psf.f_a(e_hi) == u[:3]).all() and not (e_hi == e[:3]).all()
+
+
+def test_two_handles_in_two_threads_do_not_interfere():
+    """One handle per thread is the rule (as for the reference's PSF objects); two of them working at the same time must give
+    what each gives alone."""
+    import threading
+    import numpy as np
+    import tools_amd as T
+    from oracle import oracle as O
+    cfgs = [(8, 64, 3.0, 25.0, 300), (6, 128, float(np.log2(6)), 25.0, 257)]
+    handles, targets, alone = [], [], []
+    for n, q, r, s, B in cfgs:
+        psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+        psf.trap_gen(4)
+        u = O.uniform_targets(3, B, n, q)
+        handles.append(psf); targets.append(u)
+        alone.append([psf.samp_p(u, seed=70 + i) for i in range(6)])
+    together = [[None] * 6 for _ in cfgs]
+
+    def work(k):
+        for i in range(6):
+            together[k][i] = handles[k].samp_p(targets[k], seed=70 + i)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(cfgs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(len(cfgs)):
+        for i in range(6):
+            assert (together[k][i] == alone[k][i]).all()
