@@ -50,3 +50,35 @@ def test_gpv_general_base(oracle, n, q, base, k, m_bar, r, s):
     e = psf.samp_p(u, seed=8)
     assert (e == orc.samp_p(8, u)).all()
     assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
+
+
+def test_documented_limits_are_reported_not_crashed():
+    """DESIGN.md section 8 'Limits': every one of them comes back as a status code (the mirror raises PsfError)."""
+    import tools_amd as T
+    from tools_amd import _ffi
+    GP = T.GadgetParameters
+    # lattice dimension of PSFGPV above 8192
+    with pytest.raises(T.PsfError) as ei:
+        T.PSFGPV(GP.init_default(512, 2**30), 100.0)              # m = 30801
+    assert ei.value.status == _ffi.ERR_UNSUPPORTED
+    # more than 64 gadget digits
+    with pytest.raises(T.PsfError) as ei:
+        T.PSFPerturbation(GP(4, 65, 4 * 65 + 4, 2, 2**61), 3.0, 50.0)
+    assert ei.value.status == _ffi.ERR_UNSUPPORTED
+    # modulus at or above 2^62, degenerate parameters
+    for bad in (GP(4, 62, 252, 2, 2**62), GP(0, 6, 48, 2, 64), GP(4, 6, 28, 1, 64), GP(4, 6, 28, 2, 1)):
+        with pytest.raises(T.PsfError) as ei:
+            T.PSFPerturbation(bad, 3.0, 50.0)
+        assert ei.value.status == _ffi.ERR_PARAM
+    for r, s in ((0.0, 50.0), (3.0, -1.0), (float("nan"), 50.0)):
+        with pytest.raises(T.PsfError) as ei:
+            T.PSFPerturbation(GP.init_default(4, 64), r, s)
+        assert ei.value.status == _ffi.ERR_PARAM
+    # ring modulus at or above 2^31
+    with pytest.raises(T.PsfError) as ei:
+        T.PSFGPVRing(T.GadgetParametersRing.init_default(8, 2**31 + 11), 100.0, 1.005)
+    assert ei.value.status == _ffi.ERR_UNSUPPORTED
+    # a gadget too short for q (gadget_classical.rs:170-172 panics there)
+    psf = T.PSFPerturbation(GP(4, 5, 5 * 4 + 4, 2, 64), 3.0, 50.0)
+    with pytest.raises(T.PsfError):
+        psf.trap_gen(1)
