@@ -978,6 +978,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
 // which is all the dot product needs.  Workgroup tile 128 (b) x 128 (i), wave tile 64 x 64, K step 64, LDS-DMA staging
 // (2 stages x (R tile 8 KiB | Zlo 8 KiB | Zhi 8 KiB)).  The hi plane is skipped when the gadget kernel saw no |z| > 127.
 constexpr int RC_STAGE = 3 * 8192;
+constexpr int RC_LDS = 3 * RC_STAGE;      // 72 KiB: three 24 KiB stages, or four 16 KiB stages when the hi plane is unused
 
 __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int nks,
                                                            const int8_t* __restrict__ Zlo, const int8_t* __restrict__ Zhi, size_t ld,
@@ -1006,8 +1007,12 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
     srcL[j] = Zlo + zoff;
     srcH[j] = Zhi + zoff;
   }
+  // A K step is only 16 (32 with the hi plane) short MFMAs, far less than a DMA round trip, so the stages form a ring of depth
+  // 4 (16 KiB stages, hi plane unused) or 3 (24 KiB stages) inside the same RC_LDS bytes: NS - 1 stages are always in flight.
+  const int NS = use_hi ? 3 : 4;
+  const int SS = use_hi ? 3 * 8192 : 2 * 8192;
   auto stage_load = [&](int ks, int buf) {
-    unsigned char* base = rc_smem + buf * RC_STAGE;
+    unsigned char* base = rc_smem + buf * SS;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int piece0 = (wave * 2 + j) * 64;
@@ -1017,14 +1022,21 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
         __builtin_amdgcn_global_load_lds(srcH[j] + (size_t)ks * 4 * ld * 16, (lds_void_ptr)(base + 16384 + piece0 * 16), 16, 0, 0);
     }
   };
-  stage_load(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  for (int s0 = 0; s0 < NS - 1 && s0 < nks; ++s0) stage_load(s0, s0);
   const int r16 = lane & 15, g = lane >> 4;
+  int cur = 0;                                        // ks % NS
   for (int ks = 0; ks < nks; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nks) stage_load(ks + 1, cur ^ 1);
-    const unsigned char* sR = rc_smem + cur * RC_STAGE;
+    // stage ks has landed when at most the NS - 2 younger stages (4 or 6 DMA instructions each) are outstanding
+    if (nks - 1 - ks >= NS - 2) {
+      if (use_hi) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                  // everybody's part of stage ks is in LDS; everybody is done with stage ks - 1
+    const int nxt = ks + NS - 1;
+    if (nxt < nks) stage_load(nxt, cur == 0 ? NS - 1 : cur - 1);
+    const unsigned char* sR = rc_smem + cur * SS;
     const unsigned char* sL = sR + 8192;
     const unsigned char* sH = sR + 16384;
     v4i fr[4], fl[4];
@@ -1046,9 +1058,19 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
 #pragma unroll
         for (int it = 0; it < 4; ++it) ahi[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fh[bt], fr[it], ahi[bt][it], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cur = cur + 1 == NS ? 0 : cur + 1;
   }
+  // The 128 x 128 tile of p is brought in through LDS: rows of P (coordinate-major, preimages contiguous) are read as 16-byte
+  // runs and turned by the padded LDS tile, instead of sixty-four 4-byte gathers per thread across sixteen rows each.
+  __syncthreads();                                    // the stage ring is free
+  int32_t* sP = reinterpret_cast<int32_t*>(rc_smem);  // [128][129]
+  for (int idx = tid; idx < 128 * 32; idx += 256) {
+    const int ii = idx >> 5, c4 = idx & 31;
+    const int4 v = *reinterpret_cast<const int4*>(P + (i0 + (size_t)ii) * ld + b0 + (size_t)c4 * 4);
+    int32_t* d = sP + ii * 129 + c4 * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
   // C/D map: column (here i) = lane & 15, row (here b) = 4 * (lane >> 4) + reg
 #pragma unroll
   for (int bt = 0; bt < 4; ++bt)
@@ -1056,10 +1078,10 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
     for (int it = 0; it < 4; ++it)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const size_t bb = b0 + wr * 64 + bt * 16 + 4 * g + r;
-        const size_t ii = i0 + wc * 64 + it * 16 + r16;
+        const int bl = wr * 64 + bt * 16 + 4 * g + r, il = wc * 64 + it * 16 + r16;
+        const size_t bb = b0 + bl, ii = i0 + il;
         if (bb < B && ii < mbar)
-          E[bb * m + ii] = (int64_t)P[ii * ld + bb] + (int64_t)alo[bt][it][r] + 256 * (int64_t)ahi[bt][it][r];
+          E[bb * m + ii] = (int64_t)sP[il * 129 + bl] + (int64_t)alo[bt][it][r] + 256 * (int64_t)ahi[bt][it][r];
       }
 }
 

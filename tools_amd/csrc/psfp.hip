@@ -341,6 +341,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, CH_NB * (CH_NB + 1) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB * (CH_NB + 1) / 2 + CH_NB * 64) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   if (const char* env = std::getenv("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
@@ -573,7 +574,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   }
   {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
     ScopedTimer t(h, s2, "k_recombine");
-    hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((B + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), 2 * RC_STAGE, s2, h->dR,
+    hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((B + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), RC_LDS, s2, h->dR,
                        h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo, h->dZhi, ld, h->dFail, h->dP, B, d_e, m);
     hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((B + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, s2, h->mb, h->w,
                        h->dZlo, h->dZhi, ld, h->dP, B, d_e, m);
