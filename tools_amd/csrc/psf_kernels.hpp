@@ -1022,8 +1022,50 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
         __builtin_amdgcn_global_load_lds(srcH[j] + (size_t)ks * 4 * ld * 16, (lds_void_ptr)(base + 16384 + piece0 * 16), 16, 0, 0);
     }
   };
-  for (int s0 = 0; s0 < NS - 1 && s0 < nks; ++s0) stage_load(s0, s0);
   const int r16 = lane & 15, g = lane >> 4;
+  if (!use_hi && (nks & 1) == 0) {
+    // Common case (no |z| > 127): K = 128 per stage -- 32 MFMAs per wave between two barriers instead of 16 -- in two 32 KiB stages:
+    // R tile as [k half 2][row 128][64 B], Z tile as [k group 8][preimage 128][16 B].
+    auto stage_load2 = [&](int ks2, int buf) {
+      unsigned char* base = rc_smem + buf * 32768;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int p = (wave * 4 + j) * 64 + lane;                  // 16-byte piece, 0..1023
+        const int kk = p >> 9, row = (p >> 2) & 127, col = p & 3;
+        __builtin_amdgcn_global_load_lds(R + (i0 + (size_t)row) * ldr + (size_t)ks2 * 128 + kk * 64 + col * 16,
+                                         (lds_void_ptr)(base + (wave * 4 + j) * 1024), 16, 0, 0);
+        const int kg = p >> 7, bb = p & 127;
+        __builtin_amdgcn_global_load_lds(Zlo + (((size_t)ks2 * 8 + kg) * ld + b0 + (size_t)bb) * 16,
+                                         (lds_void_ptr)(base + 16384 + (wave * 4 + j) * 1024), 16, 0, 0);
+      }
+    };
+    const int n2 = nks / 2;
+    stage_load2(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ks2 = 0; ks2 < n2; ++ks2) {
+      const int cb = ks2 & 1;
+      if (ks2 + 1 < n2) stage_load2(ks2 + 1, cb ^ 1);
+      const unsigned char* sR = rc_smem + cb * 32768;
+      const unsigned char* sL = sR + 16384;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        v4i fr[4], fl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          fr[t] = *reinterpret_cast<const v4i*>(sR + kk * 8192 + ((wc * 64 + t * 16 + r16) * 64 + g * 16));
+          fl[t] = *reinterpret_cast<const v4i*>(sL + (((kk * 4 + g) * 128 + wr * 64 + t * 16 + r16) * 16));
+        }
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) alo[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fl[bt], fr[it], alo[bt][it], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+  for (int s0 = 0; s0 < NS - 1 && s0 < nks; ++s0) stage_load(s0, s0);
   int cur = 0;                                        // ks % NS
   for (int ks = 0; ks < nks; ++ks) {
     // stage ks has landed when at most the NS - 2 younger stages (4 or 6 DMA instructions each) are outstanding
@@ -1059,6 +1101,7 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
         for (int it = 0; it < 4; ++it) ahi[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fh[bt], fr[it], ahi[bt][it], 0, 0, 0);
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
+  }
   }
   // The 128 x 128 tile of p is brought in through LDS: rows of P (coordinate-major, preimages contiguous) are read as 16-byte
   // runs and turned by the padded LDS tile, instead of sixty-four 4-byte gathers per thread across sixteen rows each.
