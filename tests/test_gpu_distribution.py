@@ -103,3 +103,25 @@ def test_two_handles_in_two_threads_do_not_interfere():
     for k in range(len(cfgs)):
         for i in range(6):
             assert (together[k][i] == alone[k][i]).all()
+
+
+def test_host_pointer_path_slices_large_batches_without_changing_a_bit(monkeypatch):
+    """psfp_samp_p cuts big batches into slices so that PCIe overlaps compute; PSF_HOST_SLICE forces slicing at a small size."""
+    import numpy as np
+    import tools_amd as T
+    from oracle import oracle as O
+    n, q = 8, 64
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), 3.0, 25.0)
+    psf.trap_gen(2)
+    u = O.uniform_targets(4, 1000, n, q)
+    monkeypatch.setenv("PSF_HOST_SLICE", "100000")
+    whole = psf.samp_p(u, seed=21, first_index=7)
+    monkeypatch.setenv("PSF_HOST_SLICE", "256")          # 256, 256, 256, 232
+    sliced = psf.samp_p(u, seed=21, first_index=7)
+    assert (whole == sliced).all()
+    big = O.uniform_targets(5, 3300, n, q)               # default policy: two halves from 3072 rows on
+    monkeypatch.delenv("PSF_HOST_SLICE")
+    a = psf.samp_p(big, seed=22)
+    monkeypatch.setenv("PSF_HOST_SLICE", "100000")
+    b = psf.samp_p(big, seed=22)
+    assert (a == b).all() and (psf.f_a(a) == big).all()

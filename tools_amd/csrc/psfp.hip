@@ -68,6 +68,8 @@ struct psfp_handle {
   int32_t* dPf = nullptr; int8_t* dP8f = nullptr;   // scratch of f_a (kept apart from the pipelined sets)
   uint64_t* dPart = nullptr; int zq_splits = 1, zq_ks = 0;   // per-split residues of the int8-MFMA Z_q product
   bool gadget_queue = true;   // task-queue gadget sampler (PSF_GADGET_QUEUE=0: lock-step kernel)
+  bool keep_fail = false;     // sliced host path: the failure flags accumulate over the slices of one call
+  bool no_slice = false;      // stage export wants the intermediates of the whole batch
   bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
   size_t ncall = 0;
   hipStream_t s1 = nullptr;
@@ -534,7 +536,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     st = h->s1;
     s2 = h->aux;
   }
-  hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
+  if (!h->keep_fail) hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
   {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
     ScopedTimer t(h, st, "k_normals");
     const size_t nwaves = (nbj * h->nkb * TR_CHUNK + NR_SEG - 1) / NR_SEG;
@@ -615,18 +617,57 @@ psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size
   psf_status rc = ensure_batch(h, B);
   if (rc != PSF_OK) return rc;
   HIP_TRY(hipMemcpy(h->dU, u, B * h->n * sizeof(uint64_t), hipMemcpyHostToDevice));
-  rc = run_samp_p(h, seed, first_index, B, h->dU, h->dE, nullptr);
-  if (rc != PSF_OK) return rc;
-  rc = psfp_last_status(h);
-  HIP_TRY(hipMemcpy(e, h->dE, B * h->m * sizeof(int64_t), hipMemcpyDeviceToHost));
-  return rc;
+  // Large batches are cut into slices of preimages: the rows of slice i cross PCIe (copy stream) while slice i+1 is computed
+  // (compute stream).  Row b draws from global index first_index + b, so slicing does not change a single bit.
+  size_t slice = B;
+  if (B >= 3072 && !h->pipeline && !h->no_slice) slice = round_up((B + 1) / 2, TR_BN);   // two halves: 84 -> 80 ms for a C3 batch; more, smaller slices cost the FP64 product more than the overlap returns
+  if (const char* env = std::getenv("PSF_HOST_SLICE")) { const long v = std::atol(env); if (v >= 128 && !h->no_slice) slice = (size_t)v < B ? (size_t)v : B; }
+  if (slice >= B) {
+    rc = run_samp_p(h, seed, first_index, B, h->dU, h->dE, nullptr);
+    if (rc != PSF_OK) return rc;
+    rc = psfp_last_status(h);
+    HIP_TRY(hipMemcpy(e, h->dE, B * h->m * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return rc;
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  hipEvent_t done[2] = {nullptr, nullptr};
+  for (auto& ev : done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), h->s1));
+  h->keep_fail = true;
+  size_t prev_off = 0, prev_n = 0;
+  int i = 0;
+  psf_status worst = PSF_OK;
+  auto fetch = [&](size_t off, size_t cnt, hipEvent_t ev) -> psf_status {
+    HIP_TRY(hipEventSynchronize(ev));
+    HIP_TRY(hipMemcpyAsync(e + off * h->m, h->dE + off * h->m, cnt * h->m * sizeof(int64_t), hipMemcpyDeviceToHost, h->aux));
+    HIP_TRY(hipStreamSynchronize(h->aux));
+    return PSF_OK;
+  };
+  for (size_t off = 0; off < B; off += slice, ++i) {
+    const size_t cnt = B - off < slice ? B - off : slice;
+    h->nbj = round_up(cnt, TR_BN) / TR_BN;
+    rc = run_samp_p(h, seed, first_index + off, cnt, h->dU + off * h->n, h->dE + off * h->m, h->s1);
+    if (rc != PSF_OK) { worst = rc; break; }
+    HIP_TRY(hipEventRecord(done[i & 1], h->s1));
+    if (prev_n) { rc = fetch(prev_off, prev_n, done[(i - 1) & 1]); if (rc != PSF_OK) { worst = rc; break; } }
+    prev_off = off; prev_n = cnt;
+  }
+  h->keep_fail = false;
+  if (worst == PSF_OK && prev_n) worst = fetch(prev_off, prev_n, done[(i - 1) & 1]);
+  h->last_stream = h->s1;
+  const psf_status st_rc = psfp_last_status(h);
+  for (auto& ev : done) hipEventDestroy(ev);
+  h->nbj = round_up(B, TR_BN) / TR_BN;
+  return worst != PSF_OK ? worst : st_rc;
 }
 
 psf_status psfp_samp_p_stages(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, double* d, double* x,
                               int64_t* p, uint64_t* v, int64_t* z, int64_t* e) {
   if (!h || !u || B == 0) return PSF_ERR_PARAM;
   std::vector<int64_t> etmp(B * h->m);
+  h->no_slice = true;
   psf_status rc = psfp_samp_p(h, seed, first_index, B, u, etmp.data());
+  h->no_slice = false;
   if (rc != PSF_OK && rc != PSF_ERR_SAMPLER) return rc;
   const size_t m = h->m, ld = h->ld;
   if (e) std::memcpy(e, etmp.data(), etmp.size() * sizeof(int64_t));

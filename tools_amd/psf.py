@@ -86,7 +86,7 @@ class PSFPerturbation:
     def samp_p(self, u, seed=0, first_index=0, out=None):
         """mp_perturbation.rs:304-336 with the key installed in the handle (trap_gen / load_key).
         out: optional (B, m) int64 C-contiguous array to fill -- a reused buffer avoids first-touch page faults on a gigabyte
-        of fresh memory (C3 batch: 86 ms per call into a reused buffer, 150-200 ms into a new one; tools/host_path_timing.py)."""
+        of fresh memory (C3 batch: 80 ms per call into a reused buffer, 150-200 ms into a new one; tools/host_path_timing.py)."""
         u = np.ascontiguousarray(u, dtype=np.uint64)
         single = u.ndim == 1
         u2 = u.reshape(-1, self.n)
