@@ -120,6 +120,9 @@ typedef struct {
   uint32_t flags;  /* reserved, 0 */
 } psfp_params;
 
+/* Limits: k <= 64, 1 < q < 2^62, and s * r * sqrt(m) < 2^23 (every coordinate of an in-domain vector then fits the three int8
+ * digit planes of the Z_q products); PSF_ERR_UNSUPPORTED otherwise.  BASELINE's largest set (n=1024, q=2^60, s=1024, r=10)
+ * reaches 3.6e6 of the 8.39e6 allowed. */
 psf_status psfp_create(const psfp_params* params, psfp_handle** out);
 void       psfp_destroy(psfp_handle*);
 /* m = m_bar + n*k */
@@ -135,6 +138,9 @@ psf_status psfp_compute_sqrt_sigma_2(psfp_handle*, double s_cov);
 /* install / read back key material (host buffers).  Any of the out pointers may be NULL. */
 psf_status psfp_load_key(psfp_handle*, const uint64_t* A, const int8_t* R, const double* sqrt_sigma2_packed);
 psf_status psfp_export_key(const psfp_handle*, uint64_t* A, int8_t* R, double* sqrt_sigma2_packed);
+/* rows [row0, row0 + nrows) of sqrt(Sigma_2) in the same packed form (row i holds i + 1 entries): the factor of BASELINE's
+ * largest set is 60.5 GB, so a caller that inspects or ships it does so in row blocks */
+psf_status psfp_export_sqrt_sigma2_rows(const psfp_handle*, size_t row0, size_t nrows, double* out);
 /* the gadget part of the trapdoor tuple: S_k (k x k) and its Gram-Schmidt vectors (columns, k x k) */
 psf_status psfp_export_gadget_basis(const psfp_handle*, int64_t* Sk, double* Sk_gso);
 

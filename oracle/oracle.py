@@ -237,11 +237,15 @@ def gen_short_basis_for_trapdoor(gp, A, R, tag=None):
 class PSFPerturbation:
     """Oracle mirror of mp_perturbation.rs:57-62 / :193-403."""
 
-    def __init__(self, gp, r, s):
+    def __init__(self, gp, r, s, with_L=True):
         self.gp, self.r, self.s = gp, float(r), float(s)
-        self._h = lib().orc_psfp_new(C.byref(gp), C.c_double(r), C.c_double(s))
+        L = lib()
+        L.orc_psfp_new_nokey.restype = C.POINTER(_Psfp)
+        L.orc_psfp_new_nokey.argtypes = [C.POINTER(GadgetParams), C.c_double, C.c_double]
+        self._h = (L.orc_psfp_new if with_L else L.orc_psfp_new_nokey)(C.byref(gp), C.c_double(r), C.c_double(s))
         if not self._h:
             raise ValueError("bad parameters")
+        self.with_L = with_L
         self.n, self.k, self.m_bar = gp.n, gp.k, gp.m_bar
         self.w = gp.n * gp.k
         self.m = self.m_bar + self.w
@@ -283,11 +287,33 @@ class PSFPerturbation:
     def trap_gen(self, seed):
         return lib().orc_psfp_trap_gen(self._h, C.c_uint64(seed))
 
-    def load_key(self, A, R, L_packed):
+    def load_key(self, A, R, L_packed=None):
         A, R = _u64(A), _i8(R)
+        assert A.shape == (self.n, self.m) and R.shape == (self.m_bar, self.w)
+        if L_packed is None:
+            assert not self.with_L, "an oracle object created with storage for sqrt(Sigma_2) needs the factor"
+            _check(lib().orc_psfp_load_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8), None))
+            return
         Lp = np.ascontiguousarray(L_packed, dtype=np.float64)
-        assert A.shape == (self.n, self.m) and R.shape == (self.m_bar, self.w) and Lp.size == self.m * (self.m + 1) // 2
+        assert Lp.size == self.m * (self.m + 1) // 2
         _check(lib().orc_psfp_load_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8), _p(Lp, C.c_double)))
+
+    def sqrt_sigma_2_leading(self, R, s_cov, m0):
+        """Rows 0..m0-1 of the Cholesky factor of Sigma_2 (unblocked recurrence), packed."""
+        R = _i8(R)
+        Lp = np.zeros(m0 * (m0 + 1) // 2)
+        rc = lib().orc_psfp_sqrt_sigma_2_leading(self._h, _p(R, C.c_int8), C.c_double(s_cov), C.c_size_t(m0), _p(Lp, C.c_double))
+        return rc, Lp
+
+    def samp_p_from_x(self, seed, index, u, x):
+        """p, v, z, e of one preimage from its centres x (every stage after x = sqrt(Sigma_2) d)."""
+        u = _u64(u).reshape(self.n)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.m)
+        p, e = np.zeros(self.m, dtype=np.int64), np.zeros(self.m, dtype=np.int64)
+        v, z = np.zeros(self.n, dtype=np.uint64), np.zeros(self.w, dtype=np.int64)
+        _check(lib().orc_psfp_samp_p_from_x(self._h, C.c_uint64(seed), C.c_uint64(index), _p(u, C.c_uint64), _p(x, C.c_double),
+                                            _p(p, C.c_int64), _p(v, C.c_uint64), _p(z, C.c_int64), _p(e, C.c_int64)))
+        return dict(p=p, v=v, z=z, e=e)
 
     def compute_sqrt_sigma_2(self, R, s_cov):
         R = _i8(R)
@@ -342,6 +368,25 @@ class PSFPerturbation:
         _check(lib().orc_randomized_nearest_plane_gadget(self._h, C.c_uint64(seed), C.c_uint64(index),
                                                          _p(v, C.c_uint64), _p(z, C.c_int64)))
         return z
+
+
+def normals(seed, index, m):
+    """d <- N(0,1)^m of preimage `index` (stream TAG_NORMAL)."""
+    L = lib()
+    return np.array([L.orc_sample_normal(seed, index, j) for j in range(m)])
+
+
+def centres_rows(L_rows, row0, nrows, m, d):
+    """x[b][r] = sum_{j <= row0 + r} L[row0 + r][j] d[b][j] for a packed row block of sqrt(Sigma_2) (ascending fma chain)."""
+    L_rows = np.ascontiguousarray(L_rows, dtype=np.float64)
+    d = np.ascontiguousarray(d, dtype=np.float64).reshape(-1, m)
+    first = row0 * (row0 + 1) // 2
+    last = (row0 + nrows) * (row0 + nrows + 1) // 2
+    assert L_rows.size == last - first
+    x = np.zeros((d.shape[0], nrows))
+    _check(lib().orc_psfp_centres_rows(_p(L_rows, C.c_double), C.c_size_t(row0), C.c_size_t(nrows), C.c_size_t(m),
+                                       _p(d, C.c_double), C.c_size_t(d.shape[0]), _p(x, C.c_double)))
+    return x
 
 
 # ---------------------------------------------------------------- PSFGPV

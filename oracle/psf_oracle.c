@@ -152,10 +152,17 @@ double orc_sample_normal(uint64_t seed, uint64_t index, uint32_t coord) {
   return 0.0;
 }
 
+/* Uniform on [0, q): 64-bit multiply-shift with Lemire's rejection of the (2^64 mod q) lowest fractions, so every
+ * residue has exactly floor(2^64 / q) accepted words (MatZq::sample_uniform, mp_perturbation.rs:222, is exactly uniform).
+ * Attempt t draws Philox block (c0, c1, t, tag); a redraw happens with probability < q / 2^64. */
 uint64_t orc_uniform_mod(uint64_t seed, uint32_t tag, uint32_t c0, uint32_t c1, uint64_t q) {
   uint32_t w[4];
-  orc_philox4x32(seed, c0, c1, 0, tag, w);
-  return mulhi64(((uint64_t)w[1] << 32) | w[0], q);
+  const uint64_t thr = (0 - q) % q; /* 2^64 mod q */
+  for (uint32_t t = 0;; ++t) {
+    orc_philox4x32(seed, c0, c1, t, tag, w);
+    const uint64_t x = ((uint64_t)w[1] << 32) | w[0];
+    if (x * q >= thr || t == 63) return mulhi64(x, q);
+  }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -467,7 +474,12 @@ static int mat_inverse_mod(const uint64_t* M, size_t n, uint64_t q, uint64_t* in
 /* ------------------------------------------------------------------------------------------
  * PSFPerturbation (mp_perturbation.rs)
  * ---------------------------------------------------------------------------------------- */
-orc_psfp* orc_psfp_new(const orc_gadget_params* gp, double r, double s) {
+static orc_psfp* psfp_new_impl(const orc_gadget_params* gp, double r, double s, int with_L);
+orc_psfp* orc_psfp_new(const orc_gadget_params* gp, double r, double s) { return psfp_new_impl(gp, r, s, 1); }
+/* the same object without storage for sqrt(Sigma_2) (h->L == NULL): for keys too large to hold twice in host memory, whose
+ * centres x = sqrt(Sigma_2) d are checked through orc_psfp_centres_rows on streamed row blocks */
+orc_psfp* orc_psfp_new_nokey(const orc_gadget_params* gp, double r, double s) { return psfp_new_impl(gp, r, s, 0); }
+static orc_psfp* psfp_new_impl(const orc_gadget_params* gp, double r, double s, int with_L) {
   if (!gp || gp->n < 1 || gp->k < 1 || gp->q <= 1 || !(r > 0) || !(s > 0)) return NULL;
   orc_psfp* h = (orc_psfp*)calloc(1, sizeof(orc_psfp));
   h->gp = *gp; h->r = r; h->s = s;
@@ -475,7 +487,7 @@ orc_psfp* orc_psfp_new(const orc_gadget_params* gp, double r, double s) {
   h->m = gp->m_bar + w;
   h->A = (uint64_t*)calloc(gp->n * h->m, sizeof(uint64_t));
   h->R = (int8_t*)calloc(gp->m_bar * w, 1);
-  h->L = (double*)calloc(h->m * (h->m + 1) / 2, sizeof(double));
+  h->L = with_L ? (double*)calloc(h->m * (h->m + 1) / 2, sizeof(double)) : NULL;
   h->Sk = (int64_t*)calloc(gp->k * gp->k, sizeof(int64_t));
   h->Sk_gso = (double*)calloc(gp->k * gp->k, sizeof(double));
   /* mp_perturbation.rs:233-234: short_basis_gadget + gso.  I_n (x) S_k is block diagonal, so its GSO is
@@ -491,13 +503,27 @@ void orc_psfp_free(orc_psfp* h) {
 
 /* mp_perturbation.rs:111-139 with Sigma = s_cov^2 I (the form trap_gen passes at :227-231):
  *   Sigma_2 = (1/2pi) r^2 ((Sigma - (b^2+1) T T^t) - I),  T = [R; I_w];  returns its lower Cholesky factor. */
+static int sqrt_sigma_2_rows(const orc_psfp* h, const int8_t* R, double s_cov, size_t m, double* Lp);
 int orc_psfp_compute_sqrt_sigma_2(const orc_psfp* h, const int8_t* R, double s_cov, double* Lp) {
+  return sqrt_sigma_2_rows(h, R, s_cov, h->gp.m_bar + h->gp.n * h->gp.k, Lp);
+}
+/* The first m0 rows of the same factor.  Row i of the Cholesky-Banachiewicz recurrence only reads rows <= i, so this is the
+ * factor of the leading m0 x m0 block of Sigma_2 and at the same time rows 0..m0-1 of the full factor: a cheap check of a
+ * device factor that spans many panels at sizes where the whole recurrence (m^3/3) is out of reach for a scalar CPU loop. */
+int orc_psfp_sqrt_sigma_2_leading(const orc_psfp* h, const int8_t* R, double s_cov, size_t m0, double* Lp) {
+  if (m0 > h->gp.m_bar + h->gp.n * h->gp.k) return ORC_ERR_PARAM;
+  return sqrt_sigma_2_rows(h, R, s_cov, m0, Lp);
+}
+static int sqrt_sigma_2_rows(const orc_psfp* h, const int8_t* R, double s_cov, size_t m, double* Lp) {
   const orc_gadget_params* gp = &h->gp;
-  size_t mb = gp->m_bar, w = gp->n * gp->k, m = mb + w;
+  size_t mb = gp->m_bar, w = gp->n * gp->k;
   const double TWO_PI = 6.283185307179586476925;
   double nf_r2 = (1.0 / TWO_PI) * (h->r * h->r);            /* :113, :132-133 */
   double s2 = s_cov * s_cov;
   int64_t b2p1 = (int64_t)(gp->base * gp->base + 1);        /* :126 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8)
+#endif
   for (size_t i = 0; i < m; ++i) {
     double* row = Lp + i * (i + 1) / 2;
     for (size_t j = 0; j <= i; ++j) {
@@ -547,7 +573,7 @@ int orc_psfp_load_key(orc_psfp* h, const uint64_t* A, const int8_t* R, const dou
   size_t n = h->gp.n, w = n * h->gp.k, m = h->m;
   memcpy(h->A, A, n * m * sizeof(uint64_t));
   memcpy(h->R, R, h->gp.m_bar * w);
-  memcpy(h->L, Lp, m * (m + 1) / 2 * sizeof(double));
+  if (h->L && Lp) memcpy(h->L, Lp, m * (m + 1) / 2 * sizeof(double));
   return ORC_OK;
 }
 
@@ -596,12 +622,32 @@ int orc_randomized_nearest_plane_gadget(const orc_psfp* h, uint64_t seed, uint64
   return rc;
 }
 
+/* x[b][i - row0] = sum_{j <= i} L[i][j] d[b][j] for the rows i = row0 .. row0 + nrows - 1 of sqrt(Sigma_2), given as a packed
+ * row block (row i holds i + 1 entries, the block starts at row row0): the contract's ascending fma chain from +0
+ * (mp_perturbation.rs:315).  d: nb x m, x: nb x nrows.  Lets a test stream a factor that does not fit in host memory twice. */
+int orc_psfp_centres_rows(const double* Lrows, size_t row0, size_t nrows, size_t m, const double* d, size_t nb, double* x) {
+  if (row0 + nrows > m) return ORC_ERR_PARAM;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+  for (size_t r = 0; r < nrows; ++r) {
+    const size_t i = row0 + r;
+    const double* li = Lrows + (i * (i + 1) / 2 - row0 * (row0 + 1) / 2);
+    for (size_t b = 0; b < nb; ++b) {
+      const double* db = d + b * m;
+      double acc = 0.0;
+      for (size_t j = 0; j <= i; ++j) acc = fma(li[j], db[j], acc);
+      x[b * nrows + r] = acc;
+    }
+  }
+  return ORC_OK;
+}
+
 /* One preimage, every intermediate exposed (mp_perturbation.rs:304-336). */
 int orc_psfp_samp_p_trace(const orc_psfp* h, uint64_t seed, uint64_t index, const uint64_t* u,
                           double* d, double* x, int64_t* p, uint64_t* v, int64_t* z, int64_t* e) {
-  const orc_gadget_params* gp = &h->gp;
-  size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = h->m;
-  uint64_t q = gp->q;
+  size_t m = h->m;
+  if (!h->L) return ORC_ERR_PARAM;
   /* :315 sample_d_common_non_spherical(sqrt(Sigma_2), r): d <- N(0,1)^m ; x = sqrt(Sigma_2) d ; p_i <- D_{Z,r,x_i} */
   for (size_t j = 0; j < m; ++j) d[j] = orc_sample_normal(seed, index, (uint32_t)j);
   for (size_t i = 0; i < m; ++i) {
@@ -610,6 +656,17 @@ int orc_psfp_samp_p_trace(const orc_psfp* h, uint64_t seed, uint64_t index, cons
     for (size_t j = 0; j <= i; ++j) acc = fma(li[j], d[j], acc);
     x[i] = acc;
   }
+  return orc_psfp_samp_p_from_x(h, seed, index, u, x, p, v, z, e);
+}
+
+/* the stages of samp_p after the centres x are known (mp_perturbation.rs:315 rounding, :318, :321-326, :328-335); needs A and R
+ * of the key but not sqrt(Sigma_2) */
+int orc_psfp_samp_p_from_x(const orc_psfp* h, uint64_t seed, uint64_t index, const uint64_t* u, const double* x,
+                           int64_t* p, uint64_t* v, int64_t* z, int64_t* e) {
+  const orc_gadget_params* gp = &h->gp;
+  size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = h->m;
+  uint64_t q = gp->q;
+  (void)k;
   for (size_t i = 0; i < m; ++i) p[i] = orc_sample_z(seed, ORC_TAG_PERTURB, index, (uint32_t)i, x[i], h->r);
   /* :318 v = u - A p */
   for (size_t i = 0; i < n; ++i) {

@@ -92,6 +92,7 @@ typedef struct {
 } orc_psfp;
 
 orc_psfp* orc_psfp_new(const orc_gadget_params* gp, double r, double s);
+orc_psfp* orc_psfp_new_nokey(const orc_gadget_params* gp, double r, double s);   /* L == NULL: see orc_psfp_centres_rows */
 void      orc_psfp_free(orc_psfp*);
 /* mp_perturbation.rs:221-244 */
 int orc_psfp_trap_gen(orc_psfp*, uint64_t seed);
@@ -99,6 +100,14 @@ int orc_psfp_trap_gen(orc_psfp*, uint64_t seed);
 int orc_psfp_load_key(orc_psfp*, const uint64_t* A, const int8_t* R, const double* L_packed);
 /* mp_perturbation.rs:111-139 ; sigma given as scalar*I (the only form trap_gen uses) */
 int orc_psfp_compute_sqrt_sigma_2(const orc_psfp*, const int8_t* R, double s_cov, double* L_packed);
+/* rows 0..m0-1 of the same factor (= the factor of the leading m0 x m0 block of Sigma_2); Lp: m0(m0+1)/2 */
+int orc_psfp_sqrt_sigma_2_leading(const orc_psfp*, const int8_t* R, double s_cov, size_t m0, double* L_packed);
+/* x = sqrt(Sigma_2) d restricted to a packed row block of the factor (streamed verification of large keys) */
+int orc_psfp_centres_rows(const double* Lrows, size_t row0, size_t nrows, size_t m, const double* d /*nb x m*/, size_t nb,
+                          double* x /*nb x nrows*/);
+/* samp_p from the centres on: p, v, z, e of one preimage (uses A, R; not L) */
+int orc_psfp_samp_p_from_x(const orc_psfp*, uint64_t seed, uint64_t index, const uint64_t* u, const double* x,
+                           int64_t* p, uint64_t* v, int64_t* z, int64_t* e);
 /* mp_perturbation.rs:304-336, B independent calls; u: B x n, e: B x m ; nthreads<=0 -> all cores */
 int orc_psfp_samp_p(const orc_psfp*, uint64_t seed, uint64_t first_index, size_t B,
                     const uint64_t* u, int64_t* e, int nthreads);

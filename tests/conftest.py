@@ -20,14 +20,37 @@ def pytest_sessionstart(session):
     if os.path.exists(lib) and os.path.exists(orc):
         return
     import subprocess
-    if not os.path.exists(lib):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools_amd", "csrc")], stdout=subprocess.DEVNULL)
-    if not os.path.exists(orc):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    try:
+        if not os.path.exists(orc):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        if not os.path.exists(lib):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools_amd", "csrc")], stdout=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError) as exc:      # a host without ROCm still runs the oracle-only tests
+        sys.stderr.write(f"[conftest] native build failed ({exc}); tests that need the library will fail or skip\n")
+
+
+def _have_gpu():
+    """True when a HIP device is usable: /dev/kfd present and the product library finds a device."""
+    if not os.path.exists("/dev/kfd"):
+        return False
+    try:
+        import ctypes
+        from tools_amd import _ffi
+        name = ctypes.create_string_buffer(64)
+        cus = ctypes.c_int(0)
+        return _ffi.lib().psf_device_info(0, name, 64, ctypes.byref(cus)) == 0
+    except Exception:
+        return False
 
 
 def pytest_collection_modifyitems(config, items):
-    """A per-test ceiling (pytest-timeout, when installed) so that one stalled test cannot hold the whole suite."""
+    """gpu-marked tests are skipped (not failed) on a host without a HIP device; a per-test ceiling (pytest-timeout,
+    when installed) so that one stalled test cannot hold the whole suite."""
+    if any(item.get_closest_marker("gpu") for item in items) and not _have_gpu():
+        skip = pytest.mark.skip(reason="no HIP device on this host (run with -m gpu on the MI355X box)")
+        for item in items:
+            if item.get_closest_marker("gpu"):
+                item.add_marker(skip)
     if not config.pluginmanager.hasplugin("timeout"):
         return
     for item in items:

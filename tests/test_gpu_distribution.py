@@ -34,6 +34,32 @@ def test_perturbation_preimages_are_spherical():
     assert abs(nrm2.mean() / (psf.m * sigma**2) - 1) < 0.02
 
 
+def test_perturbation_preimages_are_spherical_across_cholesky_panels():
+    """The same property at a size whose sqrt(Sigma_2) spans five 128-row panels (m = 537), so the blocked device Cholesky
+    (diagonal block, TRSM, MFMA SYRK) and the multi-row-block triangular product are inside the loop: a wrong trailing update
+    shows up as a wrong variance / correlation of e in the later panels."""
+    import tools_amd as T
+    n, q, r, s, B = 32, 256, 5.0, 120.0, 30000
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+    psf.trap_gen(5, export=False)
+    assert psf.m == 537
+    u = np.tile((np.arange(n, dtype=np.uint64) * 37 + 11) % q, (B, 1))
+    e = psf.samp_p(u, seed=13).astype(np.float64)
+    assert (psf.f_a(e.astype(np.int64)) == u).all()
+    sigma = s * r / math.sqrt(2 * math.pi)
+    std = e.std(axis=0)
+    assert np.abs(std / sigma - 1).max() < 0.03, (std.min(), std.max(), sigma)     # 1/sqrt(2B) = 0.4 %
+    for p0 in range(0, psf.m, 128):                                                # each Cholesky panel on its own
+        pan = (std[p0:p0 + 128] ** 2).mean() / sigma**2
+        assert abs(pan - 1) < 0.006, (p0, pan)
+    assert np.abs(e.mean(axis=0)).max() < 5.5 * sigma / math.sqrt(B) + 1.0
+    corr = np.corrcoef(e.T)
+    np.fill_diagonal(corr, 0)
+    assert np.abs(corr).max() < 6.2 / math.sqrt(B), np.abs(corr).max()             # 144k pairs: 4.7 sigma tail
+    nrm2 = (e**2).sum(axis=1)
+    assert abs(nrm2.mean() / (psf.m * sigma**2) - 1) < 0.005
+
+
 def test_gpv_preimages_have_the_right_scale():
     import tools_amd as T
     n, q, s, B = 6, 128, 60.0, 12000      # s above the smoothing parameter of the short basis so the output is ~ spherical

@@ -28,3 +28,60 @@ def test_full_size_batch_is_valid_and_matches_the_oracle_on_a_sample(config, sam
     assert d["n_gpus"] == 1 and d["data"] == "synthetic"
     if config == "c3":
         assert d["roofline"]["bound"] == "mfma" and 0.5 < d["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.timeout(2400)
+def test_c5_per_gpu_shape_is_valid_and_matches_the_oracle_on_a_sample(oracle):
+    """BASELINE.json configs[4] as one of its eight ranks sees it: n = 1024, q = 2^60 (k = 60, m = 122 980), 8192 preimages,
+    60.5 GB factor.  Every row: A e = u and check_domain.  A sample of 16 rows: every stage bit for bit against the oracle --
+    normals, centres x = sqrt(Sigma_2) d (the factor is streamed back in row blocks and pushed through the oracle's
+    ascending fma chain), perturbation, syndrome, gadget preimage, e."""
+    import numpy as np
+    import torch
+    import tools_amd as T
+    n, q, r, s, B = 1024, 2**60, 10.0, 1024.0, 8192
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+    psf.trap_gen(3, export=False)
+    m = psf.m
+    assert (psf.k, m) == (60, 122980)
+    dev = torch.device("cuda:0")
+    first = 5 * B                                               # the index range rank 5 of 8 owns
+    u = torch.empty((B, n), dtype=torch.int64, device=dev)
+    e = torch.empty((B, m), dtype=torch.int64, device=dev)
+    psf.uniform_targets_dev(u.data_ptr(), B, seed=7, first_index=first)
+    psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=1000, first_index=first)
+    torch.cuda.synchronize()
+    assert psf.last_status() == 0
+    u2 = torch.empty_like(u)
+    ok = torch.empty((B,), dtype=torch.uint8, device=dev)
+    psf.f_a_dev(e.data_ptr(), u2.data_ptr(), ok.data_ptr(), B)
+    torch.cuda.synchronize()
+    assert bool((u2 == u).all().item()) and bool(ok.all().item())
+    # ---- 16 rows spread over the batch, recomputed as a batch of their own (rows do not depend on the batch they ride in)
+    rows = [0, 1, 127, 128, 1000, 4095, 4096, 8191]
+    S = 16
+    lo = 4000
+    uh = u[lo:lo + S].cpu().numpy().astype(np.uint64)
+    st = psf.samp_p_stages(uh, seed=1000, first_index=first + lo)
+    assert (st["e"] == e[lo:lo + S].cpu().numpy()).all()
+    for rr in rows:                                             # and single rows anywhere in the batch
+        one = psf.samp_p(u[rr].cpu().numpy().astype(np.uint64), seed=1000, first_index=first + rr)
+        assert (one == e[rr].cpu().numpy()).all()
+    d_ref = np.array([oracle.normals(1000, first + lo + b, m) for b in range(S)])
+    assert (st["d"].view(np.uint64) == d_ref.view(np.uint64)).all(), "normals differ"
+    step = 2048
+    for row0 in range(0, m, step):
+        nr = min(step, m - row0)
+        Lr = psf.export_sqrt_sigma2_rows(row0, nr)
+        x_ref = oracle.centres_rows(Lr, row0, nr, m, d_ref)
+        assert (st["x"][:, row0:row0 + nr].view(np.uint64) == x_ref.view(np.uint64)).all(), f"centres differ in rows {row0}.."
+    A, R = psf.export_A_R()
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s, with_L=False)
+    orc.load_key(A, R)
+    for b in range(S):
+        fx = orc.samp_p_from_x(1000, first + lo + b, uh[b], st["x"][b])
+        assert (fx["p"] == st["p"][b]).all(), "perturbation differs"
+        assert (fx["v"] == st["v"][b]).all(), "syndrome differs"
+        assert (fx["z"] == st["z"][b]).all(), "gadget preimage differs"
+        assert (fx["e"] == st["e"][b]).all(), "preimage differs"
+    psf.close()

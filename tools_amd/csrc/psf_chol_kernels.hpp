@@ -2,7 +2,8 @@
 // on a dense row-major matrix whose LOWER triangle is significant.  Panel width 128:
 //   k_chol_diag : factor the 128 x 128 diagonal block in LDS (one workgroup); reports a non-positive pivot (:109-110)
 //   k_chol_trsm : rows below the block, x L11^t = p by forward substitution, one row per thread, row and L11 in LDS
-//   k_chol_syrk : trailing update C[i][j] -= L[i] L[j]^t on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), K = 128
+//   k_chol_syrk : trailing update C[i][j] -= L[i] L[j]^t on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), K = 128:
+//                 the 128-term product is accumulated from +0 and subtracted from C once
 // Setup path only (once per key); the factor is compared with the oracle's unblocked one within a tolerance.
 #pragma once
 #include "psf_kernels.hpp"
@@ -100,10 +101,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_syrk(double* __restrict__ A, si
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const size_t rr = r0 + wr * 64 + i * 16 + g + 4 * r, cc = c0 + wc * 64 + j * 16 + r16;
-        acc[i][j][r] = (rr < m && cc < m) ? A[rr * ld + cc] : 0.0;
-      }
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;       // the product P_i P_j^t alone; C is read in the epilogue (no spills)
   // a 16 KiB chunk = 128 rows x 16 doubles; each wave-instruction moves 8 rows x 128 B
   auto stage_load = [&](int kc, int buf) {
     double* base = ch_smem + buf * 4096;
@@ -131,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_syrk(double* __restrict__ A, si
       double a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        a[i] = -sA[(wr * 64 + i * 16 + r16) * 16 + ks * 4 + g];
+        a[i] = sA[(wr * 64 + i * 16 + r16) * 16 + ks * 4 + g];
         b[i] = sB[(wc * 64 + i * 16 + r16) * 16 + ks * 4 + g];
       }
 #pragma unroll
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_syrk(double* __restrict__ A, si
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const size_t rr = r0 + wr * 64 + i * 16 + g + 4 * r, cc = c0 + wc * 64 + j * 16 + r16;
-        if (rr < m && cc < m && cc <= rr) A[rr * ld + cc] = acc[i][j][r];
+        if (rr < m && cc < m && cc <= rr) A[rr * ld + cc] -= acc[i][j][r];
       }
 }
 

@@ -59,16 +59,17 @@ __global__ void k_repack_L(const double* __restrict__ src, size_t ld, size_t m, 
 }
 
 // inverse direction (export): chunk stream -> packed rows
-__global__ void k_unpack_L(const double* __restrict__ chunks, size_t m, double* __restrict__ packed) {
-  const size_t total = m * (m + 1) / 2;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+// entries [first, first + total) of the packed triangle (a whole key: first = 0, total = m(m+1)/2; a row block otherwise)
+__global__ void k_unpack_L(const double* __restrict__ chunks, size_t first, size_t total, double* __restrict__ packed) {
+  for (size_t g0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < total; g0 += (size_t)gridDim.x * blockDim.x) {
+    const size_t g = first + g0;
     size_t row = (size_t)((sqrt(1.0 + 8.0 * (double)g) - 1.0) * 0.5);
     while ((row + 1) * (row + 2) / 2 <= g) ++row;
     while (row * (row + 1) / 2 > g) --row;
     const size_t col = g - row * (row + 1) / 2;
     const size_t bi = row / TR_BM, bk = col / TR_BK;
     const size_t chunk = tr_rowblock_base(bi) + bk;
-    packed[g] = chunks[chunk * TR_CHUNK + tr_chunk_pos((int)(row % TR_BM), (int)(col % TR_BK))];
+    packed[g0] = chunks[chunk * TR_CHUNK + tr_chunk_pos((int)(row % TR_BM), (int)(col % TR_BK))];
   }
 }
 
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const
 // fetched from a register window of the next 192 centres by cross-lane reads.  Which lane evaluates which
 // (sample, attempt) changes nothing: the value is the first accepted attempt of the sample's own Philox stream.
 constexpr int PR_SEG = 4096;
+constexpr long long kDigitRangeP = (1ll << 23) - 1;
 
 // acc += shfl_xor(acc, off) for off = 32, 16, 8, 4, 2, 1 -- the xor butterfly of the dot256 contract -- without LDS-crossbar
 // permutes: v_permlane32_swap / v_permlane16_swap (gfx950) for the two widest levels, DPP moves for the rest.  Bit-identical to
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
       accept = sz_group4(seed, (uint32_t)coord, (uint32_t)index, tw, t, rg, c, sp.inv_s, &x);
       if (!accept && ++t >= kMaxAttempts / 4) { accept = true; f = 1; x = (long long)floor(c + 0.5); }
       if (accept) {
-        if (x > 0x1ffffff || x < -0x1ffffff) f = 1;
+        if (x > kDigitRangeP || x < -kDigitRangeP) f = 1;    // the syndrome product needs |p| < 2^23 (k_split_P)
         P[coord * ld + b] = (int32_t)x;
       }
     }
@@ -1195,9 +1197,12 @@ __global__ __launch_bounds__(256) void k_check_domain(const int64_t* __restrict_
   }
 }
 
-// e (B x m int64) -> P layout (m x ld int32), clamped to +-2^25 (anything larger already failed check_domain)
+// e (B x m int64) -> P layout (m x ld int32).  The int8-MFMA product cuts p into three balanced base-256 digits, i.e. |p| < 2^23;
+// psfp_create refuses parameter sets with s r sqrt(m) >= 2^23, so a coordinate beyond that is outside D_n (its row already failed
+// check_domain): it is clamped and the row's ok flag is cleared again here, so f_a can never report ok for a truncated row.
+constexpr int64_t kDigitRange = (1ll << 23) - 1;
 __global__ __launch_bounds__(256) void k_narrow_transpose(const int64_t* __restrict__ E, size_t m, size_t B, size_t ld,
-                                                          int32_t* __restrict__ P) {
+                                                          int32_t* __restrict__ P, uint8_t* __restrict__ ok) {
   __shared__ int32_t s[64][65];
   const int tid = threadIdx.x;
   const size_t i0 = (size_t)blockIdx.y * 64, b0 = (size_t)blockIdx.x * 64;
@@ -1205,8 +1210,10 @@ __global__ __launch_bounds__(256) void k_narrow_transpose(const int64_t* __restr
     const int bb = e >> 6, ii = e & 63;
     int64_t v = 0;
     if (b0 + bb < B && i0 + ii < m) v = E[(b0 + bb) * m + i0 + ii];
-    if (v > 0x1ffffff) v = 0x1ffffff;
-    if (v < -0x1ffffff) v = -0x1ffffff;
+    if (v > kDigitRange || v < -kDigitRange) {
+      v = v > 0 ? kDigitRange : -kDigitRange;
+      ok[b0 + bb] = 0;
+    }
     s[ii][bb] = (int32_t)v;
   }
   __syncthreads();

@@ -285,9 +285,15 @@ __device__ inline double sample_normal(uint64_t seed, uint64_t index, uint32_t c
   return 0.0;
 }
 
+// Uniform on [0, q): multiply-shift with Lemire's rejection of the 2^64 mod q lowest fractions (exactly uniform, like
+// MatZq::sample_uniform at mp_perturbation.rs:222); attempt t draws block (c0, c1, t, tag), redraw probability < q / 2^64.
 __host__ __device__ inline uint64_t uniform_mod(uint64_t seed, uint32_t tag, uint32_t c0, uint32_t c1, uint64_t q) {
-  const U4 w = philox(seed, c0, c1, 0, tag);
-  return mulhi64(((uint64_t)w.y << 32) | w.x, q);
+  const uint64_t thr = (0 - q) % q;
+  for (uint32_t t = 0;; ++t) {
+    const U4 w = philox(seed, c0, c1, t, tag);
+    const uint64_t x = ((uint64_t)w.y << 32) | w.x;
+    if (x * q >= thr || t == 63) return mulhi64(x, q);
+  }
 }
 
 }  // namespace psf

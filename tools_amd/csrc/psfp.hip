@@ -251,6 +251,11 @@ psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   if (gp.n < 1 || gp.k < 1 || gp.base < 2 || gp.q <= 1 || gp.q >= (1ull << 62) || gp.m_bar < 1) return PSF_ERR_PARAM;
   if (!(prm->r > 0.0) || !(prm->s > 0.0)) return PSF_ERR_PARAM;
   if (gp.k > 64) return PSF_ERR_UNSUPPORTED;
+  {  // every in-domain coordinate obeys |e_i| <= ||e|| <= s r sqrt(m) (mp_perturbation.rs:396-402); the int8 digit planes of the
+     // Z_q products (f_a, syndrome) cover |.| < 2^23, so larger domains are refused here instead of being truncated later
+    const double m_all = (double)gp.m_bar + (double)gp.n * (double)gp.k;
+    if (!(prm->s * prm->r * std::sqrt(m_all) < 8388607.0)) return PSF_ERR_UNSUPPORTED;
+  }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || prm->device < 0 || prm->device >= count) {
     std::fprintf(stderr, "[psf_mi355x] no usable HIP device %d (found %d); this library has no CPU fallback\n", prm->device, count);
@@ -501,11 +506,27 @@ psf_status psfp_export_key(const psfp_handle* h, uint64_t* A, int8_t* R, double*
     double* dp = nullptr;
     const size_t np = h->m * (h->m + 1) / 2;
     HIP_TRY(hipMalloc(&dp, np * sizeof(double)));
-    hipLaunchKernelGGL(k_unpack_L, dim3(grid_for(np)), dim3(256), 0, 0, h->dLt, h->m, dp);
+    hipLaunchKernelGGL(k_unpack_L, dim3(grid_for(np)), dim3(256), 0, 0, h->dLt, (size_t)0, np, dp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(Lp, dp, np * sizeof(double), hipMemcpyDeviceToHost));
     hipFree(dp);
   }
+  return PSF_OK;
+}
+
+// rows [row0, row0 + nrows) of the factor, packed (row i: i + 1 entries): keys of tens of GB are read back in pieces
+psf_status psfp_export_sqrt_sigma2_rows(const psfp_handle* h, size_t row0, size_t nrows, double* out) {
+  if (!h || (nrows && !out) || row0 + nrows > h->m || (h->prm.flags & PSFP_FLAG_NO_PERTURB)) return PSF_ERR_PARAM;
+  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (nrows == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  const size_t first = row0 * (row0 + 1) / 2, total = (row0 + nrows) * (row0 + nrows + 1) / 2 - first;
+  double* dp = nullptr;
+  HIP_TRY(hipMalloc(&dp, total * sizeof(double)));
+  hipLaunchKernelGGL(k_unpack_L, dim3(grid_for(total)), dim3(256), 0, 0, h->dLt, first, total, dp);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dp, total * sizeof(double), hipMemcpyDeviceToHost));
+  hipFree(dp);
   return PSF_OK;
 }
 
@@ -523,7 +544,6 @@ psf_status psfp_export_gadget_basis(const psfp_handle* h, int64_t* Sk, double* g
 // profiles/r01_notes.md, hence off by default; covered by tests/test_gpu_pipeline_mode.py).
 static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, hipStream_t st) {
   const size_t ld = h->ld, m = h->m;
-  if (h->timing) clear_slots(h);
   const size_t nbj = h->nbj;
   const bool pipe = h->pipeline;
   hipStream_t user_st = st, s2 = st;
@@ -606,6 +626,7 @@ psf_status psfp_samp_p_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, 
   HIP_TRY(hipSetDevice(h->prm.device));
   psf_status rc = ensure_batch(h, B);
   if (rc != PSF_OK) return rc;
+  if (h->timing) clear_slots(h);       // once per public call: the slices of a host-pointer call add up in psfp_get_timing
   return run_samp_p(h, seed, first_index, B, d_u, d_e, (hipStream_t)stream);
 }
 
@@ -617,11 +638,15 @@ psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size
   psf_status rc = ensure_batch(h, B);
   if (rc != PSF_OK) return rc;
   HIP_TRY(hipMemcpy(h->dU, u, B * h->n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (h->timing) clear_slots(h);
   // Large batches are cut into slices of preimages: the rows of slice i cross PCIe (copy stream) while slice i+1 is computed
   // (compute stream).  Row b draws from global index first_index + b, so slicing does not change a single bit.
   size_t slice = B;
   if (B >= 3072 && !h->pipeline && !h->no_slice) slice = round_up((B + 1) / 2, TR_BN);   // two halves: 84 -> 80 ms for a C3 batch; more, smaller slices cost the FP64 product more than the overlap returns
-  if (const char* env = std::getenv("PSF_HOST_SLICE")) { const long v = std::atol(env); if (v >= 128 && !h->no_slice) slice = (size_t)v < B ? (size_t)v : B; }
+  if (const char* env = std::getenv("PSF_HOST_SLICE")) {      // not under PSF_PIPELINE: the set switching has its own failure flags
+    const long v = std::atol(env);
+    if (v >= 128 && !h->no_slice && !h->pipeline) slice = (size_t)v < B ? (size_t)v : B;
+  }
   if (slice >= B) {
     rc = run_samp_p(h, seed, first_index, B, h->dU, h->dE, nullptr);
     if (rc != PSF_OK) return rc;
@@ -630,13 +655,21 @@ psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size
     return rc;
   }
   HIP_TRY(hipDeviceSynchronize());
-  hipEvent_t done[2] = {nullptr, nullptr};
-  for (auto& ev : done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  // every exit -- including a HIP error in the middle of the loop -- restores the handle's per-call state and releases the events
+  struct SliceGuard {
+    psfp_handle* h; size_t B; hipEvent_t done[2] = {nullptr, nullptr};
+    ~SliceGuard() {
+      h->keep_fail = false;
+      h->nbj = round_up(B, TR_BN) / TR_BN;
+      for (auto& ev : done) if (ev) hipEventDestroy(ev);
+    }
+  } guard{h, B};
+  hipEvent_t* done = guard.done;
+  for (int j = 0; j < 2; ++j) HIP_TRY(hipEventCreateWithFlags(&done[j], hipEventDisableTiming));
   HIP_TRY(hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), h->s1));
   h->keep_fail = true;
   size_t prev_off = 0, prev_n = 0;
   int i = 0;
-  psf_status worst = PSF_OK;
   auto fetch = [&](size_t off, size_t cnt, hipEvent_t ev) -> psf_status {
     HIP_TRY(hipEventSynchronize(ev));
     HIP_TRY(hipMemcpyAsync(e + off * h->m, h->dE + off * h->m, cnt * h->m * sizeof(int64_t), hipMemcpyDeviceToHost, h->aux));
@@ -647,18 +680,14 @@ psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size
     const size_t cnt = B - off < slice ? B - off : slice;
     h->nbj = round_up(cnt, TR_BN) / TR_BN;
     rc = run_samp_p(h, seed, first_index + off, cnt, h->dU + off * h->n, h->dE + off * h->m, h->s1);
-    if (rc != PSF_OK) { worst = rc; break; }
+    if (rc != PSF_OK) return rc;
     HIP_TRY(hipEventRecord(done[i & 1], h->s1));
-    if (prev_n) { rc = fetch(prev_off, prev_n, done[(i - 1) & 1]); if (rc != PSF_OK) { worst = rc; break; } }
+    if (prev_n) { rc = fetch(prev_off, prev_n, done[(i - 1) & 1]); if (rc != PSF_OK) return rc; }
     prev_off = off; prev_n = cnt;
   }
-  h->keep_fail = false;
-  if (worst == PSF_OK && prev_n) worst = fetch(prev_off, prev_n, done[(i - 1) & 1]);
+  if (prev_n) { rc = fetch(prev_off, prev_n, done[(i - 1) & 1]); if (rc != PSF_OK) return rc; }
   h->last_stream = h->s1;
-  const psf_status st_rc = psfp_last_status(h);
-  for (auto& ev : done) hipEventDestroy(ev);
-  h->nbj = round_up(B, TR_BN) / TR_BN;
-  return worst != PSF_OK ? worst : st_rc;
+  return psfp_last_status(h);
 }
 
 psf_status psfp_samp_p_stages(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, double* d, double* x,
@@ -754,7 +783,7 @@ psf_status psfp_f_a_dev(psfp_handle* h, size_t B, const int64_t* d_e, uint64_t* 
   hipStream_t st = (hipStream_t)stream;
   const size_t m = h->m, ld = h->ld;
   hipLaunchKernelGGL(k_check_domain, dim3((unsigned)B), dim3(256), 0, st, d_e, m, m, domain_bound(h), d_ok);   // :367
-  hipLaunchKernelGGL(k_narrow_transpose, dim3((unsigned)(ld / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, st, d_e, m, B, ld, h->dPf);
+  hipLaunchKernelGGL(k_narrow_transpose, dim3((unsigned)(ld / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, st, d_e, m, B, ld, h->dPf, d_ok);
   launch_zq_mfma(h, st, ZQ_FA, h->dPf, h->dP8f, B, nullptr, d_u, h->n);                                                    // :368
   HIP_TRY(hipGetLastError());
   h->last_stream = st;
