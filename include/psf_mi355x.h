@@ -190,7 +190,8 @@ psf_status psfp_get_timing(psfp_handle*, char* names, size_t names_len, double* 
  *   Trapdoor = (short_base, short_base_gso) (gpv.rs:61): both m x m.  They cross this ABI TRANSPOSED: row i of
  *              `basis_t` / `gso_t` is basis vector i, i.e. column i of the reference's MatZ / MatQ
  *              (gen_short_basis_for_trapdoor, short_basis_classical.rs:54-63; MatQ::gso, gpv.rs:91).
- *   samp_p (gpv.rs:152-161): sol = A.solve_gaussian_elimination(u); e = sol + SampleD(basis, gso, -sol, s).
+ *   samp_p (gpv.rs:152-161): sol = A.solve_gaussian_elimination(u); e = sol + SampleD(basis, gso, -sol, s), SampleD in the
+ *   batched blocked form of tools_amd/csrc/psf_np_kernels.hpp (any lattice dimension that fits the device memory).
  *   The elimination is factored once per key (pivot columns + n x n operator); it returns the same particular
  *   solution as eliminating [A | u] per call with unit pivots and free variables 0.
  * ---------------------------------------------------------------------------------------------- */
@@ -218,13 +219,14 @@ psf_status psfgpv_f_a_dev(psfgpv_handle*, size_t B, const int64_t* d_e, uint64_t
 psf_status psfgpv_check_domain(psfgpv_handle*, size_t B, const int64_t* e, size_t len, uint8_t* ok);         /* gpv.rs:219-224 */
 psf_status psfgpv_uniform_targets_dev(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, uint64_t* d_u, void* stream);
 psf_status psfgpv_last_status(psfgpv_handle*);
-/* HIP-event duration (ms) of the nearest-plane kernel of the last samp_p call (0 if timing was off) */
+/* HIP-event durations (ms) of the last samp_p call (0 if timing was off): the solve kernel, and the whole nearest plane
+ * (initial projection, per block one sampling and one update launch, recombination) */
 psf_status psfgpv_enable_timing(psfgpv_handle*, int on);
 psf_status psfgpv_get_timing(psfgpv_handle*, double* solve_ms, double* nearest_plane_ms);
-/* diagnostic of the last samp_p call: workgroups of the nearest-plane walk (gpv.rs:160) that ran with the integer vector
- * in doubles (0 if q >= 2^50 sent the call straight to the int64 pass) and how many of them reached the 2^52 exactness
- * bound and were re-run by the int64 pass; the result is the same either way */
-psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle*, size_t* workgroups, size_t* handed_over);
+/* diagnostic of the last samp_p call: the number of 64-row blocks the nearest-plane walk (gpv.rs:160) was cut into, and whether
+ * e = sum z_i b_i was recombined by the 64-bit integer kernel (1) instead of the int8 matrix-core planes (0) -- the former when a
+ * basis entry or a drawn z_i does not fit two balanced base-256 digits (|.| > 32639); the result is the same either way */
+psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle*, size_t* blocks, size_t* generic_recombination);
 
 /* ------------------------------------------------------------------------------------------------
  * PSFGPVRing (gpv_ring.rs:62-67, impl PSF :69-284) over R_q = Z_q[X]/(X^n + 1)

@@ -400,12 +400,6 @@ def solve_gaussian_elimination(A, q, u):
     return rc, sol
 
 
-def dot256(c, g):
-    c, g = _i64(c), np.ascontiguousarray(g, dtype=np.float64)
-    lib().orc_dot256.restype = C.c_double
-    return lib().orc_dot256(_p(c, C.c_int64), _p(g, C.c_double), C.c_size_t(c.size))
-
-
 def rot_minus_matrix(mat):
     mat = _i64(mat)
     rows, cols = mat.shape

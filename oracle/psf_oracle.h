@@ -126,8 +126,9 @@ int orc_num_threads(void);
 /* ---- PSFGPV (gpv.rs) and shared pieces: see psf_oracle_gpv.c ---- */
 int orc_solve_gaussian_elimination(const uint64_t* A, size_t n, size_t m, uint64_t q, const uint64_t* u, uint64_t* sol);
 int orc_solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, size_t* piv, uint64_t* T);
-double orc_dot256(const int64_t* c, const double* g, size_t dim);
-void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double* norm2, size_t dim, double s,
+/* G[j][i] = <b_j, b~_i> (j > i) and the blocked randomized nearest plane that uses it: contract in psf_oracle_gpv.c */
+void orc_np_gram(const int32_t* basis_t, const double* gso_t, size_t dim, double* G /*dim x dim*/);
+void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double* G, const double* norm2, size_t dim, double s,
                        uint64_t seed, uint32_t tag, uint64_t index, int64_t* c);
 /* Gram-Schmidt on the ROWS of St (MatQ::gso on the columns of the reference's matrix) */
 void orc_gso_rows(const int32_t* St, size_t m, double* Gt);

@@ -105,44 +105,74 @@ int orc_solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, size
 
 /* ------------------------------------------------------------------------------------------
  * MatZ::sample_d_precomputed_gso (gpv.rs:160; GPV08 SampleD): for i = dim-1..0:
- *   c' = <c, b~_i> / ||b~_i||^2 ; z <- D_{Z, s/||b~_i||, c'} ; c -= z b_i.      Returns c in place (the sample is
+ *   c' = <c, b~_i> / ||b~_i||^2 ; z_i <- D_{Z, s/||b~_i||, c'} ; c -= z_i b_i.      Returns c in place (the sample is
  *   (initial c) - (final c)).
- * Contract for the projection: 256 partial fma chains over j = t, t+256, ... (ascending), combined per group of
- * 64 by the xor butterfly 32,16,8,4,2,1 and then ((w0+w1)+(w2+w3)).
+ *
+ * Evaluation contract (the batched, blocked form of the same walk; the device follows it bit for bit).  With
+ *   g[j][i] = <b_j, b~_i>  (ascending fma chain over the coordinates, from +0; used for j > i only)
+ * the projection at step i is  <c - sum_{j>i} z_j b_j, b~_i> = <c0, b~_i> - sum_{j>i} z_j g[j][i].  Rows are cut into blocks
+ * of ORC_NP_BLOCK = 64 consecutive indices [64 J, 64 J + 64) (the top block may be short):
+ *   t_i  = chain_{j ascending} fma((double) c0[j], b~_i[j], .) from +0                      (all i, once)
+ *   for J descending:  for i descending inside J:
+ *        c'  = t_i * (1 / ||b~_i||^2)            (the reciprocal rounded once per key)
+ *        z_i <- D_{Z, s/||b~_i||, c'}             (the SampleZ contract of psf_oracle.c, stream (tag, index, coordinate i))
+ *        t_i' = fma(-(double) z_i, g[i][i'], t_i')            for the rows i' < i of the same block
+ *     then for every row i' below the block:  S = chain_{j in J ascending} fma((double) z_j, g[j][i'], .) from +0 ;  t_i' = t_i' - S
+ *   c_final = c0 - sum_i z_i b_i   (integers, exact).
  * basis_t / gso_t are TRANSPOSED: row i holds basis vector i (column i of the reference's matrices).
  * ---------------------------------------------------------------------------------------- */
-double orc_dot256(const int64_t* c, const double* g, size_t dim) {
-  double p[256];
-  for (int t = 0; t < 256; ++t) {
-    double acc = 0.0;
-    for (size_t j = (size_t)t; j < dim; j += 256) acc = fma((double)c[j], g[j], acc);
-    p[t] = acc;
-  }
-  double w[4];
-  for (int wv = 0; wv < 4; ++wv) {
-    double a[64], b2[64];
-    memcpy(a, p + 64 * wv, sizeof(a));
-    for (int off = 32; off >= 1; off >>= 1) {
-      for (int l = 0; l < 64; ++l) b2[l] = a[l] + a[l ^ off];
-      memcpy(a, b2, sizeof(a));
+#define ORC_NP_BLOCK 64
+
+void orc_np_gram(const int32_t* basis_t, const double* gso_t, size_t dim, double* G) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+  for (size_t j = 0; j < dim; ++j) {
+    const int32_t* bj = basis_t + j * dim;
+    for (size_t i = 0; i < j; ++i) {
+      const double* gi = gso_t + i * dim;
+      double acc = 0.0;
+      for (size_t t = 0; t < dim; ++t) acc = fma((double)bj[t], gi[t], acc);
+      G[j * dim + i] = acc;
     }
-    w[wv] = a[0];
+    for (size_t i = j; i < dim; ++i) G[j * dim + i] = 0.0;
   }
-  return (w[0] + w[1]) + (w[2] + w[3]);
 }
 
-void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double* norm2, size_t dim, double s,
+void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double* G, const double* norm2, size_t dim, double s,
                        uint64_t seed, uint32_t tag, uint64_t index, int64_t* c) {
-  for (size_t ii = dim; ii-- > 0;) {
-    const double dot = orc_dot256(c, gso_t + ii * dim, dim);
-    const double c2 = dot / norm2[ii];
-    const double s2 = s / sqrt(norm2[ii]);
-    const int64_t z = orc_sample_z(seed, tag, index, (uint32_t)ii, c2, s2);
-    if (z) {
-      const int32_t* bi = basis_t + ii * dim;
-      for (size_t j = 0; j < dim; ++j) c[j] -= z * (int64_t)bi[j];
+  double* t = (double*)malloc(dim * sizeof(double));
+  int64_t* z = (int64_t*)calloc(dim, sizeof(int64_t));
+  for (size_t i = 0; i < dim; ++i) {
+    const double* gi = gso_t + i * dim;
+    double acc = 0.0;
+    for (size_t j = 0; j < dim; ++j)
+      if (c[j]) acc = fma((double)c[j], gi[j], acc);        /* a zero term leaves the chain unchanged (it never holds -0) */
+    t[i] = acc;
+  }
+  const size_t nblk = (dim + ORC_NP_BLOCK - 1) / ORC_NP_BLOCK;
+  for (size_t jb = nblk; jb-- > 0;) {
+    const size_t j0 = jb * ORC_NP_BLOCK, j1 = j0 + ORC_NP_BLOCK < dim ? j0 + ORC_NP_BLOCK : dim;
+    for (size_t i = j1; i-- > j0;) {
+      const double inv = 1.0 / norm2[i];
+      const double cen = t[i] * inv;
+      z[i] = orc_sample_z(seed, tag, index, (uint32_t)i, cen, s / sqrt(norm2[i]));
+      const double nz = -(double)z[i];
+      const double* gi = G + i * dim;
+      for (size_t i2 = j0; i2 < i; ++i2) t[i2] = fma(nz, gi[i2], t[i2]);
+    }
+    for (size_t i2 = 0; i2 < j0; ++i2) {
+      double S = 0.0;
+      for (size_t j = j0; j < j1; ++j) S = fma((double)z[j], G[j * dim + i2], S);
+      t[i2] = t[i2] - S;
     }
   }
+  for (size_t i = 0; i < dim; ++i) {
+    if (!z[i]) continue;
+    const int32_t* bi = basis_t + i * dim;
+    for (size_t j = 0; j < dim; ++j) c[j] -= z[i] * (int64_t)bi[j];
+  }
+  free(t); free(z);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -157,6 +187,7 @@ typedef struct {
   int32_t* St;        /* m x m, row i = basis vector i of the short basis S_A */
   double* Gt;         /* m x m, row i = b~_i */
   double* norm2;      /* m */
+  double* G;          /* m x m, G[j][i] = <b_j, b~_i> for j > i (orc_np_gram) */
   size_t* piv;        /* n pivot columns */
   uint64_t* T;        /* n x n solve operator */
   int has_solver;
@@ -173,6 +204,7 @@ static orc_gpv* gpv_new_impl(const orc_gadget_params* gp, double s) {
   h->St = (int32_t*)calloc(h->m * h->m, sizeof(int32_t));
   h->Gt = (double*)calloc(h->m * h->m, sizeof(double));
   h->norm2 = (double*)calloc(h->m, sizeof(double));
+  h->G = (double*)calloc(h->m * h->m, sizeof(double));
   h->piv = (size_t*)calloc(gp->n, sizeof(size_t));
   h->T = (uint64_t*)calloc(gp->n * gp->n, sizeof(uint64_t));
   return h;
@@ -181,7 +213,7 @@ void* orc_gpv_new(const orc_gadget_params* gp, double s) { return gpv_new_impl(g
 void orc_gpv_free(void* hv) {
   orc_gpv* h = (orc_gpv*)hv;
   if (!h) return;
-  free(h->A); free(h->R); free(h->St); free(h->Gt); free(h->norm2); free(h->piv); free(h->T); free(h);
+  free(h->A); free(h->R); free(h->St); free(h->Gt); free(h->norm2); free(h->G); free(h->piv); free(h->T); free(h);
 }
 size_t orc_gpv_m(const void* h) { return ((const orc_gpv*)h)->m; }
 uint64_t* orc_gpv_A(void* h) { return ((orc_gpv*)h)->A; }
@@ -196,6 +228,7 @@ static int gpv_finish_key(orc_gpv* h) {
     for (size_t j = 0; j < m; ++j) nn = fma(h->Gt[i * m + j], h->Gt[i * m + j], nn);
     h->norm2[i] = nn;
   }
+  orc_np_gram(h->St, h->Gt, m, h->G);
   int rc = orc_solve_precompute(h->A, h->gp.n, m, h->gp.q, h->piv, h->T);
   h->has_solver = (rc == ORC_OK);
   return rc;
@@ -281,7 +314,7 @@ int orc_gpv_samp_p(const void* hv, uint64_t seed, uint64_t first_index, size_t B
       }
     }
     for (size_t j = 0; j < m; ++j) c[j] = -(int64_t)sol[j];                         /* :158 center = -sol */
-    orc_nearest_plane(h->St, h->Gt, h->norm2, m, h->s, seed, ORC_TAG_GPV, first_index + b, c);
+    orc_nearest_plane(h->St, h->Gt, h->G, h->norm2, m, h->s, seed, ORC_TAG_GPV, first_index + b, c);
     /* :160  sol + sample, sample = (-sol) - c_final */
     for (size_t j = 0; j < m; ++j) e[b * m + j] = -c[j];
     free(sol); free(c);

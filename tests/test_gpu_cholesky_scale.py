@@ -33,10 +33,12 @@ def sigma2_times(R, y, r, s, base=2):
     c = (1.0 / (2 * math.pi)) * (r * r)
     t = y[mb:].copy()                               # T^t y = R^t y_top + y_bot
     for i0 in range(0, mb, 1024):
-        t += R[i0:i0 + 1024].astype(np.float64).T @ y[i0:i0 + 1024]
+        i1 = min(i0 + 1024, mb)
+        t += R[i0:i1].astype(np.float64).T @ y[i0:i1]
     Tt = np.empty_like(y)
     for i0 in range(0, mb, 1024):
-        Tt[i0:i0 + 1024] = R[i0:i0 + 1024].astype(np.float64) @ t
+        i1 = min(i0 + 1024, mb)
+        Tt[i0:i1] = R[i0:i1].astype(np.float64) @ t
     Tt[mb:] = t
     return c * ((s * s - 1.0) * y - (base * base + 1) * Tt)
 

@@ -83,56 +83,85 @@ def test_samp_d_f_a_domain(T, oracle):
     assert psf.check_domain(np.full(m, 10, dtype=np.int64))
 
 
-@pytest.mark.parametrize("n,q,s", [(6, 128, 10.0), (10, 157, 30.0)])
-def test_nearest_plane_int64_pass_equals_fp53_pass(T, oracle, monkeypatch, n, q, s):
-    """The walk keeps c in doubles (exact below 2^52) with an int64 pass behind it; PSF_GPV_INT64=1 runs the int64 pass
-    alone.  Both must give the oracle's bits."""
+@pytest.mark.parametrize("g", [1, 2, 4])
+def test_sampler_gives_the_same_bits_for_every_lane_split(T, oracle, monkeypatch, g):
+    """k_np_sample<G> evaluates the attempts of one draw on 64 / G lanes; the value of a draw is its first accepted attempt,
+    so G = 1, 2, 4 must agree with each other and with the oracle (PSF_NP_G forces the variant)."""
+    n, q, s = 10, 157, 30.0
+    monkeypatch.setenv("PSF_NP_G", str(g))
     gp = T.GadgetParameters.init_default(n, q)
     psf = T.PSFGPV(gp, s)
     A, (bt, gt) = psf.trap_gen(5)
-    u = oracle.uniform_targets(2, 7, n, q)
+    u = oracle.uniform_targets(2, 11, n, q)          # 11: the last wave / subgroup is partly empty for every G
     e = psf.samp_p(u, seed=31, first_index=4)
-    assert psf.nearest_plane_stats() == (4, 0)
-    monkeypatch.setenv("PSF_GPV_INT64", "1")
-    psf64 = T.PSFGPV(gp, s)
-    psf64.load_key(A, bt, gt)
-    assert (psf64.samp_p(u, seed=31, first_index=4) == e).all()
-    assert psf64.nearest_plane_stats() == (0, 0)
     orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
     assert orc.load_key(A, bt, gt) == 0
     assert (e == orc.samp_p(31, u, first_index=4)).all()
+    assert psf.nearest_plane_stats() == ((psf.m + 63) // 64, 0)
 
 
-def test_nearest_plane_hands_over_when_the_fp53_bound_trips(T, oracle):
-    """q = 2^45: c0_bound + sum |z_i| max|b_i| passes 2^52 within a few steps, so every workgroup of the FP53 pass stops and
-    the int64 pass produces the result; still the oracle's bits and A e = u."""
+def test_large_modulus(T, oracle):
+    """q = 2^45: |c0| up to 2^45 enters the initial projection as doubles (exact), the walk itself never carries c."""
     n, q, s = 3, 2**45, 60.0
     gp = T.GadgetParameters.init_default(n, q)
     psf = T.PSFGPV(gp, s)
     A, (bt, gt) = psf.trap_gen(9)
     u = oracle.uniform_targets(3, 5, n, q)
     e = psf.samp_p(u, seed=11, first_index=0)
-    groups, handed = psf.nearest_plane_stats()
-    assert groups == 3 and handed == groups
     orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
     assert orc.load_key(A, bt, gt) == 0
     assert (e == orc.samp_p(11, u, first_index=0)).all()
     assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
 
 
-@pytest.mark.parametrize("n,q,jr", [(32, 256, 4), (64, 256, 8), (128, 2**15, 16), (256, 2**15, 32)])
-def test_samp_p_parity_at_every_nearest_plane_template(T, oracle, n, q, jr):
-    """Lattice dimensions that select the larger k_gpv_nearest_plane<JR> instantiations (the small configs above only reach
-    JR = 1 and 2; C2 / C4 use 25 / 14).  Key from the device, three preimages (an odd count: the last workgroup is half empty)."""
+def test_recombination_in_64_bit_integers_when_the_digit_planes_do_not_fit(T, oracle):
+    """e = sum z_i b_i runs on the int8 matrix cores when basis entries and z fit two balanced base-256 digits; otherwise the
+    64-bit integer kernel takes over: (a) a basis with an entry beyond 32639 (a unimodular transform of the device's basis, so
+    still a basis of the same lattice), decided at load_key; (b) a Gaussian so wide that some |z_i| > 32639, decided on the
+    device per call.  Both must give the oracle's bits and A e = u."""
+    n, q, s = 6, 128, 40.0
+    gp = T.GadgetParameters.init_default(n, q)
+    psf = T.PSFGPV(gp, s)
+    A, (bt, gt) = psf.trap_gen(5)
+    u = oracle.uniform_targets(2, 7, n, q)
+    psf.samp_p(u, seed=3)
+    assert psf.nearest_plane_stats()[1] == 0
+    bt2 = bt.copy()
+    bt2[-1] = bt[-1] + 40000 * bt[-2]                # the last vector: its Gram-Schmidt component (and every norm) is unchanged
+    assert np.abs(bt2).max() > 32639
+    gt2 = oracle.gso_rows(bt2)
+    big = T.PSFGPV(gp, s)
+    big.load_key(A, bt2, gt2)
+    e = big.samp_p(u, seed=3)
+    assert big.nearest_plane_stats()[1] == 1
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    assert orc.load_key(A, bt2, gt2) == 0
+    assert (e == orc.samp_p(3, u)).all()
+    assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
+    wide = T.PSFGPV(gp, 400000.0)
+    wide.load_key(A, bt, gt)
+    e = wide.samp_p(u, seed=4)
+    assert wide.nearest_plane_stats()[1] == 1
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), 400000.0)
+    assert orc.load_key(A, bt, gt) == 0
+    assert (e == orc.samp_p(4, u)).all()
+    assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
+
+
+@pytest.mark.parametrize("n,q", [(32, 256), (64, 256), (128, 2**15), (256, 2**15), (300, 2**15)])
+def test_samp_p_parity_across_block_counts(T, oracle, n, q):
+    """Lattice dimensions of 537 ... 9081 rows: 9 to 142 blocks of 64 with a short top block, the last one beyond the 8192 rows
+    the register-resident walk of round 1 was limited to.  Key from the device, three preimages (the last wave is partly empty);
+    s = 1000 makes |z| > 127 common, so the hi digit plane of z is exercised."""
     s = 1000.0
     gp = T.GadgetParameters.init_default(n, q)
     psf = T.PSFGPV(gp, s)
-    assert (psf.m + 255) // 256 <= jr and ((psf.m + 255) // 256 > jr // 2 or jr == 4)
     A, (bt, gt) = psf.trap_gen(3)
     orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
     assert orc.load_key(A, bt, gt) == 0
     u = oracle.uniform_targets(5, 3, n, q)
     e = psf.samp_p(u, seed=17, first_index=2)
-    assert psf.nearest_plane_stats()[1] == 0
+    assert psf.nearest_plane_stats() == ((psf.m + 63) // 64, 0)
     assert (e == orc.samp_p(17, u, first_index=2)).all()
+    assert np.abs(e).max() > 127
     assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()

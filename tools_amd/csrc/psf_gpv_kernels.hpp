@@ -1,10 +1,9 @@
 // psf_gpv_kernels.hpp -- HIP kernels of PSFGPV / PSFGPVRing (gpv.rs, gpv_ring.rs): short-basis assembly, Gram-Schmidt,
-// solve operator application and the batched randomized nearest plane (MatZ::sample_d_precomputed_gso, GPV08 SampleD).
+// and the R_q products of the ring variant.  The batched randomized nearest plane itself is in psf_np_kernels.hpp.
 //
 // Layout: the short basis and its Gram-Schmidt vectors are stored TRANSPOSED -- row i is basis vector i (column i of the
-// reference's matrices) -- so that step i of the nearest-plane walk streams two contiguous rows.
+// reference's matrices).
 #pragma once
-#include <type_traits>
 #include "psf_kernels.hpp"
 
 namespace psf {
@@ -139,7 +138,7 @@ __global__ void k_row_norm2_chain(const double* __restrict__ Gt, size_t m, doubl
   norm2[i] = acc;
 }
 
-// ---- solve operator: c0[b][piv[r]] = -(T u_b)[r] mod q (gpv.rs:153-158: sol = A^{-1}(u), centre = -sol); T is passed transposed ---
+// ---- modular product shared by the polynomial kernels below ------------------------------------------------------------------
 __device__ inline uint64_t mulmod_dev(uint64_t a, uint64_t b, uint64_t q) {
   if (q <= 0xffffffffull) return (a * b) % q;
   uint64_t r = 0;
@@ -149,251 +148,6 @@ __device__ inline uint64_t mulmod_dev(uint64_t a, uint64_t b, uint64_t q) {
     b >>= 1;
   }
   return r;
-}
-__global__ void k_gpv_solve(const uint64_t* __restrict__ Tt, const uint32_t* __restrict__ piv, size_t n, size_t m, uint64_t q, uint64_t two64,
-                            const uint64_t* __restrict__ U, size_t B, int64_t* __restrict__ C0) {
-  const size_t total = n * B;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t b = g / n, r = g % n;
-    uint64_t acc = 0;
-    if (q <= 0x7fffffffull) {                       // products below 2^62: sum them in 128 bits, reduce once
-      Acc128 s{0, 0};
-      for (size_t t = 0; t < n; ++t) {
-        uint64_t uq = U[b * n + t];
-        if (uq >= q) uq %= q;
-        acc128_add(s, (int64_t)(Tt[t * n + r] * uq));
-      }
-      acc = acc128_mod(s, q, two64);
-    } else {
-      for (size_t t = 0; t < n; ++t) {
-        acc += mulmod_dev(Tt[t * n + r], U[b * n + t] % q, q);
-        if (acc >= q) acc -= q;
-      }
-    }
-    C0[b * m + piv[r]] = -(int64_t)acc;
-  }
-}
-
-// ---- randomized nearest plane (MatZ::sample_d_precomputed_gso, gpv.rs:160) -----------------------------------------------------
-// One workgroup of 256 threads (4 waves, one per SIMD) walks i = dim-1..0 for 2 preimages whose integer vectors c live in
-// registers: thread t owns coordinates j = t + 256 r, r < JR.  At most 256 VGPRs, so two workgroups share a CU and, having their
-// own barriers, drift apart: one samples while the other projects or updates.  Per step:
-//   per-thread fma chains over r (ascending) -> xor butterfly per wave -> ((w0+w1)+(w2+w3))      [the contract's orc_dot256 order]
-//   c' = dot / ||b~_i||^2 ; one wave per preimage draws z with its 64 lanes evaluating attempts t = lane,
-//   lane+64, ... and taking the first accepted one (= the sequential first-accept); the Philox words of the first round do not
-//   depend on c': waves 2 and 3, idle while 0 and 1 sample, compute them before the barrier and pass them through LDS ; c -= z b_i.
-// The rows b~_i / b_i come from packed copies (k_np_pack): row stride padded to the template's JR with zeros (no bounds checks:
-// padding coordinates keep c = 0) and permuted so that a thread's coordinates r = 2a, 2a+1 (b~) / 4a..4a+3 (b) are one 16-byte
-// load, a wave's loads one contiguous KiB.  b~_{i-1} is fetched while step i samples, b_{i-1} right after step i's update.
-//
-// Two instantiations of the same walk:
-//   FP53 = true : c is kept in doubles.  The values are integers; the projection reads them without an int64 -> f64 conversion
-//                 and the update is one fma per coordinate, exact while |c| < 2^52.  That is enforced by a running bound
-//                 bnd_p = c0_bound + sum_i |z_i| max_j |b_i[j]|  (the same in every thread): the first step at which it could
-//                 reach 2^52 the workgroup writes redo[block] = 1 and stops without output.
-//   FP53 = false: c in int64, always exact.  Launched after the FP53 pass with the redo mask (workgroups whose mask is 0
-//                 return at once), or alone (redo == nullptr) when q is too large for the bound to hold.
-// Both produce the same bits: conversions of exactly representable integers and exact updates.
-#ifdef NP_PROFILE
-__device__ long long g_np_prof[8];
-#define NP_T(k) do { const long long now_ = clock64(); tacc_[k] += now_ - tprev_; tprev_ = now_; } while (0)
-#else
-#define NP_T(k) do { } while (0)
-#endif
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-__host__ __device__ constexpr int np_g2(int jr) { return (jr + 1) / 2; }      // 16-byte groups per thread and row of b~
-__host__ __device__ constexpr int np_s4(int jr) { return (jr + 3) / 4; }      // ... of b
-
-// packed rows: GtP[i][a][t][e] = b~_i[t + 256 (2a + e)], StP[i][a][t][e] = b_i[t + 256 (4a + e)], zero past dim
-__global__ __launch_bounds__(256) void k_np_pack(const int32_t* __restrict__ St, const double* __restrict__ Gt, size_t dim, int G2, int S4,
-                                                 int32_t* __restrict__ StP, double* __restrict__ GtP) {
-  const size_t i = blockIdx.x;
-  const size_t ng = (size_t)G2 * 512, ns = (size_t)S4 * 1024;
-  for (size_t pos = threadIdx.x; pos < ng; pos += 256) {
-    const size_t a = pos / 512, rem = pos % 512, t = rem / 2, e = rem & 1, j = t + 256 * (2 * a + e);
-    GtP[i * ng + pos] = j < dim ? Gt[i * dim + j] : 0.0;
-  }
-  for (size_t pos = threadIdx.x; pos < ns; pos += 256) {
-    const size_t a = pos / 1024, rem = pos % 1024, t = rem / 4, e = rem & 3, j = t + 256 * (4 * a + e);
-    StP[i * ns + pos] = j < dim ? St[i * dim + j] : 0;
-  }
-}
-
-// workgroups per CU by register budget: c takes 4 JR VGPRs in the FP53 pass (2 preimages x JR doubles), the rows 3 JR
-template <int JR, bool FP53>
-__global__ __launch_bounds__(256, JR <= 8 ? 4 : JR <= 16 ? 3 : 2) void k_gpv_nearest_plane(const int32_t* __restrict__ StP, const double* __restrict__ GtP,
-                                                              const double* __restrict__ norm2, const SampleZParams* __restrict__ sz,
-                                                              const double* __restrict__ rowmax, double c0_bound,
-                                                              size_t dim, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B,
-                                                              const int64_t* __restrict__ C0, int64_t* __restrict__ E, int* __restrict__ fail,
-                                                              int* __restrict__ redo) {
-  using CT = typename std::conditional<FP53, double, long long>::type;
-  constexpr int G2 = np_g2(JR), S4 = np_s4(JR);
-  if (!FP53 && redo && !redo[blockIdx.x]) return;
-  __shared__ double s_w[2][4];
-  __shared__ long long s_z[2];
-  __shared__ uint2 s_rng[2][64];        // (candidate word, acceptance word) of attempts 0..63 for the two preimages
-  const int tid = threadIdx.x, lane = tid & 63, t = tid;
-  const int wh = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const size_t b0 = (size_t)blockIdx.x * 2;
-  CT c[2][JR];
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int r = 0; r < JR; ++r) {
-      const size_t j = (size_t)t + 256 * r, b = b0 + k;
-      c[k][r] = (b < B && j < dim) ? (CT)C0[b * dim + j] : (CT)0;
-    }
-  double bnd[2] = {c0_bound, c0_bound};
-  double2 g2[G2];
-  int4 s4[S4];
-  // buffer loads: descriptor + uniform row offset in SGPRs, per-thread byte offset t * 16 in one VGPR -- no per-lane 64-bit
-  // address arithmetic.  A packed matrix is at most 8192 rows x 64 KiB = 512 MiB, inside the 32-bit offset range.
-  const uint32_t toff = (uint32_t)t * 16u;
-  // raw descriptors over the whole allocations (stride 0, 2^32 - 1 records, dword 3 = 0x00020000: 32-bit untyped data on the gfx9 family)
-  const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(GtP), 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(StP), 0, (int)0xffffffffu, 0x00020000);
-  auto load_g = [&](size_t i) {
-    const uint32_t row = (uint32_t)i * (uint32_t)(G2 * 4096);
-#pragma unroll
-    for (int a = 0; a < G2; ++a) {
-      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g, toff, row + (uint32_t)a * 4096u, 0);
-      g2[a].x = __hiloint2double(v.y, v.x);
-      g2[a].y = __hiloint2double(v.w, v.z);
-    }
-  };
-  auto load_s = [&](size_t i) {
-    const uint32_t row = (uint32_t)i * (uint32_t)(S4 * 4096);
-#pragma unroll
-    for (int a = 0; a < S4; ++a) {
-      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, toff, row + (uint32_t)a * 4096u, 0);
-      s4[a] = make_int4(v.x, v.y, v.z, v.w);
-    }
-  };
-  load_g(dim - 1);
-  load_s(dim - 1);
-  // waves 0 and 1 sample for preimages 0 and 1; waves 2 and 3 prepare their random words
-  const bool sampler = wh < 2;
-  const int ps = wh & 1;
-  const bool samp_live = b0 + ps < B;
-  const uint64_t index_s = first_index + b0 + ps;
-  const uint32_t tw_s = tag_word(tag, index_s);
-  int f = 0;
-#ifdef NP_PROFILE
-  long long tacc_[6] = {0, 0, 0, 0, 0, 0};
-  long long tprev_ = clock64();
-#endif
-  for (size_t ii = dim; ii-- > 0;) {
-    const double n2 = norm2[ii];
-    const double rmax = FP53 ? rowmax[ii] : 0.0;
-    const SampleZParams sp = sz[ii];
-    if (!sampler && samp_live) {                   // words of attempts 0..63
-      uint32_t wa, wb;
-      sz_attempt_words(seed, (uint32_t)ii, (uint32_t)index_s, tw_s, (uint32_t)lane, sp.sh, &wa, &wb);
-      s_rng[ps][lane] = make_uint2(wa, wb);
-    }
-    double part[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      double acc = 0.0;
-#pragma unroll
-      for (int r = 0; r < JR; ++r) acc = fma((double)c[k][r], (r & 1) ? g2[r >> 1].y : g2[r >> 1].x, acc);
-      part[k] = acc;
-    }
-    NP_T(0);
-    part[0] = wave_xor_sum(part[0]);
-    part[1] = wave_xor_sum(part[1]);
-    if (lane == 0) { s_w[0][wh] = part[0]; s_w[1][wh] = part[1]; }
-    NP_T(1);
-    const size_t nx = ii ? ii - 1 : 0;             // the last step re-reads row 0: unconditional loads keep the wait counts exact
-    load_g(nx);                                    // b~ of the next step travels while this one samples
-    __syncthreads();
-    NP_T(2);
-    if (sampler) {
-      long long z = 0;
-      if (samp_live) {                             // (sampler waves only)
-        const double dot = (s_w[ps][0] + s_w[ps][1]) + (s_w[ps][2] + s_w[ps][3]);
-        const double cen = dot / n2;
-        const SzRange rg = sz_range(cen, sp);
-        bool got = false;
-        uint2 wr = s_rng[ps][lane];
-        for (uint32_t t0 = 0; t0 < kMaxAttempts && !got; t0 += 64) {
-          const uint32_t ta = t0 + (uint32_t)lane;
-          if (t0) sz_attempt_words(seed, (uint32_t)ii, (uint32_t)index_s, tw_s, ta, sp.sh, &wr.x, &wr.y);
-          long long x = 0;
-          const bool acc = sz_attempt(seed, (uint32_t)ii, (uint32_t)index_s, tw_s, ta, wr.x, wr.y, rg, cen, sp.inv_s, &x);
-          const uint64_t mask = __ballot(acc);
-          if (mask) {
-            const int first = __ffsll((long long)mask) - 1;
-            const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, first);
-            const uint32_t xh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)x >> 32), first);
-            z = (long long)(((unsigned long long)xh << 32) | xl);
-            got = true;
-          }
-        }
-        if (!got) { f = 1; z = (long long)floor(cen + 0.5); }
-      }
-      if (lane == 0) s_z[ps] = z;
-    }
-    NP_T(3);
-    __syncthreads();
-    NP_T(4);
-    const long long za = s_z[0], zb = s_z[1];
-    if (FP53) {
-      bnd[0] = fma(fabs((double)za), rmax, bnd[0]);
-      bnd[1] = fma(fabs((double)zb), rmax, bnd[1]);
-      const bool over = !(bnd[0] < 0x1.0p52) || !(bnd[1] < 0x1.0p52);
-      if (over) {                                  // the same decision in every thread: hand the workgroup to the int64 pass
-        if (tid == 0) redo[blockIdx.x] = 1;
-        return;
-      }
-      const double nza = -(double)za, nzb = -(double)zb;
-#pragma unroll
-      for (int r = 0; r < JR; ++r) {
-        const int4 v = s4[r >> 2];
-        const double sd = (double)((r & 3) == 0 ? v.x : (r & 3) == 1 ? v.y : (r & 3) == 2 ? v.z : v.w);
-        c[0][r] = (CT)fma(nza, sd, (double)c[0][r]);
-        c[1][r] = (CT)fma(nzb, sd, (double)c[1][r]);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < JR; ++r) {
-        const int4 v = s4[r >> 2];
-        const long long sv = (long long)((r & 3) == 0 ? v.x : (r & 3) == 1 ? v.y : (r & 3) == 2 ? v.z : v.w);
-        c[0][r] -= (CT)(za * sv);
-        c[1][r] -= (CT)(zb * sv);
-      }
-    }
-    load_s(nx);                                    // b of the next step: not needed before its update
-    NP_T(5);
-  }
-#ifdef NP_PROFILE
-  if (blockIdx.x == 0 && tid == 0) for (int k = 0; k < 6; ++k) g_np_prof[k] += tacc_[k];
-  if (FP53 && tid == 0) { const double mb = bnd[0] > bnd[1] ? bnd[0] : bnd[1]; atomicMax((unsigned long long*)&g_np_prof[6], (unsigned long long)__double_as_longlong(mb)); }
-#endif
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int r = 0; r < JR; ++r) {
-      const size_t j = (size_t)t + 256 * r, b = b0 + k;
-      if (b < B && j < dim) E[b * dim + j] = -(int64_t)c[k][r];
-    }
-  if (f) atomicOr(fail, 1);
-}
-
-// max_j |b_i[j]| per basis row (one wave per row), for the FP53 bound above
-__global__ __launch_bounds__(64) void k_row_absmax_i32(const int32_t* __restrict__ St, size_t dim, double* __restrict__ rowmax) {
-  const size_t i = blockIdx.x;
-  uint32_t mx = 0;
-  for (size_t j = threadIdx.x; j < dim; j += 64) {
-    const int32_t v = St[i * dim + j];
-    const uint32_t a = v < 0 ? (uint32_t)(-(int64_t)v) : (uint32_t)v;
-    mx = a > mx ? a : mx;
-  }
-  for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, off); mx = o > mx ? o : mx; }
-  if (threadIdx.x == 0) rowmax[i] = (double)mx;
 }
 
 // ---- R_q = Z_q[X]/(X^n + 1): negacyclic product (PolynomialRingZq multiplication under gadget_ring.rs:78 and gpv_ring.rs:245-246) ----

@@ -1,0 +1,677 @@
+// psf_np_kernels.hpp -- the randomized nearest plane of PSFGPV / PSFGPVRing (MatZ::sample_d_precomputed_gso, gpv.rs:160;
+// MatPolyOverZ::sample_d after the coefficient embedding, gpv_ring.rs:204-211) in its batched, blocked form.
+//
+// GPV08 SampleD walks i = d-1 .. 0:  c' = <c, b~_i> / ||b~_i||^2 ;  z_i <- D_{Z, s/||b~_i||, c'} ;  c -= z_i b_i.
+// With g[j][i] = <b_j, b~_i> (j > i; precomputed once per key) the projection at step i is
+//     <c0, b~_i> - sum_{j > i} z_j g[j][i],
+// so the integer vector c never has to be carried along: the walk needs the d x B matrix T of running projections, and the
+// preimage is recovered at the end as e = -(c0 - sum_i z_i b_i).  Rows are cut into blocks of NP_NB = 64 indices.  Per call:
+//     T        = B~[:, pivots] C0[pivots]               k_np_gemm<false>   FP64 MFMA, K = n (c0 = -sol lives on the n pivot columns)
+//     for J descending:
+//        Z_J   <- rows of block J take the contribution of Z_(J+1), then the 64 steps of the block are sampled
+//                                                       k_np_sample<G>     one wave per G preimages, 64/G lanes evaluate the
+//                                                                          SampleZ attempts of one draw in parallel
+//        T[< J-1] -= G[< J-1, J] Z_J                    k_np_gemm<true>    FP64 MFMA, K = 64, every operand read once per batch;
+//                                                                          on a second stream: it only has to land before block
+//                                                                          J-2 is sampled, so it hides behind the sampling of J-1
+//     E        = Z^t B  (+ sol on the pivot columns)    k_np_combine8      int8 MFMA on balanced base-256 digit planes (exact)
+// Basis and Gram-Schmidt data are therefore read once per BATCH and block, not once per pair of preimages, nothing is held in
+// registers across steps except the 64 running projections of the current block, and the lattice dimension is not limited
+// by the register file.  The floating-point evaluation order is part of the library's contract ("blocked
+// nearest plane"); every kernel below follows it bit for bit: v_mfma_f64_16x16x4_f64 is an ascending-k fma chain
+// (profiles/r01_probe_mfma_f64.log), each block's contribution S is accumulated from +0 and subtracted once.
+#pragma once
+#include "psf_kernels.hpp"
+
+namespace psf {
+
+constexpr int NP_NB = 64;
+
+// chunks of the bulk panels G[< 64 J, block J] in front of block J: row-blocks of 128 rows x 4 chunks (K = 64)
+__host__ __device__ inline size_t np_panel_rowblocks(size_t J) { return (J * NP_NB + 127) / 128; }
+__host__ __device__ inline size_t np_panel_base(size_t J) { return 4 * ((J * J) / 4); }      // = 4 sum_{J' < J} ceil(J' / 2)
+
+// ---- per key ---------------------------------------------------------------------------------------------------------
+// Gd[j][i] = <b_j, b~_i> for j > i (0 elsewhere): per output one ascending fma chain over the coordinates, from +0.
+// 64 x 64 tile per workgroup, 4 x 4 outputs per thread, coordinates staged 16 at a time.
+__global__ __launch_bounds__(256) void k_np_gram(const int32_t* __restrict__ St, const double* __restrict__ Gt, size_t d, double* __restrict__ Gd) {
+  __shared__ double sB[16][65];
+  __shared__ double sG[16][65];
+  const size_t j0 = (size_t)blockIdx.y * 64, i0 = (size_t)blockIdx.x * 64;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  if (i0 > j0 + 63) {      // strictly upper tile: zeros
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const size_t j = j0 + (e >> 6), i = i0 + (e & 63);
+      if (j < d && i < d) Gd[j * d + i] = 0.0;
+    }
+    return;
+  }
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (size_t t0 = 0; t0 < d; t0 += 16) {
+    for (int e = tid; e < 64 * 16; e += 256) {
+      const int r = e >> 4, tt = e & 15;
+      const size_t t = t0 + tt;
+      sB[tt][r] = (j0 + r < d && t < d) ? (double)St[(j0 + r) * d + t] : 0.0;
+      sG[tt][r] = (i0 + r < d && t < d) ? Gt[(i0 + r) * d + t] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) {
+      double bv[4], gv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { bv[a] = sB[tt][ty * 4 + a]; gv[a] = sG[tt][tx * 4 + a]; }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fma(bv[a], gv[b], acc[a][b]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const size_t j = j0 + ty * 4 + a, i = i0 + tx * 4 + b;
+      if (j < d && i < d) Gd[j * d + i] = j > i ? acc[a][b] : 0.0;
+    }
+}
+
+// bulk panels in MFMA-fragment order (A operand of k_np_gemm<true>): chunk np_panel_base(J) + 4 rb + kc holds
+// G[row i = 128 rb + r][k = 64 J + 16 kc + kk] at tr_chunk_pos(r, kk); rows i >= 64 J (the block itself and above) are zero
+__global__ void k_np_pack_panels(const double* __restrict__ Gd, size_t d, size_t nblk, double* __restrict__ Gp) {
+  const size_t total = np_panel_base(nblk) * TR_CHUNK;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t chunk = g / TR_CHUNK;
+    const int pos = (int)(g % TR_CHUNK);
+    size_t J = (size_t)(2.0 * sqrt((double)(chunk / 4)));
+    while (np_panel_base(J + 1) <= chunk) ++J;
+    while (np_panel_base(J) > chunk) --J;
+    const size_t rel = chunk - np_panel_base(J), rb = rel / 4, kc = rel % 4;
+    const int ks = pos >> 9, tile = (pos >> 6) & 7, ln = pos & 63;
+    const size_t i = rb * 128 + tile * 16 + (ln & 15);
+    const size_t j = J * NP_NB + kc * 16 + ks * 4 + (ln >> 4);
+    Gp[g] = (i < J * NP_NB && j < d) ? Gd[j * d + i] : 0.0;
+  }
+}
+// in-block triangles: Gin[J][lj][li] = g[64 J + lj][64 J + li] for lj > li, 0 otherwise
+__global__ void k_np_pack_inblock(const double* __restrict__ Gd, size_t d, size_t nblk, double* __restrict__ Gin) {
+  const size_t total = nblk * NP_NB * NP_NB;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t J = g / (NP_NB * NP_NB), lj = (g / NP_NB) % NP_NB, li = g % NP_NB;
+    const size_t j = J * NP_NB + lj, i = J * NP_NB + li;
+    Gin[g] = (lj > li && j < d) ? Gd[j * d + i] : 0.0;
+  }
+}
+// panel between neighbouring blocks, applied inside the sampler: Gnx[J][k][li] = g[64 (J+1) + k][64 J + li] (contribution of block J+1 to block J)
+__global__ void k_np_pack_next(const double* __restrict__ Gd, size_t d, size_t nblk, double* __restrict__ Gnx) {
+  const size_t total = nblk * NP_NB * NP_NB;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t J = g / (NP_NB * NP_NB), k = (g / NP_NB) % NP_NB, li = g % NP_NB;
+    const size_t j = (J + 1) * NP_NB + k, i = J * NP_NB + li;
+    Gnx[g] = (j < d && i < d) ? Gd[j * d + i] : 0.0;
+  }
+}
+// A operand of the initial projection: chunk (rb, kc) holds b~_i[piv[16 kc + kk]] for i = 128 rb + r, zero padded
+__global__ void k_np_pack_bpiv(const double* __restrict__ Gt, const uint32_t* __restrict__ piv, size_t d, size_t n, size_t nrb, size_t nkc,
+                               double* __restrict__ Bp) {
+  const size_t total = nrb * nkc * TR_CHUNK;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t chunk = g / TR_CHUNK, rb = chunk / nkc, kc = chunk % nkc;
+    const int pos = (int)(g % TR_CHUNK);
+    const int ks = pos >> 9, tile = (pos >> 6) & 7, ln = pos & 63;
+    const size_t i = rb * 128 + tile * 16 + (ln & 15), r = kc * 16 + ks * 4 + (ln >> 4);
+    Bp[g] = (i < d && r < n) ? Gt[i * d + piv[r]] : 0.0;
+  }
+}
+// balanced base-256 digit planes of the basis, transposed for the recombination: B8[plane][j][i] (row = coordinate j, K = step i),
+// rows and K padded to 128 with zeros.  *too_big is raised when an entry does not fit two digits (|v| > 32639).
+__global__ void k_np_pack_basis8(const int32_t* __restrict__ St, size_t d, size_t dpad, int8_t* __restrict__ B8, int* __restrict__ info /*[0] too big, [1] hi plane used*/) {
+  const size_t total = dpad * dpad;
+  int big = 0, hi_used = 0;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t j = g / dpad, i = g % dpad;
+    const int32_t v = (j < d && i < d) ? St[i * d + j] : 0;
+    if (v > 32639 || v < -32639) big = 1;
+    const int32_t lo = (int32_t)(int8_t)(v & 0xff);
+    const int32_t hi = (v - lo) >> 8;
+    if (hi) hi_used = 1;
+    B8[g] = (int8_t)lo;
+    B8[total + g] = (int8_t)hi;
+  }
+  if (big) atomicOr(info, 1);
+  if (hi_used) atomicOr(info + 1, 1);
+}
+
+// ---- per call ----------------------------------------------------------------------------------------------------------
+// sol = A^{-1}(u) on the pivot columns (gpv.rs:153-156: the factored elimination, T passed transposed), written twice:
+//   Sol[r][b]           the residues, added back to the pivot columns of e at the end (gpv.rs:160: sol + sample)
+//   C0p chunk (bj, kc)  (double)(-sol): the centre c0 = -sol (gpv.rs:158) as the B operand of the initial projection
+__global__ void k_np_solve(const uint64_t* __restrict__ Tt, size_t n, size_t nk16, uint64_t q, uint64_t two64, const uint64_t* __restrict__ U,
+                           size_t B, size_t ld, uint64_t* __restrict__ Sol, double* __restrict__ C0p) {
+  const size_t total = nk16 * ld;
+  const size_t nkc = nk16 / 16;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = g % nk16, b = g / nk16;
+    uint64_t acc = 0;
+    if (r < n && b < B) {
+      if (q <= 0x7fffffffull) {                     // products below 2^62: sum them in 128 bits, reduce once
+        Acc128 s{0, 0};
+        for (size_t t = 0; t < n; ++t) {
+          uint64_t uq = U[b * n + t];
+          if (uq >= q) uq %= q;
+          acc128_add(s, (int64_t)(Tt[t * n + r] * uq));
+        }
+        acc = acc128_mod(s, q, two64);
+      } else {
+        for (size_t t = 0; t < n; ++t) {
+          const uint64_t a = Tt[t * n + r], bb = U[b * n + t] % q;
+          const uint64_t lo = a * bb, hi = __umul64hi(a, bb);
+          acc += acc128_mod(Acc128{lo, (int64_t)hi}, q, two64);
+          if (acc >= q) acc -= q;
+        }
+      }
+      Sol[r * ld + b] = acc;
+    }
+    const size_t chunk = (b / TR_BN) * nkc + r / 16;
+    C0p[chunk * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(r % 16))] = -(double)acc;
+  }
+}
+
+// T (+)= A B on the FP64 matrix cores: 128 x 128 tile per workgroup, wave tile 64 x 64, K chunks of 16 staged by LDS-DMA exactly
+// as in k_trmm_f64 (both operands are fragment-ordered chunk streams).  SUB = false: T = acc (initial projection);
+// SUB = true: T = T - acc with acc accumulated from +0 (one block's contribution S of the contract).
+template <bool SUB>
+__global__ __launch_bounds__(256, 2) void k_np_gemm(const double* __restrict__ Ach, size_t a_rb_stride, const double* __restrict__ Bch, size_t b_bj_stride,
+                                                    int nk, double* __restrict__ T, size_t ldt, size_t row_hi) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const double* gA = Ach + (size_t)bi * a_rb_stride * TR_CHUNK + lane * 2;
+  const double* gB = Bch + (size_t)bj * b_bj_stride * TR_CHUNK + lane * 2;
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  auto stage_load = [&](int kb, int buf) {
+    const double* ga = gA + (size_t)kb * TR_CHUNK;
+    const double* gb = gB + (size_t)kb * TR_CHUNK;
+    double* la = smem + buf * (2 * TR_CHUNK);
+#pragma unroll
+    for (int i = 0; i < TR_CHUNK / 512; ++i) {
+      const int piece = wave * (TR_CHUNK / 512) + i;
+      __builtin_amdgcn_global_load_lds(ga + piece * 128, (lds_void_ptr)(la + piece * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gb + piece * 128, (lds_void_ptr)(la + TR_CHUNK + piece * 128), 16, 0, 0);
+    }
+  };
+  stage_load(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kb = 0; kb < nk; ++kb) {
+    const int cur = kb & 1;
+    if (kb + 1 < nk) stage_load(kb + 1, cur ^ 1);
+    const double* sA = smem + cur * (2 * TR_CHUNK);
+    const double* sB = sA + TR_CHUNK;
+#pragma unroll
+    for (int ks = 0; ks < TR_BK / 4; ++ks) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = sA[(ks * 8 + wr * 4 + i) * 64 + lane];
+        b[i] = sB[(ks * 8 + wc * 4 + i) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const size_t row0 = (size_t)bi * TR_BM + wr * 64, col0 = (size_t)bj * TR_BN + wc * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = row0 + i * 16 + (lane >> 4) + 4 * r;
+        double* p = T + row * ldt + col0 + j * 16 + (lane & 15);
+        if (SUB) { if (row < row_hi) *p = *p - acc[i][j][r]; }      // rows from row_hi on belong to the sampler (block J-1) or are done
+        else *p = acc[i][j][r];
+      }
+}
+
+// The 64 steps of one block for G preimages per wave (LPD = 64 / G lanes per draw).  Lane (sg, lam) of a wave belongs to preimage
+// sg and holds the running projections t of the rows slot * LPD + lam of the block.  Step l (descending): the owner's t is broadcast,
+// c' = t / ||b~||^2 (as a product with the stored reciprocal), the LPD lanes evaluate attempts lam, lam + LPD, ... of the draw
+// (coordinate i, preimage index) and the first accepted attempt in attempt order wins -- the value of the sequential sampler.
+// Fast path (narrow SampleZ words, |c'| < 2^30 -- every draw of C2 / C4):
+//   * the Philox blocks do not depend on c': once per four steps lane (s, g) computes block g of step l - s (a block serves the
+//     attempts 4g .. 4g+3), the words go through a private LDS strip and every lane picks the word of its own attempt;
+//   * per-row constants come from a 32-byte LDS record, the in-block triangle row g[l][.] from LDS;
+//   * the fp32 screen (sz_screen16) classifies each attempt as rejected / certainly accepted / to be settled; only a "to be
+//     settled" attempt that precedes every certain accept pays the exact f64 decision (sz_decide).
+// Anything else (wide words, huge centres, no accept among the first LPD attempts) runs the generic rounds: per-lane Philox,
+// sz_maybe / sz_decide.  Either way the outcome is that of the sequential sampler on the same Philox streams.
+// Then the rows below in the block take t' = fma(-z, g[l][.], t').  Outputs: z as f64 in the operand layout of the update
+// product, and as three balanced base-256 int8 digit planes [i/16][b][16] for the recombination.
+#ifdef NP_PROFILE   /* cycle breakdown of k_np_sample (workgroup 0, wave 0): tools/np_profile.py */
+__device__ long long g_np_prof[8];
+#define NP_T(k) do { const long long now_ = (long long)__builtin_readcyclecounter(); tacc_[k] += now_ - tprev_; tprev_ = now_; } while (0)
+#else
+#define NP_T(k) do { } while (0)
+#endif
+
+struct NpRow { double inv_n2; float inv_sk; int32_t c6; uint32_t n_int, thr_int, thr_frac, sh; };   // 32 bytes per row; sh = 0: no fast path;
+                                                                                                      // inv_sk = sqrt(pi log2 e) / s': exp(-pi a^2) = exp2(-(a inv_sk s')^2)
+
+struct NpSampleArgs {
+  const double* T; size_t ldt;            // running projections, d_pad x ld
+  const double* Gin; const double* Gnx; const NpRow* rows; const SampleZParams* sz;
+  double* Zf; size_t nkb;                 // chunk stream (bj, kb)
+  int8_t* Z8; size_t zplane; size_t ld;   // three digit planes, zplane bytes apart
+  int* flags;                             // [0] sampler failure, [1] a second digit is in use, [2] a third, [3] |z| beyond three digits
+};
+
+// fp32 screen of the attempts (the narrow form follows sz_screen16 of psf_rng.hpp).  An attempt is classified as certainly
+// rejected / certainly accepted ("sure") / inside the +-0.1 % band around the threshold (settled by sz_decide).  The candidate index is
+// exact in fp32 (N < 2^24), a = (idx + (lo - c)) / s carries an error below 1e-6, which moves rho by < 1e-4 relative; (float)wb is
+// within 2^-24 relative.  sure means (wb + 1) 2^-sh <= 0.999 rho_f < rho, hence wb < floor(rho 2^sh): no tie, the exact rule accepts.
+// The screen only decides who pays for the exact rule; the accepted attempt and its value are always those of the exact sampler.
+template <int G>
+__global__ __launch_bounds__(256) void k_np_sample(NpSampleArgs a, size_t dim, size_t J, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B) {
+  constexpr int LPD = 64 / G, BPS = LPD / 4;
+  __shared__ __attribute__((aligned(16))) double s_gin[NP_NB * NP_NB];
+  __shared__ NpRow s_row[NP_NB];
+  __shared__ SampleZParams s_sz[NP_NB];
+  __shared__ uint2 s_words[4][256];                               // per wave: (candidate word, acceptance word) of [sg][step of the group][attempt]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t j0 = J * NP_NB;
+  const int nrows = (int)(dim - j0 < (size_t)NP_NB ? dim - j0 : (size_t)NP_NB);
+#ifdef NP_PROFILE
+  long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev_ = (long long)__builtin_readcyclecounter();
+#endif
+  {  // the in-block triangle goes to LDS by LDS-DMA (eight 1 KiB pieces per wave), the small per-row tables through registers
+    const double* src = a.Gin + J * (NP_NB * NP_NB) + lane * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int piece = wave * 8 + i;
+      __builtin_amdgcn_global_load_lds(src + piece * 128, (lds_void_ptr)(s_gin + piece * 128), 16, 0, 0);
+    }
+    if (tid < NP_NB) {
+      s_row[tid] = tid < nrows ? a.rows[j0 + tid] : NpRow{0.0, 0.f, 0, 1, 0, 0, 16};
+      s_sz[tid] = tid < nrows ? a.sz[j0 + tid] : SampleZParams{0, 0, 0, 1, 0, 0, 16};
+    }
+  }
+  const int lam = lane & (LPD - 1);
+  const int sgbase = lane & ~(LPD - 1);
+  const int sg = lane / LPD;
+  const size_t b = ((size_t)blockIdx.x * 4 + (size_t)wave) * G + (size_t)sg;
+  const bool live = b < B;
+  const uint64_t index = first_index + b;
+  const uint32_t tw = tag_word(tag, index);
+  const uint64_t sgmask = G == 1 ? ~0ull : (((1ull << LPD) - 1) << sgbase);
+  double t[G];
+  long long zr[G];
+#pragma unroll
+  for (int s = 0; s < G; ++s) {
+    const int row = s * LPD + lam;
+    t[s] = (live && row < nrows) ? a.T[(j0 + row) * a.ldt + b] : 0.0;
+    zr[s] = 0;
+  }
+  int f = 0;
+  uint2* wstrip = &s_words[wave][0];
+  if (j0 + NP_NB < dim) {
+    // the block above was sampled by the previous launch: its contribution S to my rows, S = chain_k fma(z_k, g[64 (J+1) + k][row], .)
+    // from +0, is subtracted here (the bulk update on the other stream stops below this block); g read straight from L2
+    double* zs = reinterpret_cast<double*>(wstrip);               // 256 doubles per wave: [sg][k]
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      const int k = s * LPD + lam;
+      const size_t i = j0 + NP_NB + (size_t)k;
+      zs[sg * NP_NB + k] = (live && i < dim) ? a.Zf[((b / TR_BN) * a.nkb + i / 16) * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(i % 16))] : 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const double* gn = a.Gnx + J * (NP_NB * NP_NB) + lam;
+    double S[G];
+#pragma unroll
+    for (int s = 0; s < G; ++s) S[s] = 0.0;
+    for (int k0 = 0; k0 < NP_NB; k0 += 16) {
+      double zk[16], gk[16][G];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        zk[kk] = zs[sg * NP_NB + k0 + kk];
+#pragma unroll
+        for (int s = 0; s < G; ++s) gk[kk][s] = gn[(k0 + kk) * NP_NB + s * LPD];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int s = 0; s < G; ++s) S[s] = fma(zk[kk], gk[kk][s], S[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < G; ++s) t[s] = t[s] - S[s];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  NP_T(0);
+  auto bcast_d = [&](double v, int src_in_sg) -> double {
+    if (G == 1) return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_in_sg), __builtin_amdgcn_readlane(__double2loint(v), src_in_sg));
+    return __shfl(v, sgbase + src_in_sg);
+  };
+#pragma unroll
+  for (int slot = G - 1; slot >= 0; --slot) {
+    for (int grp = BPS - 1; grp >= 0; --grp) {                    // four steps slot * LPD + 4 grp + 3 .. + 0
+      const int lbase = slot * LPD + grp * 4;
+      if (lbase >= nrows) continue;                               // short top block (uniform)
+      {  // attempt words of the four steps, first LPD attempts each: lane (s, g) serves step lbase + 3 - s.
+         // narrow rows: Philox block g holds attempts 4g .. 4g+3; wide rows: blocks g and g + BPS hold attempts 2g, 2g+1 and 2(g+BPS), 2(g+BPS)+1
+        const int s = lam / BPS, g = lam % BPS;
+        const int lstep = lbase + 3 - s;
+        const uint32_t shs = s_row[lstep].sh;
+        const uint32_t coord_s = (uint32_t)(j0 + lstep);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous group's reads are done
+        uint2* dst = wstrip + (sg * 4 + s) * LPD;
+        const U4 w = philox(seed, coord_s, (uint32_t)index, (uint32_t)g, tw);
+        if (shs != 32) {
+          uint4* d4p = reinterpret_cast<uint4*>(dst + 4 * g);
+          d4p[0] = make_uint4(w.x >> 16, w.x & 0xffffu, w.y >> 16, w.y & 0xffffu);
+          d4p[1] = make_uint4(w.z >> 16, w.z & 0xffffu, w.w >> 16, w.w & 0xffffu);
+        } else {
+          *reinterpret_cast<uint4*>(dst + 2 * g) = make_uint4(w.x, w.y, w.z, w.w);
+        }
+        if (__ballot(shs == 32)) {
+          const U4 w2 = philox(seed, coord_s, (uint32_t)index, (uint32_t)(g + BPS), tw);
+          if (shs == 32) *reinterpret_cast<uint4*>(dst + 2 * (g + BPS)) = make_uint4(w2.x, w2.y, w2.z, w2.w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+      NP_T(1);
+      // operands of the first step of the group; those of the following steps are fetched one step ahead
+      NpRow rw = s_row[lbase + 3];
+      double gl[G];
+#pragma unroll
+      for (int s2 = 0; s2 <= slot; ++s2) gl[s2] = s_gin[(lbase + 3) * NP_NB + s2 * LPD + lam];
+      uint2 wd = wstrip[(sg * 4 + 0) * LPD + lam];
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const int l = lbase + 3 - sp;
+        NpRow rwn = rw;
+        double gln[G];
+        uint2 wdn = wd;
+#pragma unroll
+        for (int s2 = 0; s2 <= slot; ++s2) gln[s2] = gl[s2];
+        if (sp < 3) {
+          rwn = s_row[l - 1];
+#pragma unroll
+          for (int s2 = 0; s2 <= slot; ++s2) gln[s2] = s_gin[(l - 1) * NP_NB + s2 * LPD + lam];
+          wdn = wstrip[(sg * 4 + sp + 1) * LPD + lam];
+        }
+        if (l < nrows) {
+          const int ls = l - slot * LPD;
+          const double tl = bcast_d(t[slot], ls);
+          const double cen = tl * rw.inv_n2;
+          const uint32_t coord = (uint32_t)(j0 + l);
+          long long z = 0;
+          bool got = !live;
+          uint32_t t0 = 0;
+          NP_T(2);
+          // --- the part of the screen that does not depend on the centre (issued before the centre is known) ----------
+          const bool narrow = rw.sh == 16;
+          const uint32_t Nf = rw.n_int - 1u;                        // candidates for a non-integral centre (the generic case)
+          uint32_t low, idx;
+          if (narrow) { const uint32_t prod = __umul24(wd.x, Nf); low = prod & 0xffffu; idx = prod >> 16; }
+          else { low = wd.x * Nf; idx = __umulhi(wd.x, Nf); }
+          const float u = (float)idx * rw.inv_sk;
+          const float wbf = (float)wd.y * (narrow ? 0x1.0p-16f : 0x1.0p-32f);
+          const float wbe = wbf + (narrow ? 0x1.0p-16f : 1e-7f);
+          const bool okidx = live && low >= rw.thr_frac;            // Lemire's rejection of the lowest fractions
+          // --- the dependent chain ----------------------------------------------------------------------------------
+          const double cc = ceil(cen);
+          const float c_rel = (float)(cc - cen) - (float)rw.c6;     // lo - c with lo = ceil(c) - ceil(6 s')
+          const int lo = (int)cc - rw.c6;
+          const float ak = fmaf(c_rel, rw.inv_sk, u);
+          const float rho = __builtin_amdgcn_exp2f(-(ak * ak));     // exp(-pi a^2)
+          const bool cand_b = okidx && wbf <= fmaf(rho, 1.001f, 1e-9f);
+          const bool sure_b = okidx && wbe <= rho * 0.999f;
+          // not covered by the lines above: integral centres (one more candidate), huge centres, candidate ranges beyond fp32
+          const bool bad = live && (cc == cen || !(fabs(cen) < 0x1.0p30) || rw.sh == 0);
+          const uint64_t mc_w = __ballot(cand_b), m1_w = __ballot(sure_b), bad_w = __ballot(bad);
+          NP_T(3);
+          // common case: the first candidate of the draw (in attempt = lane order) is a certain accept
+          bool settle = false;
+          if (G == 1) {
+            const int fl = mc_w ? __builtin_ctzll(mc_w) : 0;
+            if (bad_w == 0 && ((m1_w >> fl) & 1)) { z = (long long)(lo + __builtin_amdgcn_readlane((int)idx, fl)); got = true; }
+            else settle = live;
+          } else {
+            const uint64_t cand = mc_w & sgmask;
+            const int fl = cand ? (__ffsll((long long)cand) - 1) : lane;
+            const int xi = __shfl((int)idx, fl);
+            if (live && !(bad_w & sgmask) && ((m1_w >> fl) & 1) && cand) { z = (long long)(lo + xi); got = true; }
+            else settle = live;
+          }
+          if (__ballot(settle)) {
+            // rare: a "to be settled" attempt comes first, or there is no candidate among the first LPD attempts, or the centre is special
+            const bool usable = !(bad_w & sgmask);
+            uint64_t m1 = usable ? (m1_w & sgmask) : 0, m2 = usable ? ((mc_w & ~m1_w) & sgmask) : 0;
+            while (true) {
+              const uint64_t cand = m1 | m2;
+              const bool pending = !got && cand != 0;
+              if (!__ballot(pending)) break;
+              const int fl = pending ? (__ffsll((long long)cand) - 1) : lane;
+              const bool sure = (m1 >> fl) & 1;
+              bool acc = false;
+              if (pending && !sure && lane == fl) {               // keep every bit of the exact decision (incl. its tie-break Philox block) inside the branch
+                uint32_t ta = (uint32_t)lam;
+                asm volatile("" : "+v"(ta));
+                acc = sz_decide(seed, coord, (uint32_t)index, tw, ta, (long long)lo + (long long)idx, wd.y, cen, s_sz[l].inv_s, rw.sh);
+              }
+              const uint64_t accm = __ballot(acc);
+              const int xi = __shfl((int)idx, fl);
+              if (pending) {
+                if (sure || ((accm >> fl) & 1)) { z = (long long)(lo + xi); got = true; }
+                else m2 &= ~(1ull << fl);
+              }
+            }
+            t0 = usable ? LPD : 0;                                 // special centres start over with the generic rounds
+          }
+          NP_T(4);
+          if (__ballot(!got)) {                                      // generic rounds: attempts t0 + lam, t0 + LPD + lam, ...
+            const SampleZParams sp2 = s_sz[l];
+            const SzRange rg = sz_range(cen, sp2);
+            for (; t0 < kMaxAttempts; t0 += LPD) {
+              if (!__ballot(!got)) break;
+              bool maybe = false;
+              long long x = 0;
+              uint32_t wa = 0, wb = 0;
+              const uint32_t ta = t0 + (uint32_t)lam;
+              if (!got) {
+                sz_attempt_words(seed, coord, (uint32_t)index, tw, ta, rg.sh, &wa, &wb);
+                maybe = sz_maybe(wa, wb, rg, cen, sp2.inv_s, &x);
+              }
+              uint64_t m2 = __ballot(maybe) & sgmask;
+              while (true) {
+                const bool pending = !got && m2 != 0;
+                if (!__ballot(pending)) break;
+                const int fl = pending ? (__ffsll((long long)m2) - 1) : lane;
+                bool acc = false;
+                if (pending && lane == fl) {
+                  uint32_t tb = ta;
+                  asm volatile("" : "+v"(tb));
+                  acc = sz_decide(seed, coord, (uint32_t)index, tw, tb, x, wb, cen, sp2.inv_s, rg.sh);
+                }
+                const uint64_t accm = __ballot(acc);
+                const long long xs = __shfl(x, fl);
+                if (pending) {
+                  if ((accm >> fl) & 1) { z = xs; got = true; }
+                  else m2 &= ~(1ull << fl);
+                }
+              }
+            }
+            if (!got) { f = 1; z = (long long)floor(cen + 0.5); }
+          }
+          if (lam == ls) zr[slot] = z;
+          const double nz = -(double)z;
+#pragma unroll
+          for (int s2 = 0; s2 <= slot; ++s2) t[s2] = fma(nz, gl[s2], t[s2]);
+          NP_T(5);
+        }
+        rw = rwn; wd = wdn;
+#pragma unroll
+        for (int s2 = 0; s2 <= slot; ++s2) gl[s2] = gln[s2];
+      }
+    }
+  }
+  int use1 = 0, use2 = 0, big = 0;
+  if (live) {
+    const size_t plane = a.zplane;
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      const int row = s * LPD + lam;
+      if (row >= nrows) continue;
+      const size_t i = j0 + row;
+      const long long z = zr[s];
+      a.Zf[((b / TR_BN) * a.nkb + i / 16) * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(i % 16))] = (double)z;
+      if (z > 8355711ll || z < -8355711ll) big = 1;               // beyond three balanced digits: the 64-bit recombination takes the call
+      const int z32 = (int)z;
+      const int d0 = (int)(int8_t)(z32 & 0xff);
+      const int z1 = (z32 - d0) >> 8;
+      const int d1 = (int)(int8_t)(z1 & 0xff);
+      const int d2 = (z1 - d1) >> 8;
+      if (d1) use1 = 1;
+      if (d2) use2 = 1;
+      const size_t addr = ((i >> 4) * a.ld + b) * 16 + (i & 15);
+      a.Z8[addr] = (int8_t)d0;
+      a.Z8[plane + addr] = (int8_t)d1;
+      a.Z8[2 * plane + addr] = (int8_t)d2;
+    }
+  }
+  if (f) atomicOr(a.flags, 1);
+  if (use1) atomicOr(a.flags + 1, 1);
+  if (use2) atomicOr(a.flags + 2, 1);
+  if (big) atomicOr(a.flags + 3, 1);
+#ifdef NP_PROFILE
+  NP_T(6);
+  if (blockIdx.x == 0 && tid == 0) for (int k = 0; k < 7; ++k) atomicAdd((unsigned long long*)&g_np_prof[k], (unsigned long long)tacc_[k]);
+#endif
+}
+
+// E[b][j] (+)= scale * sum_i Z8[i][b] B8[j][i] on the int8 matrix cores (v_mfma_i32_16x16x64_i8): Z as the A operand (rows = preimages),
+// the basis plane as the B operand (columns = coordinates j), so 16 lanes hold 16 consecutive j of one preimage and the int64 stores
+// are 128-byte runs.  Workgroup tile 128 (b) x 128 (j), K = 128 per stage, two LDS stages filled by LDS-DMA.  int32 accumulation is
+// exact (at most 2^17 terms of |z b| <= 2^14).  `gate`: the pass is skipped unless *gate != 0 (hi plane of z, decided on device).
+template <bool ACCUM>
+__global__ __launch_bounds__(256, 2) void k_np_combine8(const int8_t* __restrict__ B8, size_t ldb, size_t d, int nk128, const int8_t* __restrict__ Z8, size_t ld,
+                                                        size_t B, long long scale, const int* __restrict__ gate, int64_t* __restrict__ E, size_t lde) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+  if (gate && !*gate) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const size_t b0 = (size_t)blockIdx.x * 128, i0 = (size_t)blockIdx.y * 128;
+  v4i acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = v4i{0, 0, 0, 0};
+  auto stage_load = [&](int ks2, int buf) {
+    unsigned char* base = rc_smem + buf * 32768;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = (wave * 4 + j) * 64 + lane;                  // 16-byte piece, 0..1023
+      const int kk = p >> 9, row = (p >> 2) & 127, col = p & 3;
+      __builtin_amdgcn_global_load_lds(B8 + (i0 + (size_t)row) * ldb + (size_t)ks2 * 128 + kk * 64 + col * 16,
+                                       (lds_void_ptr)(base + (wave * 4 + j) * 1024), 16, 0, 0);
+      const int kg = p >> 7, bb = p & 127;
+      __builtin_amdgcn_global_load_lds(Z8 + (((size_t)ks2 * 8 + kg) * ld + b0 + (size_t)bb) * 16,
+                                       (lds_void_ptr)(base + 16384 + (wave * 4 + j) * 1024), 16, 0, 0);
+    }
+  };
+  const int r16 = lane & 15, g = lane >> 4;
+  stage_load(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ks2 = 0; ks2 < nk128; ++ks2) {
+    const int cb = ks2 & 1;
+    if (ks2 + 1 < nk128) stage_load(ks2 + 1, cb ^ 1);
+    const unsigned char* sR = rc_smem + cb * 32768;
+    const unsigned char* sL = sR + 16384;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      v4i fr[4], fl[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fr[t] = *reinterpret_cast<const v4i*>(sR + kk * 8192 + ((wc * 64 + t * 16 + r16) * 64 + g * 16));
+        fl[t] = *reinterpret_cast<const v4i*>(sL + (((kk * 4 + g) * 128 + wr * 64 + t * 16 + r16) * 16));
+      }
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fl[bt], fr[it], acc[bt][it], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // C/D map: column (coordinate j) = lane & 15, row (preimage) = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t bb = b0 + wr * 64 + bt * 16 + 4 * g + r, jj = i0 + wc * 64 + it * 16 + r16;
+        if (bb < B && jj < d) {
+          int64_t* p = E + bb * lde + jj;
+          const int64_t v = scale * (long long)acc[bt][it][r];
+          *p = ACCUM ? *p + v : v;
+        }
+      }
+}
+
+// e[b][piv[r]] += sol[r][b]  (gpv.rs:160: sol + sample; e = -(c0 - sum z b) with c0 = -sol)
+__global__ void k_np_add_sol(const uint64_t* __restrict__ Sol, const uint32_t* __restrict__ piv, size_t n, size_t B, size_t ld, int64_t* __restrict__ E, size_t lde) {
+  const size_t total = n * B;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = g / B, b = g % B;
+    E[b * lde + piv[r]] += (int64_t)Sol[r * ld + b];
+  }
+}
+
+// The same recombination in 64-bit integers, one output per thread: for a basis or a z that does not fit two int8 digits.
+// Runs after everything else and rewrites E completely; `gate` as above (nullptr = always).
+__global__ void k_np_combine_generic(const int32_t* __restrict__ St, size_t d, const double* __restrict__ Zf, size_t nkb, const uint64_t* __restrict__ Sol,
+                                     const uint32_t* __restrict__ piv, size_t n, size_t B, size_t ld, const int* __restrict__ gate,
+                                     int64_t* __restrict__ E, size_t lde) {
+  if (gate && !*gate) return;
+  const size_t total = d * B;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g / d, j = g % d;
+    int64_t acc = 0;
+    const double* zc = Zf + (b / TR_BN) * nkb * TR_CHUNK;
+    for (size_t i = 0; i < d; ++i) {
+      const double z = zc[(i / 16) * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(i % 16))];
+      acc += (int64_t)z * (int64_t)St[i * d + j];
+    }
+    E[b * lde + j] = acc;
+  }
+  __threadfence();
+  // the pivot columns receive sol afterwards (same thread set: every (b, j) pair is owned by exactly one thread)
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = g / d, j = g % d;
+    for (size_t r = 0; r < n; ++r)
+      if (piv[r] == j) E[b * lde + j] += (int64_t)Sol[r * ld + b];
+  }
+}
+
+}  // namespace psf

@@ -12,21 +12,35 @@ struct psfgpv_handle {
   SampleZParams* dSz = nullptr;
   uint64_t* dT = nullptr;             // n x n solve operator, transposed
   uint32_t* dPiv = nullptr;           // n pivot columns
-  int64_t* dC0 = nullptr; size_t c0cap = 0;
-  int jr = 0;                         // nearest-plane template size for dim (np_template_jr)
-  int32_t* dStP = nullptr;            // packed, zero-padded copies of dSt / dGt in the nearest-plane kernel's layout (k_np_pack)
-  double* dGtP = nullptr;
-  double* dRowMax = nullptr;          // max |entry| per basis row (bound of the FP53 nearest-plane pass)
-  int* dRedo = nullptr;               // per-workgroup hand-over mask FP53 pass -> int64 pass (c0cap entries)
+  // blocked nearest plane (psf_np_kernels.hpp): per key
+  size_t nblk = 0, dpad = 0, nrb = 0, nkc = 0, nkb = 0;   // 64-row blocks; dim padded to 128; 128-row blocks; K chunks of the pivots; K chunks of dim
+  double* dGp = nullptr;              // bulk panels g[< 64 J][block J], fragment order
+  double* dGin = nullptr;             // in-block triangles, nblk x 64 x 64
+  double* dGnx = nullptr;             // panels between neighbouring blocks, nblk x 64 x 64
+  std::vector<hipEvent_t> evS, evB;   // per block: sampled / bulk update done (look-ahead over two streams)
+  NpRow* dRows = nullptr;             // per-row constants of the sampler's fast path (1 / ||b~_i||^2, SampleZ tables)
+  double* dBpiv = nullptr;            // b~_i on the pivot columns, fragment order
+  int8_t* dB8 = nullptr;              // two digit planes of the basis, transposed, dpad x dpad each
+  bool basis_hi = false, basis_generic = false;
+  // per batch
+  size_t bcap = 0, ld = 0;
+  double* dTm = nullptr;              // running projections, dpad x ld
+  double* dZf = nullptr;              // z as f64, chunk stream (ld / 128) x nkb
+  int8_t* dZ8 = nullptr; size_t zplane = 0;          // three digit planes of z, [dpad / 16][ld][16] each
+  double* dC0p = nullptr;             // -sol on the pivots, chunk stream (ld / 128) x nkc
+  uint64_t* dSol = nullptr;           // n x ld
+  int* dFlags = nullptr;              // [0] sampler failure [1] second digit of some z in use [2] third digit [3] |z| beyond three digits
+  int np_g = 0;                       // PSF_NP_G: preimages per wave of the sampler (0 = by batch size)
+  bool one_stream = false;            // PSF_NP_ONE_STREAM=1: bulk updates in line on the caller's stream (counter collection, debugging)
   bool has_key = false;
   bool timing = false;
-  unsigned last_blocks = 0;           // workgroups of the last nearest-plane launch (0 if the FP53 pass was skipped)
-  bool force_int64 = false;           // PSF_GPV_INT64=1: skip the FP53 pass (tests compare both)
+  bool last_generic = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   hipStream_t last_stream = nullptr;
 };
 
-// Gram-Schmidt of the rows of dSt into dGt (MatQ::gso, gpv.rs:91), then ||b~_i||^2 and the per-step sampler tables
+// Gram-Schmidt of the rows of dSt into dGt (MatQ::gso, gpv.rs:91), then ||b~_i||^2, the per-step sampler tables and the
+// operands of the blocked nearest plane
 static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
   const size_t d = g->dim;
   if (compute_gso) {
@@ -44,8 +58,6 @@ static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
     hipFree(dmu);
   }
   hipLaunchKernelGGL(k_row_norm2_chain, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, 0, g->dGt, d, g->dNorm2);
-  hipLaunchKernelGGL(k_row_absmax_i32, dim3((unsigned)d), dim3(64), 0, 0, g->dSt, d, g->dRowMax);
-  if (g->jr) hipLaunchKernelGGL(k_np_pack, dim3((unsigned)d), dim3(256), 0, 0, g->dSt, g->dGt, d, np_g2(g->jr), np_s4(g->jr), g->dStP, g->dGtP);
   HIP_TRY(hipGetLastError());
   std::vector<double> norm2(d);
   HIP_TRY(hipMemcpy(norm2.data(), g->dNorm2, d * sizeof(double), hipMemcpyDeviceToHost));
@@ -55,6 +67,39 @@ static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
     sz[i] = make_sample_z_params(g->s / std::sqrt(norm2[i]));
   }
   HIP_TRY(hipMemcpy(g->dSz, sz.data(), d * sizeof(SampleZParams), hipMemcpyHostToDevice));
+  {
+    std::vector<NpRow> rows(g->nblk * NP_NB, NpRow{0.0, 0.f, 0, 1, 0, 0, 16});
+    for (size_t i = 0; i < d; ++i) {
+      const SampleZParams& p = sz[i];
+      const bool fast = p.n_int < (1u << 24) && p.c6 < (1ll << 24);     // candidate indices exact in fp32 (np_screen)
+      rows[i] = NpRow{1.0 / norm2[i], (float)(p.inv_s * 2.1289340388624525), fast ? (int32_t)p.c6 : 0, p.n_int, p.thr_int, p.thr_frac, fast ? p.sh : 0u};
+    }
+    HIP_TRY(hipMemcpy(g->dRows, rows.data(), rows.size() * sizeof(NpRow), hipMemcpyHostToDevice));
+  }
+  {  // g[j][i] = <b_j, b~_i>, then its two packed forms
+    double* dGd = nullptr;
+    HIP_TRY(hipMalloc(&dGd, d * d * sizeof(double)));
+    const unsigned tiles = (unsigned)((d + 63) / 64);
+    hipLaunchKernelGGL(k_np_gram, dim3(tiles, tiles), dim3(256), 0, 0, g->dSt, g->dGt, d, dGd);
+    if (np_panel_base(g->nblk))
+      hipLaunchKernelGGL(k_np_pack_panels, dim3(grid_for(np_panel_base(g->nblk) * TR_CHUNK, 256, 256 * 64)), dim3(256), 0, 0, dGd, d, g->nblk, g->dGp);
+    hipLaunchKernelGGL(k_np_pack_inblock, dim3(grid_for(g->nblk * NP_NB * NP_NB)), dim3(256), 0, 0, dGd, d, g->nblk, g->dGin);
+    hipLaunchKernelGGL(k_np_pack_next, dim3(grid_for(g->nblk * NP_NB * NP_NB)), dim3(256), 0, 0, dGd, d, g->nblk, g->dGnx);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree(dGd);
+  }
+  {
+    int* dinfo = nullptr;
+    HIP_TRY(hipMalloc(&dinfo, 2 * sizeof(int)));
+    HIP_TRY(hipMemset(dinfo, 0, 2 * sizeof(int)));
+    hipLaunchKernelGGL(k_np_pack_basis8, dim3(grid_for(g->dpad * g->dpad, 256, 256 * 64)), dim3(256), 0, 0, g->dSt, d, g->dpad, g->dB8, dinfo);
+    int info[2] = {0, 0};
+    HIP_TRY(hipMemcpy(info, dinfo, sizeof(info), hipMemcpyDeviceToHost));
+    hipFree(dinfo);
+    g->basis_generic = info[0] != 0;
+    g->basis_hi = info[1] != 0;
+  }
   return PSF_OK;
 }
 
@@ -74,42 +119,96 @@ static psf_status gpv_build_solver(psfgpv_handle* g) {
     HIP_TRY(hipMemcpy(g->dT, Tt.data(), Tt.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMemcpy(g->dPiv, piv.data(), piv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  // b~_i restricted to the pivot columns: the A operand of the initial projection T = B~ C0 (c0 = -sol is zero elsewhere)
+  hipLaunchKernelGGL(k_np_pack_bpiv, dim3(grid_for(g->nrb * g->nkc * TR_CHUNK, 256, 256 * 64)), dim3(256), 0, 0, g->dGt, g->dPiv, g->dim, g->n, g->nrb, g->nkc, g->dBpiv);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
   return PSF_OK;
 }
 
-// template JR (coordinates per thread) for a lattice dimension; 0 = unsupported (> 8192)
-static int np_template_jr(size_t dim) {
-  const size_t jr = (dim + 255) / 256;
-  const int sizes[] = {1, 2, 4, 8, 14, 16, 25, 32};
-  for (int v : sizes) if (jr <= (size_t)v) return v;
-  return 0;
+static void free_np_batch(psfgpv_handle* g) {
+  hipFree(g->dTm); hipFree(g->dZf); hipFree(g->dZ8); hipFree(g->dC0p); hipFree(g->dSol);
+  g->dTm = g->dZf = g->dC0p = nullptr; g->dZ8 = nullptr; g->dSol = nullptr;
+  g->bcap = 0;
 }
-template <int JR>
-static void launch_np(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e) {
-  const unsigned blocks = (unsigned)((B + 1) / 2);
-  const uint64_t q = g->base->q;
-  const bool fp53 = q < (1ull << 50) && !g->force_int64;
-  g->last_blocks = fp53 ? blocks : 0;
-  if (fp53) {
-    hipMemsetAsync(g->dRedo, 0, blocks * sizeof(int), st);
-    hipLaunchKernelGGL((k_gpv_nearest_plane<JR, true>), dim3(blocks), dim3(256), 0, st, g->dStP, g->dGtP, g->dNorm2, g->dSz, g->dRowMax, (double)q,
-                       g->dim, seed, tag, first_index, B, g->dC0, d_e, g->base->dFail, g->dRedo);
-  }
-  hipLaunchKernelGGL((k_gpv_nearest_plane<JR, false>), dim3(blocks), dim3(256), 0, st, g->dStP, g->dGtP, g->dNorm2, g->dSz, g->dRowMax, 0.0,
-                     g->dim, seed, tag, first_index, B, g->dC0, d_e, g->base->dFail, fp53 ? g->dRedo : nullptr);
+static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
+  if (B <= g->bcap) return PSF_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  free_np_batch(g);
+  const size_t ld = round_up(B, TR_BN);
+  g->ld = ld;
+  HIP_TRY(hipMalloc(&g->dTm, g->dpad * ld * sizeof(double)));
+  HIP_TRY(hipMalloc(&g->dZf, ld * g->nkb * 16 * sizeof(double)));
+  g->zplane = g->dpad * ld;
+  HIP_TRY(hipMalloc(&g->dZ8, 3 * g->zplane));
+  HIP_TRY(hipMalloc(&g->dC0p, ld * g->nkc * 16 * sizeof(double)));
+  HIP_TRY(hipMalloc(&g->dSol, g->n * ld * sizeof(uint64_t)));
+  HIP_TRY(hipMemset(g->dTm, 0, g->dpad * ld * sizeof(double)));
+  HIP_TRY(hipMemset(g->dZf, 0, ld * g->nkb * 16 * sizeof(double)));      // padding rows / columns of the operands stay zero for good
+  HIP_TRY(hipMemset(g->dZ8, 0, 3 * g->zplane));
+  g->bcap = B;
+  return PSF_OK;
 }
+
+template <int G>
+static void launch_np_sample(psfgpv_handle* g, hipStream_t st, const NpSampleArgs& a, size_t J, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B) {
+  const size_t per_wg = 4 * G;
+  hipLaunchKernelGGL((k_np_sample<G>), dim3((unsigned)((B + per_wg - 1) / per_wg)), dim3(256), 0, st, a, g->dim, J, seed, tag, first_index, B);
+}
+
+// MatZ::sample_d_precomputed_gso for the whole batch (gpv.rs:160): the launch sequence of psf_np_kernels.hpp
 static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e) {
-  switch (g->jr) {
-    case 1: launch_np<1>(g, st, seed, tag, first_index, B, d_e); break;
-    case 2: launch_np<2>(g, st, seed, tag, first_index, B, d_e); break;
-    case 4: launch_np<4>(g, st, seed, tag, first_index, B, d_e); break;
-    case 8: launch_np<8>(g, st, seed, tag, first_index, B, d_e); break;
-    case 14: launch_np<14>(g, st, seed, tag, first_index, B, d_e); break;
-    case 16: launch_np<16>(g, st, seed, tag, first_index, B, d_e); break;
-    case 25: launch_np<25>(g, st, seed, tag, first_index, B, d_e); break;
-    case 32: launch_np<32>(g, st, seed, tag, first_index, B, d_e); break;
-    default: return PSF_ERR_UNSUPPORTED;                                // lattice dimension > 8192
+  const size_t ld = g->ld, nbj = round_up(B, TR_BN) / TR_BN;
+  const size_t lds_gemm = 4 * TR_CHUNK * sizeof(double);
+  hipStream_t aux = g->one_stream ? st : g->base->aux;   // bulk updates; the caller's stream carries the samplers (the critical path)
+  // T = B~[:, pivots] C0[pivots]
+  hipLaunchKernelGGL((k_np_gemm<false>), dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, g->dC0p, g->nkc, (int)g->nkc, g->dTm, ld, (size_t)0);
+  int G = g->np_g;
+  if (G != 1 && G != 2 && G != 4) G = B <= 1536 ? 1 : 2;      // one or two waves per SIMD of the chip (1024 SIMDs)
+  NpSampleArgs a{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, g->dFlags};
+  for (size_t J = g->nblk; J-- > 0;) {
+    // block J needs the bulk updates of every block >= J + 2 (block J + 1 is applied by the sampler itself)
+    if (J + 2 < g->nblk && !g->one_stream) HIP_TRY(hipStreamWaitEvent(st, g->evB[J + 2], 0));
+    switch (G) {
+      case 1: launch_np_sample<1>(g, st, a, J, seed, tag, first_index, B); break;
+      case 2: launch_np_sample<2>(g, st, a, J, seed, tag, first_index, B); break;
+      default: launch_np_sample<4>(g, st, a, J, seed, tag, first_index, B); break;
+    }
+    if (J < 2) continue;
+    // T[< 64 (J-1)] -= G[., J] Z_J on the second stream
+    if (!g->one_stream) {
+      HIP_TRY(hipEventRecord(g->evS[J], st));
+      HIP_TRY(hipStreamWaitEvent(aux, g->evS[J], 0));
+    }
+    const size_t row_hi = (J - 1) * NP_NB;
+    hipLaunchKernelGGL((k_np_gemm<true>), dim3((unsigned)nbj, (unsigned)((row_hi + 127) / 128)), dim3(256), lds_gemm, aux, g->dGp + np_panel_base(J) * TR_CHUNK, (size_t)4,
+                       g->dZf + (J * NP_NB / 16) * TR_CHUNK, g->nkb, 4, g->dTm, ld, row_hi);
+    if (!g->one_stream) HIP_TRY(hipEventRecord(g->evB[J], aux));
   }
+  if (g->nblk > 2 && !g->one_stream) HIP_TRY(hipStreamWaitEvent(st, g->evB[2], 0));   // the caller's stream is ordered after everything this call enqueued
+  // e = sum_i z_i b_i + sol
+  const psfp_handle* b = g->base;
+  const dim3 cgrid((unsigned)((B + 127) / 128), (unsigned)(g->dpad / 128));
+  const int nk128 = (int)(g->dpad / 128);
+  const size_t plane = g->dpad * g->dpad;
+  if (!g->basis_generic) {
+    // z = z0 + 256 z1 + 65536 z2, b = b0 + 256 b1: one pass per digit pair in use (the z digits beyond the first are gated on the device)
+    const int8_t* zp[3] = {g->dZ8, g->dZ8 + g->zplane, g->dZ8 + 2 * g->zplane};
+    const int* gate[3] = {nullptr, g->dFlags + 1, g->dFlags + 2};
+    bool first = true;
+    for (int zi = 0; zi < 3; ++zi)
+      for (int bi = 0; bi < (g->basis_hi ? 2 : 1); ++bi) {
+        const long long scale = 1ll << (8 * (zi + bi));
+        if (first) hipLaunchKernelGGL((k_np_combine8<false>), cgrid, dim3(256), 65536, st, g->dB8 + bi * plane, g->dpad, g->dim, nk128, zp[zi], ld, B, scale, gate[zi], d_e, g->dim);
+        else hipLaunchKernelGGL((k_np_combine8<true>), cgrid, dim3(256), 65536, st, g->dB8 + bi * plane, g->dpad, g->dim, nk128, zp[zi], ld, B, scale, gate[zi], d_e, g->dim);
+        first = false;
+      }
+    hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dSol, g->dPiv, g->n, B, ld, d_e, g->dim);
+  }
+  // integer fallback: always for a basis beyond two int8 digits, otherwise only if a z left the three-digit range (decided on the device)
+  hipLaunchKernelGGL(k_np_combine_generic, dim3(grid_for(g->dim * B, 256, 256 * 64)), dim3(256), 0, st, g->dSt, g->dim, g->dZf, g->nkb, g->dSol, g->dPiv, g->n, B, ld,
+                     g->basis_generic ? (const int*)nullptr : (const int*)(g->dFlags + 3), d_e, g->dim);
+  (void)b;
   return PSF_OK;
 }
 
@@ -131,7 +230,6 @@ psf_status psfgpv_create(const psfgpv_params* prm, psfgpv_handle** out) {
   psfp_handle* b = nullptr;
   const psf_status rc = psfp_create(&bp, &b);
   if (rc != PSF_OK) return rc;
-  if (b->m > 8192) { psfp_destroy(b); return PSF_ERR_UNSUPPORTED; }
   psfgpv_handle* g = new psfgpv_handle();
   g->base = b; g->s = prm->s; g->n = b->n; g->m = b->m; g->dim = b->m;
   const psf_status rc2 = psfgpv_init(g);
@@ -142,19 +240,34 @@ psf_status psfgpv_create(const psfgpv_params* prm, psfgpv_handle** out) {
 
 static psf_status psfgpv_init(psfgpv_handle* g) {
   const size_t d = g->dim;
+  g->nblk = (d + NP_NB - 1) / NP_NB;
+  g->dpad = round_up(d, 128);
+  g->nrb = g->dpad / 128;
+  g->nkc = round_up(g->n, 16) / 16;
+  g->nkb = round_up(d, NP_NB) / 16;
   HIP_TRY(hipMalloc(&g->dSt, d * d * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&g->dGt, d * d * sizeof(double)));
   HIP_TRY(hipMalloc(&g->dNorm2, d * sizeof(double)));
-  HIP_TRY(hipMalloc(&g->dRowMax, d * sizeof(double)));
-  g->jr = np_template_jr(d);
-  if (g->jr) {
-    HIP_TRY(hipMalloc(&g->dGtP, d * (size_t)np_g2(g->jr) * 512 * sizeof(double)));
-    HIP_TRY(hipMalloc(&g->dStP, d * (size_t)np_s4(g->jr) * 1024 * sizeof(int32_t)));
-  }
-  { const char* ev = getenv("PSF_GPV_INT64"); g->force_int64 = ev && ev[0] == '1'; }
   HIP_TRY(hipMalloc(&g->dSz, d * sizeof(SampleZParams)));
   HIP_TRY(hipMalloc(&g->dT, g->n * g->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&g->dPiv, g->n * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&g->dGp, (np_panel_base(g->nblk) + 1) * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipMalloc(&g->dGin, g->nblk * NP_NB * NP_NB * sizeof(double)));
+  HIP_TRY(hipMalloc(&g->dGnx, g->nblk * NP_NB * NP_NB * sizeof(double)));
+  g->evS.assign(g->nblk, nullptr); g->evB.assign(g->nblk, nullptr);
+  for (auto& e : g->evS) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : g->evB) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipMalloc(&g->dRows, g->nblk * NP_NB * sizeof(NpRow)));
+  HIP_TRY(hipMalloc(&g->dBpiv, g->nrb * g->nkc * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipMalloc(&g->dB8, 2 * g->dpad * g->dpad));
+  HIP_TRY(hipMalloc(&g->dFlags, 4 * sizeof(int)));
+  HIP_TRY(hipMemset(g->dFlags, 0, 4 * sizeof(int)));
+  { const char* ev = getenv("PSF_NP_G"); g->np_g = ev ? atoi(ev) : 0; }
+  { const char* ev = getenv("PSF_NP_ONE_STREAM"); g->one_stream = ev && ev[0] == '1'; }
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_gemm<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_gemm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
   return PSF_OK;
 }
@@ -162,7 +275,11 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
 void psfgpv_destroy(psfgpv_handle* g) {
   if (!g) return;
   hipSetDevice(g->base->prm.device);
-  hipFree(g->dSt); hipFree(g->dGt); hipFree(g->dNorm2); hipFree(g->dSz); hipFree(g->dT); hipFree(g->dPiv); hipFree(g->dC0); hipFree(g->dRowMax); hipFree(g->dRedo); hipFree(g->dStP); hipFree(g->dGtP);
+  free_np_batch(g);
+  hipFree(g->dSt); hipFree(g->dGt); hipFree(g->dNorm2); hipFree(g->dSz); hipFree(g->dT); hipFree(g->dPiv);
+  hipFree(g->dGp); hipFree(g->dGin); hipFree(g->dGnx);
+  for (auto& e : g->evS) if (e) hipEventDestroy(e);
+  for (auto& e : g->evB) if (e) hipEventDestroy(e); hipFree(g->dRows); hipFree(g->dBpiv); hipFree(g->dB8); hipFree(g->dFlags);
   for (auto& e : g->ev) if (e) hipEventDestroy(e);
   psfp_destroy(g->base);
   delete g;
@@ -238,20 +355,13 @@ psf_status psfgpv_samp_p_dev(psfgpv_handle* g, uint64_t seed, uint64_t first_ind
   psfp_handle* b = g->base;
   HIP_TRY(hipSetDevice(b->prm.device));
   hipStream_t st = (hipStream_t)stream;
-  if (B > g->c0cap) {
-    hipFree(g->dC0);
-    g->dC0 = nullptr;
-    HIP_TRY(hipMalloc(&g->dC0, B * g->dim * sizeof(int64_t)));
-    hipFree(g->dRedo);
-    g->dRedo = nullptr;
-    HIP_TRY(hipMalloc(&g->dRedo, (B + 1) * sizeof(int)));
-    g->c0cap = B;
-  }
+  psf_status rcb = ensure_np_batch(g, B);
+  if (rcb != PSF_OK) return rcb;
   HIP_TRY(hipMemsetAsync(b->dFail, 0, 2 * sizeof(int), st));
-  HIP_TRY(hipMemsetAsync(g->dC0, 0, B * g->dim * sizeof(int64_t), st));
+  HIP_TRY(hipMemsetAsync(g->dFlags, 0, 4 * sizeof(int), st));
   if (g->timing) hipEventRecord(g->ev[0], st);
   // :153-158  sol = A.solve(u), centre = -sol
-  hipLaunchKernelGGL(k_gpv_solve, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dT, g->dPiv, g->n, g->dim, b->q, b->two64, d_u, B, g->dC0);
+  hipLaunchKernelGGL(k_np_solve, dim3(grid_for(g->nkc * 16 * g->ld)), dim3(256), 0, st, g->dT, g->n, g->nkc * 16, b->q, b->two64, d_u, B, g->ld, g->dSol, g->dC0p);
   if (g->timing) hipEventRecord(g->ev[1], st);
   // :160  sol + sample_d_precomputed_gso(basis, gso, centre, s)
   const psf_status rc = launch_nearest_plane(g, st, seed, TAG_GPV, first_index, B, d_e);
@@ -263,7 +373,15 @@ psf_status psfgpv_samp_p_dev(psfgpv_handle* g, uint64_t seed, uint64_t first_ind
   return PSF_OK;
 }
 
-psf_status psfgpv_last_status(psfgpv_handle* g) { return g ? psfp_last_status(g->base) : PSF_ERR_PARAM; }
+psf_status psfgpv_last_status(psfgpv_handle* g) {
+  if (!g) return PSF_ERR_PARAM;
+  const psf_status rc = psfp_last_status(g->base);        // synchronises the stream of the last call
+  if (rc != PSF_OK) return rc;
+  int fl[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(fl, g->dFlags, sizeof(fl), hipMemcpyDeviceToHost));
+  g->last_generic = g->basis_generic || fl[3] != 0;
+  return fl[0] ? PSF_ERR_SAMPLER : PSF_OK;
+}
 
 psf_status psfgpv_samp_p(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
   if (!g || (B && (!u || !e))) return PSF_ERR_PARAM;
@@ -314,15 +432,13 @@ psf_status psfgpv_get_timing(psfgpv_handle* g, double* solve_ms, double* nearest
   if (nearest_plane_ms) *nearest_plane_ms = c;
   return PSF_OK;
 }
-psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle* g, size_t* workgroups, size_t* handed_over) {
+psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle* g, size_t* blocks, size_t* generic_recombination) {
   if (!g) return PSF_ERR_PARAM;
   HIP_TRY(hipStreamSynchronize(g->last_stream));
-  std::vector<int> redo(g->last_blocks);
-  if (g->last_blocks) HIP_TRY(hipMemcpy(redo.data(), g->dRedo, redo.size() * sizeof(int), hipMemcpyDeviceToHost));
-  size_t cnt = 0;
-  for (int v : redo) cnt += v != 0;
-  if (workgroups) *workgroups = g->last_blocks;
-  if (handed_over) *handed_over = cnt;
+  int fl[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(fl, g->dFlags, sizeof(fl), hipMemcpyDeviceToHost));
+  if (blocks) *blocks = g->nblk;
+  if (generic_recombination) *generic_recombination = (g->basis_generic || fl[3]) ? 1 : 0;
   return PSF_OK;
 }
 

@@ -302,7 +302,7 @@ class PSFGPV:
         check(lib().psfgpv_enable_timing(self._h, C.c_int(1 if on else 0)), "enable_timing")
 
     def nearest_plane_stats(self):
-        """(workgroups of the FP53 pass, workgroups handed over to the int64 pass) of the last samp_p call."""
+        """(64-row blocks walked by the nearest plane, 1 if the last samp_p call recombined in 64-bit integers instead of int8 planes)."""
         a, b = C.c_size_t(0), C.c_size_t(0)
         check(lib().psfgpv_get_nearest_plane_stats(self._h, C.byref(a), C.byref(b)), "nearest_plane_stats")
         return a.value, b.value
@@ -310,7 +310,7 @@ class PSFGPV:
     def get_timing(self):
         a, b = C.c_double(0), C.c_double(0)
         check(lib().psfgpv_get_timing(self._h, C.byref(a), C.byref(b)), "get_timing")
-        return {"k_gpv_solve": a.value, "k_gpv_nearest_plane": b.value}
+        return {"k_np_solve": a.value, "nearest_plane": b.value}
 
 
 class PSFGPVRing:
@@ -424,4 +424,4 @@ class PSFGPVRing:
     def get_timing(self):
         a, b = C.c_double(0), C.c_double(0)
         check(lib().psfring_get_timing(self._h, C.byref(a), C.byref(b)), "get_timing")
-        return {"k_gpv_solve": a.value, "k_gpv_nearest_plane": b.value}
+        return {"k_np_solve": a.value, "nearest_plane": b.value}
