@@ -172,6 +172,18 @@ def main():
             if roof["traffic"]:                      # the HBM side of the same launch, for the metric's "HBM-BW%"
                 roof["hbm_GBps"] = round(roof["traffic"] / (trmm * 1e-3) / 1e9, 1)
                 roof["hbm_frac_of_peak"] = round(roof["traffic"] / (trmm * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)
+        npl = kern_ms.get("nearest_plane")
+        if npl and roof is None:
+            # PSFGPV / PSFGPVRing: the nearest plane (gpv.rs:160) as a whole -- per block one k_np_step launch (sampler workgroups + FP64-MFMA
+            # update tiles), then the int8-MFMA recombination.  Algorithmic work per preimage: 2 d^2 FP64 flop (projection + update,
+            # SURVEY.md 8d); the walk itself is d sequential draws per preimage, so the phase is latency bound, not MFMA bound.
+            flops = 2.0 * float(m) * float(m) * B
+            ach = flops / (npl * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "nearest plane: k_np_project + d/64 x k_np_step + k_np_combine8", "achieved": round(ach, 3),
+                    "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": load_traffic(args.config, B),
+                    "launch_ms": round(npl, 3), "flops_per_launch": flops, "serial_steps": int(m),
+                    "us_per_serial_step": round(npl * 1e3 / m, 4),
+                    "note": "latency bound: d sequential SampleZ draws per preimage (one launch per 64 of them); frac is the FP64 share of the phase"}
         out = {
             "metric": "preimages/sec (whole node) + HBM-BW% for samp_p, n=512 q~2^30 batch=4096",
             "value": round(value, 2), "unit": "preimages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

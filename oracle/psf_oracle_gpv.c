@@ -117,7 +117,7 @@ int orc_solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, size
  *        c'  = t_i * (1 / ||b~_i||^2)            (the reciprocal rounded once per key)
  *        z_i <- D_{Z, s/||b~_i||, c'}             (the SampleZ contract of psf_oracle.c, stream (tag, index, coordinate i))
  *        t_i' = fma(-(double) z_i, g[i][i'], t_i')            for the rows i' < i of the same block
- *     then for every row i' below the block:  S = chain_{j in J ascending} fma((double) z_j, g[j][i'], .) from +0 ;  t_i' = t_i' - S
+ *     then for every row i' below the block, for j in J ascending:  t_i' = fma(-(double) z_j, g[j][i'], t_i')
  *   c_final = c0 - sum_i z_i b_i   (integers, exact).
  * basis_t / gso_t are TRANSPOSED: row i holds basis vector i (column i of the reference's matrices).
  * ---------------------------------------------------------------------------------------- */
@@ -162,9 +162,9 @@ void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double
       for (size_t i2 = j0; i2 < i; ++i2) t[i2] = fma(nz, gi[i2], t[i2]);
     }
     for (size_t i2 = 0; i2 < j0; ++i2) {
-      double S = 0.0;
-      for (size_t j = j0; j < j1; ++j) S = fma((double)z[j], G[j * dim + i2], S);
-      t[i2] = t[i2] - S;
+      double acc = t[i2];
+      for (size_t j = j0; j < j1; ++j) acc = fma(-(double)z[j], G[j * dim + i2], acc);
+      t[i2] = acc;
     }
   }
   for (size_t i = 0; i < dim; ++i) {

@@ -26,4 +26,4 @@ steps = m
 tot = sum(out[:7])
 for k, nm in enumerate(names):
     print(f"{nm:42s} {out[k]:12d} cycles  {out[k]/steps:9.1f} per step  {100*out[k]/tot:5.1f} %")
-print("total", tot, "cycles at 100 MHz?" , tot / steps, "per step")
+print("total", tot, "clock64 ticks for wave 0 of workgroup 0;", tot / steps, "per step;  slowest wave of any single launch:", out[7], "ticks (wave 0 average per launch:", tot // ((m + 63) // 64), ")")

@@ -6,20 +6,20 @@
 //     <c0, b~_i> - sum_{j > i} z_j g[j][i],
 // so the integer vector c never has to be carried along: the walk needs the d x B matrix T of running projections, and the
 // preimage is recovered at the end as e = -(c0 - sum_i z_i b_i).  Rows are cut into blocks of NP_NB = 64 indices.  Per call:
-//     T        = B~[:, pivots] C0[pivots]               k_np_gemm<false>   FP64 MFMA, K = n (c0 = -sol lives on the n pivot columns)
+//     T        = B~[:, pivots] C0[pivots]               k_np_project   FP64 MFMA, K = n (c0 = -sol lives on the n pivot columns)
 //     for J descending:
 //        Z_J   <- rows of block J take the contribution of Z_(J+1), then the 64 steps of the block are sampled
-//                                                       k_np_sample<G>     one wave per G preimages, 64/G lanes evaluate the
+//                                                       np_sample_body<G>     one wave per G preimages, 64/G lanes evaluate the
 //                                                                          SampleZ attempts of one draw in parallel
-//        T[< J-1] -= G[< J-1, J] Z_J                    k_np_gemm<true>    FP64 MFMA, K = 64, every operand read once per batch;
-//                                                                          on a second stream: it only has to land before block
-//                                                                          J-2 is sampled, so it hides behind the sampling of J-1
+//        T[< J-1] -= G[< J-1, J] Z_J                    np_update_tile     FP64 MFMA, K = 64 per block, every operand read once per
+//                                                                          batch; extra workgroups of the NEXT block's launch
+//                                                                          (k_np_step), near rows per block, far rows per panel
 //     E        = Z^t B  (+ sol on the pivot columns)    k_np_combine8      int8 MFMA on balanced base-256 digit planes (exact)
 // Basis and Gram-Schmidt data are therefore read once per BATCH and block, not once per pair of preimages, nothing is held in
 // registers across steps except the 64 running projections of the current block, and the lattice dimension is not limited
 // by the register file.  The floating-point evaluation order is part of the library's contract ("blocked
 // nearest plane"); every kernel below follows it bit for bit: v_mfma_f64_16x16x4_f64 is an ascending-k fma chain
-// (profiles/r01_probe_mfma_f64.log), each block's contribution S is accumulated from +0 and subtracted once.
+// (profiles/r01_probe_mfma_f64.log), so a block's contribution t = fma(-z_j, g[j][.], t), j ascending, is one MFMA K loop with T as the accumulator.
 #pragma once
 #include "psf_kernels.hpp"
 
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_np_gram(const int32_t* __restrict__ St,
     }
 }
 
-// bulk panels in MFMA-fragment order (A operand of k_np_gemm<true>): chunk np_panel_base(J) + 4 rb + kc holds
+// bulk panels in MFMA-fragment order (A operand of np_update_tile): chunk np_panel_base(J) + 4 rb + kc holds
 // G[row i = 128 rb + r][k = 64 J + 16 kc + kk] at tr_chunk_pos(r, kk); rows i >= 64 J (the block itself and above) are zero
 __global__ void k_np_pack_panels(const double* __restrict__ Gd, size_t d, size_t nblk, double* __restrict__ Gp) {
   const size_t total = np_panel_base(nblk) * TR_CHUNK;
@@ -97,13 +97,22 @@ __global__ void k_np_pack_panels(const double* __restrict__ Gd, size_t d, size_t
     Gp[g] = (i < J * NP_NB && j < d) ? Gd[j * d + i] : 0.0;
   }
 }
-// in-block triangles: Gin[J][lj][li] = g[64 J + lj][64 J + li] for lj > li, 0 otherwise
+// in-block triangles, packed: Gin[J][l (l - 1) / 2 + li] = g[64 J + l][64 J + li] for li < l  (2016 entries, padded to NP_TRI = 2048)
+constexpr int NP_TRI = 2048;
 __global__ void k_np_pack_inblock(const double* __restrict__ Gd, size_t d, size_t nblk, double* __restrict__ Gin) {
-  const size_t total = nblk * NP_NB * NP_NB;
+  const size_t total = nblk * NP_TRI;
   for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t J = g / (NP_NB * NP_NB), lj = (g / NP_NB) % NP_NB, li = g % NP_NB;
-    const size_t j = J * NP_NB + lj, i = J * NP_NB + li;
-    Gin[g] = (lj > li && j < d) ? Gd[j * d + i] : 0.0;
+    const size_t J = g / NP_TRI, e = g % NP_TRI;
+    double v = 0.0;
+    if (e < (size_t)NP_NB * (NP_NB - 1) / 2) {
+      size_t l = (size_t)((1.0 + sqrt(1.0 + 8.0 * (double)e)) * 0.5);
+      while (l * (l - 1) / 2 > e) --l;
+      while ((l + 1) * l / 2 <= e) ++l;
+      const size_t li = e - l * (l - 1) / 2;
+      const size_t j = J * NP_NB + l, i = J * NP_NB + li;
+      if (j < d) v = Gd[j * d + i];
+    }
+    Gin[g] = v;
   }
 }
 // panel between neighbouring blocks, applied inside the sampler: Gnx[J][k][li] = g[64 (J+1) + k][64 J + li] (contribution of block J+1 to block J)
@@ -181,12 +190,11 @@ __global__ void k_np_solve(const uint64_t* __restrict__ Tt, size_t n, size_t nk1
   }
 }
 
-// T (+)= A B on the FP64 matrix cores: 128 x 128 tile per workgroup, wave tile 64 x 64, K chunks of 16 staged by LDS-DMA exactly
-// as in k_trmm_f64 (both operands are fragment-ordered chunk streams).  SUB = false: T = acc (initial projection);
-// SUB = true: T = T - acc with acc accumulated from +0 (one block's contribution S of the contract).
-template <bool SUB>
-__global__ __launch_bounds__(256, 2) void k_np_gemm(const double* __restrict__ Ach, size_t a_rb_stride, const double* __restrict__ Bch, size_t b_bj_stride,
-                                                    int nk, double* __restrict__ T, size_t ldt, size_t row_hi) {
+// Initial projection T = A B on the FP64 matrix cores: 128 x 128 tile per workgroup, wave tile 64 x 64, K chunks of 16 staged by
+// LDS-DMA exactly as in k_trmm_f64 (both operands are fragment-ordered chunk streams).  The per-block updates of the walk are
+// np_update_tile below.
+__global__ __launch_bounds__(256, 2) void k_np_project(const double* __restrict__ Ach, size_t a_rb_stride, const double* __restrict__ Bch, size_t b_bj_stride,
+                                                       int nk, double* __restrict__ T, size_t ldt) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int bi = blockIdx.y, bj = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -241,10 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_np_gemm(const double* __restrict__ A
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const size_t row = row0 + i * 16 + (lane >> 4) + 4 * r;
-        double* p = T + row * ldt + col0 + j * 16 + (lane & 15);
-        if (SUB) { if (row < row_hi) *p = *p - acc[i][j][r]; }      // rows from row_hi on belong to the sampler (block J-1) or are done
-        else *p = acc[i][j][r];
+        T[(row0 + i * 16 + (lane >> 4) + 4 * r) * ldt + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
       }
 }
 
@@ -264,7 +269,11 @@ __global__ __launch_bounds__(256, 2) void k_np_gemm(const double* __restrict__ A
 // product, and as three balanced base-256 int8 digit planes [i/16][b][16] for the recombination.
 #ifdef NP_PROFILE   /* cycle breakdown of k_np_sample (workgroup 0, wave 0): tools/np_profile.py */
 __device__ long long g_np_prof[8];
+#if NP_PROFILE == 2   /* only the prologue / steps / epilogue split: no stamps inside the step loop */
+#define NP_T(k) do { if ((k) == 0 || (k) == 6) { const long long now_ = (long long)__builtin_readcyclecounter(); tacc_[k] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
 #define NP_T(k) do { const long long now_ = (long long)__builtin_readcyclecounter(); tacc_[k] += now_ - tprev_; tprev_ = now_; } while (0)
+#endif
 #else
 #define NP_T(k) do { } while (0)
 #endif
@@ -285,41 +294,119 @@ struct NpSampleArgs {
 // exact in fp32 (N < 2^24), a = (idx + (lo - c)) / s carries an error below 1e-6, which moves rho by < 1e-4 relative; (float)wb is
 // within 2^-24 relative.  sure means (wb + 1) 2^-sh <= 0.999 rho_f < rho, hence wb < floor(rho 2^sh): no tie, the exact rule accepts.
 // The screen only decides who pays for the exact rule; the accepted attempt and its value are always those of the exact sampler.
+__device__ inline size_t j0_of(size_t J) { return J * NP_NB; }
+
+// Two waves per G preimages.  The HELPER wave runs ahead and produces, for every step and attempt, what does not depend on the
+// centre: the Philox words (once per four steps lane (s, g) computes block g of step l - s; a block serves four narrow or two wide
+// attempts; the words cross a private LDS strip), the candidate index for a non-integral centre, its Lemire test, idx / s' and the
+// scaled acceptance word -- a 16-byte record per (step, attempt) in an LDS ring of two groups of four steps.  The SAMPLER wave
+// owns the dependent chain and nothing else: broadcast t, c' = t / ||b~||^2, ceil, c_rel, one fma + exp2 per lane, two compares,
+// first candidate by s_ff1, z, and the fma that updates the rows below.  The waves meet through two LDS counters (groups produced /
+// consumed); all eight waves of a workgroup are resident by construction, so the spin-waits always make progress.
 template <int G>
-__global__ __launch_bounds__(256) void k_np_sample(NpSampleArgs a, size_t dim, size_t J, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B) {
+__device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned wg, const NpSampleArgs& a, size_t dim, size_t J, uint64_t seed, uint32_t tag,
+                                               uint64_t first_index, size_t B) {
   constexpr int LPD = 64 / G, BPS = LPD / 4;
-  __shared__ __attribute__((aligned(16))) double s_gin[NP_NB * NP_NB];
-  __shared__ NpRow s_row[NP_NB];
-  __shared__ SampleZParams s_sz[NP_NB];
-  __shared__ uint2 s_words[4][256];                               // per wave: (candidate word, acceptance word) of [sg][step of the group][attempt]
+  static_assert(G == 1 || G == 2, "one or two preimages per wave pair");
+  // carved from the launch's dynamic LDS (shared with the update tiles of the same launch): 16 + 2 + 8 + 32 + 4 KiB + counters < 64 KiB
+  double* s_tri = reinterpret_cast<double*>(smem_raw);                                      // in-block triangle, packed, NP_TRI
+  NpRow* s_row = reinterpret_cast<NpRow*>(smem_raw + 16384);                                // NP_NB
+  uint2 (*s_words)[256] = reinterpret_cast<uint2 (*)[256]>(smem_raw + 16384 + 2048);        // helper: (candidate word, acceptance word) of [sg][step][attempt]
+  uint4 (*s_ring)[8 * 64] = reinterpret_cast<uint4 (*)[8 * 64]>(smem_raw + 16384 + 2048 + 8192);         // per pair: records of two groups of four steps
+  double (*s_zs)[128] = reinterpret_cast<double (*)[128]>(smem_raw + 16384 + 2048 + 8192 + 32768);       // sampler: z of the block above, [sg][k]
+  int (*s_cnt)[2] = reinterpret_cast<int (*)[2]>(smem_raw + 16384 + 2048 + 8192 + 32768 + 4096);         // per pair: groups produced, groups consumed
+  const SampleZParams* g_sz = a.sz + j0_of(J);                                              // full SampleZ tables: rare paths only, read from L2
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool helper = wave >= 4;
+  const int pw = helper ? ((wave + 1) & 3) : wave;                  // waves w and w + 4 share a SIMD: a sampler and ITS helper sit on different ones
   const size_t j0 = J * NP_NB;
   const int nrows = (int)(dim - j0 < (size_t)NP_NB ? dim - j0 : (size_t)NP_NB);
 #ifdef NP_PROFILE
   long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev_ = (long long)__builtin_readcyclecounter();
 #endif
-  {  // the in-block triangle goes to LDS by LDS-DMA (eight 1 KiB pieces per wave), the small per-row tables through registers
-    const double* src = a.Gin + J * (NP_NB * NP_NB) + lane * 2;
+  {  // the in-block triangle goes to LDS by LDS-DMA (two 1 KiB pieces per wave), the small per-row tables through registers
+    const double* src = a.Gin + J * NP_TRI + lane * 2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int piece = wave * 8 + i;
-      __builtin_amdgcn_global_load_lds(src + piece * 128, (lds_void_ptr)(s_gin + piece * 128), 16, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave * 2 + i;
+      __builtin_amdgcn_global_load_lds(src + piece * 128, (lds_void_ptr)(s_tri + piece * 128), 16, 0, 0);
     }
     if (tid < NP_NB) {
       s_row[tid] = tid < nrows ? a.rows[j0 + tid] : NpRow{0.0, 0.f, 0, 1, 0, 0, 16};
-      s_sz[tid] = tid < nrows ? a.sz[j0 + tid] : SampleZParams{0, 0, 0, 1, 0, 0, 16};
     }
+    if (tid < 8) s_cnt[tid >> 1][tid & 1] = 0;
   }
   const int lam = lane & (LPD - 1);
   const int sgbase = lane & ~(LPD - 1);
   const int sg = lane / LPD;
-  const size_t b = ((size_t)blockIdx.x * 4 + (size_t)wave) * G + (size_t)sg;
+  const size_t b = ((size_t)wg * 4 + (size_t)pw) * G + (size_t)sg;
   const bool live = b < B;
   const uint64_t index = first_index + b;
   const uint32_t tw = tag_word(tag, index);
   const uint64_t sgmask = G == 1 ? ~0ull : (((1ull << LPD) - 1) << sgbase);
+  int* cnt_prod = &s_cnt[pw][0];
+  int* cnt_cons = &s_cnt[pw][1];
+  uint4* ring = &s_ring[pw][0];
+
+  if (helper) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint2* wstrip = &s_words[pw][0];
+    int k = 0;
+#pragma unroll
+    for (int slot = G - 1; slot >= 0; --slot) {
+      for (int grp = BPS - 1; grp >= 0; --grp) {                    // four steps slot * LPD + 4 grp + 3 .. + 0
+        const int lbase = slot * LPD + grp * 4;
+        if (lbase >= nrows) continue;                               // short top block (uniform; the sampler skips the same groups)
+        while (__hip_atomic_load(cnt_cons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k - 1) __builtin_amdgcn_s_sleep(1);
+        {  // attempt words of the four steps, first LPD attempts each: lane (s, g) serves step lbase + 3 - s.
+           // narrow rows: Philox block g holds attempts 4g .. 4g+3; wide rows: blocks g and g + BPS hold attempts 2g, 2g+1 and 2(g+BPS), 2(g+BPS)+1
+          const int s = lam / BPS, g = lam % BPS;
+          const int lstep = lbase + 3 - s;
+          const uint32_t shs = s_row[lstep].sh;
+          const uint32_t coord_s = (uint32_t)(j0 + lstep);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous group's reads of the strip are done
+          uint2* dst = wstrip + (sg * 4 + s) * LPD;
+          const U4 w = philox(seed, coord_s, (uint32_t)index, (uint32_t)g, tw);
+          if (shs != 32) {
+            uint4* d4p = reinterpret_cast<uint4*>(dst + 4 * g);
+            d4p[0] = make_uint4(w.x >> 16, w.x & 0xffffu, w.y >> 16, w.y & 0xffffu);
+            d4p[1] = make_uint4(w.z >> 16, w.z & 0xffffu, w.w >> 16, w.w & 0xffffu);
+          } else {
+            *reinterpret_cast<uint4*>(dst + 2 * g) = make_uint4(w.x, w.y, w.z, w.w);
+          }
+          if (__ballot(shs == 32)) {
+            const U4 w2 = philox(seed, coord_s, (uint32_t)index, (uint32_t)(g + BPS), tw);
+            if (shs == 32) *reinterpret_cast<uint4*>(dst + 2 * (g + BPS)) = make_uint4(w2.x, w2.y, w2.z, w2.w);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+          const int l = lbase + 3 - sp;
+          const NpRow rw = s_row[l];
+          const uint2 wd = wstrip[(sg * 4 + sp) * LPD + lam];
+          const bool narrow = rw.sh == 16;
+          const uint32_t Nf = rw.n_int - 1u;                        // candidates for a non-integral centre (the generic case)
+          uint32_t low, idx;
+          if (narrow) { const uint32_t prod = __umul24(wd.x, Nf); low = prod & 0xffffu; idx = prod >> 16; }
+          else { low = wd.x * Nf; idx = __umulhi(wd.x, Nf); }
+          const float u = (float)idx * rw.inv_sk;
+          const float wbf = (float)wd.y * (narrow ? 0x1.0p-16f : 0x1.0p-32f);
+          const bool okidx = live && low >= rw.thr_frac;            // Lemire's rejection of the lowest fractions
+          ring[((k & 1) * 4 + sp) * 64 + lane] = make_uint4(__float_as_uint(u), __float_as_uint(wbf), (idx & 0x7fffffffu) | (okidx ? 0x80000000u : 0u), wd.y);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        ++k;
+        if (lane == 0) __hip_atomic_store(cnt_prod, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    return;
+  }
+
+  // ---- sampler wave ------------------------------------------------------------------------------------------------------
   double t[G];
   long long zr[G];
 #pragma unroll
@@ -329,38 +416,31 @@ __global__ __launch_bounds__(256) void k_np_sample(NpSampleArgs a, size_t dim, s
     zr[s] = 0;
   }
   int f = 0;
-  uint2* wstrip = &s_words[wave][0];
   if (j0 + NP_NB < dim) {
-    // the block above was sampled by the previous launch: its contribution S to my rows, S = chain_k fma(z_k, g[64 (J+1) + k][row], .)
-    // from +0, is subtracted here (the bulk update on the other stream stops below this block); g read straight from L2
-    double* zs = reinterpret_cast<double*>(wstrip);               // 256 doubles per wave: [sg][k]
+    // the block above was sampled by the previous launch: its contribution to my rows, t = fma(-z_k, g[64 (J+1) + k][row], t) for k
+    // ascending, is applied here (the update tiles stop below this block); g read straight from L2
+    double* zs = &s_zs[pw][0];
 #pragma unroll
     for (int s = 0; s < G; ++s) {
-      const int k = s * LPD + lam;
-      const size_t i = j0 + NP_NB + (size_t)k;
-      zs[sg * NP_NB + k] = (live && i < dim) ? a.Zf[((b / TR_BN) * a.nkb + i / 16) * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(i % 16))] : 0.0;
+      const int kk = s * LPD + lam;
+      const size_t i = j0 + NP_NB + (size_t)kk;
+      zs[sg * NP_NB + kk] = (live && i < dim) ? a.Zf[((b / TR_BN) * a.nkb + i / 16) * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(i % 16))] : 0.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const double* gn = a.Gnx + J * (NP_NB * NP_NB) + lam;
-    double S[G];
+    for (int k0 = 0; k0 < NP_NB; k0 += 8) {
+      double zk[8], gk[8][G];
 #pragma unroll
-    for (int s = 0; s < G; ++s) S[s] = 0.0;
-    for (int k0 = 0; k0 < NP_NB; k0 += 16) {
-      double zk[16], gk[16][G];
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
+      for (int kk = 0; kk < 8; ++kk) {
         zk[kk] = zs[sg * NP_NB + k0 + kk];
 #pragma unroll
         for (int s = 0; s < G; ++s) gk[kk][s] = gn[(k0 + kk) * NP_NB + s * LPD];
       }
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk)
+      for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-        for (int s = 0; s < G; ++s) S[s] = fma(zk[kk], gk[kk][s], S[s]);
+        for (int s = 0; s < G; ++s) t[s] = fma(-zk[kk], gk[kk][s], t[s]);
     }
-#pragma unroll
-    for (int s = 0; s < G; ++s) t[s] = t[s] - S[s];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -369,53 +449,36 @@ __global__ __launch_bounds__(256) void k_np_sample(NpSampleArgs a, size_t dim, s
     if (G == 1) return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_in_sg), __builtin_amdgcn_readlane(__double2loint(v), src_in_sg));
     return __shfl(v, sgbase + src_in_sg);
   };
+  auto tri_at = [&](int l, int col) -> double { return col < l ? s_tri[l * (l - 1) / 2 + col] : 0.0; };
+  int k = 0;
 #pragma unroll
   for (int slot = G - 1; slot >= 0; --slot) {
-    for (int grp = BPS - 1; grp >= 0; --grp) {                    // four steps slot * LPD + 4 grp + 3 .. + 0
+    for (int grp = BPS - 1; grp >= 0; --grp) {
       const int lbase = slot * LPD + grp * 4;
-      if (lbase >= nrows) continue;                               // short top block (uniform)
-      {  // attempt words of the four steps, first LPD attempts each: lane (s, g) serves step lbase + 3 - s.
-         // narrow rows: Philox block g holds attempts 4g .. 4g+3; wide rows: blocks g and g + BPS hold attempts 2g, 2g+1 and 2(g+BPS), 2(g+BPS)+1
-        const int s = lam / BPS, g = lam % BPS;
-        const int lstep = lbase + 3 - s;
-        const uint32_t shs = s_row[lstep].sh;
-        const uint32_t coord_s = (uint32_t)(j0 + lstep);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous group's reads are done
-        uint2* dst = wstrip + (sg * 4 + s) * LPD;
-        const U4 w = philox(seed, coord_s, (uint32_t)index, (uint32_t)g, tw);
-        if (shs != 32) {
-          uint4* d4p = reinterpret_cast<uint4*>(dst + 4 * g);
-          d4p[0] = make_uint4(w.x >> 16, w.x & 0xffffu, w.y >> 16, w.y & 0xffffu);
-          d4p[1] = make_uint4(w.z >> 16, w.z & 0xffffu, w.w >> 16, w.w & 0xffffu);
-        } else {
-          *reinterpret_cast<uint4*>(dst + 2 * g) = make_uint4(w.x, w.y, w.z, w.w);
-        }
-        if (__ballot(shs == 32)) {
-          const U4 w2 = philox(seed, coord_s, (uint32_t)index, (uint32_t)(g + BPS), tw);
-          if (shs == 32) *reinterpret_cast<uint4*>(dst + 2 * (g + BPS)) = make_uint4(w2.x, w2.y, w2.z, w2.w);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      }
+      if (lbase >= nrows) continue;
+      while (__hip_atomic_load(cnt_prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       NP_T(1);
+      const uint4* rslot = ring + (k & 1) * 4 * 64 + lane;
       // operands of the first step of the group; those of the following steps are fetched one step ahead
       NpRow rw = s_row[lbase + 3];
       double gl[G];
 #pragma unroll
-      for (int s2 = 0; s2 <= slot; ++s2) gl[s2] = s_gin[(lbase + 3) * NP_NB + s2 * LPD + lam];
-      uint2 wd = wstrip[(sg * 4 + 0) * LPD + lam];
+      for (int s2 = 0; s2 <= slot; ++s2) gl[s2] = tri_at(lbase + 3, s2 * LPD + lam);
+      uint4 rec = rslot[0];
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp) {
         const int l = lbase + 3 - sp;
         NpRow rwn = rw;
         double gln[G];
-        uint2 wdn = wd;
+        uint4 recn = rec;
 #pragma unroll
         for (int s2 = 0; s2 <= slot; ++s2) gln[s2] = gl[s2];
         if (sp < 3) {
           rwn = s_row[l - 1];
 #pragma unroll
-          for (int s2 = 0; s2 <= slot; ++s2) gln[s2] = s_gin[(l - 1) * NP_NB + s2 * LPD + lam];
-          wdn = wstrip[(sg * 4 + sp + 1) * LPD + lam];
+          for (int s2 = 0; s2 <= slot; ++s2) gln[s2] = tri_at(l - 1, s2 * LPD + lam);
+          recn = rslot[(sp + 1) * 64];
         }
         if (l < nrows) {
           const int ls = l - slot * LPD;
@@ -426,16 +489,11 @@ __global__ __launch_bounds__(256) void k_np_sample(NpSampleArgs a, size_t dim, s
           bool got = !live;
           uint32_t t0 = 0;
           NP_T(2);
-          // --- the part of the screen that does not depend on the centre (issued before the centre is known) ----------
           const bool narrow = rw.sh == 16;
-          const uint32_t Nf = rw.n_int - 1u;                        // candidates for a non-integral centre (the generic case)
-          uint32_t low, idx;
-          if (narrow) { const uint32_t prod = __umul24(wd.x, Nf); low = prod & 0xffffu; idx = prod >> 16; }
-          else { low = wd.x * Nf; idx = __umulhi(wd.x, Nf); }
-          const float u = (float)idx * rw.inv_sk;
-          const float wbf = (float)wd.y * (narrow ? 0x1.0p-16f : 0x1.0p-32f);
+          const float u = __uint_as_float(rec.x), wbf = __uint_as_float(rec.y);
+          const uint32_t idx = rec.z & 0x7fffffffu;
+          const bool okidx = (rec.z >> 31) != 0;
           const float wbe = wbf + (narrow ? 0x1.0p-16f : 1e-7f);
-          const bool okidx = live && low >= rw.thr_frac;            // Lemire's rejection of the lowest fractions
           // --- the dependent chain ----------------------------------------------------------------------------------
           const double cc = ceil(cen);
           const float c_rel = (float)(cc - cen) - (float)rw.c6;     // lo - c with lo = ceil(c) - ceil(6 s')
@@ -475,7 +533,7 @@ __global__ __launch_bounds__(256) void k_np_sample(NpSampleArgs a, size_t dim, s
               if (pending && !sure && lane == fl) {               // keep every bit of the exact decision (incl. its tie-break Philox block) inside the branch
                 uint32_t ta = (uint32_t)lam;
                 asm volatile("" : "+v"(ta));
-                acc = sz_decide(seed, coord, (uint32_t)index, tw, ta, (long long)lo + (long long)idx, wd.y, cen, s_sz[l].inv_s, rw.sh);
+                acc = sz_decide(seed, coord, (uint32_t)index, tw, ta, (long long)lo + (long long)idx, rec.w, cen, g_sz[l].inv_s, rw.sh);
               }
               const uint64_t accm = __ballot(acc);
               const int xi = __shfl((int)idx, fl);
@@ -488,7 +546,7 @@ __global__ __launch_bounds__(256) void k_np_sample(NpSampleArgs a, size_t dim, s
           }
           NP_T(4);
           if (__ballot(!got)) {                                      // generic rounds: attempts t0 + lam, t0 + LPD + lam, ...
-            const SampleZParams sp2 = s_sz[l];
+            const SampleZParams sp2 = g_sz[l];
             const SzRange rg = sz_range(cen, sp2);
             for (; t0 < kMaxAttempts; t0 += LPD) {
               if (!__ballot(!got)) break;
@@ -527,10 +585,13 @@ __global__ __launch_bounds__(256) void k_np_sample(NpSampleArgs a, size_t dim, s
           for (int s2 = 0; s2 <= slot; ++s2) t[s2] = fma(nz, gl[s2], t[s2]);
           NP_T(5);
         }
-        rw = rwn; wd = wdn;
+        rw = rwn; rec = recn;
 #pragma unroll
         for (int s2 = 0; s2 <= slot; ++s2) gl[s2] = gln[s2];
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // my reads of this group's ring slots are complete
+      ++k;
+      if (lane == 0) __hip_atomic_store(cnt_cons, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   int use1 = 0, use2 = 0, big = 0;
@@ -563,8 +624,109 @@ __global__ __launch_bounds__(256) void k_np_sample(NpSampleArgs a, size_t dim, s
   if (big) atomicOr(a.flags + 3, 1);
 #ifdef NP_PROFILE
   NP_T(6);
-  if (blockIdx.x == 0 && tid == 0) for (int k = 0; k < 7; ++k) atomicAdd((unsigned long long*)&g_np_prof[k], (unsigned long long)tacc_[k]);
+  if (wg == 0 && tid == 0) for (int kk = 0; kk < 7; ++kk) atomicAdd((unsigned long long*)&g_np_prof[kk], (unsigned long long)tacc_[kk]);
+  if (lane == 0) {      // spread over the sampler waves of the launch: slowest wave, accumulated over the launches of the call
+    long long tot = 0;
+    for (int kk = 0; kk < 7; ++kk) tot += tacc_[kk];
+    atomicMax((unsigned long long*)&g_np_prof[7], (unsigned long long)tot);
+  }
 #endif
+}
+
+// One update tile of a launch: T[rows, 128 preimages] takes the blocks J_first, J_first - 1, ... (`nsub` of them, in this order), each as
+// the contract's chain t = fma(-z_j, g[j][row], t) over its 64 rows j ascending -- exactly a v_mfma_f64_16x16x4_f64 K loop with the T tile
+// as the accumulator and -g as the A operand.  The tile is loaded once, stays in the accumulator registers across all the blocks of
+// the job and is stored once: the far rows of the walk cross HBM once per panel of NP_PANEL blocks instead of once per block.
+// Rows outside [row_lo, row_hi) belong to somebody else (the sampler, another job) and are not written.
+constexpr int NP_PANEL = 8;
+struct NpUpdateJob { int J_first, nsub; int rb0, nrb; size_t row_lo, row_hi; };
+
+__device__ __forceinline__ void np_update_tile(double* smem, unsigned tile, const NpUpdateJob& job, int nbj, const double* __restrict__ Gp, const double* __restrict__ Zf,
+                                               size_t nkb, double* __restrict__ T, size_t ldt) {
+  // 128 x 128 tile, eight waves as 4 x 2, wave tile 32 x 64 (64 accumulator VGPRs: the launch must keep four waves per SIMD so that
+  // sampler and update workgroups share the CUs)
+  const int bj = (int)(tile % (unsigned)nbj), bi = job.rb0 + (int)(tile / (unsigned)nbj);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const size_t row0 = (size_t)bi * TR_BM + wr * 32, col0 = (size_t)bj * TR_BN + wc * 64;
+  d4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = T[(row0 + i * 16 + (lane >> 4) + 4 * r) * ldt + col0 + j * 16 + (lane & 15)];
+  const int nk = 4 * job.nsub;                                   // K chunks of 16 over all the blocks of the job
+  auto stage_load = [&](int kc, int buf) {
+    const size_t Jb = (size_t)(job.J_first - (kc >> 2));
+    const double* ga = Gp + (np_panel_base(Jb) + (size_t)bi * 4 + (size_t)(kc & 3)) * TR_CHUNK + lane * 2;
+    const double* gb = Zf + ((size_t)bj * nkb + Jb * (NP_NB / 16) + (size_t)(kc & 3)) * TR_CHUNK + lane * 2;
+    double* la = smem + buf * (2 * TR_CHUNK);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave * 2 + i;                            // sixteen 1 KiB pieces per chunk
+      __builtin_amdgcn_global_load_lds(ga + piece * 128, (lds_void_ptr)(la + piece * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gb + piece * 128, (lds_void_ptr)(la + TR_CHUNK + piece * 128), 16, 0, 0);
+    }
+  };
+  stage_load(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nk) stage_load(kc + 1, cur ^ 1);
+    const double* sA = smem + cur * (2 * TR_CHUNK);
+    const double* sB = sA + TR_CHUNK;
+#pragma unroll
+    for (int ks = 0; ks < TR_BK / 4; ++ks) {
+      double av[2], bv[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = -sA[(ks * 8 + wr * 2 + i) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bv[i] = sB[(ks * 8 + wc * 4 + i) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = row0 + i * 16 + (lane >> 4) + 4 * r;
+        if (row >= job.row_lo && row < job.row_hi) T[row * ldt + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
+      }
+}
+
+// One launch per block J of the walk (512 threads per workgroup, 64 KiB of dynamic LDS):
+//   workgroups [0, nS)   sample block J (np_sample_body): the critical path
+//   then the update tiles of up to three jobs, which hide behind the sampling:
+//     window  block J + 1, sampled by the previous launch, goes into the rows from the start of the panel below its own down to
+//             (not including) block J, which takes it inside the sampler
+//     far A   once per panel, in the launch of the first block of the panel below: all blocks of the completed panel go into the rows
+//             of the panel after next (the rows the coming window updates will touch, so they must be served first)
+//     far B   in the same launch, the same blocks into all rows further down (needed one panel later)
+// so no second stream, no events, and the far rows of T are touched once per panel instead of once per block.
+struct NpStepJobs { NpUpdateJob job[3]; unsigned ntiles[3]; };
+
+template <int G>
+__global__ __launch_bounds__(512, 4) void k_np_step(NpSampleArgs a, size_t dim, size_t J, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, unsigned nS,
+                                                    NpStepJobs jobs, int nbj, const double* __restrict__ Gp, double* __restrict__ Tm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char np_smem[];
+  unsigned id = blockIdx.x;
+  if (id < nS) { np_sample_body<G>(np_smem, id, a, dim, J, seed, tag, first_index, B); return; }
+  id -= nS;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (id < jobs.ntiles[q]) { np_update_tile(reinterpret_cast<double*>(np_smem), id, jobs.job[q], nbj, Gp, a.Zf, a.nkb, Tm, a.ldt); return; }
+    id -= jobs.ntiles[q];
+  }
 }
 
 // E[b][j] (+)= scale * sum_i Z8[i][b] B8[j][i] on the int8 matrix cores (v_mfma_i32_16x16x64_i8): Z as the A operand (rows = preimages),

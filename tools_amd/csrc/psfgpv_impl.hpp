@@ -15,9 +15,8 @@ struct psfgpv_handle {
   // blocked nearest plane (psf_np_kernels.hpp): per key
   size_t nblk = 0, dpad = 0, nrb = 0, nkc = 0, nkb = 0;   // 64-row blocks; dim padded to 128; 128-row blocks; K chunks of the pivots; K chunks of dim
   double* dGp = nullptr;              // bulk panels g[< 64 J][block J], fragment order
-  double* dGin = nullptr;             // in-block triangles, nblk x 64 x 64
+  double* dGin = nullptr;             // in-block triangles, packed, nblk x NP_TRI
   double* dGnx = nullptr;             // panels between neighbouring blocks, nblk x 64 x 64
-  std::vector<hipEvent_t> evS, evB;   // per block: sampled / bulk update done (look-ahead over two streams)
   NpRow* dRows = nullptr;             // per-row constants of the sampler's fast path (1 / ||b~_i||^2, SampleZ tables)
   double* dBpiv = nullptr;            // b~_i on the pivot columns, fragment order
   int8_t* dB8 = nullptr;              // two digit planes of the basis, transposed, dpad x dpad each
@@ -31,7 +30,6 @@ struct psfgpv_handle {
   uint64_t* dSol = nullptr;           // n x ld
   int* dFlags = nullptr;              // [0] sampler failure [1] second digit of some z in use [2] third digit [3] |z| beyond three digits
   int np_g = 0;                       // PSF_NP_G: preimages per wave of the sampler (0 = by batch size)
-  bool one_stream = false;            // PSF_NP_ONE_STREAM=1: bulk updates in line on the caller's stream (counter collection, debugging)
   bool has_key = false;
   bool timing = false;
   bool last_generic = false;
@@ -83,7 +81,7 @@ static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
     hipLaunchKernelGGL(k_np_gram, dim3(tiles, tiles), dim3(256), 0, 0, g->dSt, g->dGt, d, dGd);
     if (np_panel_base(g->nblk))
       hipLaunchKernelGGL(k_np_pack_panels, dim3(grid_for(np_panel_base(g->nblk) * TR_CHUNK, 256, 256 * 64)), dim3(256), 0, 0, dGd, d, g->nblk, g->dGp);
-    hipLaunchKernelGGL(k_np_pack_inblock, dim3(grid_for(g->nblk * NP_NB * NP_NB)), dim3(256), 0, 0, dGd, d, g->nblk, g->dGin);
+    hipLaunchKernelGGL(k_np_pack_inblock, dim3(grid_for(g->nblk * NP_TRI)), dim3(256), 0, 0, dGd, d, g->nblk, g->dGin);
     hipLaunchKernelGGL(k_np_pack_next, dim3(grid_for(g->nblk * NP_NB * NP_NB)), dim3(256), 0, 0, dGd, d, g->nblk, g->dGnx);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -150,42 +148,46 @@ static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
   return PSF_OK;
 }
 
-template <int G>
-static void launch_np_sample(psfgpv_handle* g, hipStream_t st, const NpSampleArgs& a, size_t J, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B) {
-  const size_t per_wg = 4 * G;
-  hipLaunchKernelGGL((k_np_sample<G>), dim3((unsigned)((B + per_wg - 1) / per_wg)), dim3(256), 0, st, a, g->dim, J, seed, tag, first_index, B);
-}
-
-// MatZ::sample_d_precomputed_gso for the whole batch (gpv.rs:160): the launch sequence of psf_np_kernels.hpp
+// MatZ::sample_d_precomputed_gso for the whole batch (gpv.rs:160): the launch sequence of psf_np_kernels.hpp, one stream
 static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e) {
   const size_t ld = g->ld, nbj = round_up(B, TR_BN) / TR_BN;
   const size_t lds_gemm = 4 * TR_CHUNK * sizeof(double);
-  hipStream_t aux = g->one_stream ? st : g->base->aux;   // bulk updates; the caller's stream carries the samplers (the critical path)
   // T = B~[:, pivots] C0[pivots]
-  hipLaunchKernelGGL((k_np_gemm<false>), dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, g->dC0p, g->nkc, (int)g->nkc, g->dTm, ld, (size_t)0);
+  hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, g->dC0p, g->nkc, (int)g->nkc, g->dTm, ld);
   int G = g->np_g;
-  if (G != 1 && G != 2 && G != 4) G = B <= 1536 ? 1 : 2;      // one or two waves per SIMD of the chip (1024 SIMDs)
+  if (G != 1 && G != 2) G = B <= 1536 ? 1 : 2;      // one or two wave pairs per SIMD of the chip (1024 SIMDs)
   NpSampleArgs a{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, g->dFlags};
+  const unsigned nS = (unsigned)((B + 4 * (size_t)G - 1) / (4 * (size_t)G));
+  const size_t W = NP_PANEL;
   for (size_t J = g->nblk; J-- > 0;) {
-    // block J needs the bulk updates of every block >= J + 2 (block J + 1 is applied by the sampler itself)
-    if (J + 2 < g->nblk && !g->one_stream) HIP_TRY(hipStreamWaitEvent(st, g->evB[J + 2], 0));
-    switch (G) {
-      case 1: launch_np_sample<1>(g, st, a, J, seed, tag, first_index, B); break;
-      case 2: launch_np_sample<2>(g, st, a, J, seed, tag, first_index, B); break;
-      default: launch_np_sample<4>(g, st, a, J, seed, tag, first_index, B); break;
+    NpStepJobs jobs;
+    for (int q = 0; q < 3; ++q) { jobs.job[q] = NpUpdateJob{0, 0, 0, 0, 0, 0}; jobs.ntiles[q] = 0; }
+    auto set_job = [&](int q, size_t J_first, size_t nsub, size_t rb0, size_t rb1, size_t lo, size_t hi) {
+      if (rb1 <= rb0 || hi <= lo) return;
+      jobs.job[q] = NpUpdateJob{(int)J_first, (int)nsub, (int)rb0, (int)(rb1 - rb0), lo, hi};
+      jobs.ntiles[q] = (unsigned)((rb1 - rb0) * nbj);
+    };
+    // window: block J + 1 into the rows from the start of the panel below its own up to block J (whose rows the sampler updates itself)
+    if (J + 1 < g->nblk) {
+      const size_t P = (J + 1) / W;
+      const size_t lo = P >= 1 ? (P - 1) * W * NP_NB : 0, hi = J * NP_NB;
+      set_job(0, J + 1, 1, lo / 128, (hi + 127) / 128, lo, hi);
     }
-    if (J < 2) continue;
-    // T[< 64 (J-1)] -= G[., J] Z_J on the second stream
-    if (!g->one_stream) {
-      HIP_TRY(hipEventRecord(g->evS[J], st));
-      HIP_TRY(hipStreamWaitEvent(aux, g->evS[J], 0));
+    // far: block J belongs to panel Pj; the panel above it, Pj + 1, is complete
+    const size_t Pj = J / W, P = Pj + 1;
+    if (P * W < g->nblk && P >= 2) {
+      const size_t top = std::min(g->nblk, (P + 1) * W) - 1, nsub = top - P * W + 1;
+      const size_t near_lo = (P - 2) * W * NP_NB, near_hi = (P - 1) * W * NP_NB;      // rows of panel P - 2
+      const size_t i = (P * W - 1) - J;                                               // 0 .. W-1: position of this launch inside panel P - 1
+      if (i == 0) set_job(1, top, nsub, near_lo / 128, near_hi / 128, near_lo, near_hi);
+      // the rows further down only need it before panel P - 2 starts; measured on MI355X: spreading these tiles over the launches of the panel
+      // stretches every one of them (a tile's K loop over the whole panel is latency bound), so they all ride in the first launch as well
+      if (i == 0) set_job(2, top, nsub, 0, near_lo / 128, 0, near_lo);
     }
-    const size_t row_hi = (J - 1) * NP_NB;
-    hipLaunchKernelGGL((k_np_gemm<true>), dim3((unsigned)nbj, (unsigned)((row_hi + 127) / 128)), dim3(256), lds_gemm, aux, g->dGp + np_panel_base(J) * TR_CHUNK, (size_t)4,
-                       g->dZf + (J * NP_NB / 16) * TR_CHUNK, g->nkb, 4, g->dTm, ld, row_hi);
-    if (!g->one_stream) HIP_TRY(hipEventRecord(g->evB[J], aux));
+    const unsigned ntot = nS + jobs.ntiles[0] + jobs.ntiles[1] + jobs.ntiles[2];
+    if (G == 1) hipLaunchKernelGGL((k_np_step<1>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, g->dTm);
+    else hipLaunchKernelGGL((k_np_step<2>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, g->dTm);
   }
-  if (g->nblk > 2 && !g->one_stream) HIP_TRY(hipStreamWaitEvent(st, g->evB[2], 0));   // the caller's stream is ordered after everything this call enqueued
   // e = sum_i z_i b_i + sol
   const psfp_handle* b = g->base;
   const dim3 cgrid((unsigned)((B + 127) / 128), (unsigned)(g->dpad / 128));
@@ -252,20 +254,17 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipMalloc(&g->dT, g->n * g->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&g->dPiv, g->n * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&g->dGp, (np_panel_base(g->nblk) + 1) * TR_CHUNK * sizeof(double)));
-  HIP_TRY(hipMalloc(&g->dGin, g->nblk * NP_NB * NP_NB * sizeof(double)));
+  HIP_TRY(hipMalloc(&g->dGin, g->nblk * NP_TRI * sizeof(double)));
   HIP_TRY(hipMalloc(&g->dGnx, g->nblk * NP_NB * NP_NB * sizeof(double)));
-  g->evS.assign(g->nblk, nullptr); g->evB.assign(g->nblk, nullptr);
-  for (auto& e : g->evS) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto& e : g->evB) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_TRY(hipMalloc(&g->dRows, g->nblk * NP_NB * sizeof(NpRow)));
   HIP_TRY(hipMalloc(&g->dBpiv, g->nrb * g->nkc * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipMalloc(&g->dB8, 2 * g->dpad * g->dpad));
   HIP_TRY(hipMalloc(&g->dFlags, 4 * sizeof(int)));
   HIP_TRY(hipMemset(g->dFlags, 0, 4 * sizeof(int)));
   { const char* ev = getenv("PSF_NP_G"); g->np_g = ev ? atoi(ev) : 0; }
-  { const char* ev = getenv("PSF_NP_ONE_STREAM"); g->one_stream = ev && ev[0] == '1'; }
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_gemm<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_gemm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_project), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
@@ -277,9 +276,7 @@ void psfgpv_destroy(psfgpv_handle* g) {
   hipSetDevice(g->base->prm.device);
   free_np_batch(g);
   hipFree(g->dSt); hipFree(g->dGt); hipFree(g->dNorm2); hipFree(g->dSz); hipFree(g->dT); hipFree(g->dPiv);
-  hipFree(g->dGp); hipFree(g->dGin); hipFree(g->dGnx);
-  for (auto& e : g->evS) if (e) hipEventDestroy(e);
-  for (auto& e : g->evB) if (e) hipEventDestroy(e); hipFree(g->dRows); hipFree(g->dBpiv); hipFree(g->dB8); hipFree(g->dFlags);
+  hipFree(g->dGp); hipFree(g->dGin); hipFree(g->dGnx); hipFree(g->dRows); hipFree(g->dBpiv); hipFree(g->dB8); hipFree(g->dFlags);
   for (auto& e : g->ev) if (e) hipEventDestroy(e);
   psfp_destroy(g->base);
   delete g;
