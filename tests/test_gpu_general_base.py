@@ -57,9 +57,9 @@ def test_documented_limits_are_reported_not_crashed():
     import tools_amd as T
     from tools_amd import _ffi
     GP = T.GadgetParameters
-    # lattice dimension of PSFGPV above 8192
+    # a Gaussian so wide that an in-domain coordinate would not fit the three int8 digits of the Z_q products (s r sqrt(m) >= 2^23)
     with pytest.raises(T.PsfError) as ei:
-        T.PSFGPV(GP.init_default(512, 2**30), 100.0)              # m = 30801
+        T.PSFPerturbation(GP.init_default(8, 64), 1000.0, 1000.0)
     assert ei.value.status == _ffi.ERR_UNSUPPORTED
     # more than 64 gadget digits
     with pytest.raises(T.PsfError) as ei:
