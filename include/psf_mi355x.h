@@ -88,6 +88,24 @@ psf_status psf_short_basis_gadget(const psf_gadget_params* gp, int64_t* out);
 psf_status psf_gen_short_basis_for_trapdoor(const psf_gadget_params* gp, const uint64_t* tag /*n x n*/,
                                             const uint64_t* A /*n x m*/, const int8_t* R /*m_bar x nk*/,
                                             int64_t* out);
+/* gen_trapdoor (gadget_classical.rs:56-68) for a caller-supplied A_bar (n x m_bar) and tag H (n x n, NULL = identity, :61-66):
+ * R <- PlusMinusOneZero (trapdoor_distribution.rs:82-86) from `seed`, A = [A_bar | H G - A_bar R] computed on the device.
+ * PSF_ERR_MODULUS if base^k < q. */
+psf_status psf_gen_trapdoor(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const uint64_t* tag, uint64_t seed,
+                            uint64_t* A /*n x m*/, int8_t* R /*m_bar x nk*/);
+/* gen_trapdoor_ring_lwe (gadget_ring.rs:62-81): r, e <- SampleZ(s) from `seed`, a = [1 | a_bar | g^t - (a_bar r + e)] in R_q
+ * (gp from psf_gadget_params_ring_default; q < 2^31).  a_bar: n coefficients; a: (k+2) x n; r, e: k x n */
+psf_status psf_gen_trapdoor_ring_lwe(int device, const psf_gadget_params* gp, const uint64_t* a_bar, double s, uint64_t seed,
+                                     uint64_t* a, int64_t* r, int64_t* e);
+/* gen_gadget_ring (gadget_ring.rs:103-109): the k constant polynomials base^j, out[j] = constant term */
+psf_status psf_gen_gadget_ring(uint64_t k, uint64_t base, int64_t* out);
+/* find_solution_gadget_ring (gadget_ring.rs:145-166): u (n coefficients of an element of R_q) -> out[k x n], polynomial i = i-th digit
+ * of every coefficient (index i + j k of the classical solution, :160) */
+psf_status psf_find_solution_gadget_ring(int device, const uint64_t* u, size_t n, uint64_t q, uint64_t k, uint64_t base, int64_t* out);
+/* gen_short_basis_for_trapdoor_ring (short_basis_ring.rs:64-79): out[(row * n(k+2) + col) * n + coeff], (k+2) x n(k+2) polynomials */
+psf_status psf_gen_short_basis_for_trapdoor_ring(const psf_gadget_params* gp, const uint64_t* a, const int64_t* r, const int64_t* e, int64_t* out);
+/* contiguous shares of `total` rows over `world` workers; the first total % world workers get one row more */
+psf_status psf_shard_range(size_t total, int world, int rank, size_t* first, size_t* count);
 /* PolynomialRingZq product in R_q = Z_q[X]/(X^n + 1) (common_moduli.rs:41-48), the arithmetic under the MatPolynomialRingZq
  * products at gadget_ring.rs:78 and gpv_ring.rs:245-246: out[c] = a[c] * b[c] mod (X^n + 1, q) for `count` pairs of n
  * coefficients (constant term first); a as residues, b as signed integers (a MatPolyOverZ entry).  Runs on the device. */
@@ -153,6 +171,11 @@ psf_status psfp_samp_p(psfp_handle*, uint64_t seed, uint64_t first_index, size_t
 psf_status psfp_f_a(psfp_handle*, size_t B, const int64_t* e, uint64_t* u);
 /* PSF::check_domain (mp_perturbation.rs:396-402) for rows of length `len`; ok[b] = 0/1 */
 psf_status psfp_check_domain(psfp_handle*, size_t B, const int64_t* e, size_t len, uint8_t* ok);
+
+/* One job over `count` handles, one per GPU of the node, each holding the same key (psfp_trap_gen with the same seed, or psfp_load_key):
+ * the B rows are cut into contiguous shares (psf_shard_range), share i is computed by handles[i] on its own device, all devices at once.
+ * Row b uses global index first_index + b, so the result equals psfp_samp_p on one handle bit for bit.  Host buffers. */
+psf_status psfp_samp_p_multi(psfp_handle* const* handles, int count, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
 
 /* device-resident variants: d_u, d_e are HIP device pointers, stream is a hipStream_t (NULL = default).
  * Asynchronous with respect to the host; errors detected on device are reported by psfp_last_status. */

@@ -89,3 +89,18 @@ def test_product_never_imports_oracle():
         if os.path.isfile(path) and path.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
             txt = open(path).read()
             assert "psf_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, path
+
+
+def test_shard_range_partitions_the_rows():
+    """psf_shard_range (the split psfp_samp_p_multi uses): contiguous, complete, at most one row apart; equals tools_amd.shard.split_rows."""
+    from tools_amd import gadget
+    from tools_amd.shard import split_rows
+    for total in (0, 1, 7, 64, 65536, 4097):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for rank in range(world):
+                first, count = gadget.shard_range(total, world, rank)
+                assert first == nxt and (first, count) == split_rows(total, rank, world)
+                assert count in (total // world, total // world + 1)
+                nxt = first + count
+            assert nxt == total

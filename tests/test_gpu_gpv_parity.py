@@ -148,7 +148,7 @@ def test_recombination_in_64_bit_integers_when_the_digit_planes_do_not_fit(T, or
     assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
 
 
-@pytest.mark.parametrize("n,q", [(32, 256), (64, 256), (128, 2**15), (256, 2**15), (300, 2**15)])
+@pytest.mark.parametrize("n,q", [(32, 256), (64, 256), (128, 2**15), (300, 2**15)])
 def test_samp_p_parity_across_block_counts(T, oracle, n, q):
     """Lattice dimensions of 537 ... 9081 rows: 9 to 142 blocks of 64 with a short top block, the last one beyond the 8192 rows
     the register-resident walk of round 1 was limited to.  Key from the device, three preimages (the last wave is partly empty);

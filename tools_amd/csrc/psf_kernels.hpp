@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
 // S[i][c] = sum_t a[i][t] * p[t][c]  (a in [0,q) as u64, p small signed), reduced mod q, then an epilogue:
 //   ZQ_SYNDROME : out[i][c] = (u[c][i] - S) mod q      out n x ld   (mp_perturbation.rs:318)
 //   ZQ_FA       : out[c][i] = S mod q                   out B x n    (mp_perturbation.rs:368)
-//   ZQ_TRAPDOOR : A[i][off + c] = (G[i][c] - S) mod q   (gadget_classical.rs:66, tag = I)
+//   ZQ_TRAPDOOR : A[i][off + c] = ((H G)[i][c] - S) mod q   (gadget_classical.rs:66; tag H = identity when `tagm` is null)
 // a is split into 31-bit limbs; each 32-term tile is summed in int64 (|a_limb * p| < 2^31 * 2^25) and folded
 // into a 128-bit running total, so no intermediate ever wraps for any q < 2^62.
 enum ZqMode { ZQ_SYNDROME = 0, ZQ_FA = 1, ZQ_TRAPDOOR = 2 };
@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256) void k_zq_matmul(int mode, const uint64_t* __r
                                                    size_t nrows, size_t K, const PT* __restrict__ Pm, size_t ldp, size_t ncols,
                                                    uint64_t q, uint64_t two64, uint64_t two31,
                                                    const uint64_t* __restrict__ U, uint64_t* __restrict__ out, size_t ldo,
-                                                   size_t out_off, const uint64_t* __restrict__ gvec, uint64_t gk) {
+                                                   size_t out_off, const uint64_t* __restrict__ gvec, uint64_t gk,
+                                                   const uint64_t* __restrict__ tagm) {
   // tile 64 (rows i) x 64 (cols c), K tile 32; thread -> 4 x 4 outputs
   __shared__ uint32_t sAlo[64][33];
   __shared__ uint32_t sAhi[WIDE ? 64 : 1][33];
@@ -505,8 +506,13 @@ __global__ __launch_bounds__(256) void k_zq_matmul(int mode, const uint64_t* __r
       } else if (mode == ZQ_FA) {
         out[cc * ldo + i] = s;
       } else {
-        // G[i][cc] = base^(cc % gk) if cc / gk == i (gadget_classical.rs:91-107)
-        const uint64_t g = (cc / gk == i) ? gvec[cc % gk] : 0;  // gvec[t] = base^t mod q
+        // G[j][cc] = base^(cc % gk) if cc / gk == j (gadget_classical.rs:91-107), so (H G)[i][cc] = H[i][cc / gk] base^(cc % gk)
+        uint64_t g;                                             // gvec[t] = base^t mod q
+        if (!tagm) g = (cc / gk == i) ? gvec[cc % gk] : 0;
+        else {
+          const uint64_t hv = tagm[i * nrows + cc / gk] % q, gv = gvec[cc % gk];
+          g = acc128_mod(Acc128{hv * gv, (int64_t)__umul64hi(hv, gv)}, q, two64);
+        }
         out[i * ldo + out_off + cc] = g >= s ? g - s : g + q - s;
       }
     }

@@ -542,41 +542,80 @@ psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t coun
   return psf_poly_mul_negacyclic_method(device, q, n, count, a, b, out, ntt ? 1 : 0);
 }
 
-// gpv_ring.rs:91-98 + gen_trapdoor_ring_lwe (gadget_ring.rs:62-81); r, e <- SampleZ(s_td) (trapdoor_distribution.rs:112-122)
-psf_status psfring_trap_gen(psfring_handle* h, uint64_t seed) {
-  if (!h) return PSF_ERR_PARAM;
-  const size_t n = h->gp.n, k = h->gp.k;
-  const SampleZParams sp = make_sample_z_params(h->s_td);
-  h->r.assign(k * n, 0); h->e.assign(k * n, 0); h->a.assign((k + 2) * n, 0);
+// gen_trapdoor_ring_lwe (gadget_ring.rs:62-81) with r, e <- SampleZ(s) (trapdoor_distribution.rs:112-122) drawn from `seed`:
+// A = [1 | a_bar | g_j - (a_bar r_j + e_j)] mod (X^n + 1, q); the k products a_bar * r_j run on the device (NTT kernel when q allows)
+psf_status psf_gen_trapdoor_ring_lwe(int device, const psf_gadget_params* gp, const uint64_t* a_bar, double s, uint64_t seed, uint64_t* a, int64_t* r, int64_t* e) {
+  if (!gp || !a_bar || !a || !r || !e || !(s > 0.0) || gp->n < 1 || gp->k < 1 || gp->q <= 1) return PSF_ERR_PARAM;
+  if (gp->q >= (1ull << 31)) return PSF_ERR_UNSUPPORTED;
+  const size_t n = gp->n, k = gp->k;
+  const uint64_t q = gp->q;
+  const SampleZParams sp = make_sample_z_params(s);
   int fail = 0;
   for (size_t j = 0; j < k; ++j)
     for (size_t c = 0; c < n; ++c) {
-      h->r[j * n + c] = sample_z(seed, TAG_RING_R, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);
-      h->e[j * n + c] = sample_z(seed, TAG_RING_E, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);
+      r[j * n + c] = sample_z(seed, TAG_RING_R, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);      // :69
+      e[j * n + c] = sample_z(seed, TAG_RING_E, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);      // :70
     }
   if (fail) return PSF_ERR_SAMPLER;
-  std::vector<uint64_t> a_bar(n);
-  for (size_t c = 0; c < n; ++c) a_bar[c] = uniform_mod(seed, TAG_RING_A, (uint32_t)c, 0, h->gp.q);   // gpv_ring.rs:92-94
-  // A = [1 | a_bar | g_j - (a_bar r_j + e_j)] (gadget_ring.rs:74-78); the k products a_bar * r_j run on the device
-  {
-    const uint64_t q = h->gp.q;
-    std::vector<uint64_t> abar_rep(k * n), prod(k * n);
-    for (size_t j = 0; j < k; ++j) std::copy(a_bar.begin(), a_bar.end(), abar_rep.begin() + j * n);
-    const psf_status rc = psf_poly_mul_negacyclic(h->g->base->prm.device, q, n, k, abar_rep.data(), h->r.data(), prod.data());
-    if (rc != PSF_OK) return rc;
-    h->a[0] = 1 % q;
-    for (size_t c = 0; c < n; ++c) h->a[n + c] = a_bar[c] % q;
-    uint64_t gpow = 1 % q;
-    for (size_t j = 0; j < k; ++j) {
-      for (size_t c = 0; c < n; ++c) {
-        i128 v = (c == 0 ? (i128)gpow : (i128)0) - ((i128)prod[j * n + c] + h->e[j * n + c]);
-        v %= (i128)q;
-        if (v < 0) v += q;
-        h->a[(2 + j) * n + c] = (uint64_t)v;
-      }
-      gpow = mulmod_u64(gpow, h->gp.base % q, q);
+  std::vector<uint64_t> abar_rep(k * n), prod(k * n);
+  for (size_t j = 0; j < k; ++j)
+    for (size_t c = 0; c < n; ++c) abar_rep[j * n + c] = a_bar[c] % q;
+  const psf_status rc = psf_poly_mul_negacyclic(device, q, n, k, abar_rep.data(), r, prod.data());   // a_bar * r (:78)
+  if (rc != PSF_OK) return rc;
+  for (size_t c = 0; c < (k + 2) * n; ++c) a[c] = 0;
+  a[0] = 1 % q;                                                                                 // :74-76
+  for (size_t c = 0; c < n; ++c) a[n + c] = a_bar[c] % q;
+  uint64_t gpow = 1 % q;
+  for (size_t j = 0; j < k; ++j) {                                                              // g^t - (a_bar r + e), :77-78
+    for (size_t c = 0; c < n; ++c) {
+      i128 v = (c == 0 ? (i128)gpow : (i128)0) - ((i128)prod[j * n + c] + e[j * n + c]);
+      v %= (i128)q;
+      if (v < 0) v += q;
+      a[(2 + j) * n + c] = (uint64_t)v;
     }
+    gpow = mulmod_u64(gpow, gp->base % q, q);
   }
+  return PSF_OK;
+}
+
+// gen_gadget_ring (gadget_ring.rs:103-109): k constant polynomials base^j; out[j] = the constant term
+psf_status psf_gen_gadget_ring(uint64_t k, uint64_t base, int64_t* out) { return psf_gen_gadget_vec(k, base, out); }
+
+// find_solution_gadget_ring (gadget_ring.rs:145-166): u in R_q as n coefficients -> k polynomials, polynomial i = the i-th base-`base` digit of
+// every coefficient (index i + j k of the classical solution, :160).  The digits come from the device kernel.
+psf_status psf_find_solution_gadget_ring(int device, const uint64_t* u, size_t n, uint64_t q, uint64_t k, uint64_t base, int64_t* out) {
+  if (!u || !out || n < 1) return PSF_ERR_PARAM;
+  std::vector<int64_t> classical(k * n);
+  const psf_status rc = psf_find_solution_gadget_mat(device, u, n, 1, q, k, base, classical.data());   // out[k j + i] = digit i of u_j
+  if (rc != PSF_OK) return rc;
+  for (size_t i = 0; i < k; ++i)
+    for (size_t j = 0; j < n; ++j) out[i * n + j] = classical[i + j * k];
+  return PSF_OK;
+}
+
+// gen_short_basis_for_trapdoor_ring (short_basis_ring.rs:64-79): the (k+2) x n(k+2) matrix of polynomials sa_l * sa_r reduced by X^n + 1,
+// out[(row * n(k+2) + col) * n + coefficient]
+psf_status psf_gen_short_basis_for_trapdoor_ring(const psf_gadget_params* gp, const uint64_t* a, const int64_t* r, const int64_t* e, int64_t* out) {
+  if (!gp || !a || !r || !e || !out) return PSF_ERR_PARAM;
+  std::vector<int32_t> bt;
+  const psf_status rc = ring_short_basis_t(*gp, a, r, e, bt);
+  if (rc != PSF_OK) return rc;
+  const size_t n = gp->n, K = gp->k + 2, d = n * K;
+  for (size_t col = 0; col < d; ++col)
+    for (size_t row = 0; row < K; ++row)
+      for (size_t c = 0; c < n; ++c) out[(row * d + col) * n + c] = bt[col * d + row * n + c];
+  return PSF_OK;
+}
+
+// gpv_ring.rs:91-98: a_bar uniform (:92-94), then gen_trapdoor_ring_lwe
+psf_status psfring_trap_gen(psfring_handle* h, uint64_t seed) {
+  if (!h) return PSF_ERR_PARAM;
+  const size_t n = h->gp.n, k = h->gp.k;
+  h->r.assign(k * n, 0); h->e.assign(k * n, 0); h->a.assign((k + 2) * n, 0);
+  std::vector<uint64_t> a_bar(n);
+  for (size_t c = 0; c < n; ++c) a_bar[c] = uniform_mod(seed, TAG_RING_A, (uint32_t)c, 0, h->gp.q);
+  const psf_status rc = psf_gen_trapdoor_ring_lwe(h->g->base->prm.device, &h->gp, a_bar.data(), h->s_td, seed, h->a.data(), h->r.data(), h->e.data());
+  if (rc != PSF_OK) return rc;
   return ring_install(h);
 }
 

@@ -416,14 +416,14 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov) {
 }
 
 // A[:, m_bar:] = G - A_bar R  (gadget_classical.rs:66): the one product still on the limb kernel (setup path, R in int8)
-static void launch_zq_trapdoor(psfp_handle* h) {
+static void launch_zq_trapdoor(psfp_handle* h, const uint64_t* d_tag = nullptr) {
   dim3 grid((unsigned)((h->w + 63) / 64), (unsigned)((h->n + 63) / 64));
   if (h->wide)
     hipLaunchKernelGGL((k_zq_matmul<int8_t, true>), grid, dim3(256), 0, 0, (int)ZQ_TRAPDOOR, h->dA, h->m, (size_t)0, h->n, h->mb, h->dR, h->ldr, h->w,
-                       h->q, h->two64, h->two31, (const uint64_t*)nullptr, h->dA, h->m, h->mb, h->dGvec, (uint64_t)h->k);
+                       h->q, h->two64, h->two31, (const uint64_t*)nullptr, h->dA, h->m, h->mb, h->dGvec, (uint64_t)h->k, d_tag);
   else
     hipLaunchKernelGGL((k_zq_matmul<int8_t, false>), grid, dim3(256), 0, 0, (int)ZQ_TRAPDOOR, h->dA, h->m, (size_t)0, h->n, h->mb, h->dR, h->ldr, h->w,
-                       h->q, h->two64, h->two31, (const uint64_t*)nullptr, h->dA, h->m, h->mb, h->dGvec, (uint64_t)h->k);
+                       h->q, h->two64, h->two31, (const uint64_t*)nullptr, h->dA, h->m, h->mb, h->dGvec, (uint64_t)h->k, d_tag);
 }
 
 static void split_A(psfp_handle* h) {
@@ -456,6 +456,40 @@ static psf_status gen_A_R(psfp_handle* h, uint64_t seed) {
   launch_zq_trapdoor(h);
   HIP_TRY(hipGetLastError());
   split_A(h);
+  return PSF_OK;
+}
+
+// gen_trapdoor (gadget_classical.rs:56-68) as a free function: caller-supplied A_bar and tag H, R <- PlusMinusOneZero from `seed`
+// (the stream psfp_trap_gen uses), A = [A_bar | H G - A_bar R] on the device
+psf_status psf_gen_trapdoor(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const uint64_t* tag, uint64_t seed, uint64_t* A, int8_t* R) {
+  if (!gp || !a_bar || !A || !R) return PSF_ERR_PARAM;
+  psfp_params prm;
+  prm.gp = *gp; prm.r = 1.0; prm.s = 1.0; prm.device = device; prm.flags = PSFP_FLAG_NO_PERTURB;
+  psfp_handle* h = nullptr;
+  psf_status rc = psfp_create(&prm, &h);
+  if (rc != PSF_OK) return rc;
+  if (gadget_too_short(gp->base, h->k, h->q)) { psfp_destroy(h); return PSF_ERR_MODULUS; }
+  uint64_t* dtag = nullptr;
+  auto fail = [&](psf_status st) { hipFree(dtag); psfp_destroy(h); return st; };
+  if (hipMemcpy2D(h->dA, h->m * sizeof(uint64_t), a_bar, h->mb * sizeof(uint64_t), h->mb * sizeof(uint64_t), h->n, hipMemcpyHostToDevice) != hipSuccess) return fail(PSF_ERR_HIP);
+  if (tag) {
+    if (hipMalloc(&dtag, h->n * h->n * sizeof(uint64_t)) != hipSuccess) return fail(PSF_ERR_HIP);
+    if (hipMemcpy(dtag, tag, h->n * h->n * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return fail(PSF_ERR_HIP);
+  }
+  hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);      // gadget_classical.rs:62-64
+  launch_zq_trapdoor(h, dtag);                                                                                            // :66
+  if (hipGetLastError() != hipSuccess) return fail(PSF_ERR_HIP);
+  if (hipMemcpy(A, h->dA, h->n * h->m * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return fail(PSF_ERR_HIP);
+  if (hipMemcpy2D(R, h->w, h->dR, h->ldr, h->w, h->mb, hipMemcpyDeviceToHost) != hipSuccess) return fail(PSF_ERR_HIP);
+  return fail(PSF_OK);
+}
+
+// contiguous shares of `total` rows for `world` workers: the first total % world workers get one row more
+psf_status psf_shard_range(size_t total, int world, int rank, size_t* first, size_t* count) {
+  if (world < 1 || rank < 0 || rank >= world || !first || !count) return PSF_ERR_PARAM;
+  const size_t base = total / (size_t)world, rem = total % (size_t)world;
+  *count = base + ((size_t)rank < rem ? 1 : 0);
+  *first = (size_t)rank * base + ((size_t)rank < rem ? (size_t)rank : rem);
   return PSF_OK;
 }
 
@@ -689,6 +723,46 @@ psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size
   if (prev_n) { rc = fetch(prev_off, prev_n, done[(i - 1) & 1]); if (rc != PSF_OK) return rc; }
   h->last_stream = h->s1;
   return psfp_last_status(h);
+}
+
+// One job over several handles (one per GPU of the node, each with the same key): rows are cut into contiguous shares
+// (psf_shard_range), share i is computed by handles[i] on its own device and stream, all of them at once; row b draws from the global
+// index first_index + b, so the result equals the single-handle one bit for bit.  Host buffers; no collective is involved -- the
+// "gather" of SURVEY.md 8e is each device's copy into its slice of e.
+psf_status psfp_samp_p_multi(psfp_handle* const* handles, int count, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
+  if (!handles || count < 1 || (B && (!u || !e))) return PSF_ERR_PARAM;
+  for (int i = 0; i < count; ++i) {
+    if (!handles[i]) return PSF_ERR_PARAM;
+    if (!handles[i]->has_key) return PSF_ERR_NO_KEY;
+    if (handles[i]->n != handles[0]->n || handles[i]->m != handles[0]->m || handles[i]->q != handles[0]->q) return PSF_ERR_PARAM;
+  }
+  if (B == 0) return PSF_OK;
+  std::vector<size_t> first(count), cnt(count);
+  for (int i = 0; i < count; ++i) psf_shard_range(B, count, i, &first[i], &cnt[i]);
+  psf_status worst = PSF_OK;
+  // enqueue everything first (uploads, the samp_p launch sequence, downloads: all asynchronous on the handle's own stream) ...
+  for (int i = 0; i < count && worst == PSF_OK; ++i) {
+    psfp_handle* h = handles[i];
+    if (!cnt[i]) continue;
+    HIP_TRY(hipSetDevice(h->prm.device));
+    psf_status rc = ensure_batch(h, cnt[i]);
+    if (rc != PSF_OK) { worst = rc; break; }
+    if (h->timing) clear_slots(h);
+    HIP_TRY(hipMemcpyAsync(h->dU, u + first[i] * h->n, cnt[i] * h->n * sizeof(uint64_t), hipMemcpyHostToDevice, h->s1));
+    rc = run_samp_p(h, seed, first_index + first[i], cnt[i], h->dU, h->dE, h->s1);
+    if (rc != PSF_OK) { worst = rc; break; }
+    HIP_TRY(hipMemcpyAsync(e + first[i] * h->m, h->dE, cnt[i] * h->m * sizeof(int64_t), hipMemcpyDeviceToHost, h->s1));
+  }
+  // ... then wait for every device
+  for (int i = 0; i < count; ++i) {
+    psfp_handle* h = handles[i];
+    if (!cnt[i]) continue;
+    HIP_TRY(hipSetDevice(h->prm.device));
+    h->last_stream = h->s1;
+    const psf_status rc = psfp_last_status(h);
+    if (rc != PSF_OK && worst == PSF_OK) worst = rc;
+  }
+  return worst;
 }
 
 psf_status psfp_samp_p_stages(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, double* d, double* x,

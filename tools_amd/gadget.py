@@ -102,3 +102,69 @@ def poly_mul_negacyclic(a, b, q, device=0, method=None):
                                                    _p(a2, C.c_uint64), _p(b2, C.c_int64), _p(out, C.c_uint64), C.c_int(method)),
               "poly_mul_negacyclic")
     return out[0] if single else out
+
+
+def gen_trapdoor(gp, a_bar, tag=None, seed=0, device=0):
+    """gen_trapdoor (gadget_classical.rs:56-68): caller-supplied A_bar and tag H; returns (A, R), R <- PlusMinusOneZero from `seed`."""
+    c = gp.c if hasattr(gp, "c") else gp
+    a_bar = np.ascontiguousarray(a_bar, dtype=np.uint64)
+    assert a_bar.shape == (c.n, c.m_bar)
+    w = c.n * c.k
+    A = np.zeros((c.n, c.m_bar + w), dtype=np.uint64)
+    R = np.zeros((c.m_bar, w), dtype=np.int8)
+    tagp = None
+    if tag is not None:
+        tag = np.ascontiguousarray(tag, dtype=np.uint64)
+        assert tag.shape == (c.n, c.n)
+        tagp = _p(tag, C.c_uint64)
+    check(lib().psf_gen_trapdoor(C.c_int(device), C.byref(c), _p(a_bar, C.c_uint64), tagp, C.c_uint64(seed), _p(A, C.c_uint64), _p(R, C.c_int8)),
+          "gen_trapdoor")
+    return A, R
+
+
+def gen_trapdoor_ring_lwe(gp, a_bar, s, seed=0, device=0):
+    """gen_trapdoor_ring_lwe (gadget_ring.rs:62-81): returns (a [(k+2) x n], r [k x n], e [k x n])."""
+    c = gp.c if hasattr(gp, "c") else gp
+    a_bar = np.ascontiguousarray(a_bar, dtype=np.uint64).reshape(c.n)
+    a = np.zeros((c.k + 2, c.n), dtype=np.uint64)
+    r = np.zeros((c.k, c.n), dtype=np.int64)
+    e = np.zeros((c.k, c.n), dtype=np.int64)
+    check(lib().psf_gen_trapdoor_ring_lwe(C.c_int(device), C.byref(c), _p(a_bar, C.c_uint64), C.c_double(s), C.c_uint64(seed),
+                                          _p(a, C.c_uint64), _p(r, C.c_int64), _p(e, C.c_int64)), "gen_trapdoor_ring_lwe")
+    return a, r, e
+
+
+def gen_gadget_ring(k, base):
+    """gen_gadget_ring (gadget_ring.rs:103-109): constant terms of the k constant polynomials."""
+    out = np.zeros(k, dtype=np.int64)
+    check(lib().psf_gen_gadget_ring(C.c_uint64(k), C.c_uint64(base), _p(out, C.c_int64)), "gen_gadget_ring")
+    return out
+
+
+def find_solution_gadget_ring(u, q, k, base, device=0):
+    """find_solution_gadget_ring (gadget_ring.rs:145-166): u (n coefficients) -> k x n digit polynomials."""
+    u = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1)
+    out = np.zeros((k, u.size), dtype=np.int64)
+    check(lib().psf_find_solution_gadget_ring(C.c_int(device), _p(u, C.c_uint64), C.c_size_t(u.size), C.c_uint64(q), C.c_uint64(k), C.c_uint64(base),
+                                              _p(out, C.c_int64)), "find_solution_gadget_ring")
+    return out
+
+
+def gen_short_basis_for_trapdoor_ring(gp, a, r, e):
+    """gen_short_basis_for_trapdoor_ring (short_basis_ring.rs:64-79): (k+2) x n(k+2) x n array of polynomial coefficients."""
+    c = gp.c if hasattr(gp, "c") else gp
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    r = np.ascontiguousarray(r, dtype=np.int64)
+    e = np.ascontiguousarray(e, dtype=np.int64)
+    K = c.k + 2
+    out = np.zeros((K, c.n * K, c.n), dtype=np.int64)
+    check(lib().psf_gen_short_basis_for_trapdoor_ring(C.byref(c), _p(a, C.c_uint64), _p(r, C.c_int64), _p(e, C.c_int64), _p(out, C.c_int64)),
+          "gen_short_basis_for_trapdoor_ring")
+    return out
+
+
+def shard_range(total, world, rank):
+    """psf_shard_range: (first, count) of worker `rank`'s contiguous share of `total` rows."""
+    first, count = C.c_size_t(0), C.c_size_t(0)
+    check(lib().psf_shard_range(C.c_size_t(total), C.c_int(world), C.c_int(rank), C.byref(first), C.byref(count)), "shard_range")
+    return first.value, count.value

@@ -199,6 +199,18 @@ class PSFPerturbation:
         return list(zip(nm, list(ms)[:cnt.value]))
 
 
+def samp_p_multi(psfs, u, seed=0, first_index=0):
+    """psfp_samp_p_multi: one batch over several PSFPerturbation handles (one per GPU, same key), rows cut into contiguous shares."""
+    n, m = psfs[0].n, psfs[0].m
+    u2 = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, n)
+    B = u2.shape[0]
+    e = np.zeros((B, m), dtype=np.int64)
+    arr = (C.c_void_p * len(psfs))(*[p._h for p in psfs])
+    check(lib().psfp_samp_p_multi(arr, C.c_int(len(psfs)), C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64), _p(e, C.c_int64)),
+          "samp_p_multi")
+    return e
+
+
 class PSFGPV:
     """gpv.rs:53-57 / impl PSF :59-225 on one MI355X.  The trapdoor (short basis, GSO) is exchanged TRANSPOSED:
     row i = basis vector i = column i of the reference's matrices."""
