@@ -1,0 +1,677 @@
+//! `impl PSF` for the MI355X-native preimage-sampling library (`libpsf_mi355x.so`, C ABI in `include/psf_mi355x.h`).
+//!
+//! Drop-in for ONE hot path of qfall-tools: `PSF::samp_p` (and the `trap_gen` / `samp_d` / `f_a` / `check_domain` around it) of
+//! `PSFPerturbation` (src/primitive/psf/mp_perturbation.rs:193-403), `PSFGPV` (gpv.rs:59-225) and `PSFGPVRing`
+//! (gpv_ring.rs:69-284).  The types below wrap the reference's own parameter structs and implement the reference's trait
+//! (src/primitive/psf.rs:39-81) with the same associated types, so a caller switches by changing the constructor.
+//!
+//! UNVERIFIED SOURCE.  No Rust toolchain, qfall-math or FLINT exists in the build environment of this repository, so this file has
+//! never been compiled.  Calls into qfall-math are restricted to methods the reference's own sources use (`get_entry`, `set_entry`,
+//! `get_num_rows`, `get_num_columns`, `get_q`, `get_mod`, `get_coeff`, `set_coeff`, `MatZ::new`, `MatZq::new`, `MatQ::new`,
+//! `Z::from`, `Q::from`, `i64::try_from(&Z)`, `f64::from(&Q)`); where a generic parameter had to be guessed it is annotated.
+//!
+//! Semantics that differ from the reference, by construction of the library:
+//! * randomness comes from Philox streams keyed by a 64-bit seed (the trait has no seed argument, psf.rs:48-80): every wrapper owns a
+//!   `seed` and a call counter; call `reseed` for reproducible runs;
+//! * where the reference panics (`.unwrap()` / `assert!`: mp_perturbation.rs:190,315,333,367) the library returns a status and the shim
+//!   panics with the library's message;
+//! * key material handed to `samp_p` / `f_a` is uploaded when it differs from what the handle holds (the reference is stateless).
+#![allow(non_snake_case)]
+
+pub mod ffi;
+
+use std::cell::{Cell, RefCell};
+use std::ffi::CStr;
+
+use qfall_math::integer::{MatPolyOverZ, MatZ, PolyOverZ, Z};
+use qfall_math::integer_mod_q::{MatPolynomialRingZq, MatZq, Modulus};
+use qfall_math::rational::{MatQ, Q};
+use qfall_math::traits::*;
+use qfall_tools::primitive::psf::{PSF, PSFGPV, PSFGPVRing, PSFPerturbation};
+use qfall_tools::sample::g_trapdoor::gadget_parameters::{GadgetParameters, GadgetParametersRing};
+
+// ------------------------------------------------------------------------------------------------------------------------
+// status handling and conversions between qfall-math values and the flat row-major arrays of the ABI
+// ------------------------------------------------------------------------------------------------------------------------
+
+/// Panics with the library's message unless `status` is PSF_OK -- the reference panics in the same situations.
+fn check(status: ffi::psf_status, what: &str) {
+    if status != ffi::PSF_OK {
+        let msg = unsafe { CStr::from_ptr(ffi::psf_status_string(status)) }.to_string_lossy().into_owned();
+        panic!("{what}: psf_status {status} ({msg})");
+    }
+}
+
+fn z_to_u64(z: &Z) -> u64 {
+    u64::try_from(z).expect("value does not fit 64 bits")
+}
+
+fn z_to_i64(z: &Z) -> i64 {
+    i64::try_from(z).expect("value does not fit 64 bits")
+}
+
+/// `GadgetParameters` -> `psf_gadget_params` (gadget_parameters.rs:44-52; the distribution is PlusMinusOneZero inside the library).
+fn gp_to_c(gp: &GadgetParameters) -> ffi::psf_gadget_params {
+    ffi::psf_gadget_params { n: z_to_u64(&gp.n), k: z_to_u64(&gp.k), m_bar: z_to_u64(&gp.m_bar), base: z_to_u64(&gp.base), q: z_to_u64(&Z::from(&gp.q)) }
+}
+
+/// `GadgetParametersRing` -> `psf_gadget_params` (gadget_parameters.rs:73-81; modulus polynomial X^n + 1, distribution SampleZ).
+fn gp_ring_to_c(gp: &GadgetParametersRing) -> ffi::psf_gadget_params {
+    ffi::psf_gadget_params { n: z_to_u64(&gp.n), k: z_to_u64(&gp.k), m_bar: z_to_u64(&gp.m_bar), base: z_to_u64(&gp.base), q: z_to_u64(&Z::from(&gp.modulus.get_q())) }
+}
+
+/// MatZq -> rows of least non-negative residues.
+fn matzq_to_rows(a: &MatZq) -> Vec<u64> {
+    let (rows, cols) = (a.get_num_rows(), a.get_num_columns());
+    let mut out = Vec::with_capacity((rows * cols) as usize);
+    for i in 0..rows {
+        for j in 0..cols {
+            let entry: Z = a.get_entry(i, j).unwrap(); // [unverified] GetEntry<Z> for MatZq: the representative in [0, q)
+            out.push(z_to_u64(&entry));
+        }
+    }
+    out
+}
+
+fn matzq_from_rows(rows: i64, cols: i64, q: &Modulus, data: &[u64]) -> MatZq {
+    let mut out = MatZq::new(rows, cols, q);
+    for i in 0..rows {
+        for j in 0..cols {
+            out.set_entry(i, j, Z::from(data[(i * cols + j) as usize])).unwrap();
+        }
+    }
+    out
+}
+
+fn matz_to_rows_i64(a: &MatZ) -> Vec<i64> {
+    let (rows, cols) = (a.get_num_rows(), a.get_num_columns());
+    let mut out = Vec::with_capacity((rows * cols) as usize);
+    for i in 0..rows {
+        for j in 0..cols {
+            let entry: Z = a.get_entry(i, j).unwrap();
+            out.push(z_to_i64(&entry));
+        }
+    }
+    out
+}
+
+fn matz_to_rows_i8(a: &MatZ) -> Vec<i8> {
+    matz_to_rows_i64(a).into_iter().map(|v| i8::try_from(v).expect("trapdoor entry outside {-1,0,1}")).collect()
+}
+
+fn matz_from_rows<T: Copy + Into<i64>>(rows: i64, cols: i64, data: &[T]) -> MatZ {
+    let mut out = MatZ::new(rows, cols);
+    for i in 0..rows {
+        for j in 0..cols {
+            let v: i64 = data[(i * cols + j) as usize].into();
+            out.set_entry(i, j, Z::from(v)).unwrap();
+        }
+    }
+    out
+}
+
+/// Lower-triangular MatQ -> packed rows (row i holds i + 1 doubles): the form psfp_load_key takes for sqrt(Sigma_2).
+fn matq_lower_to_packed(l: &MatQ) -> Vec<f64> {
+    let m = l.get_num_rows();
+    let mut out = Vec::with_capacity((m * (m + 1) / 2) as usize);
+    for i in 0..m {
+        for j in 0..=i {
+            let entry: Q = l.get_entry(i, j).unwrap();
+            out.push(f64::from(&entry));
+        }
+    }
+    out
+}
+
+fn matq_lower_from_packed(m: i64, packed: &[f64]) -> MatQ {
+    let mut out = MatQ::new(m, m);
+    let mut at = 0usize;
+    for i in 0..m {
+        for j in 0..=i {
+            out.set_entry(i, j, Q::from(packed[at])).unwrap();
+            at += 1;
+        }
+    }
+    out
+}
+
+/// rows x cols doubles -> MatQ, optionally transposed (the ABI ships the Gram-Schmidt vectors one per ROW, the reference one per COLUMN).
+fn matq_from_rows(rows: i64, cols: i64, data: &[f64], transpose: bool) -> MatQ {
+    let mut out = if transpose { MatQ::new(cols, rows) } else { MatQ::new(rows, cols) };
+    for i in 0..rows {
+        for j in 0..cols {
+            let v = Q::from(data[(i * cols + j) as usize]);
+            if transpose { out.set_entry(j, i, v).unwrap() } else { out.set_entry(i, j, v).unwrap() }
+        }
+    }
+    out
+}
+
+fn matq_to_rows_t(a: &MatQ) -> Vec<f64> {
+    // column c of the reference's matrix becomes row c
+    let (rows, cols) = (a.get_num_rows(), a.get_num_columns());
+    let mut out = Vec::with_capacity((rows * cols) as usize);
+    for c in 0..cols {
+        for r in 0..rows {
+            let entry: Q = a.get_entry(r, c).unwrap();
+            out.push(f64::from(&entry));
+        }
+    }
+    out
+}
+
+fn matz_to_rows_t_i32(a: &MatZ) -> Vec<i32> {
+    let (rows, cols) = (a.get_num_rows(), a.get_num_columns());
+    let mut out = Vec::with_capacity((rows * cols) as usize);
+    for c in 0..cols {
+        for r in 0..rows {
+            let entry: Z = a.get_entry(r, c).unwrap();
+            out.push(i32::try_from(z_to_i64(&entry)).expect("basis entry does not fit 32 bits"));
+        }
+    }
+    out
+}
+
+/// 1 x cols (or cols x 1) MatPolyOverZ -> cols rows of n coefficients, constant term first.
+fn matpoly_to_rows(p: &MatPolyOverZ, n: i64) -> Vec<i64> {
+    let (rows, cols) = (p.get_num_rows(), p.get_num_columns());
+    let mut out = Vec::with_capacity((rows * cols * n) as usize);
+    for i in 0..rows {
+        for j in 0..cols {
+            let poly: PolyOverZ = p.get_entry(i, j).unwrap();
+            for c in 0..n {
+                let coeff: Z = poly.get_coeff(c).unwrap();
+                out.push(z_to_i64(&coeff));
+            }
+        }
+    }
+    out
+}
+
+fn matpoly_from_rows(rows: i64, cols: i64, n: i64, data: &[i64]) -> MatPolyOverZ {
+    let mut out = MatPolyOverZ::new(rows, cols);
+    for i in 0..rows {
+        for j in 0..cols {
+            let mut poly = PolyOverZ::default();
+            for c in 0..n {
+                poly.set_coeff(c, data[((i * cols + j) * n + c) as usize]).unwrap();
+            }
+            out.set_entry(i, j, &poly).unwrap();
+        }
+    }
+    out
+}
+
+/// MatPolynomialRingZq -> least non-negative residues of every coefficient, entry by entry.
+fn matpolyring_to_rows(a: &MatPolynomialRingZq, n: i64) -> Vec<u64> {
+    let repr: MatPolyOverZ = a.get_representative_least_nonnegative_residue();
+    matpoly_to_rows(&repr, n).into_iter().map(|v| u64::try_from(v).unwrap()).collect()
+}
+
+/// Call counter -> seed of the next sampling call: seeds of different calls never coincide for one wrapper.
+fn next_seed(seed: &Cell<u64>, calls: &Cell<u64>) -> u64 {
+    let c = calls.get();
+    calls.set(c + 1);
+    seed.get().wrapping_add(0x9E3779B97F4A7C15u64.wrapping_mul(c + 1))
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// PSFPerturbation (mp_perturbation.rs:57-62, impl PSF :193-403)
+// ------------------------------------------------------------------------------------------------------------------------
+
+/// `PSFPerturbation` whose `trap_gen` / `samp_d` / `samp_p` / `f_a` / `check_domain` run on one MI355X.
+pub struct GpuPSFPerturbation {
+    /// the reference's parameter struct (gp, r, s): kept public so that code written against it keeps compiling
+    pub params: PSFPerturbation,
+    handle: *mut ffi::psfp_handle,
+    seed: Cell<u64>,
+    calls: Cell<u64>,
+    /// the (A, R, sqrt(Sigma_2)) the handle currently holds, to skip the upload when samp_p is called again with the same key
+    installed: RefCell<Option<(MatZq, MatZ, MatQ)>>,
+}
+
+impl GpuPSFPerturbation {
+    /// `device`: HIP device ordinal.  Panics if the parameters are outside the library's limits (psf_mi355x.h, psfp_create).
+    pub fn new(params: PSFPerturbation, device: i32, seed: u64) -> Self {
+        let c = ffi::psfp_params { gp: gp_to_c(&params.gp), r: f64::from(&params.r), s: f64::from(&params.s), device, flags: 0 };
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ffi::psfp_create(&c, &mut handle) }, "psfp_create");
+        Self { params, handle, seed: Cell::new(seed), calls: Cell::new(0), installed: RefCell::new(None) }
+    }
+
+    pub fn reseed(&self, seed: u64) {
+        self.seed.set(seed);
+        self.calls.set(0);
+    }
+
+    fn dims(&self) -> (i64, i64, i64, i64) {
+        let gp = gp_to_c(&self.params.gp);
+        let (n, k, mb) = (gp.n as i64, gp.k as i64, gp.m_bar as i64);
+        (n, k, mb, mb + n * k)
+    }
+
+    /// Uploads (A, R, sqrt(Sigma_2)) unless the handle already holds exactly these.
+    fn ensure_key(&self, a: &MatZq, r: &MatZ, sqrt_sigma_2: &MatQ) {
+        if let Some((ia, ir, il)) = self.installed.borrow().as_ref() {
+            if ia == a && ir == r && il == sqrt_sigma_2 {
+                return;
+            }
+        }
+        let (av, rv, lv) = (matzq_to_rows(a), matz_to_rows_i8(r), matq_lower_to_packed(sqrt_sigma_2));
+        check(unsafe { ffi::psfp_load_key(self.handle, av.as_ptr(), rv.as_ptr(), lv.as_ptr()) }, "psfp_load_key");
+        *self.installed.borrow_mut() = Some((a.clone(), r.clone(), sqrt_sigma_2.clone()));
+    }
+
+    /// B independent `samp_p` calls with one key: the batched form the library is built for (row b of `targets` = one syndrome).
+    pub fn samp_p_batch(&self, a: &MatZq, td: &<Self as PSF>::Trapdoor, targets: &MatZq) -> MatZ {
+        let (n, _, _, m) = self.dims();
+        self.ensure_key(a, &td.0, &td.1);
+        let b = targets.get_num_rows();
+        assert_eq!(targets.get_num_columns(), n, "one syndrome of length n per row");
+        let u = matzq_to_rows(targets);
+        let mut e = vec![0i64; (b * m) as usize];
+        let seed = next_seed(&self.seed, &self.calls);
+        check(unsafe { ffi::psfp_samp_p(self.handle, seed, 0, b as usize, u.as_ptr(), e.as_mut_ptr()) }, "psfp_samp_p");
+        matz_from_rows(b, m, &e)
+    }
+}
+
+impl Drop for GpuPSFPerturbation {
+    fn drop(&mut self) {
+        unsafe { ffi::psfp_destroy(self.handle) }
+    }
+}
+
+impl PSF for GpuPSFPerturbation {
+    type A = MatZq;
+    type Trapdoor = (MatZ, MatQ, (MatZ, MatQ));
+    type Domain = MatZ;
+    type Range = MatZq;
+
+    /// mp_perturbation.rs:221-244 on the device; returns the same tuple shape as the reference.
+    fn trap_gen(&self) -> (MatZq, (MatZ, MatQ, (MatZ, MatQ))) {
+        let (n, k, mb, m) = self.dims();
+        check(unsafe { ffi::psfp_trap_gen(self.handle, next_seed(&self.seed, &self.calls)) }, "psfp_trap_gen");
+        let mut a = vec![0u64; (n * m) as usize];
+        let mut r = vec![0i8; (mb * n * k) as usize];
+        let mut l = vec![0f64; (m * (m + 1) / 2) as usize];
+        check(unsafe { ffi::psfp_export_key(self.handle, a.as_mut_ptr(), r.as_mut_ptr(), l.as_mut_ptr()) }, "psfp_export_key");
+        let mut sk = vec![0i64; (k * k) as usize];
+        let mut gso = vec![0f64; (k * k) as usize];
+        check(unsafe { ffi::psfp_export_gadget_basis(self.handle, sk.as_mut_ptr(), gso.as_mut_ptr()) }, "psfp_export_gadget_basis");
+        let a_mat = matzq_from_rows(n, m, &self.params.gp.q, &a);
+        let r_mat = matz_from_rows(mb, n * k, &r);
+        let l_mat = matq_lower_from_packed(m, &l);
+        // (S, S~) of mp_perturbation.rs:233-234 are I_n (x) S_k and its GSO: rebuilt from the k x k block
+        let mut s_mat = MatZ::new(n * k, n * k);
+        let mut s_gso = MatQ::new(n * k, n * k);
+        for blk in 0..n {
+            for i in 0..k {
+                for j in 0..k {
+                    s_mat.set_entry(blk * k + i, blk * k + j, Z::from(sk[(i * k + j) as usize])).unwrap();
+                    s_gso.set_entry(blk * k + i, blk * k + j, Q::from(gso[(i * k + j) as usize])).unwrap();
+                }
+            }
+        }
+        *self.installed.borrow_mut() = Some((a_mat.clone(), r_mat.clone(), l_mat.clone()));
+        (a_mat, (r_mat, l_mat, (s_mat, s_gso)))
+    }
+
+    /// mp_perturbation.rs:264-267
+    fn samp_d(&self) -> MatZ {
+        let (_, _, _, m) = self.dims();
+        let mut e = vec![0i64; m as usize];
+        check(unsafe { ffi::psfp_samp_d(self.handle, next_seed(&self.seed, &self.calls), 0, 1, e.as_mut_ptr()) }, "psfp_samp_d");
+        matz_from_rows(m, 1, &e)
+    }
+
+    /// mp_perturbation.rs:304-336: one preimage (use `samp_p_batch` for throughput)
+    fn samp_p(&self, a: &MatZq, td: &Self::Trapdoor, u: &MatZq) -> MatZ {
+        let (n, _, _, m) = self.dims();
+        self.ensure_key(a, &td.0, &td.1);
+        assert!(u.get_num_rows() == n && u.get_num_columns() == 1, "u must be an n x 1 column (mp_perturbation.rs:318)");
+        let uv = matzq_to_rows(u);
+        let mut e = vec![0i64; m as usize];
+        check(unsafe { ffi::psfp_samp_p(self.handle, next_seed(&self.seed, &self.calls), 0, 1, uv.as_ptr(), e.as_mut_ptr()) }, "psfp_samp_p");
+        matz_from_rows(m, 1, &e)
+    }
+
+    /// mp_perturbation.rs:366-369; panics like the reference's assert! when sigma is not in the domain
+    fn f_a(&self, a: &MatZq, sigma: &MatZ) -> MatZq {
+        let (n, _, _, m) = self.dims();
+        assert!(sigma.get_num_rows() == m && sigma.get_num_columns() == 1, "sigma must be a column vector of length m");
+        // only A matters for f_a: if the caller's A is not the installed one, upload it with the trapdoor part the handle holds
+        let upload = match self.installed.borrow().as_ref() {
+            Some((ia, _, _)) if ia == a => None,
+            Some((_, ir, il)) => Some((matzq_to_rows(a), matz_to_rows_i8(ir), matq_lower_to_packed(il))),
+            None => panic!("f_a before trap_gen / samp_p: the handle holds no key"),
+        };
+        if let Some((av, rv, lv)) = upload {
+            check(unsafe { ffi::psfp_load_key(self.handle, av.as_ptr(), rv.as_ptr(), lv.as_ptr()) }, "psfp_load_key");
+            if let Some(inst) = self.installed.borrow_mut().as_mut() {
+                inst.0 = a.clone();
+            }
+        }
+        let e = matz_to_rows_i64(sigma);
+        let mut u = vec![0u64; n as usize];
+        check(unsafe { ffi::psfp_f_a(self.handle, 1, e.as_ptr(), u.as_mut_ptr()) }, "psfp_f_a");
+        matzq_from_rows(n, 1, &self.params.gp.q, &u)
+    }
+
+    /// mp_perturbation.rs:396-402
+    fn check_domain(&self, sigma: &MatZ) -> bool {
+        if !sigma.is_column_vector() {
+            return false;
+        }
+        let e = matz_to_rows_i64(sigma);
+        let mut ok = [0u8; 1];
+        check(unsafe { ffi::psfp_check_domain(self.handle, 1, e.as_ptr(), e.len(), ok.as_mut_ptr()) }, "psfp_check_domain");
+        ok[0] != 0
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// PSFGPV (gpv.rs:53-57, impl PSF :59-225)
+// ------------------------------------------------------------------------------------------------------------------------
+
+pub struct GpuPSFGPV {
+    pub params: PSFGPV,
+    handle: *mut ffi::psfgpv_handle,
+    seed: Cell<u64>,
+    calls: Cell<u64>,
+    installed: RefCell<Option<(MatZq, MatZ, MatQ)>>,
+}
+
+impl GpuPSFGPV {
+    pub fn new(params: PSFGPV, device: i32, seed: u64) -> Self {
+        let c = ffi::psfgpv_params { gp: gp_to_c(&params.gp), s: f64::from(&params.s), device, flags: 0 };
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ffi::psfgpv_create(&c, &mut handle) }, "psfgpv_create");
+        Self { params, handle, seed: Cell::new(seed), calls: Cell::new(0), installed: RefCell::new(None) }
+    }
+
+    pub fn reseed(&self, seed: u64) {
+        self.seed.set(seed);
+        self.calls.set(0);
+    }
+
+    fn dims(&self) -> (i64, i64) {
+        let gp = gp_to_c(&self.params.gp);
+        (gp.n as i64, (gp.m_bar + gp.n * gp.k) as i64)
+    }
+
+    fn ensure_key(&self, a: &MatZq, basis: &MatZ, gso: &MatQ) {
+        if let Some((ia, ib, ig)) = self.installed.borrow().as_ref() {
+            if ia == a && ib == basis && ig == gso {
+                return;
+            }
+        }
+        // the ABI takes both matrices transposed: row i = basis vector i (psf_mi355x.h, PSFGPV section)
+        let (av, bt, gt) = (matzq_to_rows(a), matz_to_rows_t_i32(basis), matq_to_rows_t(gso));
+        check(unsafe { ffi::psfgpv_load_key(self.handle, av.as_ptr(), bt.as_ptr(), gt.as_ptr()) }, "psfgpv_load_key");
+        *self.installed.borrow_mut() = Some((a.clone(), basis.clone(), gso.clone()));
+    }
+
+    /// B independent `samp_p` calls with one key (row b of `targets` = one syndrome).
+    pub fn samp_p_batch(&self, a: &MatZq, td: &(MatZ, MatQ), targets: &MatZq) -> MatZ {
+        let (n, m) = self.dims();
+        self.ensure_key(a, &td.0, &td.1);
+        let b = targets.get_num_rows();
+        assert_eq!(targets.get_num_columns(), n);
+        let u = matzq_to_rows(targets);
+        let mut e = vec![0i64; (b * m) as usize];
+        check(unsafe { ffi::psfgpv_samp_p(self.handle, next_seed(&self.seed, &self.calls), 0, b as usize, u.as_ptr(), e.as_mut_ptr()) }, "psfgpv_samp_p");
+        matz_from_rows(b, m, &e)
+    }
+}
+
+impl Drop for GpuPSFGPV {
+    fn drop(&mut self) {
+        unsafe { ffi::psfgpv_destroy(self.handle) }
+    }
+}
+
+impl PSF for GpuPSFGPV {
+    type A = MatZq;
+    type Trapdoor = (MatZ, MatQ);
+    type Domain = MatZ;
+    type Range = MatZq;
+
+    /// gpv.rs:83-94
+    fn trap_gen(&self) -> (MatZq, (MatZ, MatQ)) {
+        let (n, m) = self.dims();
+        check(unsafe { ffi::psfgpv_trap_gen(self.handle, next_seed(&self.seed, &self.calls)) }, "psfgpv_trap_gen");
+        let mut a = vec![0u64; (n * m) as usize];
+        let mut bt = vec![0i32; (m * m) as usize];
+        let mut gt = vec![0f64; (m * m) as usize];
+        check(unsafe { ffi::psfgpv_export_key(self.handle, a.as_mut_ptr(), std::ptr::null_mut(), bt.as_mut_ptr(), gt.as_mut_ptr()) }, "psfgpv_export_key");
+        let a_mat = matzq_from_rows(n, m, &self.params.gp.q, &a);
+        // rows of the ABI's matrices are the reference's columns
+        let mut basis = MatZ::new(m, m);
+        for i in 0..m {
+            for j in 0..m {
+                basis.set_entry(j, i, Z::from(bt[(i * m + j) as usize] as i64)).unwrap();
+            }
+        }
+        let gso = matq_from_rows(m, m, &gt, true);
+        *self.installed.borrow_mut() = Some((a_mat.clone(), basis.clone(), gso.clone()));
+        (a_mat, (basis, gso))
+    }
+
+    /// gpv.rs:113-116
+    fn samp_d(&self) -> MatZ {
+        let (_, m) = self.dims();
+        let mut e = vec![0i64; m as usize];
+        check(unsafe { ffi::psfgpv_samp_d(self.handle, next_seed(&self.seed, &self.calls), 0, 1, e.as_mut_ptr()) }, "psfgpv_samp_d");
+        matz_from_rows(m, 1, &e)
+    }
+
+    /// gpv.rs:152-161
+    fn samp_p(&self, a: &MatZq, td: &(MatZ, MatQ), u: &MatZq) -> MatZ {
+        let (n, m) = self.dims();
+        self.ensure_key(a, &td.0, &td.1);
+        assert!(u.get_num_rows() == n && u.get_num_columns() == 1);
+        let uv = matzq_to_rows(u);
+        let mut e = vec![0i64; m as usize];
+        check(unsafe { ffi::psfgpv_samp_p(self.handle, next_seed(&self.seed, &self.calls), 0, 1, uv.as_ptr(), e.as_mut_ptr()) }, "psfgpv_samp_p");
+        matz_from_rows(m, 1, &e)
+    }
+
+    /// gpv.rs:190-193
+    fn f_a(&self, a: &MatZq, sigma: &MatZ) -> MatZq {
+        let (n, m) = self.dims();
+        assert!(sigma.get_num_rows() == m && sigma.get_num_columns() == 1);
+        match self.installed.borrow().as_ref() {
+            Some((ia, _, _)) if ia == a => {}
+            Some((_, ib, ig)) => {
+                let (av, bt, gt) = (matzq_to_rows(a), matz_to_rows_t_i32(ib), matq_to_rows_t(ig));
+                check(unsafe { ffi::psfgpv_load_key(self.handle, av.as_ptr(), bt.as_ptr(), gt.as_ptr()) }, "psfgpv_load_key");
+            }
+            None => panic!("f_a before trap_gen / samp_p: the handle holds no key"),
+        }
+        let e = matz_to_rows_i64(sigma);
+        let mut u = vec![0u64; n as usize];
+        check(unsafe { ffi::psfgpv_f_a(self.handle, 1, e.as_ptr(), u.as_mut_ptr()) }, "psfgpv_f_a");
+        matzq_from_rows(n, 1, &self.params.gp.q, &u)
+    }
+
+    /// gpv.rs:219-224
+    fn check_domain(&self, sigma: &MatZ) -> bool {
+        if !sigma.is_column_vector() {
+            return false;
+        }
+        let e = matz_to_rows_i64(sigma);
+        let mut ok = [0u8; 1];
+        check(unsafe { ffi::psfgpv_check_domain(self.handle, 1, e.as_ptr(), e.len(), ok.as_mut_ptr()) }, "psfgpv_check_domain");
+        ok[0] != 0
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// PSFGPVRing (gpv_ring.rs:62-67, impl PSF :69-284)
+// ------------------------------------------------------------------------------------------------------------------------
+
+pub struct GpuPSFGPVRing {
+    pub params: PSFGPVRing,
+    handle: *mut ffi::psfring_handle,
+    seed: Cell<u64>,
+    calls: Cell<u64>,
+    installed: RefCell<Option<(MatPolynomialRingZq, MatPolyOverZ, MatPolyOverZ)>>,
+}
+
+impl GpuPSFGPVRing {
+    pub fn new(params: PSFGPVRing, device: i32, seed: u64) -> Self {
+        let c = ffi::psfring_params { gp: gp_ring_to_c(&params.gp), s: f64::from(&params.s), s_td: f64::from(&params.s_td), device, flags: 0 };
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ffi::psfring_create(&c, &mut handle) }, "psfring_create");
+        Self { params, handle, seed: Cell::new(seed), calls: Cell::new(0), installed: RefCell::new(None) }
+    }
+
+    pub fn reseed(&self, seed: u64) {
+        self.seed.set(seed);
+        self.calls.set(0);
+    }
+
+    /// (ring degree n, gadget length k)
+    fn dims(&self) -> (i64, i64) {
+        let gp = gp_ring_to_c(&self.params.gp);
+        (gp.n as i64, gp.k as i64)
+    }
+
+    fn ensure_key(&self, a: &MatPolynomialRingZq, r: &MatPolyOverZ, e: &MatPolyOverZ) {
+        if let Some((ia, ir, ie)) = self.installed.borrow().as_ref() {
+            if ia == a && ir == r && ie == e {
+                return;
+            }
+        }
+        let (n, _) = self.dims();
+        let (av, rv, ev) = (matpolyring_to_rows(a, n), matpoly_to_rows(r, n), matpoly_to_rows(e, n));
+        check(unsafe { ffi::psfring_load_key(self.handle, av.as_ptr(), rv.as_ptr(), ev.as_ptr()) }, "psfring_load_key");
+        *self.installed.borrow_mut() = Some((a.clone(), r.clone(), e.clone()));
+    }
+}
+
+impl Drop for GpuPSFGPVRing {
+    fn drop(&mut self) {
+        unsafe { ffi::psfring_destroy(self.handle) }
+    }
+}
+
+impl PSF for GpuPSFGPVRing {
+    type A = MatPolynomialRingZq;
+    type Trapdoor = (MatPolyOverZ, MatPolyOverZ);
+    type Domain = MatPolyOverZ;
+    type Range = MatPolynomialRingZq;
+
+    /// gpv_ring.rs:91-98
+    fn trap_gen(&self) -> (MatPolynomialRingZq, (MatPolyOverZ, MatPolyOverZ)) {
+        let (n, k) = self.dims();
+        check(unsafe { ffi::psfring_trap_gen(self.handle, next_seed(&self.seed, &self.calls)) }, "psfring_trap_gen");
+        let mut a = vec![0u64; ((k + 2) * n) as usize];
+        let mut r = vec![0i64; (k * n) as usize];
+        let mut e = vec![0i64; (k * n) as usize];
+        check(unsafe { ffi::psfring_export_key(self.handle, a.as_mut_ptr(), r.as_mut_ptr(), e.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut()) }, "psfring_export_key");
+        let a_i64: Vec<i64> = a.iter().map(|&v| v as i64).collect();
+        let a_poly = matpoly_from_rows(1, k + 2, n, &a_i64);
+        let a_mat = MatPolynomialRingZq::from((&a_poly, &self.params.gp.modulus));
+        let (r_mat, e_mat) = (matpoly_from_rows(1, k, n, &r), matpoly_from_rows(1, k, n, &e));
+        *self.installed.borrow_mut() = Some((a_mat.clone(), r_mat.clone(), e_mat.clone()));
+        (a_mat, (r_mat, e_mat))
+    }
+
+    /// gpv_ring.rs:118-122
+    fn samp_d(&self) -> MatPolyOverZ {
+        let (n, k) = self.dims();
+        let mut sigma = vec![0i64; ((k + 2) * n) as usize];
+        check(unsafe { ffi::psfring_samp_d(self.handle, next_seed(&self.seed, &self.calls), 0, 1, sigma.as_mut_ptr()) }, "psfring_samp_d");
+        matpoly_from_rows(k + 2, 1, n, &sigma)
+    }
+
+    /// gpv_ring.rs:160-212 (short basis, elimination and Gram-Schmidt vectors are built once per key inside the library)
+    fn samp_p(&self, a: &MatPolynomialRingZq, td: &(MatPolyOverZ, MatPolyOverZ), u: &MatPolynomialRingZq) -> MatPolyOverZ {
+        let (n, k) = self.dims();
+        self.ensure_key(a, &td.0, &td.1);
+        let uv = matpolyring_to_rows(u, n);
+        assert_eq!(uv.len() as i64, n, "u is one element of R_q");
+        let mut sigma = vec![0i64; ((k + 2) * n) as usize];
+        check(unsafe { ffi::psfring_samp_p(self.handle, next_seed(&self.seed, &self.calls), 0, 1, uv.as_ptr(), sigma.as_mut_ptr()) }, "psfring_samp_p");
+        matpoly_from_rows(k + 2, 1, n, &sigma)
+    }
+
+    /// gpv_ring.rs:243-247
+    fn f_a(&self, a: &MatPolynomialRingZq, sigma: &MatPolyOverZ) -> MatPolynomialRingZq {
+        let (n, _) = self.dims();
+        match self.installed.borrow().as_ref() {
+            Some((ia, _, _)) if ia == a => {}
+            Some((_, ir, ie)) => {
+                let (av, rv, ev) = (matpolyring_to_rows(a, n), matpoly_to_rows(ir, n), matpoly_to_rows(ie, n));
+                check(unsafe { ffi::psfring_load_key(self.handle, av.as_ptr(), rv.as_ptr(), ev.as_ptr()) }, "psfring_load_key");
+            }
+            None => panic!("f_a before trap_gen / samp_p: the handle holds no key"),
+        }
+        let s = matpoly_to_rows(sigma, n);
+        let mut u = vec![0u64; n as usize];
+        check(unsafe { ffi::psfring_f_a(self.handle, 1, s.as_ptr(), u.as_mut_ptr()) }, "psfring_f_a");
+        let u_i64: Vec<i64> = u.iter().map(|&v| v as i64).collect();
+        MatPolynomialRingZq::from((&matpoly_from_rows(1, 1, n, &u_i64), &self.params.gp.modulus))
+    }
+
+    /// gpv_ring.rs:274-283
+    fn check_domain(&self, sigma: &MatPolyOverZ) -> bool {
+        let (n, _) = self.dims();
+        if sigma.get_num_columns() != 1 {
+            return false;
+        }
+        let s = matpoly_to_rows(sigma, n);
+        let mut ok = [0u8; 1];
+        check(unsafe { ffi::psfring_check_domain(self.handle, 1, s.as_ptr(), s.len(), ok.as_mut_ptr()) }, "psfring_check_domain");
+        ok[0] != 0
+    }
+}
+
+#[cfg(test)]
+mod test_drop_in {
+    //! The reference's own PSF tests (mp_perturbation.rs:433-448, gpv.rs:254-268, gpv_ring.rs:318-334), pointed at the GPU types.
+    use super::*;
+
+    #[test]
+    fn perturbation_samp_p_is_a_preimage() {
+        for (n, q) in [(5, 256), (6, 128)] {
+            let psf = GpuPSFPerturbation::new(
+                PSFPerturbation { gp: GadgetParameters::init_default(n, q), r: Q::from(n).log(2).unwrap(), s: Q::from(25) },
+                0,
+                1,
+            );
+            let (a, td) = psf.trap_gen();
+            let domain_sample = psf.samp_d();
+            let range_fa = psf.f_a(&a, &domain_sample);
+            let preimage = psf.samp_p(&a, &td, &range_fa);
+            assert_eq!(range_fa, psf.f_a(&a, &preimage));
+            assert!(psf.check_domain(&preimage));
+        }
+    }
+
+    #[test]
+    fn gpv_samp_p_is_a_preimage() {
+        let psf = GpuPSFGPV::new(PSFGPV { gp: GadgetParameters::init_default(5, 256), s: Q::from(10) }, 0, 2);
+        let (a, td) = psf.trap_gen();
+        let range_fa = psf.f_a(&a, &psf.samp_d());
+        let preimage = psf.samp_p(&a, &td, &range_fa);
+        assert_eq!(range_fa, psf.f_a(&a, &preimage));
+        assert!(psf.check_domain(&preimage));
+    }
+
+    #[test]
+    fn ring_samp_p_is_a_preimage() {
+        let psf = GpuPSFGPVRing::new(
+            PSFGPVRing { gp: GadgetParametersRing::init_default(8, 512), s: Q::from(100), s_td: Q::from(1.005_f64) },
+            0,
+            3,
+        );
+        let (a, td) = psf.trap_gen();
+        let range_fa = psf.f_a(&a, &psf.samp_d());
+        let preimage = psf.samp_p(&a, &td, &range_fa);
+        assert_eq!(range_fa, psf.f_a(&a, &preimage));
+        assert!(psf.check_domain(&preimage));
+    }
+}

@@ -1,0 +1,74 @@
+"""The Rust shim crate (shim/) cannot be compiled here (no cargo / rustc / qfall-math / FLINT: SURVEY.md F3, F8).  What can be checked
+without a toolchain is checked: the `extern "C"` block is generated from include/psf_mi355x.h and is up to date; every function in it is
+exported by the built library with the header's arity; every ffi function and every helper the `impl PSF` blocks call is defined; the
+trait methods of psf.rs:39-81 are implemented for all three types; the benches carry the reference's names (benches/psf.rs:26-100)."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "shim")
+
+
+def read(*parts):
+    with open(os.path.join(*parts)) as fh:
+        return fh.read()
+
+
+def test_extern_block_is_generated_from_the_header_and_up_to_date():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_every_extern_function_is_exported_with_the_headers_arity():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi as G
+    protos = {name: params for _, name, params in G.parse_prototypes(read(ROOT, "include", "psf_mi355x.h"))}
+    ffi = read(SHIM, "src", "ffi.rs")
+    rust = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (\w+)\(([^)]*)\)", ffi)}
+    assert set(rust) == set(protos) and len(rust) >= 70
+    for name, args in rust.items():
+        n_rust = 0 if not args.strip() else len(args.split(","))
+        assert n_rust == len(protos[name]), name
+    lib = os.path.join(ROOT, "tools_amd", "lib", "libpsf_mi355x.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = set(line.split()[-1] for line in syms.splitlines() if line.strip())
+    missing = sorted(set(rust) - exported)
+    assert not missing, missing
+
+
+def test_impls_only_use_defined_functions_and_cover_the_trait():
+    lib = read(SHIM, "src", "lib.rs")
+    ffi_names = set(re.findall(r"pub fn (\w+)\(", read(SHIM, "src", "ffi.rs")))
+    used_ffi = set(re.findall(r"ffi::(psf\w+)\(", lib))
+    assert used_ffi and used_ffi <= ffi_names, sorted(used_ffi - ffi_names)
+    defined = set(re.findall(r"\bfn (\w+)", lib))
+    # free-function calls: identifier directly followed by "(" that is neither a method (preceded by "."), a path segment (preceded by "::"),
+    # a macro, a keyword, nor a tuple-struct / enum constructor (capitalised)
+    calls = set(m.group(1) for m in re.finditer(r"(?<![\w.:!])([a-z_][a-z0-9_]*)\(", re.sub(r"//[^\n]*", "", lib)))
+    calls -= {"if", "while", "for", "match", "fn", "unsafe", "loop", "return", "drop", "assert", "panic", "vec", "format", "check_domain", "allow", "cfg", "test"}
+    undefined = sorted(c for c in calls if c not in defined)
+    assert not undefined, undefined
+    for helper in ("matzq_from_rows", "matq_lower_from_packed", "ensure_key", "next_seed", "dims"):      # the helpers round 1 left undefined
+        assert helper in defined
+    for ty in ("GpuPSFPerturbation", "GpuPSFGPV", "GpuPSFGPVRing"):
+        block = lib[lib.index(f"impl PSF for {ty}"):]
+        block = block[:block.index("\n}\n") + 3]
+        for method in ("fn trap_gen(&self)", "fn samp_d(&self)", "fn samp_p(&self", "fn f_a(&self", "fn check_domain(&self"):
+            assert method in block, (ty, method)
+        for assoc in ("type A =", "type Trapdoor =", "type Domain =", "type Range ="):
+            assert assoc in block, (ty, assoc)
+    # balanced delimiters (a cheap syntax sanity check of a file no compiler has seen)
+    code = re.sub(r'"(?:[^"\\]|\\.)*"', '""', re.sub(r"//[^\n]*", "", lib))
+    for o, c in ("()", "[]", "{}"):
+        assert code.count(o) == code.count(c), (o, code.count(o), code.count(c))
+
+
+def test_benches_mirror_the_references_names():
+    b = read(SHIM, "benches", "psf.rs")
+    for name in ("PSF GPV n=8", "PSF Perturbation n=8", "PSF Perturbation n=64"):      # benches/psf.rs:38, :63, :90
+        assert f'"{name} (MI355X)"' in b
+    assert "criterion_group!" in b and "criterion_main!" in read(SHIM, "benches", "benchmarks.rs")
+    cargo = read(SHIM, "Cargo.toml")
+    assert 'name = "benchmarks"' in cargo and "harness = false" in cargo and "qfall-tools" in cargo
