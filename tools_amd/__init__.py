@@ -8,3 +8,4 @@ from ._ffi import PsfError, LIB_PATH  # noqa: F401
 from .psf import GadgetParameters, GadgetParametersRing, PSFPerturbation, PSFGPV, PSFGPVRing  # noqa: F401
 from . import gadget  # noqa: F401
 from . import textio  # noqa: F401
+from . import serde_json  # noqa: F401
