@@ -602,3 +602,43 @@ class PSFGPVRing:
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+# ---------------------------------------------------------------- faithful mode (GMP exact rationals; timing model of reference-style arithmetic)
+_faith = None
+
+
+def faithful_lib():
+    """libpsf_faithful.so (oracle/psf_faithful_gmp.c), or None where GMP was not available at build time."""
+    global _faith
+    if _faith is None:
+        path = os.path.join(_HERE, "libpsf_faithful.so")
+        if not os.path.exists(path):
+            subprocess.call(["make", "-C", _HERE, "faithful"], stdout=subprocess.DEVNULL)
+        if not os.path.exists(path):
+            return None
+        lib()                                   # the oracle proper must be loaded first (the faithful library links against it)
+        _faith = C.CDLL(path)
+    return _faith
+
+
+def faithful_psfp_samp_p(orc, seed, index, u):
+    """One PSFPerturbation::samp_p call in mpq / mpz arithmetic (dense rational mat-vec, dense nk x nk GSO, [R; I] rebuilt)."""
+    F = faithful_lib()
+    u = _u64(u).reshape(orc.n)
+    e = np.zeros(orc.m, dtype=np.int64)
+    _check(F.orc_faithful_psfp_samp_p(orc._h, C.c_uint64(seed), C.c_uint64(index), _p(u, C.c_uint64), _p(e, C.c_int64)))
+    return e
+
+
+def faithful_gpv_samp_p(A, q, basis_t, gso_t, s, seed, index, u):
+    """One PSFGPV::samp_p call: per-call elimination, nearest plane on the dense m x m rational Gram-Schmidt matrix."""
+    F = faithful_lib()
+    A, u = _u64(A), _u64(u).reshape(-1)
+    n, m = A.shape
+    bt = np.ascontiguousarray(basis_t, dtype=np.int32)
+    gt = np.ascontiguousarray(gso_t, dtype=np.float64)
+    e = np.zeros(m, dtype=np.int64)
+    _check(F.orc_faithful_gpv_samp_p(_p(A, C.c_uint64), C.c_size_t(n), C.c_size_t(m), C.c_uint64(q), _p(bt, C.c_int32), _p(gt, C.c_double),
+                                     C.c_double(s), C.c_uint64(seed), C.c_uint64(index), _p(u, C.c_uint64), _p(e, C.c_int64)))
+    return e

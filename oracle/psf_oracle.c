@@ -697,93 +697,201 @@ int orc_num_threads(void) {
 #endif
 }
 
-/* Batch of B independent samp_p calls; identical results to the trace routine (same summation orders),
- * restructured so that GRP preimages share each pass over sqrt(Sigma_2), A and R. */
-#define GRP 16
+/* Batch of B independent samp_p calls; identical results to the trace routine (same summation orders), restructured as a
+ * cache-blocked triangular product so that one pass over sqrt(Sigma_2), A and R serves a whole group of preimages:
+ *   group   = ORC_GRP preimages (one OpenMP task each)
+ *   x = L d : rows in panels of ORC_MC, coordinates in chunks of ORC_KC ascending; the accumulators of a panel (MC x GRP) stay in
+ *             L2 while the chunks of D (KC x GRP) stream through; micro-tile 4 rows x 32 preimages = 16 vector accumulators.
+ *             Every x[i][b] is still ONE fma chain over j = 0..i in ascending order from +0, so the bits are those of the
+ *             scalar loop of orc_psfp_samp_p_trace.  The hot loop is compiled for AVX-512 / AVX2+FMA / baseline and
+ *             dispatched at load time (target_clones), because the library is built in one container and runs on another host. */
+#define ORC_GRP 256
+#define ORC_MC 128
+#define ORC_KC 256
+#define GRP ORC_GRP
+
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__) && !defined(ORC_NO_CLONES)
+#define ORC_CLONES __attribute__((target_clones("avx512f", "avx2,fma", "default")))
+#else
+#define ORC_CLONES
+#endif
+
+/* acc[r][b] = fma(L[i0 + r][j], D[j][b], acc[r][b]) for j = j0 .. j1-1 (ascending), r < 4, b in [b0, b0 + 32): all four rows lie
+ * entirely below the chunk, i.e. j1 <= i0 + 1 */
+ORC_CLONES
+static void tile_4x32(const double* const lrow[4], size_t j0, size_t j1, const double* D, double* const arow[4], size_t b0) {
+  double a0[32], a1[32], a2[32], a3[32];
+  for (int b = 0; b < 32; ++b) { a0[b] = arow[0][b0 + b]; a1[b] = arow[1][b0 + b]; a2[b] = arow[2][b0 + b]; a3[b] = arow[3][b0 + b]; }
+  for (size_t j = j0; j < j1; ++j) {
+    const double* dj = D + j * GRP + b0;
+    const double l0 = lrow[0][j], l1 = lrow[1][j], l2 = lrow[2][j], l3 = lrow[3][j];
+#pragma GCC ivdep
+    for (int b = 0; b < 32; ++b) {
+      const double d = dj[b];
+      a0[b] = __builtin_fma(l0, d, a0[b]);
+      a1[b] = __builtin_fma(l1, d, a1[b]);
+      a2[b] = __builtin_fma(l2, d, a2[b]);
+      a3[b] = __builtin_fma(l3, d, a3[b]);
+    }
+  }
+  for (int b = 0; b < 32; ++b) { arow[0][b0 + b] = a0[b]; arow[1][b0 + b] = a1[b]; arow[2][b0 + b] = a2[b]; arow[3][b0 + b] = a3[b]; }
+}
+/* one row against a chunk that reaches its diagonal: j = j0 .. min(j1, i + 1) - 1 */
+ORC_CLONES
+static void row_chunk(const double* li, size_t j0, size_t jend, const double* D, double* ai) {
+  for (size_t j = j0; j < jend; ++j) {
+    const double l = li[j];
+    const double* dj = D + j * GRP;
+#pragma GCC ivdep
+    for (int b = 0; b < GRP; ++b) ai[b] = __builtin_fma(l, dj[b], ai[b]);
+  }
+}
+
 int orc_psfp_samp_p(const orc_psfp* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u,
                     int64_t* e, int nthreads) {
   const orc_gadget_params* gp = &h->gp;
-  size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = h->m;
-  uint64_t q = gp->q;
-  size_t ngroups = (B + GRP - 1) / GRP;
+  const size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = h->m;
+  const uint64_t q = gp->q;
+  const size_t ngroups = (B + GRP - 1) / GRP, npanels = (m + ORC_MC - 1) / ORC_MC;
   int status = ORC_OK;
+  if (!h->L) return ORC_ERR_PARAM;
+  if (B == 0) return ORC_OK;
   double* norm2 = (double*)malloc(2 * k * sizeof(double));
   gadget_tables(h, norm2, norm2 + k);
+  /* all groups at once, so that every phase has (groups x panels) or (groups x preimages) independent tasks for the threads */
+  double* Dall = (double*)calloc(ngroups * m * GRP, sizeof(double));
+  int32_t* Pall = (int32_t*)calloc(ngroups * m * GRP, sizeof(int32_t));
+  int32_t* Zall = (int32_t*)calloc(ngroups * w * GRP, sizeof(int32_t));
+  int64_t* maxp_g = (int64_t*)calloc(ngroups, sizeof(int64_t));
 #ifdef _OPENMP
   if (nthreads <= 0) nthreads = omp_get_max_threads();
+#endif
+  /* ---- d <- N(0,1)^m (:315) */
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(dynamic, 64) num_threads(nthreads)
+#endif
+  for (size_t g = 0; g < ngroups; ++g)
+    for (size_t j = 0; j < m; ++j) {
+      const size_t b0 = g * GRP, nb = (B - b0 < GRP) ? B - b0 : GRP;
+      double* D = Dall + g * m * GRP;
+      for (size_t b = 0; b < nb; ++b) D[j * GRP + b] = orc_sample_normal(seed, first_index + b0 + b, (uint32_t)j);
+    }
+  /* ---- x = sqrt(Sigma_2) d, p_i <- D_{Z,r,x_i} (:315): one task per (group, panel of ORC_MC rows), heavy panels first */
+#ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
 #endif
-  for (size_t g = 0; g < ngroups; ++g) {
-    size_t b0 = g * GRP, nb = (B - b0 < GRP) ? B - b0 : GRP;
-    double* D = (double*)calloc(m * GRP, sizeof(double));
-    int32_t* P = (int32_t*)calloc(m * GRP, sizeof(int32_t));
-    int32_t* Z = (int32_t*)calloc(w * GRP, sizeof(int32_t));
-    uint64_t* v = (uint64_t*)malloc(n * sizeof(uint64_t));
-    int64_t* zt = (int64_t*)malloc(w * sizeof(int64_t));
-    int64_t maxp = 0;
-    for (size_t j = 0; j < m; ++j)
-      for (size_t b = 0; b < nb; ++b) D[j * GRP + b] = orc_sample_normal(seed, first_index + b0 + b, (uint32_t)j);
-    for (size_t i = 0; i < m; ++i) {
-      const double* li = h->L + i * (i + 1) / 2;
-      double acc[GRP];
-      for (int b = 0; b < GRP; ++b) acc[b] = 0.0;
-      for (size_t j = 0; j <= i; ++j) {
-        double l = li[j];
-        const double* dj = D + j * GRP;
-        for (int b = 0; b < GRP; ++b) acc[b] = __builtin_fma(l, dj[b], acc[b]);
+  for (size_t task = 0; task < ngroups * npanels; ++task) {
+    const size_t g = task % ngroups, pn = npanels - 1 - task / ngroups;
+    const size_t b0 = g * GRP, nb = (B - b0 < GRP) ? B - b0 : GRP;
+    const double* D = Dall + g * m * GRP;
+    int32_t* P = Pall + g * m * GRP;
+    double* acc = (double*)malloc(ORC_MC * GRP * sizeof(double));
+    const size_t i0 = pn * ORC_MC;
+    const size_t rows = m - i0 < ORC_MC ? m - i0 : ORC_MC;
+    for (size_t t = 0; t < rows * GRP; ++t) acc[t] = 0.0;
+    for (size_t j0 = 0; j0 < i0 + rows; j0 += ORC_KC) {              /* chunks in ascending order: the chain of every element stays ascending */
+      const size_t j1 = j0 + ORC_KC;
+      size_t first_full = 0;
+      while (first_full < rows && i0 + first_full + 1 < j1) ++first_full;   /* row i sees the full chunk iff j1 <= i + 1 */
+      for (size_t rr = 0; rr < first_full; ++rr) {                   /* rows that cross or end inside the chunk: one by one */
+        const size_t i = i0 + rr;
+        if (j0 > i) continue;
+        const size_t jend = j1 < i + 1 ? j1 : i + 1;
+        row_chunk(h->L + i * (i + 1) / 2, j0, jend, D, acc + rr * GRP);
       }
+      size_t rr = first_full;
+      for (; rr + 4 <= rows; rr += 4) {                              /* the rest: 4 x 32 tiles */
+        const double* lrow[4]; double* arow[4];
+        for (int t = 0; t < 4; ++t) { const size_t i = i0 + rr + t; lrow[t] = h->L + i * (i + 1) / 2; arow[t] = acc + (rr + t) * GRP; }
+        for (size_t bb = 0; bb < GRP; bb += 32) tile_4x32(lrow, j0, j1, D, arow, bb);
+      }
+      for (; rr < rows; ++rr) {
+        const size_t i = i0 + rr;
+        row_chunk(h->L + i * (i + 1) / 2, j0, j1, D, acc + rr * GRP);
+      }
+    }
+    int64_t maxp = 0;
+    for (size_t rr = 0; rr < rows; ++rr) {
+      const size_t i = i0 + rr;
       for (size_t b = 0; b < nb; ++b) {
-        int64_t pv = orc_sample_z(seed, ORC_TAG_PERTURB, first_index + b0 + b, (uint32_t)i, acc[b], h->r);
+        int64_t pv = orc_sample_z(seed, ORC_TAG_PERTURB, first_index + b0 + b, (uint32_t)i, acc[rr * GRP + b], h->r);
         P[i * GRP + b] = (int32_t)pv;
         int64_t ap = pv < 0 ? -pv : pv;
         if (ap > maxp) maxp = ap;
       }
     }
-    /* v = u - A p : int64 chunks when q*max|p|*chunk fits, else 128-bit */
-    int fast = (q < ((uint64_t)1 << 31)) && (maxp < ((int64_t)1 << 24));
-    for (size_t b = 0; b < nb; ++b) {
-      for (size_t i = 0; i < n; ++i) {
-        const uint64_t* ai = h->A + i * m;
-        uint64_t red;
-        if (fast) {
-          i128 tot = 0;
-          for (size_t j0 = 0; j0 < m; j0 += 128) {
-            size_t j1 = j0 + 128 < m ? j0 + 128 : m;
-            int64_t acc = 0;
-            for (size_t j = j0; j < j1; ++j) acc += (int64_t)ai[j] * P[j * GRP + b];
-            tot += acc;
-          }
-          red = reduce_i128(tot, q);
-        } else {
-          i128 acc = 0;
-          for (size_t j = 0; j < m; ++j) acc += (i128)ai[j] * P[j * GRP + b];
-          red = reduce_i128(acc, q);
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+    { if (maxp > maxp_g[g]) maxp_g[g] = maxp; }
+    free(acc);
+  }
+  /* ---- v = u - A p (:318), z <- gadget sampler (:321-326): one task per preimage */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+  for (size_t bg = 0; bg < B; ++bg) {
+    const size_t g = bg / GRP, b = bg % GRP;
+    const int32_t* P = Pall + g * m * GRP;
+    int32_t* Z = Zall + g * w * GRP;
+    uint64_t* v = (uint64_t*)malloc(n * sizeof(uint64_t));
+    int64_t* zt = (int64_t*)malloc(w * sizeof(int64_t));
+    /* int64 chunks when q * max|p| * chunk fits, else 128-bit */
+    const int fast = (q < ((uint64_t)1 << 31)) && (maxp_g[g] < ((int64_t)1 << 24));
+    for (size_t i = 0; i < n; ++i) {
+      const uint64_t* ai = h->A + i * m;
+      uint64_t red;
+      if (fast) {
+        i128 tot = 0;
+        for (size_t j0 = 0; j0 < m; j0 += 128) {
+          size_t j1 = j0 + 128 < m ? j0 + 128 : m;
+          int64_t acc2 = 0;
+          for (size_t j = j0; j < j1; ++j) acc2 += (int64_t)ai[j] * P[j * GRP + b];
+          tot += acc2;
         }
-        v[i] = submod(u[(b0 + b) * n + i] % q, red, q);
+        red = reduce_i128(tot, q);
+      } else {
+        i128 acc2 = 0;
+        for (size_t j = 0; j < m; ++j) acc2 += (i128)ai[j] * P[j * GRP + b];
+        red = reduce_i128(acc2, q);
       }
-      int rc = gadget_sample_one(h, norm2, norm2 + k, seed, first_index + b0 + b, v, zt);
-      if (rc) { status = rc; }
-      for (size_t c = 0; c < w; ++c) Z[c * GRP + b] = (int32_t)zt[c];
+      v[i] = submod(u[bg * n + i] % q, red, q);
     }
-    /* e = p + [R; I] z */
-    for (size_t i = 0; i < mb; ++i) {
-      int32_t acc[GRP];
-      for (int b = 0; b < GRP; ++b) acc[b] = 0;
+    int rc = gadget_sample_one(h, norm2, norm2 + k, seed, first_index + bg, v, zt);
+    if (rc) { status = rc; }
+    for (size_t c = 0; c < w; ++c) Z[c * GRP + b] = (int32_t)zt[c];
+    free(v); free(zt);
+  }
+  /* ---- e = p + [R; I] z (:328-335): one task per (group, 64 rows of R) */
+  const size_t nrt = (mb + 63) / 64;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+  for (size_t task = 0; task < ngroups * nrt; ++task) {
+    const size_t g = task / nrt, i0 = (task % nrt) * 64, i1 = i0 + 64 < mb ? i0 + 64 : mb;
+    const size_t b0 = g * GRP, nb = (B - b0 < GRP) ? B - b0 : GRP;
+    const int32_t* P = Pall + g * m * GRP;
+    const int32_t* Z = Zall + g * w * GRP;
+    int32_t racc[GRP];
+    for (size_t i = i0; i < i1; ++i) {
+      for (int b = 0; b < GRP; ++b) racc[b] = 0;
       const int8_t* ri = h->R + i * w;
       for (size_t c = 0; c < w; ++c) {
-        int32_t rv = ri[c];
+        const int32_t rv = ri[c];
+        if (!rv) continue;
         const int32_t* zc = Z + c * GRP;
-        for (int b = 0; b < GRP; ++b) acc[b] += rv * zc[b];
+        for (int b = 0; b < GRP; ++b) racc[b] += rv * zc[b];
       }
-      for (size_t b = 0; b < nb; ++b) e[(b0 + b) * m + i] = (int64_t)P[i * GRP + b] + acc[b];
+      for (size_t b = 0; b < nb; ++b) e[(b0 + b) * m + i] = (int64_t)P[i * GRP + b] + racc[b];
     }
-    for (size_t c = 0; c < w; ++c)
-      for (size_t b = 0; b < nb; ++b) e[(b0 + b) * m + mb + c] = (int64_t)P[(mb + c) * GRP + b] + Z[c * GRP + b];
-    free(D); free(P); free(Z); free(v); free(zt);
+    if (task % nrt == 0)
+      for (size_t c = 0; c < w; ++c)
+        for (size_t b = 0; b < nb; ++b) e[(b0 + b) * m + mb + c] = (int64_t)P[(mb + c) * GRP + b] + Z[c * GRP + b];
   }
-  free(norm2);
+  free(Dall); free(Pall); free(Zall); free(maxp_g); free(norm2);
   return status;
 }
+#undef GRP
 
 /* mp_perturbation.rs:264-267: D_{Z^m, s*r} centred at 0 */
 int orc_psfp_samp_d(const orc_psfp* h, uint64_t seed, uint64_t first_index, size_t B, int64_t* e) {
