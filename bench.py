@@ -261,7 +261,7 @@ def cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, seed, sample):
     import numpy as np
     from oracle import oracle as O
     O.build()
-    threads = O.num_threads()
+    threads, quota_note = effective_cpus(O.num_threads())
     if scheme == "PSFPerturbation":
         S = sample or min(u.shape[0], 1024)          # four groups of 256 preimages x 241 row panels: enough tasks for every thread
         A, (R, Lp, _) = psf.export_key()
@@ -306,7 +306,22 @@ def cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, seed, sample):
             "sample": f"{S} of the batch's preimages (same key, seed and targets), {dt:.1f} s wall, {how}",
             "single_thread": {"value": round(S1 / dt1, 3), "threads": 1, "sample": f"{S1} preimages, {dt1:.1f} s wall"},
             "cpu": model, "matches_gpu_bitwise": same,
-            "note": "port, lightly tuned: blocked AVX-512/AVX2 triangular product, scalar samplers; see profiles/ for the GMP 'faithful mode' legs"}
+            "note": "port, lightly tuned: blocked AVX-512/AVX2 triangular product, scalar samplers; see profiles/ for the GMP 'faithful mode' legs" + quota_note}
+
+
+def effective_cpus(omp_threads):
+    """Threads the CPU leg may really use: the OpenMP default, capped by the cgroup CPU quota of the box (the GPU boxes expose every
+    hardware thread to nproc but run under a quota of 16 CPUs; 128 threads on 16 CPUs' worth of time only add scheduling overhead)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            cap = max(1, int(int(quota) / int(period)))
+            if cap < omp_threads:
+                return cap, f"; threads capped at the cgroup CPU quota ({cap} of {omp_threads} hardware threads)"
+    except (OSError, ValueError):
+        pass
+    return omp_threads, ""
 
 
 if __name__ == "__main__":
