@@ -135,8 +135,19 @@ typedef struct {
   double r;        /* rounding parameter (mp_perturbation.rs:60) */
   double s;        /* Gaussian parameter (mp_perturbation.rs:61) */
   int32_t device;  /* HIP device ordinal */
-  uint32_t flags;  /* reserved, 0 */
+  uint32_t flags;  /* 0, or PSFP_FLAG_STRUCTURED_SQRT */
 } psfp_params;
+
+/* Opt-in: a STRUCTURED square root of Sigma_2 instead of the dense Cholesky factor of mp_perturbation.rs:138.  With Sigma = s^2 I,
+ *   Sigma_2 = c [[alpha I - kappa R R^t, -kappa R], [-kappa R^t, beta I]],  c = r^2 / 2 pi, kappa = base^2 + 1, alpha = s^2 - 1, beta = alpha - kappa,
+ * factors as B B^t with B = [[L_1, -g R], [0, h I]], L_1 = chol(c (alpha I - kappa (alpha / beta) R R^t)) (m_bar x m_bar), g = sqrt(c) kappa / sqrt(beta),
+ * h = sqrt(c beta).  The perturbation is sampled as x_top = L_1 d_1 - g R d_2, x_bot = h d_2: a quarter of the FP64 work, a key of m_bar(m_bar+1)/2 doubles
+ * instead of m(m+1)/2, trap_gen eight times cheaper.  Any square root of Sigma_2 gives the same distribution (the reference's sampler only needs
+ * B B^t = Sigma_2); individual outputs differ from the dense path, so this is a different -- labelled -- algorithm, not the parity path.
+ * d_2 is taken in fixed point (multiples of 2^-32) so that R d_2 is an exact integer sum.  In this mode the `sqrt_sigma2_packed` arguments of
+ * psfp_load_key / psfp_export_key / psfp_export_sqrt_sigma2_rows hold L_1 (m_bar(m_bar+1)/2 doubles); psfp_load_key expects a factor produced with the
+ * handle's (r, s). */
+#define PSFP_FLAG_STRUCTURED_SQRT 2u
 
 /* Limits: k <= 64, 1 < q < 2^62, and s * r * sqrt(m) < 2^23 (every coordinate of an in-domain vector then fits the three int8
  * digit planes of the Z_q products); PSF_ERR_UNSUPPORTED otherwise.  BASELINE's largest set (n=1024, q=2^60, s=1024, r=10)

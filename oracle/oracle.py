@@ -305,6 +305,24 @@ class PSFPerturbation:
         rc = lib().orc_psfp_sqrt_sigma_2_leading(self._h, _p(R, C.c_int8), C.c_double(s_cov), C.c_size_t(m0), _p(Lp, C.c_double))
         return rc, Lp
 
+    def structured_sqrt(self, R, s_cov):
+        """L_1 of the structured square root of Sigma_2 (m_bar(m_bar+1)/2 doubles, packed rows)."""
+        R = _i8(R)
+        Lp = np.zeros(self.m_bar * (self.m_bar + 1) // 2)
+        rc = lib().orc_psfp_structured_sqrt(self._h, _p(R, C.c_int8), C.c_double(s_cov), _p(Lp, C.c_double))
+        return rc, Lp
+
+    def samp_p_structured_trace(self, L1_packed, s_cov, seed, index, u):
+        """One preimage through the structured square root (A, R from load_key); all stages."""
+        u = _u64(u).reshape(self.n)
+        L1 = np.ascontiguousarray(L1_packed, dtype=np.float64)
+        d, x = np.zeros(self.m), np.zeros(self.m)
+        p, e = np.zeros(self.m, dtype=np.int64), np.zeros(self.m, dtype=np.int64)
+        v, z = np.zeros(self.n, dtype=np.uint64), np.zeros(self.w, dtype=np.int64)
+        _check(lib().orc_psfp_samp_p_structured_trace(self._h, _p(L1, C.c_double), C.c_double(s_cov), C.c_uint64(seed), C.c_uint64(index), _p(u, C.c_uint64),
+                                                      _p(d, C.c_double), _p(x, C.c_double), _p(p, C.c_int64), _p(v, C.c_uint64), _p(z, C.c_int64), _p(e, C.c_int64)))
+        return dict(d=d, x=x, p=p, v=v, z=z, e=e)
+
     def samp_p_from_x(self, seed, index, u, x):
         """p, v, z, e of one preimage from its centres x (every stage after x = sqrt(Sigma_2) d)."""
         u = _u64(u).reshape(self.n)

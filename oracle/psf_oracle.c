@@ -556,6 +556,87 @@ static int sqrt_sigma_2_rows(const orc_psfp* h, const int8_t* R, double s_cov, s
   return ORC_OK;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Structured square root of Sigma_2 (the library's labelled opt-in, PSFP_FLAG_STRUCTURED_SQRT; not the reference's Cholesky path):
+ *   Sigma_2 = c [[alpha I - kappa R R^t, -kappa R], [-kappa R^t, beta I]]   (c = r^2 / 2 pi, kappa = b^2 + 1, alpha = s^2 - 1, beta = alpha - kappa)
+ *           = B B^t,  B = [[L_1, -g R], [0, h I]],  L_1 L_1^t = c (alpha I - kappa (alpha / beta) R R^t),  g = sqrt(c) kappa / sqrt(beta),  h = sqrt(c beta)
+ * so x = B d is  x_top = L_1 d_1 - g R d_2,  x_bot = h d_2  -- the same distribution as sqrt(Sigma_2) d of mp_perturbation.rs:315 for ANY square root.
+ * Contract: d_1 = normals of coordinates < m_bar; d_2[c] = q_c 2^-32 with q_c = floor(n 2^32 + 1/2) for the normal n of coordinate m_bar + c;
+ * y_i = ascending fma chain of L_1 d_1; x_i = fma(-g, (double)(sum_c R[i][c] q_c) 2^-32, y_i) (the integer sum is exact); x_{m_bar+c} = h d_2[c].
+ * ---------------------------------------------------------------------------------------- */
+void orc_psfp_structured_constants(const orc_psfp* h, double s_cov, double* g, double* hh, double* kab) {
+  const double TWO_PI = 6.283185307179586476925;
+  const double nf_r2 = (1.0 / TWO_PI) * (h->r * h->r);
+  const double kappa = (double)(h->gp.base * h->gp.base + 1), alpha = s_cov * s_cov - 1.0, beta = alpha - kappa;
+  *g = (sqrt(nf_r2) * kappa) / sqrt(beta);
+  *hh = sqrt(nf_r2 * beta);
+  *kab = kappa * (alpha / beta);
+}
+
+/* L_1 (m_bar x m_bar lower, packed by rows) */
+int orc_psfp_structured_sqrt(const orc_psfp* h, const int8_t* R, double s_cov, double* Lp) {
+  const orc_gadget_params* gp = &h->gp;
+  const size_t mb = gp->m_bar, w = gp->n * gp->k;
+  const double TWO_PI = 6.283185307179586476925;
+  const double nf_r2 = (1.0 / TWO_PI) * (h->r * h->r), s2 = s_cov * s_cov;
+  double g, hh, kab;
+  orc_psfp_structured_constants(h, s_cov, &g, &hh, &kab);
+  if (!((s2 - 1.0) - (double)(gp->base * gp->base + 1) > 0.0)) return ORC_ERR_NOT_PD;
+  for (size_t i = 0; i < mb; ++i) {
+    double* row = Lp + i * (i + 1) / 2;
+    for (size_t j = 0; j <= i; ++j) {
+      int32_t acc = 0;
+      const int8_t *ri = R + i * w, *rj = R + j * w;
+      for (size_t c = 0; c < w; ++c) acc += (int32_t)ri[c] * rj[c];
+      double sp = (i == j ? s2 : 0.0) - kab * (double)acc;       /* same expression shape as the dense assembly */
+      if (i == j) sp = sp - 1.0;
+      row[j] = nf_r2 * sp;
+    }
+  }
+  for (size_t i = 0; i < mb; ++i) {
+    double* li = Lp + i * (i + 1) / 2;
+    for (size_t j = 0; j <= i; ++j) {
+      const double* lj = Lp + j * (j + 1) / 2;
+      double sum = li[j];
+      for (size_t t = 0; t < j; ++t) sum = fma(-li[t], lj[t], sum);
+      if (i == j) {
+        if (!(sum > 0.0)) return ORC_ERR_NOT_PD;
+        li[j] = sqrt(sum);
+      } else li[j] = sum / lj[j];
+    }
+  }
+  return ORC_OK;
+}
+
+/* one preimage in structured mode, every intermediate exposed; L1p as above, s_cov the Gaussian parameter the factor was built for */
+int orc_psfp_samp_p_structured_trace(const orc_psfp* h, const double* L1p, double s_cov, uint64_t seed, uint64_t index, const uint64_t* u,
+                                     double* d, double* x, int64_t* p, uint64_t* v, int64_t* z, int64_t* e) {
+  const size_t mb = h->gp.m_bar, w = h->gp.n * h->gp.k, m = h->m;
+  double g, hh, kab;
+  orc_psfp_structured_constants(h, s_cov, &g, &hh, &kab);
+  int64_t* q = (int64_t*)malloc(w * sizeof(int64_t));
+  for (size_t j = 0; j < mb; ++j) d[j] = orc_sample_normal(seed, index, (uint32_t)j);
+  for (size_t c = 0; c < w; ++c) {
+    const double nrm = orc_sample_normal(seed, index, (uint32_t)(mb + c));
+    const double sc = floor(nrm * 0x1.0p32 + 0.5);
+    q[c] = (int64_t)sc;
+    d[mb + c] = sc * 0x1.0p-32;
+  }
+  for (size_t i = 0; i < mb; ++i) {
+    const double* li = L1p + i * (i + 1) / 2;
+    double acc = 0.0;
+    for (size_t j = 0; j <= i; ++j) acc = fma(li[j], d[j], acc);
+    const int8_t* ri = h->R + i * w;
+    int64_t tot = 0;
+    for (size_t c = 0; c < w; ++c) tot += (int64_t)ri[c] * q[c];
+    x[i] = fma(-g, (double)tot * 0x1.0p-32, acc);
+  }
+  for (size_t c = 0; c < w; ++c) x[mb + c] = hh * d[mb + c];
+  free(q);
+  (void)m;
+  return orc_psfp_samp_p_from_x(h, seed, index, u, x, p, v, z, e);
+}
+
 /* mp_perturbation.rs:221-244 (tag = identity, :223) */
 int orc_psfp_trap_gen(orc_psfp* h, uint64_t seed) {
   const orc_gadget_params* gp = &h->gp;

@@ -108,6 +108,10 @@ int orc_psfp_centres_rows(const double* Lrows, size_t row0, size_t nrows, size_t
 /* samp_p from the centres on: p, v, z, e of one preimage (uses A, R; not L) */
 int orc_psfp_samp_p_from_x(const orc_psfp*, uint64_t seed, uint64_t index, const uint64_t* u, const double* x,
                            int64_t* p, uint64_t* v, int64_t* z, int64_t* e);
+/* structured square root of Sigma_2 (the product's labelled opt-in; contract in psf_oracle.c) */
+int orc_psfp_structured_sqrt(const orc_psfp*, const int8_t* R, double s_cov, double* L1_packed /*m_bar(m_bar+1)/2*/);
+int orc_psfp_samp_p_structured_trace(const orc_psfp*, const double* L1_packed, double s_cov, uint64_t seed, uint64_t index, const uint64_t* u,
+                                     double* d, double* x, int64_t* p, uint64_t* v, int64_t* z, int64_t* e);
 /* mp_perturbation.rs:304-336, B independent calls; u: B x n, e: B x m ; nthreads<=0 -> all cores */
 int orc_psfp_samp_p(const orc_psfp*, uint64_t seed, uint64_t first_index, size_t B,
                     const uint64_t* u, int64_t* e, int nthreads);

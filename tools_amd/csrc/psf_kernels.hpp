@@ -81,8 +81,15 @@ __global__ void k_unpack_L(const double* __restrict__ chunks, size_t first, size
 constexpr int NR_SEG = 4096;   // two chunks
 __device__ inline int lane_rank(uint64_t mask);
 
+// Structured sqrt(Sigma_2) (opt-in, struct NormalsFixed): the coordinates from `split` on (the gadget half, d_2) are taken in FIXED POINT,
+// d = q 2^-32 with q = floor(n 2^32 + 1/2) for the drawn normal n -- so that R d_2 is an exact integer sum on the int8 matrix cores.
+// For those coordinates the kernel also writes the five balanced base-256 digits of q as int8 planes [c/16][b][16] (c = coordinate - split)
+// and the finished centre x = h d into X (the bottom block of the factor is a multiple of the identity).
+struct NormalsFixed { size_t split; int8_t* planes; size_t plane_bytes; size_t ld; double* X; double h; };
+constexpr int kFixPlanes = 5;      // |q| < 2^39: normals beyond +-64 do not occur
+
 __global__ __launch_bounds__(256) void k_normals_wave(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t nkb, size_t nbj,
-                                                      double* __restrict__ Dt, int* __restrict__ fail) {
+                                                      double* __restrict__ Dt, int* __restrict__ fail, NormalsFixed fx) {
   const int lane = threadIdx.x & 63;
   const size_t total = nbj * nkb * TR_CHUNK;
   const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NR_SEG;
@@ -123,6 +130,21 @@ __global__ __launch_bounds__(256) void k_normals_wave(uint64_t seed, uint64_t fi
         accept = u <= det_exp(-0.25 * (x * x));
         v = x;
         if (!accept && ++t >= kMaxAttempts) { accept = true; f = 1; v = 0.0; }
+        if (accept && fx.planes && coord >= fx.split) {              // fixed-point coordinate of the structured factor
+          const double sc = floor(v * 0x1.0p32 + 0.5);
+          if (!(fabs(sc) < 0x1.0p38)) f = 1;                         // five balanced digits cover |q| < 2^39
+          long long qv = (long long)sc;
+          v = sc * 0x1.0p-32;
+          const size_t c = coord - fx.split;
+          const size_t addr = ((c >> 4) * fx.ld + b) * 16 + (c & 15);
+#pragma unroll
+          for (int pl = 0; pl < kFixPlanes; ++pl) {
+            const long long dg = (long long)(int8_t)(qv & 0xff);
+            fx.planes[(size_t)pl * fx.plane_bytes + addr] = (int8_t)dg;
+            qv = (qv - dg) >> 8;
+          }
+          fx.X[coord * fx.ld + b] = fx.h * v;
+        }
       }
       if (accept) Dt[my] = v;
     }
@@ -196,7 +218,7 @@ __host__ inline unsigned tr_grid_size(int nbi, int nbj, int GR = 8, int GC = 8) 
 }
 
 __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const double* __restrict__ Lt, const double* __restrict__ Dt,
-                                                     double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx, int GR, int GC) {
+                                                     double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx, int GR, int GC, size_t row_hi) {
   // LDS: 2 stages x (A chunk 2048 doubles | B chunk 2048 doubles); filled by LDS-DMA (global_load_lds_dwordx4), no
   // staging registers: the accumulators (128 VGPRs) leave no room to hold a chunk in flight (hipcc serialised
   // register-staged prefetch loads behind vmcnt(0) waits).
@@ -268,7 +290,10 @@ __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        X[(row0 + i * 16 + (lane >> 4) + 4 * r) * ldx + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
+      {
+        const size_t row = row0 + i * 16 + (lane >> 4) + 4 * r;      // rows from row_hi on are padding of the factor (structured mode: they belong to x_bot)
+        if (row < row_hi) X[row * ldx + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
+      }
 }
 
 // ---- p_i <- D_{Z, r, x_i} ------------------------------------------------------------------------------
@@ -702,6 +727,92 @@ __global__ void k_zq_combine(int mode, const uint64_t* __restrict__ part, int sp
       out[cc * ldo + i] = s;
     }
   }
+}
+
+// ---- structured sqrt(Sigma_2): x_top -= g (R d_2) on the int8 matrix cores ---------------------------------------------------------
+// R (ternary) as the A operand, tile-packed like the digit planes of A (k_pack_R8); the five digit planes of q = d_2 2^32 as the B operand
+// ([c/16][b][16], written by k_normals_wave).  Per plane an exact int32 sum over the w columns (|.| <= w 128 < 2^31), the planes are
+// combined in int64 (|sum_c R q| < w 2^39 < 2^62), converted to double ONCE and folded into the centre:
+//   X[i][b] = fma(-g, (double)(sum_c R[i][c] q[c][b]) 2^-32, X[i][b])      (X holds L_1 d_1 from k_trmm_f64 on entry)
+// 64 x 64 tile per workgroup (4 waves, 2 x 2 of 32 x 32), K steps of 64, LDS-DMA double buffering as in k_zq_mfma.
+__global__ void k_pack_R8(const int8_t* __restrict__ R, size_t ldr, size_t mbar, size_t w, size_t rows_pad, size_t K_pad, int8_t* __restrict__ R8) {
+  const size_t total = rows_pad * K_pad;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / K_pad, kk = g % K_pad;
+    const int8_t v = (i < mbar && kk < w) ? R[i * ldr + kk] : (int8_t)0;
+    R8[((i / 64) * (K_pad / 64) + kk / 64) * 4096 + (i % 64) * 64 + (kk % 64)] = v;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_rd2_mfma(const int8_t* __restrict__ R8, size_t K_pad, const int8_t* __restrict__ D8, size_t plane_bytes, size_t ld,
+                                                     size_t mbar, double g, double* __restrict__ X) {
+  constexpr int NP = kFixPlanes, STAGE = (1 + NP) * 4096, NS = 3;      // three 24 KiB stages in flight: a K step is only 20 short MFMAs per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char rd_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const size_t b0 = (size_t)blockIdx.x * 64, i0 = (size_t)blockIdx.y * 64;
+  const int nks = (int)(K_pad / 64);
+  v4i acc[NP][2][2];
+#pragma unroll
+  for (int c = 0; c < NP; ++c)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc[c][x][y] = v4i{0, 0, 0, 0};
+  const int pA = wave * 64 + lane;   // 16-byte piece of a 4 KiB tile
+  const int8_t* srcA = R8 + (size_t)blockIdx.y * (K_pad / 64) * 4096 + (size_t)pA * 16;
+  const int8_t* srcP = D8 + ((size_t)(pA >> 6) * ld + b0 + (size_t)(pA & 63)) * 16;
+  auto stage_load = [&](int ks, int buf) {
+    unsigned char* base = rd_smem + buf * STAGE + wave * 1024;
+    __builtin_amdgcn_global_load_lds(srcA + (size_t)ks * 4096, (lds_void_ptr)base, 16, 0, 0);
+#pragma unroll
+    for (int e = 0; e < NP; ++e)
+      __builtin_amdgcn_global_load_lds(srcP + (size_t)e * plane_bytes + (size_t)ks * 4 * ld * 16, (lds_void_ptr)(base + (1 + e) * 4096), 16, 0, 0);
+  };
+  for (int s0 = 0; s0 < NS - 1 && s0 < nks; ++s0) stage_load(s0, s0);
+  const int r16 = lane & 15, gq = lane >> 4;
+  int cur = 0;
+  for (int ks = 0; ks < nks; ++ks) {
+    // stage ks has landed when at most the NS - 2 younger stages (1 + NP DMA instructions each) are outstanding
+    if (nks - 1 - ks >= NS - 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(1 + NP == 6, "the wait count above is the number of DMA instructions per stage");
+    __syncthreads();                                  // everybody's part of stage ks is in LDS; everybody is done with stage ks - 1
+    const int nxt = ks + NS - 1;
+    if (nxt < nks) stage_load(nxt, cur == 0 ? NS - 1 : cur - 1);
+    const unsigned char* sb = rd_smem + cur * STAGE;
+    v4i fa[2], fp[NP][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) fa[x] = *reinterpret_cast<const v4i*>(sb + ((wr * 32 + x * 16 + r16) * 64 + gq * 16));
+#pragma unroll
+    for (int e = 0; e < NP; ++e)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) fp[e][y] = *reinterpret_cast<const v4i*>(sb + (1 + e) * 4096 + ((gq * 64 + wc * 32 + y * 16 + r16) * 16));
+#pragma unroll
+    for (int e = 0; e < NP; ++e)
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[e][x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[x], fp[e][y], acc[e][x][y], 0, 0, 0);
+    cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  // C/D map: column (preimage) = lane & 15, row (i) = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        long long tot = 0;
+#pragma unroll
+        for (int e = NP - 1; e >= 0; --e) tot = tot * 256 + (long long)acc[e][x][y][r];
+        const size_t i = i0 + wr * 32 + x * 16 + 4 * gq + r, cc = b0 + wc * 32 + y * 16 + r16;
+        if (i < mbar) {
+          const double rd = (double)tot * 0x1.0p-32;
+          X[i * ld + cc] = fma(-g, rd, X[i * ld + cc]);
+        }
+      }
 }
 
 // ---- gadget: digit decomposition + randomized nearest plane on S_k ------------------------------------

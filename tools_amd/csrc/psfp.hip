@@ -14,6 +14,7 @@
 #include "psf_chol_kernels.hpp"
 
 #define PSFP_FLAG_NO_PERTURB 1u   // internal: handle used as the Z_q / f_a engine of PSFGPV(Ring); no sqrt(Sigma_2) buffers
+// PSFP_FLAG_STRUCTURED_SQRT (2u) is public: include/psf_mi355x.h
 
 using namespace psf;
 
@@ -45,8 +46,13 @@ struct psfp_handle {
   uint64_t* dA = nullptr;      // n x m
   int8_t* dR = nullptr;        // mb x ldr
   size_t ldr = 0;
-  double* dLt = nullptr;       // chunk stream of sqrt(Sigma_2)
+  double* dLt = nullptr;       // chunk stream of sqrt(Sigma_2) (structured mode: of L_1, the m_bar x m_bar block)
   size_t M_pad = 0, nbi = 0, nkb = 0;
+  // structured sqrt(Sigma_2) (PSFP_FLAG_STRUCTURED_SQRT): x_top = L_1 d_1 - g R d_2, x_bot = h d_2
+  bool structured = false;
+  size_t mL = 0, nbiL = 0;     // order of the stored triangular factor (m, or m_bar) and its row blocks
+  int8_t* dR8 = nullptr;       // R tile-packed for k_rd2_mfma, round_up(m_bar, 64) x ldr
+  double g_const = 0, h_const = 0;
   // gadget tables
   int32_t* dRng = nullptr;
   int32_t* dSk = nullptr; double* dGso = nullptr; double* dNorm2 = nullptr; SampleZParams* dSz = nullptr;
@@ -65,7 +71,8 @@ struct psfp_handle {
   // Two sets of the per-batch intermediates: consecutive samp_p calls alternate between them so that the sampling
   // stages of call i (stream aux) overlap the normals + FP64 product of call i+1 (stream s1).
   struct BatchSet { double* dDt = nullptr; double* dX = nullptr; int32_t* dP = nullptr; int8_t* dP8 = nullptr; uint64_t* dV = nullptr;
-                    int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; int* dFail = nullptr; } sets[2];
+                    int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; int* dFail = nullptr; int8_t* dD8 = nullptr; } sets[2];
+  int8_t* dD8 = nullptr;                      // five digit planes of d_2 2^32 (structured mode), [ldr/16][ld][16] each
   int32_t* dPf = nullptr; int8_t* dP8f = nullptr;   // scratch of f_a (kept apart from the pipelined sets)
   uint64_t* dPart = nullptr; int zq_splits = 1, zq_ks = 0;   // per-split residues of the int8-MFMA Z_q product
   bool gadget_queue = true;   // task-queue gadget sampler (PSF_GADGET_QUEUE=0: lock-step kernel)
@@ -86,13 +93,13 @@ static size_t gadget_lds_bytes(size_t k) { return k * k * 8 + k * 8 + k * sizeof
 
 static void select_set(psfp_handle* h, int i) {
   const auto& t = h->sets[i];
-  h->dDt = t.dDt; h->dX = t.dX; h->dP = t.dP; h->dP8 = t.dP8; h->dV = t.dV; h->dZlo = t.dZlo; h->dZhi = t.dZhi; h->dFail = t.dFail;
+  h->dDt = t.dDt; h->dX = t.dX; h->dP = t.dP; h->dP8 = t.dP8; h->dV = t.dV; h->dZlo = t.dZlo; h->dZhi = t.dZhi; h->dFail = t.dFail; h->dD8 = t.dD8;
 }
 
 static void free_batch(psfp_handle* h) {
   for (auto& t : h->sets) {
-    hipFree(t.dDt); hipFree(t.dX); hipFree(t.dP); hipFree(t.dP8); hipFree(t.dV); hipFree(t.dZlo); hipFree(t.dZhi);
-    t.dDt = t.dX = nullptr; t.dP = nullptr; t.dP8 = nullptr; t.dV = nullptr; t.dZlo = t.dZhi = nullptr;
+    hipFree(t.dDt); hipFree(t.dX); hipFree(t.dP); hipFree(t.dP8); hipFree(t.dV); hipFree(t.dZlo); hipFree(t.dZhi); hipFree(t.dD8);
+    t.dDt = t.dX = nullptr; t.dP = nullptr; t.dP8 = nullptr; t.dV = nullptr; t.dZlo = t.dZhi = nullptr; t.dD8 = nullptr;
   }
   hipFree(h->dPf); hipFree(h->dP8f); hipFree(h->dPart); hipFree(h->dU); hipFree(h->dE); hipFree(h->dOk);
   h->dPf = nullptr; h->dP8f = nullptr; h->dPart = nullptr; h->dU = nullptr; h->dE = nullptr; h->dOk = nullptr;
@@ -125,6 +132,10 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
       HIP_TRY(hipMemset(t.dZlo, 0, h->ldr * ld));
       HIP_TRY(hipMemset(t.dZhi, 0, h->ldr * ld));
       HIP_TRY(hipMemset(t.dP, 0, h->M_pad * ld * sizeof(int32_t)));
+      if (h->structured) {
+        HIP_TRY(hipMalloc(&t.dD8, kFixPlanes * h->ldr * ld));
+        HIP_TRY(hipMemset(t.dD8, 0, kFixPlanes * h->ldr * ld));
+      }
     }
   }
   HIP_TRY(hipMalloc(&h->dPf, h->M_pad * ld * sizeof(int32_t)));
@@ -280,6 +291,9 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   h->M_pad = round_up(h->m, TR_BM);
   h->nbi = h->M_pad / TR_BM;
   h->nkb = h->M_pad / TR_BK;
+  h->structured = (prm->flags & PSFP_FLAG_STRUCTURED_SQRT) != 0 && !(prm->flags & PSFP_FLAG_NO_PERTURB);
+  h->mL = h->structured ? h->mb : h->m;
+  h->nbiL = round_up(h->mL, TR_BM) / TR_BM;
   h->ldr = round_up(h->w, 64);          // K of the int8 MFMA product, zero padded
   h->mb_pad = round_up(h->mb, 128);
   h->n_pad = round_up(h->n, 64);
@@ -298,7 +312,8 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipMalloc(&h->dA, h->n * h->m * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dR, h->mb_pad * h->ldr));
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
-  if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dLt, tr_total_chunks(h->nbi) * TR_CHUNK * sizeof(double)));
+  if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dLt, tr_total_chunks(h->nbiL) * TR_CHUNK * sizeof(double)));
+  if (h->structured) HIP_TRY(hipMalloc(&h->dR8, round_up(h->mb, 64) * h->ldr));
   for (auto& t : h->sets) {                             // [0] sampler failure, [1] some |z| > 127
     HIP_TRY(hipMalloc(&t.dFail, 2 * sizeof(int)));
     HIP_TRY(hipMemset(t.dFail, 0, 2 * sizeof(int)));
@@ -350,6 +365,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB * (CH_NB + 1) / 2 + CH_NB * 64) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rd2_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (1 + kFixPlanes) * 4096));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   if (const char* env = std::getenv("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
@@ -363,7 +379,7 @@ void psfp_destroy(psfp_handle* h) {
   free_batch(h);
   clear_slots(h);
   if (h->aux) hipStreamDestroy(h->aux);
-  hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt);
+  hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dR8);
   for (auto& t : h->sets) hipFree(t.dFail);
   if (h->s1) hipStreamDestroy(h->s1);
   for (int i = 0; i < 2; ++i) { if (h->evT[i]) hipEventDestroy(h->evT[i]); if (h->evP[i]) hipEventDestroy(h->evP[i]); }
@@ -377,13 +393,24 @@ void psfp_destroy(psfp_handle* h) {
 size_t psfp_m(const psfp_handle* h) { return h ? h->m : 0; }
 
 // Sigma_2 assembly (dense lower) + Cholesky + repack.  mp_perturbation.rs:111-139.
+// Structured mode factors Sigma_2 = c [[alpha I - kappa R R^t, -kappa R], [-kappa R^t, beta I]]  (c = r^2 / 2 pi, kappa = b^2 + 1, alpha = s^2 - 1,
+// beta = alpha - kappa) as B B^t with B = [[L_1 / sqrt c, -kappa R / sqrt beta], [0, sqrt beta I]] sqrt c, where L_1 is the Cholesky factor of
+// c (alpha I - kappa (alpha / beta) R R^t): only that m_bar x m_bar block is assembled, factored and stored.
 static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov) {
   const double TWO_PI = 6.283185307179586476925;
   const double nf_r2 = (1.0 / TWO_PI) * (h->prm.r * h->prm.r);
   const double s2 = s_cov * s_cov;
-  const double b2p1 = (double)(h->prm.gp.base * h->prm.gp.base + 1);
+  double b2p1 = (double)(h->prm.gp.base * h->prm.gp.base + 1);
+  const size_t m = h->mL;
+  if (h->structured) {
+    const double kappa = b2p1, alpha = s2 - 1.0, beta = alpha - kappa;
+    if (!(beta > 0.0)) return PSF_ERR_NOT_PD;
+    b2p1 = kappa * (alpha / beta);                                   // the R R^t block of the Schur-complemented top-left corner
+    h->g_const = (std::sqrt(nf_r2) * kappa) / std::sqrt(beta);
+    h->h_const = std::sqrt(nf_r2 * beta);
+    hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(round_up(h->mb, 64) * h->ldr, 256, 256 * 64)), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, round_up(h->mb, 64), h->ldr, h->dR8);
+  }
   double* dS = nullptr;
-  const size_t m = h->m;
   HIP_TRY(hipMalloc(&dS, m * m * sizeof(double)));
   HIP_TRY(hipMemset(dS, 0, m * m * sizeof(double)));
   const unsigned tiles = (unsigned)((m + 63) / 64);
@@ -408,7 +435,7 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov) {
   HIP_TRY(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));
   hipFree(dinfo);
   if (info != 0) { hipFree(dS); return PSF_ERR_NOT_PD; }            // mp_perturbation.rs:109-110
-  hipLaunchKernelGGL(k_repack_L<false>, dim3(grid_for(tr_total_chunks(h->nbi) * TR_CHUNK)), dim3(256), 0, 0, dS, m, m, h->dLt, h->nbi);
+  hipLaunchKernelGGL(k_repack_L<false>, dim3(grid_for(tr_total_chunks(h->nbiL) * TR_CHUNK)), dim3(256), 0, 0, dS, m, m, h->dLt, h->nbiL);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   hipFree(dS);
@@ -520,10 +547,18 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
   HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
   split_A(h);
   double* dp = nullptr;
-  const size_t np = h->m * (h->m + 1) / 2;
+  const size_t np = h->mL * (h->mL + 1) / 2;
   HIP_TRY(hipMalloc(&dp, np * sizeof(double)));
   HIP_TRY(hipMemcpy(dp, Lp, np * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_repack_L<true>, dim3(grid_for(tr_total_chunks(h->nbi) * TR_CHUNK)), dim3(256), 0, 0, dp, (size_t)0, h->m, h->dLt, h->nbi);
+  hipLaunchKernelGGL(k_repack_L<true>, dim3(grid_for(tr_total_chunks(h->nbiL) * TR_CHUNK)), dim3(256), 0, 0, dp, (size_t)0, h->mL, h->dLt, h->nbiL);
+  if (h->structured) {      // the constants of the structured factor follow from (r, s): the same expressions as build_sqrt_sigma2
+    const double nf_r2 = (1.0 / 6.283185307179586476925) * (h->prm.r * h->prm.r), kappa = (double)(h->prm.gp.base * h->prm.gp.base + 1);
+    const double alpha = h->prm.s * h->prm.s - 1.0, beta = alpha - kappa;
+    if (!(beta > 0.0)) { hipFree(dp); return PSF_ERR_NOT_PD; }
+    h->g_const = (std::sqrt(nf_r2) * kappa) / std::sqrt(beta);
+    h->h_const = std::sqrt(nf_r2 * beta);
+    hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(round_up(h->mb, 64) * h->ldr, 256, 256 * 64)), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, round_up(h->mb, 64), h->ldr, h->dR8);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   hipFree(dp);
@@ -539,7 +574,7 @@ psf_status psfp_export_key(const psfp_handle* h, uint64_t* A, int8_t* R, double*
   if (R) HIP_TRY(hipMemcpy2D(R, h->w, h->dR, h->ldr, h->w, h->mb, hipMemcpyDeviceToHost));
   if (Lp) {
     double* dp = nullptr;
-    const size_t np = h->m * (h->m + 1) / 2;
+    const size_t np = h->mL * (h->mL + 1) / 2;
     HIP_TRY(hipMalloc(&dp, np * sizeof(double)));
     hipLaunchKernelGGL(k_unpack_L, dim3(grid_for(np)), dim3(256), 0, 0, h->dLt, (size_t)0, np, dp);
     HIP_TRY(hipGetLastError());
@@ -551,7 +586,7 @@ psf_status psfp_export_key(const psfp_handle* h, uint64_t* A, int8_t* R, double*
 
 // rows [row0, row0 + nrows) of the factor, packed (row i: i + 1 entries): keys of tens of GB are read back in pieces
 psf_status psfp_export_sqrt_sigma2_rows(const psfp_handle* h, size_t row0, size_t nrows, double* out) {
-  if (!h || (nrows && !out) || row0 + nrows > h->m || (h->prm.flags & PSFP_FLAG_NO_PERTURB)) return PSF_ERR_PARAM;
+  if (!h || (nrows && !out) || row0 + nrows > h->mL || (h->prm.flags & PSFP_FLAG_NO_PERTURB)) return PSF_ERR_PARAM;
   if (!h->has_key) return PSF_ERR_NO_KEY;
   if (nrows == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
@@ -595,12 +630,18 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
     ScopedTimer t(h, st, "k_normals");
     const size_t nwaves = (nbj * h->nkb * TR_CHUNK + NR_SEG - 1) / NR_SEG;
-    hipLaunchKernelGGL(k_normals_wave, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail);
+    const NormalsFixed fx = h->structured ? NormalsFixed{h->mb, h->dD8, h->ldr * ld, ld, h->dX, h->h_const} : NormalsFixed{0, nullptr, 0, 0, nullptr, 0.0};
+    hipLaunchKernelGGL(k_normals_wave, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail, fx);
   }
-  {  // x = sqrt(Sigma_2) d
+  {  // x = sqrt(Sigma_2) d   (structured: the m_bar x m_bar block L_1 d_1; rows from m_bar on already hold x_bot = h d_2)
     ScopedTimer t(h, st, "k_trmm_f64");
-    hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbi, (int)nbj, 8, 8)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
-                       h->dLt, h->dDt, h->dX, (int)h->nbi, (int)nbj, h->nkb, ld, 8, 8);
+    hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
+                       h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, h->structured ? h->mb : h->M_pad);
+  }
+  if (h->structured) {  // x_top -= g R d_2 (exact integer sum on the int8 matrix cores)
+    ScopedTimer t(h, st, "k_rd2_mfma");
+    hipLaunchKernelGGL(k_rd2_mfma, dim3((unsigned)(ld / 64), (unsigned)(round_up(h->mb, 64) / 64)), dim3(256), 3 * (1 + kFixPlanes) * 4096, st, h->dR8, h->ldr, h->dD8, h->ldr * ld, ld,
+                       h->mb, h->g_const, h->dX);
   }
   if (pipe) {
     HIP_TRY(hipEventRecord(h->evT[cur], st));

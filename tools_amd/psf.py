@@ -52,9 +52,12 @@ class GadgetParametersRing(GadgetParameters):
 class PSFPerturbation:
     """mp_perturbation.rs:57-62 / impl PSF :193-403 on one MI355X."""
 
-    def __init__(self, gp, r, s, device=0):
+    STRUCTURED_SQRT = 2      # PSFP_FLAG_STRUCTURED_SQRT
+
+    def __init__(self, gp, r, s, device=0, structured=False):
         self.gp, self.r, self.s, self.device = gp, float(r), float(s), device
-        prm = PsfpParams(gp.c, self.r, self.s, device, 0)
+        self.structured = bool(structured)
+        prm = PsfpParams(gp.c, self.r, self.s, device, self.STRUCTURED_SQRT if structured else 0)
         h = C.c_void_p()
         check(lib().psfp_create(C.byref(prm), C.byref(h)), "PSFPerturbation")
         self._h = h
@@ -127,7 +130,8 @@ class PSFPerturbation:
     def export_key(self):
         A = np.zeros((self.n, self.m), dtype=np.uint64)
         R = np.zeros((self.m_bar, self.w), dtype=np.int8)
-        Lp = np.zeros(self.m * (self.m + 1) // 2, dtype=np.float64)
+        mL = self.m_bar if self.structured else self.m      # structured mode stores L_1 (m_bar x m_bar)
+        Lp = np.zeros(mL * (mL + 1) // 2, dtype=np.float64)
         check(lib().psfp_export_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8), _p(Lp, C.c_double)), "export_key")
         Sk = np.zeros((self.k, self.k), dtype=np.int64)
         gso = np.zeros((self.k, self.k), dtype=np.float64)
@@ -135,7 +139,7 @@ class PSFPerturbation:
         return A, (R, Lp, (Sk, gso))
 
     def export_sqrt_sigma2_rows(self, row0, nrows):
-        """Rows [row0, row0 + nrows) of sqrt(Sigma_2), packed (row i holds i + 1 entries)."""
+        """Rows [row0, row0 + nrows) of sqrt(Sigma_2) (structured mode: of L_1), packed (row i holds i + 1 entries)."""
         total = (row0 + nrows) * (row0 + nrows + 1) // 2 - row0 * (row0 + 1) // 2
         out = np.zeros(total, dtype=np.float64)
         check(lib().psfp_export_sqrt_sigma2_rows(self._h, C.c_size_t(row0), C.c_size_t(nrows), _p(out, C.c_double)), "export_sqrt_sigma2_rows")
@@ -152,7 +156,8 @@ class PSFPerturbation:
         A = np.ascontiguousarray(A, dtype=np.uint64)
         R = np.ascontiguousarray(R, dtype=np.int8)
         Lp = np.ascontiguousarray(sqrt_sigma2_packed, dtype=np.float64)
-        assert A.shape == (self.n, self.m) and R.shape == (self.m_bar, self.w) and Lp.size == self.m * (self.m + 1) // 2
+        mL = self.m_bar if self.structured else self.m
+        assert A.shape == (self.n, self.m) and R.shape == (self.m_bar, self.w) and Lp.size == mL * (mL + 1) // 2
         check(lib().psfp_load_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8), _p(Lp, C.c_double)), "load_key")
 
     def compute_sqrt_sigma_2(self, s_cov):
