@@ -1,5 +1,7 @@
 """Cycle breakdown of k_np_sample (workgroup 0, wave 0, summed over the blocks of one samp_p call) from a -DNP_PROFILE build:
-  hipcc ... -DNP_PROFILE -o tools_amd/lib/libpsf_np_profile.so ;  PSF_LIB=tools_amd/lib/libpsf_np_profile.so python tools/np_profile.py c2"""
+  cd tools_amd/csrc && hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -DNP_PROFILE=1 -shared -o ../lib/libpsf_np_profile.so -x hip psfp.hip psf_host.cpp
+  PSF_LIB=$PWD/tools_amd/lib/libpsf_np_profile.so python tools/np_profile.py c2        (-DNP_PROFILE=2: prologue / steps / epilogue only, no stamps inside the step loop;
+  a stamp costs ~85 ticks, so the per-phase figures of NP_PROFILE=1 are upper bounds)"""
 import ctypes as C, os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

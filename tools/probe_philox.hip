@@ -7,6 +7,7 @@
 using namespace psf;
 
 __global__ void k_probe(int mode, int iters, unsigned long long* out, unsigned* sink) {
+  __shared__ unsigned lds[1024];
   const unsigned long long w0 = wall_clock64();
   const long long c0 = clock64();
   unsigned acc = threadIdx.x;
@@ -19,6 +20,8 @@ __global__ void k_probe(int mode, int iters, unsigned long long* out, unsigned* 
     else if (mode == 3) { d = ceil(d * 1.0000001) + 0.25; }                   // ceil + mul + add (f64)
     else if (mode == 4) { const unsigned long long m = __ballot(acc & 1); acc += (unsigned)__builtin_ctzll(m | 1) + (unsigned)__builtin_amdgcn_readlane((int)acc, (int)(i & 63)); }
     else if (mode == 5) { acc = (unsigned)(((unsigned long long)acc * 0xD2511F53u) >> 32) ^ i; }   // dependent v_mad_u64_u32 chain
+    else if (mode == 6) { d = fma(d, 1.0000001, 0.5); __builtin_amdgcn_s_sleep(4); }                // mostly asleep: does the shader clock follow?
+    else if (mode == 7) { lds[threadIdx.x] = acc; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); acc = lds[(threadIdx.x + 1) & 255] + i; }   // LDS round trip
   }
   const long long c1 = clock64();
   const unsigned long long w1 = wall_clock64();
@@ -29,9 +32,9 @@ __global__ void k_probe(int mode, int iters, unsigned long long* out, unsigned* 
 int main() {
   unsigned long long* out; unsigned* sink;
   hipMalloc(&out, 16); hipMalloc(&sink, 1024 * 256 * 4);
-  const char* names[] = {"philox block", "f64 fma (dependent)", "exp2f + add (dependent)", "ceil+mul+add f64", "ballot+ctz+readlane", "v_mad_u64_u32 (dependent)"};
+  const char* names[] = {"philox block", "f64 fma (dependent)", "exp2f + add (dependent)", "ceil+mul+add f64", "ballot+ctz+readlane", "v_mad_u64_u32 (dependent)", "f64 fma + s_sleep 4", "LDS write + read (dependent)"};
   for (int waves = 1; waves <= 4; waves *= 4)
-    for (int mode = 0; mode < 6; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
       const int iters = 20000;
       hipLaunchKernelGGL(k_probe, dim3(256), dim3(256 * waves), 0, 0, mode, iters, out, sink);   // one (or four) wave(s) per SIMD
       hipDeviceSynchronize();
