@@ -148,12 +148,15 @@ def test_recombination_in_64_bit_integers_when_the_digit_planes_do_not_fit(T, or
     assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
 
 
-@pytest.mark.parametrize("n,q", [(32, 256), (64, 256), (128, 2**15), (300, 2**15)])
-def test_samp_p_parity_across_block_counts(T, oracle, n, q):
+@pytest.mark.parametrize("n,q,immediate", [(32, 256, 0), (64, 256, 1), (128, 2**15, 0), (128, 2**15, 1), (300, 2**15, 0)])
+def test_samp_p_parity_across_block_counts(T, oracle, monkeypatch, n, q, immediate):
     """Lattice dimensions of 537 ... 9081 rows: 9 to 142 blocks of 64 with a short top block, the last one beyond the 8192 rows
     the register-resident walk of round 1 was limited to.  Key from the device, three preimages (the last wave is partly empty);
-    s = 1000 makes |z| > 127 common, so the hi digit plane of z is exercised."""
+    s = 1000 makes |z| > 127 common, so the hi digit plane of z is exercised.  Both schedules of the updates below a block (the
+    library picks by batch size; PSF_NP_IMMEDIATE forces one): every block into every row below it in the next launch, or only into
+    the rows of its own and the next panel of 8 blocks with the rest deferred until its panel is complete -- same fma chains, same bits."""
     s = 1000.0
+    monkeypatch.setenv("PSF_NP_IMMEDIATE", str(immediate))
     gp = T.GadgetParameters.init_default(n, q)
     psf = T.PSFGPV(gp, s)
     A, (bt, gt) = psf.trap_gen(3)

@@ -428,18 +428,28 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const double* gn = a.Gnx + J * (NP_NB * NP_NB) + lam;
-    for (int k0 = 0; k0 < NP_NB; k0 += 8) {
-      double zk[8], gk[8][G];
+    // the rows of g are requested one batch ahead (the next batch travels while the current one is consumed): the L2 round trips overlap
+    constexpr int HB = 16 / G;
+    double gk[2][HB][G];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        zk[kk] = zs[sg * NP_NB + k0 + kk];
+    for (int kk = 0; kk < HB; ++kk)
 #pragma unroll
-        for (int s = 0; s < G; ++s) gk[kk][s] = gn[(k0 + kk) * NP_NB + s * LPD];
+      for (int s = 0; s < G; ++s) gk[0][kk][s] = gn[kk * NP_NB + s * LPD];
+#pragma unroll
+    for (int k0 = 0; k0 < NP_NB; k0 += HB) {
+      const int cur = (k0 / HB) & 1;
+      if (k0 + HB < NP_NB) {
+#pragma unroll
+        for (int kk = 0; kk < HB; ++kk)
+#pragma unroll
+          for (int s = 0; s < G; ++s) gk[cur ^ 1][kk][s] = gn[(k0 + HB + kk) * NP_NB + s * LPD];
       }
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk)
+      for (int kk = 0; kk < HB; ++kk) {
+        const double zk = zs[sg * NP_NB + k0 + kk];
 #pragma unroll
-        for (int s = 0; s < G; ++s) t[s] = fma(-zk[kk], gk[kk][s], t[s]);
+        for (int s = 0; s < G; ++s) t[s] = fma(-zk, gk[cur][kk][s], t[s]);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -618,10 +628,11 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
       a.Z8[2 * plane + addr] = (int8_t)d2;
     }
   }
-  if (f) atomicOr(a.flags, 1);
-  if (use1) atomicOr(a.flags + 1, 1);
-  if (use2) atomicOr(a.flags + 2, 1);
-  if (big) atomicOr(a.flags + 3, 1);
+  // one atomic per wave at most, and none once the flag is up (at C2 / C4 "second digit in use" is raised by almost every wave of every launch)
+  if (__ballot(f) && lane == 0) atomicOr(a.flags, 1);
+  if (__ballot(use1) && lane == 0 && __hip_atomic_load(a.flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(a.flags + 1, 1);
+  if (__ballot(use2) && lane == 0 && __hip_atomic_load(a.flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(a.flags + 2, 1);
+  if (__ballot(big) && lane == 0) atomicOr(a.flags + 3, 1);
 #ifdef NP_PROFILE
   NP_T(6);
   if (wg == 0 && tid == 0) for (int kk = 0; kk < 7; ++kk) atomicAdd((unsigned long long*)&g_np_prof[kk], (unsigned long long)tacc_[kk]);

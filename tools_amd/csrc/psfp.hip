@@ -174,6 +174,13 @@ static void clear_slots(psfp_handle* h) {
   h->slots.clear();
 }
 
+#ifdef TRMM_CLOCK_PROBE
+extern "C" void psf_debug_trmm_clk(unsigned long long* out, int reset) {
+  if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trmm_clk), sizeof(unsigned long long) * 4);
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_trmm_clk), z, sizeof(z)); }
+}
+#endif
+
 extern "C" {
 
 const char* psf_status_string(psf_status s) {
@@ -635,6 +642,11 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   }
   {  // x = sqrt(Sigma_2) d   (structured: the m_bar x m_bar block L_1 d_1; rows from m_bar on already hold x_bot = h d_2)
     ScopedTimer t(h, st, "k_trmm_f64");
+    static const int variant = std::getenv("PSF_TRMM_VARIANT") ? std::atoi(std::getenv("PSF_TRMM_VARIANT")) : 0;
+    if (variant == 1)
+      hipLaunchKernelGGL(k_trmm_f64_reg, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 0, st,
+                         h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, h->structured ? h->mb : h->M_pad);
+    else
     hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
                        h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, h->structured ? h->mb : h->M_pad);
   }
