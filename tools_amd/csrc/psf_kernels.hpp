@@ -217,10 +217,12 @@ __host__ inline unsigned tr_grid_size(int nbi, int nbj, int GR = 8, int GC = 8) 
   return rounds * 8u * 64u;
 }
 
-#ifdef TRMM_CLOCK_PROBE   /* measurement build only (tools/trmm_clock_probe.py): shader-clock ticks and 100 MHz real-time ticks each workgroup spent */
+#ifdef TRMM_CLOCK_PROBE   /* measurement builds only (tools/trmm_clock_probe.py, tools/probe_trmm.hip): shader-clock ticks and 100 MHz real-time ticks per workgroup */
 __device__ unsigned long long g_trmm_clk[4];
+__device__ unsigned long long* g_trmm_log;      /* optional: per workgroup {start, end} in 100 MHz ticks */
 #define TR_CLK_BEGIN const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
-#define TR_CLK_END if (threadIdx.x == 0) { atomicAdd(&g_trmm_clk[0], clock64() - clk0); atomicAdd(&g_trmm_clk[1], wall_clock64() - rt0); atomicAdd(&g_trmm_clk[2], 1ull); }
+#define TR_CLK_END if (threadIdx.x == 0) { const unsigned long long rt1 = wall_clock64(); atomicAdd(&g_trmm_clk[0], clock64() - clk0); atomicAdd(&g_trmm_clk[1], rt1 - rt0); atomicAdd(&g_trmm_clk[2], 1ull); \
+    if (g_trmm_log) { g_trmm_log[2 * (size_t)blockIdx.x] = rt0; g_trmm_log[2 * (size_t)blockIdx.x + 1] = rt1; } }
 #else
 #define TR_CLK_BEGIN
 #define TR_CLK_END
@@ -306,12 +308,14 @@ __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const
   TR_CLK_END
 }
 
-// Same product, operands streamed from global memory straight into MFMA operand registers: the chunk streams are already in
-// fragment order, so k-step s of a wave is eight 512-byte loads (4 A fragments, 4 B fragments) at stream offset 512 s.  No LDS, no
-// barrier: the four waves of a workgroup only share cache lines.  TR_PD k-steps are in flight per wave.
-constexpr int TR_PD = 4;
-// hipcc hoists plain loads of an unrolled prefetch ring to the top of the loop body and drains them with vmcnt(0) at its end, so
-// the loads and their waits are written out: loads return in order, hence "all but the newest 8 (TR_PD - 1) have landed".
+// Same product, operands streamed from global memory straight into MFMA operand registers: the chunk streams are already in fragment order, so
+// k-step s of a wave is eight 512-byte loads (4 A fragments, 4 B fragments) at stream offset 512 s.  No LDS, no barrier: the four waves of a
+// workgroup only share cache lines.  TR_PD k-steps are in flight per wave.  Bit-identical to k_trmm_f64 (same ascending chains); measured on
+// MI355X at C3: 54.0 vs 55.0 ms inside the library, 0.967 of the FP64 MFMA peak AT THE CLOCK THE KERNEL RUNS AT (2.25-2.35 GHz under this load;
+// a loop with the same MFMAs and no loads at all reaches 0.963, profiles/r02_notes.md).
+constexpr int TR_PD = 6;
+// hipcc hoists plain loads of an unrolled prefetch ring to the top of the loop body and drains them with vmcnt(0) at its end, so the loads and
+// their waits are written out: loads return in order, hence "all but the newest 8 (TR_PD - 1) have landed".
 #define TR_LOAD8(dst, voff, base, imm) asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(voff), "s"(base) : "memory")
 #define TR_WAIT(n, A, Bv) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(Bv[0]), "+v"(Bv[1]), "+v"(Bv[2]), "+v"(Bv[3]))
 __global__ __launch_bounds__(256, 2) void k_trmm_f64_reg(const double* __restrict__ Lt, const double* __restrict__ Dt,
@@ -319,10 +323,11 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64_reg(const double* __restric
   int bi, bj;
   tr_map_block(blockIdx.x, nbi, nbj, GR, GC, &bi, &bj);
   if (bi < 0 || bi >= nbi || bj >= nbj) return;
+  TR_CLK_BEGIN
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int nsteps = TR_KB_PER_BLOCK * (bi + 1) * (TR_BK / 4);       // a multiple of TR_PD
+  const int nsteps = TR_KB_PER_BLOCK * (bi + 1) * (TR_BK / 4);
   const double* gA = Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK + (size_t)(wr * 4) * 64;      // wave-uniform
   const double* gB = Dt + (size_t)bj * nkb * TR_CHUNK + (size_t)(wc * 4) * 64;
   const uint32_t voff = (uint32_t)lane * 8u;
@@ -342,21 +347,26 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64_reg(const double* __restric
     TR_LOAD8(av[3], voff, pa, 1536); TR_LOAD8(bv[3], voff, pb, 1536);
   };
 #pragma unroll
-  for (int u = 0; u < TR_PD; ++u) issue(a[u], b[u], u);
+  for (int u = 0; u < TR_PD; ++u) issue(a[u], b[u], u);                    // at least 32 steps per row-block
   for (int s0 = 0; s0 < nsteps; s0 += TR_PD) {
 #pragma unroll
     for (int u = 0; u < TR_PD; ++u) {
-      TR_WAIT(24, a[u], b[u]);                                         // 8 (TR_PD - 1)
+      if (s0 + u < nsteps) {                                           // the number of k-steps is a multiple of 32, not of TR_PD
+        TR_WAIT(40, a[u], b[u]);                                       // 8 (TR_PD - 1)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+      }
       int sn = s0 + u + TR_PD;
       sn = sn < nsteps ? sn : nsteps - 1;                              // past the end: re-read the last step (never consumed)
       issue(a[u], b[u], sn);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the re-reads behind the last step are never consumed: their destination registers must stay allocated until they have landed (a load that
+  // lands in a register the compiler has reused since corrupts it -- seen as a memory fault through a clobbered store address)
+#pragma unroll
+  for (int u = 0; u < TR_PD; ++u) TR_WAIT(0, a[u], b[u]);
   const size_t row0 = (size_t)bi * TR_BM + wr * 64, col0 = (size_t)bj * TR_BN + wc * 64;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64_reg(const double* __restric
         const size_t row = row0 + i * 16 + (lane >> 4) + 4 * r;
         if (row < row_hi) X[row * ldx + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
       }
+  TR_CLK_END
 }
 
 // ---- p_i <- D_{Z, r, x_i} ------------------------------------------------------------------------------

@@ -642,13 +642,14 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   }
   {  // x = sqrt(Sigma_2) d   (structured: the m_bar x m_bar block L_1 d_1; rows from m_bar on already hold x_bot = h d_2)
     ScopedTimer t(h, st, "k_trmm_f64");
-    static const int variant = std::getenv("PSF_TRMM_VARIANT") ? std::atoi(std::getenv("PSF_TRMM_VARIANT")) : 0;
+    // default: operands streamed into registers (k_trmm_f64_reg); PSF_TRMM_VARIANT=0 selects the LDS-staged kernel (same bits)
+    static const int variant = std::getenv("PSF_TRMM_VARIANT") ? std::atoi(std::getenv("PSF_TRMM_VARIANT")) : 1;
+    const dim3 grid(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8));
+    const size_t row_hi = h->structured ? h->mb : h->M_pad;
     if (variant == 1)
-      hipLaunchKernelGGL(k_trmm_f64_reg, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 0, st,
-                         h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, h->structured ? h->mb : h->M_pad);
+      hipLaunchKernelGGL(k_trmm_f64_reg, grid, dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
     else
-    hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 4 * TR_CHUNK * sizeof(double), st,
-                       h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, h->structured ? h->mb : h->M_pad);
+      hipLaunchKernelGGL(k_trmm_f64, grid, dim3(256), 4 * TR_CHUNK * sizeof(double), st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
   }
   if (h->structured) {  // x_top -= g R d_2 (exact integer sum on the int8 matrix cores)
     ScopedTimer t(h, st, "k_rd2_mfma");
