@@ -168,10 +168,12 @@ def main():
         roof = None
         if trmm:
             ach = flops_per_launch / (trmm * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "k_trmm_f64", "achieved": round(ach, 3), "peak": PEAK_F64_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": load_traffic(args.config, B),
+            kname = "k_trmm_f64_reg" if os.environ.get("PSF_TRMM_VARIANT", "1") == "1" else "k_trmm_f64"      # the library's default and its LDS-staged alternative
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 3), "peak": PEAK_F64_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": load_traffic(args.config + (":structured" if args.structured else ""), B),
                     "traffic_source": "profiles/trmm_traffic.json (rocprofv3 PMC passes; null when psf_kernels.hpp changed since)",
-                    "launch_ms": round(trmm, 3), "flops_per_launch": flops_per_launch}
+                    "launch_ms": round(trmm, 3), "flops_per_launch": flops_per_launch,
+                    "clock_note": "peak is priced at the nominal 2.4 GHz; under this kernel the shader clock sits at 2.25-2.37 GHz (tools/trmm_clock_probe.py, profiles/r02_probe_trmm.log)"}
             if roof["traffic"]:                      # the HBM side of the same launch, for the metric's "HBM-BW%"
                 roof["hbm_GBps"] = round(roof["traffic"] / (trmm * 1e-3) / 1e9, 1)
                 roof["hbm_frac_of_peak"] = round(roof["traffic"] / (trmm * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)
@@ -183,7 +185,8 @@ def main():
             flops = 2.0 * float(m) * float(m) * B
             ach = flops / (npl * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "nearest plane: k_np_project + d/64 x k_np_step + k_np_combine8", "achieved": round(ach, 3),
-                    "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": load_traffic(args.config, B),
+                    "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": None,
+                    "traffic_note": "not measured: rocprofv3 --pmc FETCH_SIZE segfaults on this launch sequence at C2 and did not finish within 45 minutes at C4 (profiles/r02_notes.md)",
                     "launch_ms": round(npl, 3), "flops_per_launch": flops, "serial_steps": int(m),
                     "us_per_serial_step": round(npl * 1e3 / m, 4),
                     "note": "latency bound: d sequential SampleZ draws per preimage (one launch per 64 of them); frac is the FP64 share of the phase"}

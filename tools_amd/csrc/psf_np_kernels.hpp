@@ -333,6 +333,17 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
       const int piece = wave * 2 + i;
       __builtin_amdgcn_global_load_lds(src + piece * 128, (lds_void_ptr)(s_tri + piece * 128), 16, 0, 0);
     }
+    if (j0 + NP_NB < dim) {
+      // g of the block above against this block's rows (32 KiB, the same for every wave): staged once per workgroup in the record ring, which the
+      // helpers only start to fill behind the second barrier below (four 1 KiB pieces per wave)
+      const double* srcn = a.Gnx + J * (NP_NB * NP_NB) + lane * 2;
+      double* stage = reinterpret_cast<double*>(&s_ring[0][0]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        __builtin_amdgcn_global_load_lds(srcn + piece * 128, (lds_void_ptr)(stage + piece * 128), 16, 0, 0);
+      }
+    }
     if (tid < NP_NB) {
       s_row[tid] = tid < nrows ? a.rows[j0 + tid] : NpRow{0.0, 0.f, 0, 1, 0, 0, 16};
     }
@@ -352,7 +363,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
 
   if (helper) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();                                                // tables and the staged g have landed
+    __syncthreads();                                                // the samplers have consumed the staged g: the ring is free
     uint2* wstrip = &s_words[pw][0];
     int k = 0;
 #pragma unroll
@@ -416,40 +428,27 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
     zr[s] = 0;
   }
   int f = 0;
-  if (j0 + NP_NB < dim) {
+  const bool above = j0 + NP_NB < dim;
+  double* zs = &s_zs[pw][0];
+  if (above) {
     // the block above was sampled by the previous launch: its contribution to my rows, t = fma(-z_k, g[64 (J+1) + k][row], t) for k
-    // ascending, is applied here (the update tiles stop below this block); g read straight from L2
-    double* zs = &s_zs[pw][0];
+    // ascending, is applied here (the update tiles stop below this block)
 #pragma unroll
     for (int s = 0; s < G; ++s) {
       const int kk = s * LPD + lam;
       const size_t i = j0 + NP_NB + (size_t)kk;
       zs[sg * NP_NB + kk] = (live && i < dim) ? a.Zf[((b / TR_BN) * a.nkb + i / 16) * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(i % 16))] : 0.0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const double* gn = a.Gnx + J * (NP_NB * NP_NB) + lam;
-    // the rows of g are requested one batch ahead (the next batch travels while the current one is consumed): the L2 round trips overlap
-    constexpr int HB = 16 / G;
-    double gk[2][HB][G];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (above) {
+    const double* stage = reinterpret_cast<const double*>(&s_ring[0][0]) + lam;
+#pragma unroll 16
+    for (int kk = 0; kk < NP_NB; ++kk) {
+      const double zk = zs[sg * NP_NB + kk];
 #pragma unroll
-    for (int kk = 0; kk < HB; ++kk)
-#pragma unroll
-      for (int s = 0; s < G; ++s) gk[0][kk][s] = gn[kk * NP_NB + s * LPD];
-#pragma unroll
-    for (int k0 = 0; k0 < NP_NB; k0 += HB) {
-      const int cur = (k0 / HB) & 1;
-      if (k0 + HB < NP_NB) {
-#pragma unroll
-        for (int kk = 0; kk < HB; ++kk)
-#pragma unroll
-          for (int s = 0; s < G; ++s) gk[cur ^ 1][kk][s] = gn[(k0 + HB + kk) * NP_NB + s * LPD];
-      }
-#pragma unroll
-      for (int kk = 0; kk < HB; ++kk) {
-        const double zk = zs[sg * NP_NB + k0 + kk];
-#pragma unroll
-        for (int s = 0; s < G; ++s) t[s] = fma(-zk, gk[cur][kk][s], t[s]);
-      }
+      for (int s = 0; s < G; ++s) t[s] = fma(-zk, stage[kk * NP_NB + s * LPD], t[s]);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
