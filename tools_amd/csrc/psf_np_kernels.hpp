@@ -269,13 +269,26 @@ __global__ __launch_bounds__(256, 2) void k_np_project(const double* __restrict_
 // product, and as three balanced base-256 int8 digit planes [i/16][b][16] for the recombination.
 #ifdef NP_PROFILE   /* cycle breakdown of k_np_sample (workgroup 0, wave 0): tools/np_profile.py */
 __device__ long long g_np_prof[8];
-#if NP_PROFILE == 2   /* only the prologue / steps / epilogue split: no stamps inside the step loop */
+__device__ unsigned long long g_np_events[4];      /* over all sampler waves: steps, steps that entered the settle loop, steps that entered the generic rounds, steps with a special centre */
+#if NP_PROFILE == 4   /* event counts only (the atomics distort every timing) */
+#define NP_EVENT(k) do { if (lane == 0) atomicAdd(&g_np_events[k], 1ull); } while (0)
+#else
+#define NP_EVENT(k) do { } while (0)
+#endif
+__device__ unsigned long long g_np_sum[8], g_np_max[8];      /* NP_PROFILE == 3: per bucket, summed / maximised over ALL sampler waves (per wave and launch) */
+#if NP_PROFILE == 3   /* prologue | chain up to the ballots | settle | generic rounds | update | epilogue, every sampler wave */
+__device__ unsigned long long g_np_single[8];    /* [0] largest single settle phase, [1] largest single generic phase, [2] settle phases > 4096 ticks, [3] generic phases > 4096 ticks, [4] largest single chain phase, [5] chain phases > 4096 */
+#define NP_T(k) do { if ((k) == 0 || (k) >= 3) { const long long now_ = (long long)__builtin_readcyclecounter(); const long long d_ = now_ - tprev_; tacc_[k] += d_; tprev_ = now_; \
+    if ((k) == 4) { if (d_ > smax_[0]) smax_[0] = d_; if (d_ > 4096) ++smax_[2]; } if ((k) == 7) { if (d_ > smax_[1]) smax_[1] = d_; if (d_ > 4096) ++smax_[3]; } \
+    if ((k) == 3) { if (d_ > smax_[4]) smax_[4] = d_; if (d_ > 4096) ++smax_[5]; } } } while (0)
+#elif NP_PROFILE == 2   /* only the prologue / steps / epilogue split: no stamps inside the step loop */
 #define NP_T(k) do { if ((k) == 0 || (k) == 6) { const long long now_ = (long long)__builtin_readcyclecounter(); tacc_[k] += now_ - tprev_; tprev_ = now_; } } while (0)
 #else
 #define NP_T(k) do { const long long now_ = (long long)__builtin_readcyclecounter(); tacc_[k] += now_ - tprev_; tprev_ = now_; } while (0)
 #endif
 #else
 #define NP_T(k) do { } while (0)
+#define NP_EVENT(k) do { } while (0)
 #endif
 
 struct NpRow { double inv_n2; float inv_sk; int32_t c6; uint32_t n_int, thr_int, thr_frac, sh; };   // 32 bytes per row; sh = 0: no fast path;
@@ -324,6 +337,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
   const int nrows = (int)(dim - j0 < (size_t)NP_NB ? dim - j0 : (size_t)NP_NB);
 #ifdef NP_PROFILE
   long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long smax_[6] = {0, 0, 0, 0, 0, 0};
+  (void)smax_;
   long long tprev_ = (long long)__builtin_readcyclecounter();
 #endif
   {  // the in-block triangle goes to LDS by LDS-DMA (two 1 KiB pieces per wave), the small per-row tables through registers
@@ -515,6 +530,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           const bool bad = live && (cc == cen || !(fabs(cen) < 0x1.0p30) || rw.sh == 0);
           const uint64_t mc_w = __ballot(cand_b), m1_w = __ballot(sure_b), bad_w = __ballot(bad);
           NP_T(3);
+          NP_EVENT(0);
+          if (bad_w) NP_EVENT(3);
           // common case: the first candidate of the draw (in attempt = lane order) is a certain accept
           bool settle = false;
           if (G == 1) {
@@ -529,6 +546,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
             else settle = live;
           }
           if (__ballot(settle)) {
+            NP_EVENT(1);
             // rare: a "to be settled" attempt comes first, or there is no candidate among the first LPD attempts, or the centre is special
             const bool usable = !(bad_w & sgmask);
             uint64_t m1 = usable ? (m1_w & sgmask) : 0, m2 = usable ? ((mc_w & ~m1_w) & sgmask) : 0;
@@ -555,6 +573,9 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           }
           NP_T(4);
           if (__ballot(!got)) {                                      // generic rounds: attempts t0 + lam, t0 + LPD + lam, ...
+            NP_EVENT(2);
+            // (an "accepted for certain" class here as in the first round was measured: C2 3.5 % slower, C4 unchanged -- the rounds are rare and the
+            // extra live values cost the hot path registers)
             const SampleZParams sp2 = g_sz[l];
             const SzRange rg = sz_range(cen, sp2);
             for (; t0 < kMaxAttempts; t0 += LPD) {
@@ -588,6 +609,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
             }
             if (!got) { f = 1; z = (long long)floor(cen + 0.5); }
           }
+          NP_T(7);
           if (lam == ls) zr[slot] = z;
           const double nz = -(double)z;
 #pragma unroll
@@ -637,8 +659,13 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
   if (wg == 0 && tid == 0) for (int kk = 0; kk < 7; ++kk) atomicAdd((unsigned long long*)&g_np_prof[kk], (unsigned long long)tacc_[kk]);
   if (lane == 0) {      // spread over the sampler waves of the launch: slowest wave, accumulated over the launches of the call
     long long tot = 0;
-    for (int kk = 0; kk < 7; ++kk) tot += tacc_[kk];
+    for (int kk = 0; kk < 8; ++kk) tot += tacc_[kk];
     atomicMax((unsigned long long*)&g_np_prof[7], (unsigned long long)tot);
+#if NP_PROFILE == 3
+    for (int kk = 0; kk < 8; ++kk) { atomicAdd(&g_np_sum[kk], (unsigned long long)tacc_[kk]); atomicMax(&g_np_max[kk], (unsigned long long)tacc_[kk]); }
+    atomicMax(&g_np_single[0], (unsigned long long)smax_[0]); atomicMax(&g_np_single[1], (unsigned long long)smax_[1]); atomicMax(&g_np_single[4], (unsigned long long)smax_[4]);
+    atomicAdd(&g_np_single[2], (unsigned long long)smax_[2]); atomicAdd(&g_np_single[3], (unsigned long long)smax_[3]); atomicAdd(&g_np_single[5], (unsigned long long)smax_[5]);
+#endif
   }
 #endif
 }

@@ -223,6 +223,21 @@ extern "C" void psf_debug_np_prof(long long* out, int reset) {
   if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_np_prof), sizeof(long long) * 8);
   if (reset) { long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_np_prof), z, sizeof(z)); }
 }
+extern "C" void psf_debug_np_spread(unsigned long long* sum, unsigned long long* mx, int reset) {
+  if (sum) hipMemcpyFromSymbol(sum, HIP_SYMBOL(g_np_sum), sizeof(unsigned long long) * 8);
+  if (mx) hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_np_max), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_np_sum), z, sizeof(z)); hipMemcpyToSymbol(HIP_SYMBOL(g_np_max), z, sizeof(z)); }
+}
+#if NP_PROFILE == 3
+extern "C" void psf_debug_np_single(unsigned long long* out, int reset) {
+  if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_np_single), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_np_single), z, sizeof(z)); }
+}
+#endif
+extern "C" void psf_debug_np_events(unsigned long long* out, int reset) {
+  if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_np_events), sizeof(unsigned long long) * 4);
+  if (reset) { unsigned long long z[4] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_np_events), z, sizeof(z)); }
+}
 #endif
 
 extern "C" {

@@ -643,7 +643,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   {  // x = sqrt(Sigma_2) d   (structured: the m_bar x m_bar block L_1 d_1; rows from m_bar on already hold x_bot = h d_2)
     ScopedTimer t(h, st, "k_trmm_f64");
     // default: operands streamed into registers (k_trmm_f64_reg); PSF_TRMM_VARIANT=0 selects the LDS-staged kernel (same bits)
-    static const int variant = std::getenv("PSF_TRMM_VARIANT") ? std::atoi(std::getenv("PSF_TRMM_VARIANT")) : 1;
+    const char* venv = std::getenv("PSF_TRMM_VARIANT");      // read per call: the tests compare the two kernels inside one process
+    const int variant = venv ? std::atoi(venv) : 1;
     const dim3 grid(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8));
     const size_t row_hi = h->structured ? h->mb : h->M_pad;
     if (variant == 1)
