@@ -633,6 +633,11 @@ __global__ __launch_bounds__(256) void k_zq_matmul(int mode, const uint64_t* __r
 // sum_k a_k p_k = sum_c 256^c T_c,  T_c = sum_{i+j=c} sum_k d_i[k] e_j[k]: each (i,j) pair is one int8 MFMA product
 // accumulated exactly in int32 (<= 16384 terms of |d e| <= 2^14 per pair, <= 3 pairs per class before the fold), and
 // every 16384 coordinates the classes are folded into a running residue mod q.  Integer arithmetic: exact.
+// Operand tiles of the int8 MFMA kernels that are staged as [row][64 bytes] (one row = the 64 coordinates of a K step = four 16-byte k groups): the lanes that
+// read k group g of 16 consecutive rows would all start in the same 16 of the 64 LDS banks (row stride 64 B: a 4-way conflict on every ds_read_b128).  The
+// groups of a row are therefore stored rotated by row / 4: group g of row r sits in slot (g + r / 4) mod 4, and the 16 lanes cover all 64 banks once.
+__host__ __device__ inline int i8_slot(int row, int group) { return (group + (row >> 2)) & 3; }
+
 __global__ void k_split_A(const uint64_t* __restrict__ A, size_t lda, size_t n, size_t K, size_t n_pad, size_t K_pad, int NA,
                           int8_t* __restrict__ A8) {
   const size_t total = n_pad * K_pad;
@@ -641,8 +646,8 @@ __global__ void k_split_A(const uint64_t* __restrict__ A, size_t lda, size_t n, 
     int64_t a = (i < n && kk < K) ? (int64_t)A[i * lda + kk] : 0;
     for (int d = 0; d < NA; ++d) {
       int64_t dig = (d + 1 < NA) ? (int64_t)(int8_t)(a & 0xff) : a;
-      // tile-packed: [digit][row tile of 64][k step of 64][row in tile][64 bytes] -- one 4 KiB tile is one contiguous read
-      const size_t off = (((size_t)d * (n_pad / 64) + i / 64) * (K_pad / 64) + kk / 64) * 4096 + (i % 64) * 64 + (kk % 64);
+      // tile-packed: [digit][row tile of 64][k step of 64][row in tile][64 bytes, k groups rotated: i8_slot] -- one 4 KiB tile is one contiguous read
+      const size_t off = (((size_t)d * (n_pad / 64) + i / 64) * (K_pad / 64) + kk / 64) * 4096 + (i % 64) * 64 + i8_slot((int)(i % 64), (int)((kk % 64) >> 4)) * 16 + (kk % 16);
       A8[off] = (int8_t)dig;
       a = (a - dig) >> 8;
     }
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, 
 #pragma unroll
     for (int d = 0; d < NA; ++d)
 #pragma unroll
-      for (int x = 0; x < 2; ++x) fa[d][x] = *reinterpret_cast<const v4i*>(sb + d * 4096 + ((wr * 32 + x * 16 + r16) * 64 + g * 16));
+      for (int x = 0; x < 2; ++x) fa[d][x] = *reinterpret_cast<const v4i*>(sb + d * 4096 + ((wr * 32 + x * 16 + r16) * 64 + i8_slot(wr * 32 + x * 16 + r16, g) * 16));
 #pragma unroll
     for (int e = 0; e < 3; ++e)
 #pragma unroll
@@ -825,7 +830,7 @@ __global__ void k_pack_R8(const int8_t* __restrict__ R, size_t ldr, size_t mbar,
   for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const size_t i = g / K_pad, kk = g % K_pad;
     const int8_t v = (i < mbar && kk < w) ? R[i * ldr + kk] : (int8_t)0;
-    R8[((i / 64) * (K_pad / 64) + kk / 64) * 4096 + (i % 64) * 64 + (kk % 64)] = v;
+    R8[((i / 64) * (K_pad / 64) + kk / 64) * 4096 + (i % 64) * 64 + i8_slot((int)(i % 64), (int)((kk % 64) >> 4)) * 16 + (kk % 16)] = v;
   }
 }
 
@@ -869,7 +874,7 @@ __global__ __launch_bounds__(256, 2) void k_rd2_mfma(const int8_t* __restrict__ 
     const unsigned char* sb = rd_smem + cur * STAGE;
     v4i fa[2], fp[NP][2];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) fa[x] = *reinterpret_cast<const v4i*>(sb + ((wr * 32 + x * 16 + r16) * 64 + gq * 16));
+    for (int x = 0; x < 2; ++x) fa[x] = *reinterpret_cast<const v4i*>(sb + ((wr * 32 + x * 16 + r16) * 64 + i8_slot(wr * 32 + x * 16 + r16, gq) * 16));
 #pragma unroll
     for (int e = 0; e < NP; ++e)
 #pragma unroll
@@ -1205,8 +1210,8 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
   const int8_t* srcR[2]; const int8_t* srcL[2]; const int8_t* srcH[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int p = (wave * 2 + j) * 64 + lane;                 // 16-byte piece index, 0..511
-    srcR[j] = R + (i0 + (size_t)(p >> 2)) * ldr + (size_t)(p & 3) * 16;
+    const int p = (wave * 2 + j) * 64 + lane;                 // 16-byte piece index, 0..511: LDS slot (row p / 4, position p % 4) takes k group (position - row / 4) mod 4
+    srcR[j] = R + (i0 + (size_t)(p >> 2)) * ldr + (size_t)(((p & 3) - (p >> 4)) & 3) * 16;
     const size_t zoff = ((size_t)(p >> 7) * ld + b0 + (size_t)(p & 127)) * 16;
     srcL[j] = Zlo + zoff;
     srcH[j] = Zhi + zoff;
@@ -1235,7 +1240,7 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int p = (wave * 4 + j) * 64 + lane;                  // 16-byte piece, 0..1023
-        const int kk = p >> 9, row = (p >> 2) & 127, col = p & 3;
+        const int kk = p >> 9, row = (p >> 2) & 127, col = ((p & 3) - (row >> 2)) & 3;      // the k group this LDS position holds (i8_slot inverted)
         __builtin_amdgcn_global_load_lds(R + (i0 + (size_t)row) * ldr + (size_t)ks2 * 128 + kk * 64 + col * 16,
                                          (lds_void_ptr)(base + (wave * 4 + j) * 1024), 16, 0, 0);
         const int kg = p >> 7, bb = p & 127;
@@ -1257,7 +1262,7 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
         v4i fr[4], fl[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          fr[t] = *reinterpret_cast<const v4i*>(sR + kk * 8192 + ((wc * 64 + t * 16 + r16) * 64 + g * 16));
+          fr[t] = *reinterpret_cast<const v4i*>(sR + kk * 8192 + ((wc * 64 + t * 16 + r16) * 64 + i8_slot(wc * 64 + t * 16 + r16, g) * 16));
           fl[t] = *reinterpret_cast<const v4i*>(sL + (((kk * 4 + g) * 128 + wr * 64 + t * 16 + r16) * 16));
         }
 #pragma unroll
@@ -1288,7 +1293,7 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
     v4i fr[4], fl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      fr[t] = *reinterpret_cast<const v4i*>(sR + ((wc * 64 + t * 16 + r16) * 64 + g * 16));
+      fr[t] = *reinterpret_cast<const v4i*>(sR + ((wc * 64 + t * 16 + r16) * 64 + i8_slot(wc * 64 + t * 16 + r16, g) * 16));
       fl[t] = *reinterpret_cast<const v4i*>(sL + ((g * 128 + wr * 64 + t * 16 + r16) * 16));
     }
 #pragma unroll

@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void k_np_combine8(const int8_t* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int p = (wave * 4 + j) * 64 + lane;                  // 16-byte piece, 0..1023
-      const int kk = p >> 9, row = (p >> 2) & 127, col = p & 3;
+      const int kk = p >> 9, row = (p >> 2) & 127, col = ((p & 3) - (row >> 2)) & 3;      // k groups rotated by row / 4 in LDS (i8_slot, psf_kernels.hpp): no bank conflicts
       __builtin_amdgcn_global_load_lds(B8 + (i0 + (size_t)row) * ldb + (size_t)ks2 * 128 + kk * 64 + col * 16,
                                        (lds_void_ptr)(base + (wave * 4 + j) * 1024), 16, 0, 0);
       const int kg = p >> 7, bb = p & 127;
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void k_np_combine8(const int8_t* __restrict
       v4i fr[4], fl[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        fr[t] = *reinterpret_cast<const v4i*>(sR + kk * 8192 + ((wc * 64 + t * 16 + r16) * 64 + g * 16));
+        fr[t] = *reinterpret_cast<const v4i*>(sR + kk * 8192 + ((wc * 64 + t * 16 + r16) * 64 + i8_slot(wc * 64 + t * 16 + r16, g) * 16));
         fl[t] = *reinterpret_cast<const v4i*>(sL + (((kk * 4 + g) * 128 + wr * 64 + t * 16 + r16) * 16));
       }
 #pragma unroll
