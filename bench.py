@@ -168,7 +168,7 @@ def main():
         roof = None
         if trmm:
             ach = flops_per_launch / (trmm * 1e-3) / 1e12
-            kname = "k_trmm_f64_reg" if os.environ.get("PSF_TRMM_VARIANT", "1") == "1" else "k_trmm_f64"      # the library's default and its LDS-staged alternative
+            kname = {"2": "k_trmm_f64_big", "1": "k_trmm_f64_reg"}.get(os.environ.get("PSF_TRMM_VARIANT", "2"), "k_trmm_f64")      # the library's default and its two alternatives
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 3), "peak": PEAK_F64_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": load_traffic(args.config + (":structured" if args.structured else ""), B),
                     "traffic_source": "profiles/trmm_traffic.json (rocprofv3 PMC passes; null when psf_kernels.hpp changed since)",

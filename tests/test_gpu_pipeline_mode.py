@@ -43,25 +43,26 @@ def test_pipelined_mode_is_bit_identical():
     assert run("0") == run("1")
 
 
-def test_both_fp64_product_kernels_give_the_same_bits(monkeypatch):
-    """k_trmm_f64_reg (operands streamed into registers, the default) and k_trmm_f64 (LDS-staged, PSF_TRMM_VARIANT=0) run the same ascending
-    fma chains: x and everything downstream must agree bit for bit, here on a key of several row-blocks (m = 932: 8 blocks of 128, ragged top)
-    and a batch that leaves part of the last column block empty; also in structured mode (the m_bar x m_bar block only, rows beyond it kept)."""
+def test_the_fp64_product_kernels_give_the_same_bits(monkeypatch):
+    """k_trmm_f64_big (one workgroup per CU, accumulators in AccVGPRs: the default), k_trmm_f64_reg (PSF_TRMM_VARIANT=1) and k_trmm_f64 (LDS-staged,
+    PSF_TRMM_VARIANT=0) run the same ascending fma chains: x and everything downstream must agree bit for bit, here on keys of several row-blocks
+    (m = 932: 8 blocks of 128 with a ragged top; structured: 484 rows = 4 blocks, and with n = 40 an ODD number of row-blocks, so the last 256-row
+    tile has an empty lower half) and a batch that leaves part of the last column block empty."""
     import numpy as np
     import tools_amd as T
-    for structured in (False, True):
-        gp = T.GadgetParameters.init_default(64, 128)
+    for n, structured in ((64, False), (64, True), (40, False)):
+        gp = T.GadgetParameters.init_default(n, 128)
         psf = T.PSFPerturbation(gp, 3.0, 300.0, structured=structured)
         psf.trap_gen(4, export=False)
-        u = np.random.default_rng(5).integers(0, 128, size=(300, 64), dtype=np.int64)
+        u = np.random.default_rng(5).integers(0, 128, size=(300, n), dtype=np.int64)
         res = {}
-        for v in ("0", "1"):
+        for v in ("0", "1", "2"):
             monkeypatch.setenv("PSF_TRMM_VARIANT", v)
-            st = psf.samp_p_stages(u, seed=9)
-            res[v] = st
-        for key in ("x", "p", "e"):
-            assert (res["0"][key] == res["1"][key]).all(), (structured, key)
-        assert (psf.f_a(res["1"]["e"]) == u).all()
+            res[v] = psf.samp_p_stages(u, seed=9)
+        for v in ("0", "1"):
+            for key in ("x", "p", "e"):
+                assert (res[v][key] == res["2"][key]).all(), (n, structured, v, key)
+        assert (psf.f_a(res["2"]["e"]) == u).all()
 
 
 def test_lock_step_gadget_kernel_is_bit_identical():

@@ -90,6 +90,74 @@ __global__ __launch_bounds__(256, 2) void k_reg_variant(const double* __restrict
   TR_CLK_END
 }
 
+// One workgroup per CU: 4 waves, each alone on its SIMD with a 128 x 64 tile (256 AccVGPRs of accumulators, MFMAs as asm statements), workgroup tile 256 x 128 = two
+// row-blocks x one column block.  A wave streams all 8 A fragments of its row-block and 4 B fragments per k-step (12 loads for 32 MFMAs: 25 % fewer operand bytes per flop than
+// two 128 x 128 workgroups per CU), PD steps in flight.  No co-resident partner: nothing hides a stall, but nothing competes either (every workgroup runs at the same pace).
+#define TR_WAIT12(n, A, Bv) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), \
+                                         "+v"(Bv[0]), "+v"(Bv[1]), "+v"(Bv[2]), "+v"(Bv[3]))
+template <int PD, int MODE>
+__global__ __launch_bounds__(256, 1) void k_big_variant(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X, int nbi, int nbj, size_t nkb,
+                                                        size_t ldx, int GR, int GC) {
+  int bt, bj;
+  const int nbt = nbi / 2;                                           // row tiles of 256 (the probe's nbi is even)
+  tr_map_block(blockIdx.x, nbt, nbj, GR, GC, &bt, &bj);
+  if (bt < 0 || bt >= nbt || bj >= nbj) return;
+  TR_CLK_BEGIN
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int bi = 2 * bt + wr;
+  const int nsteps = TR_KB_PER_BLOCK * (bi + 1) * (TR_BK / 4);
+  const double* gA = Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK;
+  const double* gB = Dt + (size_t)bj * nkb * TR_CHUNK + (size_t)(wc * 4) * 64;
+  const uint32_t voff = (uint32_t)lane * 8u;
+  d4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  double a[PD][8], b[PD][4];
+  auto issue = [&](double (&av)[8], double (&bv)[4], int s) {
+    if (MODE == 1) s &= 7;
+    const double* pa = gA + (size_t)s * 512;
+    const double* pb = gB + (size_t)s * 512;
+    TR_LOAD8(av[0], voff, pa, 0); TR_LOAD8(av[1], voff, pa, 512); TR_LOAD8(av[2], voff, pa, 1024); TR_LOAD8(av[3], voff, pa, 1536);
+    TR_LOAD8(av[4], voff, pa, 2048); TR_LOAD8(av[5], voff, pa, 2560); TR_LOAD8(av[6], voff, pa, 3072); TR_LOAD8(av[7], voff, pa, 3584);
+    TR_LOAD8(bv[0], voff, pb, 0); TR_LOAD8(bv[1], voff, pb, 512); TR_LOAD8(bv[2], voff, pb, 1024); TR_LOAD8(bv[3], voff, pb, 1536);
+  };
+#pragma unroll
+  for (int u = 0; u < PD; ++u) issue(a[u], b[u], u);
+  for (int s0 = 0; s0 < nsteps; s0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      if (s0 + u < nsteps) {
+        if (PD == 4) TR_WAIT12(36, a[u], b[u]);
+        if (PD == 5) TR_WAIT12(48, a[u], b[u]);
+        if (PD == 6) TR_WAIT12(60, a[u], b[u]);
+        if (PD == 3) TR_WAIT12(24, a[u], b[u]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[u][i]), "v"(b[u][j]));
+      }
+      int sn = s0 + u + PD;
+      sn = sn < nsteps ? sn : nsteps - 1;
+      issue(a[u], b[u], sn);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PD; ++u) TR_WAIT12(0, a[u], b[u]);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  const size_t row0 = (size_t)bi * TR_BM, col0 = (size_t)bj * TR_BN + wc * 64;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[(row0 + i * 16 + (lane >> 4) + 4 * r) * ldx + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
+  TR_CLK_END
+}
+
 // Experiment kept for the record (profiles/r02_notes.md): the register-streamed kernel in two phases -- phase 1 the chunks left of the row group's
 // diagonal super-block (the same count for all 8 row-blocks of a super-tile), phase 2 the ragged rest continuing the chains from X -- with optional
 // meeting points of the 64 workgroups of a super-tile in phase 1 (a counter per super-tile and meeting, 60 us timeout, no meetings after a timeout).
@@ -314,6 +382,15 @@ int main(int argc, char** argv) {
       hipEventRecord(e0, 0);
       switch (which) {
         case 0: hipLaunchKernelGGL(k_trmm_f64, dim3(grid), dim3(256), 4 * TR_CHUNK * sizeof(double), 0, L, D, X, nbi, nbj, nkb, ldx, GR, GC, (size_t)nbi * 128); break;
+        case 19: hipLaunchKernelGGL((k_big_variant<4, 0>), dim3(tr_grid_size(nbi / 2, nbj, 4, 8)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 4, 8); break;
+        case 20: hipLaunchKernelGGL((k_big_variant<5, 0>), dim3(tr_grid_size(nbi / 2, nbj, 4, 8)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 4, 8); break;
+        case 21: hipLaunchKernelGGL((k_big_variant<4, 1>), dim3(tr_grid_size(nbi / 2, nbj, 4, 8)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 4, 8); break;
+        case 22: hipLaunchKernelGGL((k_big_variant<4, 0>), dim3(tr_grid_size(nbi / 2, nbj, 8, 4)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 8, 4); break;
+        case 23: hipLaunchKernelGGL((k_big_variant<4, 0>), dim3(tr_grid_size(nbi / 2, nbj, 2, 16)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 2, 16); break;
+        case 24: hipLaunchKernelGGL((k_big_variant<4, 0>), dim3(tr_grid_size(nbi / 2, nbj, 16, 2)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 16, 2); break;
+        case 25: hipLaunchKernelGGL((k_big_variant<4, 0>), dim3(tr_grid_size(nbi / 2, nbj, 32, 1)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 32, 1); break;
+        case 26: hipLaunchKernelGGL((k_big_variant<4, 0>), dim3(tr_grid_size(nbi / 2, nbj, 1, 32)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 1, 32); break;
+        case 27: hipLaunchKernelGGL((k_big_variant<6, 0>), dim3(tr_grid_size(nbi / 2, nbj, 8, 4)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 8, 4); break;
         case 12: hipLaunchKernelGGL(k_trmm_f64_reg, dim3(grid), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, GR, GC, (size_t)nbi * 128); break;
         case 13: for (int ph = 1; ph <= 2; ++ph) hipLaunchKernelGGL(k_reg_phase_meet, dim3(grid), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, GR, GC, (size_t)nbi * 128, ph, (unsigned*)nullptr); break;
         case 15: hipMemsetAsync(meet, 0, (size_t)tr_group_count(nbi, nbj, GR, GC) * TR_SYNC_SLOTS * 4, 0);
@@ -383,6 +460,15 @@ int main(int argc, char** argv) {
   }
 #endif
   run("k_trmm_f64_reg (library, 6 in flight)", 12, true);
+  run("one workgroup / CU, wave tile 128 x 64 in AccVGPRs, 4 in flight, 4 x 8 super-tiles", 19, true);
+  run("same, 5 in flight", 20, true);
+  run("same, 4 in flight, loads re-read 8 steps (cache hits)", 21, false);
+  run("same, 4 in flight, 8 x 4 super-tiles", 22, true);
+  run("same, 4 in flight, 2 x 16 super-tiles", 23, true);
+  run("same, 4 in flight, 16 x 2 super-tiles", 24, true);
+  run("same, 4 in flight, 32 x 1 super-tiles", 25, true);
+  run("same, 4 in flight, 1 x 32 super-tiles", 26, true);
+  run("same, 6 in flight, 8 x 4 super-tiles", 27, true);
   run("k_trmm_f64_reg in two phases", 13, true);
   run("k_trmm_f64_reg in two phases, meeting points in phase 1", 15, true);
 #ifdef TRMM_CLOCK_PROBE

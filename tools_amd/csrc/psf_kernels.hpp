@@ -214,7 +214,7 @@ __host__ inline unsigned tr_grid_size(int nbi, int nbj, int GR = 8, int GC = 8) 
   const int ncg = (nbj + GC - 1) / GC, nrg = (nbi + GR - 1) / GR;
   const unsigned groups = (unsigned)(ncg * nrg);
   const unsigned rounds = (groups + 7) / 8;
-  return rounds * 8u * 64u;
+  return rounds * 8u * (unsigned)(GR * GC);
 }
 
 #ifdef TRMM_CLOCK_PROBE   /* measurement builds only (tools/trmm_clock_probe.py, tools/probe_trmm.hip): shader-clock ticks and 100 MHz real-time ticks per workgroup */
@@ -378,6 +378,84 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64_reg(const double* __restric
         const size_t row = row0 + i * 16 + (lane >> 4) + 4 * r;
         if (row < row_hi) X[row * ldx + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
       }
+  TR_CLK_END
+}
+
+// The default since the end of round 2: ONE workgroup per CU, four waves, each alone on its SIMD with a 128 x 64 tile of X -- 256 AccVGPRs of
+// accumulators (the MFMAs are asm statements: hipcc keeps builtin accumulators in architectural VGPRs) and the operand ring in the 256
+// architectural ones.  Workgroup tile 256 x 128 = two row-blocks x one column block; wave (wr, wc) streams all 8 A fragments of row-block
+// 2 bt + wr and the 4 B fragments of its half of the column block: 12 loads for 32 MFMAs per k-step, a quarter fewer operand bytes per flop than
+// two 128 x 128 workgroups per CU, TR_BIG_PD k-steps in flight.  No co-resident workgroup: nothing competes for the matrix cores, so the 32
+// workgroups of an XCD (a super-tile of 8 row tiles x 4 column blocks) run at one pace and share their fetches in L2.  Same ascending chains,
+// same bits.  Measured at C3 (tools/probe_trmm.hip, profiles/r02_notes.md): 52.2 ms against 53.1-54.3 (k_trmm_f64_reg) and 54.9 (k_trmm_f64) in the
+// same runs, 0.946 of the FP64 peak at 2.4 GHz, FETCH_SIZE 63 GB against 138 / 121.
+constexpr int TR_BIG_PD = 4;
+#define TR_WAIT12(n, A, Bv) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), \
+                                         "+v"(Bv[0]), "+v"(Bv[1]), "+v"(Bv[2]), "+v"(Bv[3]))
+__global__ __launch_bounds__(256, 1) void k_trmm_f64_big(const double* __restrict__ Lt, const double* __restrict__ Dt,
+                                                         double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx, int GR, int GC, size_t row_hi) {
+  int bt, bj;
+  const int nbt = (nbi + 1) / 2;                                     // row tiles of 256
+  tr_map_block(blockIdx.x, nbt, nbj, GR, GC, &bt, &bj);
+  if (bt < 0 || bt >= nbt || bj >= nbj) return;
+  TR_CLK_BEGIN
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int bi = 2 * bt + wr;
+  if (bi < nbi) {                                                    // an odd number of row-blocks leaves the last tile's lower half empty (no barrier in here)
+    const int nsteps = TR_KB_PER_BLOCK * (bi + 1) * (TR_BK / 4);     // a multiple of 32
+    const double* gA = Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK;                    // wave-uniform
+    const double* gB = Dt + (size_t)bj * nkb * TR_CHUNK + (size_t)(wc * 4) * 64;
+    const uint32_t voff = (uint32_t)lane * 8u;
+    d4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    double a[TR_BIG_PD][8], b[TR_BIG_PD][4];
+    auto issue = [&](double (&av)[8], double (&bv)[4], int s) {
+      const double* pa = gA + (size_t)s * 512;
+      const double* pb = gB + (size_t)s * 512;
+      TR_LOAD8(av[0], voff, pa, 0); TR_LOAD8(av[1], voff, pa, 512); TR_LOAD8(av[2], voff, pa, 1024); TR_LOAD8(av[3], voff, pa, 1536);
+      TR_LOAD8(av[4], voff, pa, 2048); TR_LOAD8(av[5], voff, pa, 2560); TR_LOAD8(av[6], voff, pa, 3072); TR_LOAD8(av[7], voff, pa, 3584);
+      TR_LOAD8(bv[0], voff, pb, 0); TR_LOAD8(bv[1], voff, pb, 512); TR_LOAD8(bv[2], voff, pb, 1024); TR_LOAD8(bv[3], voff, pb, 1536);
+    };
+#pragma unroll
+    for (int u = 0; u < TR_BIG_PD; ++u) issue(a[u], b[u], u);
+    for (int s0 = 0; s0 < nsteps; s0 += TR_BIG_PD) {
+#pragma unroll
+      for (int u = 0; u < TR_BIG_PD; ++u) {
+        TR_WAIT12(36, a[u], b[u]);                                   // 12 (TR_BIG_PD - 1): all but the three newest k-steps have landed
+        static_assert(TR_BIG_PD == 4, "the wait count above is 12 (TR_BIG_PD - 1)");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[u][i]), "v"(b[u][j]));
+        int sn = s0 + u + TR_BIG_PD;
+        sn = sn < nsteps ? sn : nsteps - 1;                          // past the end: re-read the last step (never consumed)
+        issue(a[u], b[u], sn);
+      }
+    }
+    // the unconsumed re-reads keep their registers until they have landed (see k_trmm_f64_reg)
+#pragma unroll
+    for (int u = 0; u < TR_BIG_PD; ++u) TR_WAIT12(0, a[u], b[u]);
+    // The hazard recogniser does not see MFMAs inside asm statements: nothing may read an accumulator until the last MFMA has retired (16 passes = 64
+    // cycles).  The stores below cannot move above this statement (memory clobber), and the accumulator written last is the one stored last.
+    // (Naming the accumulators as in/out operands here made hipcc keep half of them in architectural VGPRs and copy them around every MFMA.)
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    const size_t row0 = (size_t)bi * TR_BM, col0 = (size_t)bj * TR_BN + wc * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+          const size_t row = row0 + i * 16 + (lane >> 4) + 4 * r;
+          if (row < row_hi) X[row * ldx + col0 + j * 16 + (lane & 15)] = acc[i][j][r];
+        }
+  }
   TR_CLK_END
 }
 

@@ -642,15 +642,17 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   }
   {  // x = sqrt(Sigma_2) d   (structured: the m_bar x m_bar block L_1 d_1; rows from m_bar on already hold x_bot = h d_2)
     ScopedTimer t(h, st, "k_trmm_f64");
-    // default: operands streamed into registers (k_trmm_f64_reg); PSF_TRMM_VARIANT=0 selects the LDS-staged kernel (same bits)
-    const char* venv = std::getenv("PSF_TRMM_VARIANT");      // read per call: the tests compare the two kernels inside one process
-    const int variant = venv ? std::atoi(venv) : 1;
-    const dim3 grid(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8));
+    // default: k_trmm_f64_big (one workgroup per CU, accumulators in AccVGPRs); PSF_TRMM_VARIANT=1: k_trmm_f64_reg (two 128 x 128 workgroups per CU,
+    // operands streamed into registers), 0: k_trmm_f64 (LDS-staged, round 1).  Same bits from all three.
+    const char* venv = std::getenv("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
+    const int variant = venv ? std::atoi(venv) : 2;
     const size_t row_hi = h->structured ? h->mb : h->M_pad;
-    if (variant == 1)
-      hipLaunchKernelGGL(k_trmm_f64_reg, grid, dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
+    if (variant == 2)
+      hipLaunchKernelGGL(k_trmm_f64_big, dim3(tr_grid_size(((int)h->nbiL + 1) / 2, (int)nbj, 8, 4)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 4, row_hi);
+    else if (variant == 1)
+      hipLaunchKernelGGL(k_trmm_f64_reg, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
     else
-      hipLaunchKernelGGL(k_trmm_f64, grid, dim3(256), 4 * TR_CHUNK * sizeof(double), st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
+      hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 4 * TR_CHUNK * sizeof(double), st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
   }
   if (h->structured) {  // x_top -= g R d_2 (exact integer sum on the int8 matrix cores)
     ScopedTimer t(h, st, "k_rd2_mfma");
