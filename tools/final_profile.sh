@@ -11,6 +11,7 @@ done
 timeout 300 python3 bench.py --config c3 --structured > $O/bench_c3s.log 2>&1; tail -1 $O/bench_c3s.log > $O/bench_c3_structured.json
 timeout 600 python3 bench.py --config c5 --steps 2 --warmup 1 > $O/bench_c5.log 2>&1; tail -1 $O/bench_c5.log > $O/bench_c5_one_gpu.json
 PSF_TRMM_VARIANT=0 timeout 300 python3 bench.py --config c3 --no-cpu-baseline > $O/bench_c3_lds.log 2>&1; tail -1 $O/bench_c3_lds.log > $O/bench_c3_lds_kernel.json
+PSF_TRMM_VARIANT=1 timeout 300 python3 bench.py --config c3 --no-cpu-baseline > $O/bench_c3_reg.log 2>&1; tail -1 $O/bench_c3_reg.log > $O/bench_c3_reg_kernel.json
 cd /tmp
 for cfg in c3 c2 c4; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$cfg -o t --output-format csv -- python3 $R/bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline > $O/rocprof_$cfg.log 2>&1
@@ -25,7 +26,7 @@ cd $R
 timeout 600 tools/pmc_traffic.sh c3 k_trmm_f64 > $O/traffic_c3.json 2>$O/traffic_c3.err
 timeout 600 tools/pmc_traffic.sh c3 k_trmm_f64 --structured > $O/traffic_c3_structured.json 2>>$O/traffic_c3.err
 timeout 300 tools/bin/probe_trmm 240 32 3 > $O/probe_trmm.log 2>/dev/null
-timeout 300 bash tools/pmc_probe_trmm.sh 0xb000 > $O/probe_trmm_traffic.log 2>&1
+timeout 300 bash tools/pmc_probe_trmm.sh 0x10001000 > $O/probe_trmm_traffic.log 2>&1
 timeout 100 tools/bin/probe_xcc > $O/probe_xcc.log 2>&1
 timeout 300 bash tools/pmc_l2share.sh > $O/probe_l2share.log 2>&1
 PSF_LIB=$R/tools_amd/lib/libpsf_clock_probe.so timeout 300 python3 tools/trmm_clock_probe.py > $O/trmm_clock.log 2>&1

@@ -391,6 +391,7 @@ int main(int argc, char** argv) {
         case 25: hipLaunchKernelGGL((k_big_variant<4, 0>), dim3(tr_grid_size(nbi / 2, nbj, 32, 1)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 32, 1); break;
         case 26: hipLaunchKernelGGL((k_big_variant<4, 0>), dim3(tr_grid_size(nbi / 2, nbj, 1, 32)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 1, 32); break;
         case 27: hipLaunchKernelGGL((k_big_variant<6, 0>), dim3(tr_grid_size(nbi / 2, nbj, 8, 4)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 8, 4); break;
+        case 28: hipLaunchKernelGGL(k_trmm_f64_big, dim3(tr_grid_size((nbi + 1) / 2, nbj, 8, 4)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 8, 4, (size_t)nbi * 128); break;
         case 12: hipLaunchKernelGGL(k_trmm_f64_reg, dim3(grid), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, GR, GC, (size_t)nbi * 128); break;
         case 13: for (int ph = 1; ph <= 2; ++ph) hipLaunchKernelGGL(k_reg_phase_meet, dim3(grid), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, GR, GC, (size_t)nbi * 128, ph, (unsigned*)nullptr); break;
         case 15: hipMemsetAsync(meet, 0, (size_t)tr_group_count(nbi, nbj, GR, GC) * TR_SYNC_SLOTS * 4, 0);
@@ -460,6 +461,7 @@ int main(int argc, char** argv) {
   }
 #endif
   run("k_trmm_f64_reg (library, 6 in flight)", 12, true);
+  run("k_trmm_f64_big (library default: one workgroup / CU, 8 x 4 super-tiles)", 28, true);
   run("one workgroup / CU, wave tile 128 x 64 in AccVGPRs, 4 in flight, 4 x 8 super-tiles", 19, true);
   run("same, 5 in flight", 20, true);
   run("same, 4 in flight, loads re-read 8 steps (cache hits)", 21, false);

@@ -647,8 +647,12 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     const char* venv = std::getenv("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
     const int variant = venv ? std::atoi(venv) : 2;
     const size_t row_hi = h->structured ? h->mb : h->M_pad;
-    if (variant == 2)
-      hipLaunchKernelGGL(k_trmm_f64_big, dim3(tr_grid_size(((int)h->nbiL + 1) / 2, (int)nbj, 8, 4)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 4, row_hi);
+    if (variant == 2) {
+      int GR = 8, GC = 4;                                     // super-tile of an XCD's 32 resident workgroups; PSF_TRMM_GR x PSF_TRMM_GC for experiments (product = 32)
+      if (const char* e1 = std::getenv("PSF_TRMM_GR")) if (const char* e2 = std::getenv("PSF_TRMM_GC")) { GR = std::atoi(e1); GC = std::atoi(e2); }
+      if (GR < 1 || GC < 1 || GR * GC != 32) { GR = 8; GC = 4; }
+      hipLaunchKernelGGL(k_trmm_f64_big, dim3(tr_grid_size(((int)h->nbiL + 1) / 2, (int)nbj, GR, GC)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, GR, GC, row_hi);
+    }
     else if (variant == 1)
       hipLaunchKernelGGL(k_trmm_f64_reg, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
     else
