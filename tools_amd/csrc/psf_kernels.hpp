@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const
 
 // Same product, operands streamed from global memory straight into MFMA operand registers: the chunk streams are already in fragment order, so
 // k-step s of a wave is eight 512-byte loads (4 A fragments, 4 B fragments) at stream offset 512 s.  No LDS, no barrier: the four waves of a
-// workgroup only share cache lines.  TR_PD k-steps are in flight per wave.  Bit-identical to k_trmm_f64 (same ascending chains); measured on
+// workgroup only share cache lines.  TR_PD k-steps are in flight per wave.  Bit-identical to k_trmm_f64 (same ascending chains); PSF_TRMM_VARIANT=1
+// (the default is k_trmm_f64_big below); measured on
 // MI355X at C3: 54.0 vs 55.0 ms inside the library, 0.967 of the FP64 MFMA peak AT THE CLOCK THE KERNEL RUNS AT (2.25-2.35 GHz under this load;
 // a loop with the same MFMAs and no loads at all reaches 0.963, profiles/r02_notes.md).
 constexpr int TR_PD = 6;
