@@ -391,6 +391,9 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64_reg(const double* __restric
 // same bits.  Measured at C3 (tools/probe_trmm.hip, profiles/r02_notes.md): 52.2 ms against 53.1-54.3 (k_trmm_f64_reg) and 54.9 (k_trmm_f64) in the
 // same runs, 0.946 of the FP64 peak at 2.4 GHz, FETCH_SIZE 63 GB against 138 / 121.
 constexpr int TR_BIG_PD = 4;
+#ifndef TR_BIG_UNROLL
+#define TR_BIG_UNROLL 2      /* rounds of the operand ring per loop iteration (must divide 8); measured 1 -> 2: +0.4 %, 4: no more */
+#endif
 #define TR_WAIT12(n, A, Bv) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), \
                                          "+v"(Bv[0]), "+v"(Bv[1]), "+v"(Bv[2]), "+v"(Bv[3]))
 __global__ __launch_bounds__(256, 1) void k_trmm_f64_big(const double* __restrict__ Lt, const double* __restrict__ Dt,
@@ -424,7 +427,9 @@ __global__ __launch_bounds__(256, 1) void k_trmm_f64_big(const double* __restric
     };
 #pragma unroll
     for (int u = 0; u < TR_BIG_PD; ++u) issue(a[u], b[u], u);
-    for (int s0 = 0; s0 < nsteps; s0 += TR_BIG_PD) {
+    for (int s0 = 0; s0 < nsteps; s0 += TR_BIG_PD * TR_BIG_UNROLL) {      // nsteps is a multiple of 32
+#pragma unroll
+      for (int rnd = 0; rnd < TR_BIG_UNROLL; ++rnd)
 #pragma unroll
       for (int u = 0; u < TR_BIG_PD; ++u) {
         TR_WAIT12(36, a[u], b[u]);                                   // 12 (TR_BIG_PD - 1): all but the three newest k-steps have landed
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void k_trmm_f64_big(const double* __restric
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[u][i]), "v"(b[u][j]));
-        int sn = s0 + u + TR_BIG_PD;
+        int sn = s0 + rnd * TR_BIG_PD + u + TR_BIG_PD;
         sn = sn < nsteps ? sn : nsteps - 1;                          // past the end: re-read the last step (never consumed)
         issue(a[u], b[u], sn);
       }
