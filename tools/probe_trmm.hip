@@ -121,9 +121,16 @@ __global__ __launch_bounds__(256, 1) void k_big_variant(const double* __restrict
     if (MODE == 1) s &= 7;
     const double* pa = gA + (size_t)s * 512;
     const double* pb = gB + (size_t)s * 512;
+#define TR_LOAD8NT(dst, voff, base, imm) asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #imm " nt" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+    if (MODE == 2 || MODE == 4) {
+      TR_LOAD8NT(av[0], voff, pa, 0); TR_LOAD8NT(av[1], voff, pa, 512); TR_LOAD8NT(av[2], voff, pa, 1024); TR_LOAD8NT(av[3], voff, pa, 1536);
+      TR_LOAD8NT(av[4], voff, pa, 2048); TR_LOAD8NT(av[5], voff, pa, 2560); TR_LOAD8NT(av[6], voff, pa, 3072); TR_LOAD8NT(av[7], voff, pa, 3584);
+    } else {
     TR_LOAD8(av[0], voff, pa, 0); TR_LOAD8(av[1], voff, pa, 512); TR_LOAD8(av[2], voff, pa, 1024); TR_LOAD8(av[3], voff, pa, 1536);
     TR_LOAD8(av[4], voff, pa, 2048); TR_LOAD8(av[5], voff, pa, 2560); TR_LOAD8(av[6], voff, pa, 3072); TR_LOAD8(av[7], voff, pa, 3584);
-    TR_LOAD8(bv[0], voff, pb, 0); TR_LOAD8(bv[1], voff, pb, 512); TR_LOAD8(bv[2], voff, pb, 1024); TR_LOAD8(bv[3], voff, pb, 1536);
+    }
+    if (MODE == 3 || MODE == 4) { TR_LOAD8NT(bv[0], voff, pb, 0); TR_LOAD8NT(bv[1], voff, pb, 512); TR_LOAD8NT(bv[2], voff, pb, 1024); TR_LOAD8NT(bv[3], voff, pb, 1536); }
+    else { TR_LOAD8(bv[0], voff, pb, 0); TR_LOAD8(bv[1], voff, pb, 512); TR_LOAD8(bv[2], voff, pb, 1024); TR_LOAD8(bv[3], voff, pb, 1536); }
   };
 #pragma unroll
   for (int u = 0; u < PD; ++u) issue(a[u], b[u], u);
@@ -392,6 +399,9 @@ int main(int argc, char** argv) {
         case 26: hipLaunchKernelGGL((k_big_variant<4, 0>), dim3(tr_grid_size(nbi / 2, nbj, 1, 32)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 1, 32); break;
         case 27: hipLaunchKernelGGL((k_big_variant<6, 0>), dim3(tr_grid_size(nbi / 2, nbj, 8, 4)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 8, 4); break;
         case 28: hipLaunchKernelGGL(k_trmm_f64_big, dim3(tr_grid_size((nbi + 1) / 2, nbj, 8, 4)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 8, 4, (size_t)nbi * 128); break;
+        case 29: hipLaunchKernelGGL((k_big_variant<4, 2>), dim3(tr_grid_size(nbi / 2, nbj, 8, 4)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 8, 4); break;
+        case 30: hipLaunchKernelGGL((k_big_variant<4, 3>), dim3(tr_grid_size(nbi / 2, nbj, 8, 4)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 8, 4); break;
+        case 31: hipLaunchKernelGGL((k_big_variant<4, 4>), dim3(tr_grid_size(nbi / 2, nbj, 8, 4)), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, 8, 4); break;
         case 12: hipLaunchKernelGGL(k_trmm_f64_reg, dim3(grid), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, GR, GC, (size_t)nbi * 128); break;
         case 13: for (int ph = 1; ph <= 2; ++ph) hipLaunchKernelGGL(k_reg_phase_meet, dim3(grid), dim3(256), 0, 0, L, D, X, nbi, nbj, nkb, ldx, GR, GC, (size_t)nbi * 128, ph, (unsigned*)nullptr); break;
         case 15: hipMemsetAsync(meet, 0, (size_t)tr_group_count(nbi, nbj, GR, GC) * TR_SYNC_SLOTS * 4, 0);
@@ -471,6 +481,9 @@ int main(int argc, char** argv) {
   run("same, 4 in flight, 32 x 1 super-tiles", 25, true);
   run("same, 4 in flight, 1 x 32 super-tiles", 26, true);
   run("same, 6 in flight, 8 x 4 super-tiles", 27, true);
+  run("same, 4 in flight, 8 x 4, A loads non-temporal", 29, true);
+  run("same, 4 in flight, 8 x 4, B loads non-temporal", 30, true);
+  run("same, 4 in flight, 8 x 4, all loads non-temporal", 31, true);
   run("k_trmm_f64_reg in two phases", 13, true);
   run("k_trmm_f64_reg in two phases, meeting points in phase 1", 15, true);
 #ifdef TRMM_CLOCK_PROBE
