@@ -519,6 +519,15 @@ def gso_rows(basis_t):
     return out
 
 
+def gso_rows_leading(basis_rows):
+    """Gram-Schmidt of the leading rows of a (transposed) basis: basis_rows is nrows x width, row i = basis vector i."""
+    bt = np.ascontiguousarray(basis_rows, dtype=np.int32)
+    nrows, width = bt.shape
+    out = np.zeros((nrows, width), dtype=np.float64)
+    lib().orc_gso_rows_leading(_p(bt, C.c_int32), C.c_size_t(nrows), C.c_size_t(width), _p(out, C.c_double))
+    return out
+
+
 def ring_trap_gen(gp, s_td, seed):
     n, k = gp.n, gp.k
     a = np.zeros((k + 2, n), dtype=np.uint64)

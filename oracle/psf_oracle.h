@@ -136,6 +136,7 @@ void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double
                        uint64_t seed, uint32_t tag, uint64_t index, int64_t* c);
 /* Gram-Schmidt on the ROWS of St (MatQ::gso on the columns of the reference's matrix) */
 void orc_gso_rows(const int32_t* St, size_t m, double* Gt);
+void orc_gso_rows_leading(const int32_t* St, size_t nrows, size_t width, double* Gt);
 void* orc_gpv_new(const orc_gadget_params* gp, double s);
 void orc_gpv_free(void*);
 size_t orc_gpv_m(const void*);

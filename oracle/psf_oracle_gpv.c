@@ -257,6 +257,29 @@ static void gso_rows(const int32_t* St, size_t m, double* Gt) {
 
 void orc_gso_rows(const int32_t* St, size_t m, double* Gt) { gso_rows(St, m, Gt); }
 
+/* The same chain for the LEADING nrows vectors of a basis of dimension `width` (row i of St = basis vector i, ld = width): Gram-Schmidt
+ * vector i reads only vectors <= i, so the leading rows of a full-size key (C2: 6208, C4: 3584) are cheap to restate exactly.  Test infrastructure
+ * for tests/test_gpu_gpv_scale.py (the leading-rows trick of orc_psfp_sqrt_sigma_2_leading). */
+void orc_gso_rows_leading(const int32_t* St, size_t nrows, size_t width, double* Gt) {
+  double* norm2 = (double*)malloc(nrows * sizeof(double));
+  for (size_t i = 0; i < nrows; ++i) {
+    double* gi = Gt + i * width;
+    const int32_t* bi = St + i * width;
+    for (size_t j = 0; j < width; ++j) gi[j] = (double)bi[j];
+    for (size_t l = 0; l < i; ++l) {
+      const double* gl = Gt + l * width;
+      double num = 0.0;
+      for (size_t j = 0; j < width; ++j) num = fma((double)bi[j], gl[j], num);
+      const double mu = num / norm2[l];
+      for (size_t j = 0; j < width; ++j) gi[j] = fma(-mu, gl[j], gi[j]);
+    }
+    double nn = 0.0;
+    for (size_t j = 0; j < width; ++j) nn = fma(gi[j], gi[j], nn);
+    norm2[i] = nn;
+  }
+  free(norm2);
+}
+
 /* gpv.rs:83-94 */
 int orc_gpv_trap_gen(void* hv, uint64_t seed) {
   orc_gpv* h = (orc_gpv*)hv;

@@ -425,6 +425,26 @@ __global__ __launch_bounds__(256, 1) void k_trmm_f64_big(const double* __restric
       TR_LOAD8(av[4], voff, pa, 2048); TR_LOAD8(av[5], voff, pa, 2560); TR_LOAD8(av[6], voff, pa, 3072); TR_LOAD8(av[7], voff, pa, 3584);
       TR_LOAD8(bv[0], voff, pb, 0); TR_LOAD8(bv[1], voff, pb, 512); TR_LOAD8(bv[2], voff, pb, 1024); TR_LOAD8(bv[3], voff, pb, 1536);
     };
+    // One k-step: 32 MFMAs and the 12 loads that refill the SAME ring slot with step `sn`.  Every statement is asm volatile, so the emitted order is the
+    // written one (volatile asms keep their relative order; the compiler may still move plain scalar address arithmetic between them): each operand register
+    // is reloaded right after its last reader has issued -- an A fragment after its row of four MFMAs; for the B fragments the last two rows are walked
+    // column-wise so that b[3] .. b[0] are released one by one.  Each accumulator still sees its k-steps in ascending order: same bits as before.
+#define TR_MFMA(i, j) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(av[i]), "v"(bv[j]))
+    auto step = [&](double (&av)[8], double (&bv)[4], int sn) {
+      const double* pa = gA + (size_t)sn * 512;
+      const double* pb = gB + (size_t)sn * 512;
+      TR_MFMA(0, 0); TR_MFMA(0, 1); TR_MFMA(0, 2); TR_MFMA(0, 3); TR_LOAD8(av[0], voff, pa, 0);
+      TR_MFMA(1, 0); TR_MFMA(1, 1); TR_MFMA(1, 2); TR_MFMA(1, 3); TR_LOAD8(av[1], voff, pa, 512);
+      TR_MFMA(2, 0); TR_MFMA(2, 1); TR_MFMA(2, 2); TR_MFMA(2, 3); TR_LOAD8(av[2], voff, pa, 1024);
+      TR_MFMA(3, 0); TR_MFMA(3, 1); TR_MFMA(3, 2); TR_MFMA(3, 3); TR_LOAD8(av[3], voff, pa, 1536);
+      TR_MFMA(4, 0); TR_MFMA(4, 1); TR_MFMA(4, 2); TR_MFMA(4, 3); TR_LOAD8(av[4], voff, pa, 2048);
+      TR_MFMA(5, 0); TR_MFMA(5, 1); TR_MFMA(5, 2); TR_MFMA(5, 3); TR_LOAD8(av[5], voff, pa, 2560);
+      TR_MFMA(6, 3); TR_MFMA(7, 3); TR_LOAD8(bv[3], voff, pb, 1536);
+      TR_MFMA(6, 2); TR_MFMA(7, 2); TR_LOAD8(bv[2], voff, pb, 1024);
+      TR_MFMA(6, 1); TR_MFMA(7, 1); TR_LOAD8(bv[1], voff, pb, 512);
+      TR_MFMA(6, 0); TR_MFMA(7, 0); TR_LOAD8(bv[0], voff, pb, 0);
+      TR_LOAD8(av[6], voff, pa, 3072); TR_LOAD8(av[7], voff, pa, 3584);
+    };
 #pragma unroll
     for (int u = 0; u < TR_BIG_PD; ++u) issue(a[u], b[u], u);
     for (int s0 = 0; s0 < nsteps; s0 += TR_BIG_PD * TR_BIG_UNROLL) {      // nsteps is a multiple of 32
@@ -434,20 +454,18 @@ __global__ __launch_bounds__(256, 1) void k_trmm_f64_big(const double* __restric
       for (int u = 0; u < TR_BIG_PD; ++u) {
         TR_WAIT12(36, a[u], b[u]);                                   // 12 (TR_BIG_PD - 1): all but the three newest k-steps have landed
         static_assert(TR_BIG_PD == 4, "the wait count above is 12 (TR_BIG_PD - 1)");
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[u][i]), "v"(b[u][j]));
         int sn = s0 + rnd * TR_BIG_PD + u + TR_BIG_PD;
         sn = sn < nsteps ? sn : nsteps - 1;                          // past the end: re-read the last step (never consumed)
-        issue(a[u], b[u], sn);
+        step(a[u], b[u], sn);
       }
     }
+#undef TR_MFMA
     // the unconsumed re-reads keep their registers until they have landed (see k_trmm_f64_reg)
 #pragma unroll
     for (int u = 0; u < TR_BIG_PD; ++u) TR_WAIT12(0, a[u], b[u]);
     // The hazard recogniser does not see MFMAs inside asm statements: nothing may read an accumulator until the last MFMA has retired (16 passes = 64
-    // cycles).  The stores below cannot move above this statement (memory clobber), and the accumulator written last is the one stored last.
+    // cycles).  The MFMAs and this statement are all asm volatile, so none of them can sink below it; the stores cannot move above it (memory clobber), and
+    // the accumulator reads (v_accvgpr_read) feed only those stores.  tests/test_kernel_isa.py checks the emitted order on every build.
     // (Naming the accumulators as in/out operands here made hipcc keep half of them in architectural VGPRs and copy them around every MFMA.)
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     const size_t row0 = (size_t)bi * TR_BM, col0 = (size_t)bj * TR_BN + wc * 64;
