@@ -104,6 +104,10 @@ psf_status psf_gen_gadget_ring(uint64_t k, uint64_t base, int64_t* out);
 psf_status psf_find_solution_gadget_ring(int device, const uint64_t* u, size_t n, uint64_t q, uint64_t k, uint64_t base, int64_t* out);
 /* gen_short_basis_for_trapdoor_ring (short_basis_ring.rs:64-79): out[(row * n(k+2) + col) * n + coeff], (k+2) x n(k+2) polynomials */
 psf_status psf_gen_short_basis_for_trapdoor_ring(const psf_gadget_params* gp, const uint64_t* a, const int64_t* r, const int64_t* e, int64_t* out);
+/* Gram-Schmidt orthogonalisation of the ROWS of an integer matrix on the device -- the `MatQ::gso` step of PSFGPV::trap_gen (gpv.rs:88-91) and of
+ * MatPolyOverZ::sample_d (gpv_ring.rs:205), as a free function: basis_t[rows x width] (row i = basis vector i), out[rows x width] = b~_i.
+ * Blocked, re-orthogonalised, FP64 matrix cores (psf_gemm_kernels.hpp).  PSF_ERR_PARAM if the rows are linearly dependent. */
+psf_status psf_gso_rows(int device, const int32_t* basis_t, size_t rows, size_t width, double* out);
 /* contiguous shares of `total` rows over `world` workers; the first total % world workers get one row more */
 psf_status psf_shard_range(size_t total, int world, int rank, size_t* first, size_t* count);
 /* PolynomialRingZq product in R_q = Z_q[X]/(X^n + 1) (common_moduli.rs:41-48), the arithmetic under the MatPolynomialRingZq

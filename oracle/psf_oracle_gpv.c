@@ -234,51 +234,39 @@ static int gpv_finish_key(orc_gpv* h) {
   return rc;
 }
 
-/* Gram-Schmidt on the rows of St (= columns of S_A), MatQ::gso at gpv.rs:88 */
-static void gso_rows(const int32_t* St, size_t m, double* Gt) {
-  double* norm2 = (double*)malloc(m * sizeof(double));
-  for (size_t i = 0; i < m; ++i) {
-    double* gi = Gt + i * m;
-    const int32_t* bi = St + i * m;
-    for (size_t j = 0; j < m; ++j) gi[j] = (double)bi[j];
-    for (size_t l = 0; l < i; ++l) {
-      const double* gl = Gt + l * m;
-      double num = 0.0;
-      for (size_t j = 0; j < m; ++j) num = fma((double)bi[j], gl[j], num);
-      const double mu = num / norm2[l];
-      for (size_t j = 0; j < m; ++j) gi[j] = fma(-mu, gl[j], gi[j]);
-    }
-    double nn = 0.0;
-    for (size_t j = 0; j < m; ++j) nn = fma(gi[j], gi[j], nn);
-    norm2[i] = nn;
-  }
-  free(norm2);
-}
-
-void orc_gso_rows(const int32_t* St, size_t m, double* Gt) { gso_rows(St, m, Gt); }
-
-/* The same chain for the LEADING nrows vectors of a basis of dimension `width` (row i of St = basis vector i, ld = width): Gram-Schmidt
- * vector i reads only vectors <= i, so the leading rows of a full-size key (C2: 6208, C4: 3584) are cheap to restate exactly.  Test infrastructure
- * for tests/test_gpu_gpv_scale.py (the leading-rows trick of orc_psfp_sqrt_sigma_2_leading). */
-void orc_gso_rows_leading(const int32_t* St, size_t nrows, size_t width, double* Gt) {
-  double* norm2 = (double*)malloc(nrows * sizeof(double));
+/* Gram-Schmidt on the rows of St (= columns of S_A), MatQ::gso at gpv.rs:88 -- which is EXACT (rationals).  The restatement works in
+ * floating point, so it is written to stay close to the exact result at every size: modified Gram-Schmidt (the coefficient of b~_l is taken
+ * from the CURRENT remainder of the vector, not from the original b_i), every vector orthogonalised twice ("twice is enough"), dot products
+ * accumulated in long double.  A single classical pass in double -- round 2's form -- loses orthogonality as (|b_i| / |b~_i|)^2 eps, which at
+ * C2 (d = 6208, shortest b~ ~ 0.026 from vectors of norm ~ 100) reached 1.6e-6.  The device's blocked form (psf_gemm_kernels.hpp) is compared
+ * with this chain within a tolerance; the leading `nrows` vectors of a `width`-dimensional basis only need the rows above them. */
+static void gso_chain(const int32_t* St, size_t nrows, size_t width, double* Gt) {
+  long double* norm2 = (long double*)malloc(nrows * sizeof(long double));
   for (size_t i = 0; i < nrows; ++i) {
     double* gi = Gt + i * width;
     const int32_t* bi = St + i * width;
     for (size_t j = 0; j < width; ++j) gi[j] = (double)bi[j];
-    for (size_t l = 0; l < i; ++l) {
-      const double* gl = Gt + l * width;
-      double num = 0.0;
-      for (size_t j = 0; j < width; ++j) num = fma((double)bi[j], gl[j], num);
-      const double mu = num / norm2[l];
-      for (size_t j = 0; j < width; ++j) gi[j] = fma(-mu, gl[j], gi[j]);
-    }
-    double nn = 0.0;
-    for (size_t j = 0; j < width; ++j) nn = fma(gi[j], gi[j], nn);
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t l = 0; l < i; ++l) {
+        const double* gl = Gt + l * width;
+        long double num = 0.0L;
+        for (size_t j = 0; j < width; ++j) num += (long double)gi[j] * (long double)gl[j];
+        const double mu = (double)(num / norm2[l]);
+        for (size_t j = 0; j < width; ++j) gi[j] = fma(-mu, gl[j], gi[j]);
+      }
+    long double nn = 0.0L;
+    for (size_t j = 0; j < width; ++j) nn += (long double)gi[j] * (long double)gi[j];
     norm2[i] = nn;
   }
   free(norm2);
 }
+static void gso_rows(const int32_t* St, size_t m, double* Gt) { gso_chain(St, m, m, Gt); }
+
+void orc_gso_rows(const int32_t* St, size_t m, double* Gt) { gso_rows(St, m, Gt); }
+
+/* The same chain for the LEADING nrows vectors of a basis of dimension `width` (row i of St = basis vector i, ld = width): test infrastructure
+ * for tests/test_gpu_gpv_scale.py (the leading-rows trick of orc_psfp_sqrt_sigma_2_leading). */
+void orc_gso_rows_leading(const int32_t* St, size_t nrows, size_t width, double* Gt) { gso_chain(St, nrows, width, Gt); }
 
 /* gpv.rs:83-94 */
 int orc_gpv_trap_gen(void* hv, uint64_t seed) {

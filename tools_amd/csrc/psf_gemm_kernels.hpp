@@ -1,0 +1,291 @@
+// psf_gemm_kernels.hpp -- a plain FP64 product on the matrix cores for the key-generation paths (row-major operands, any shape):
+//     C = beta C + alpha (A op(B)) diag(colscale)         A: M x K,  op(B) = B^t with B: N x K ("NT")  or  B: K x N ("NN")
+// and the blocked Gram-Schmidt orthogonalisation built on it (MatQ::gso, gpv.rs:91; inside MatPolyOverZ::sample_d, gpv_ring.rs:205).
+//
+// Workgroup tile 128 x 128, four waves (2 x 2) with 64 x 64 wave tiles of v_mfma_f64_16x16x4_f64, K chunks of 16.  Both operand tiles are kept
+// K-MAJOR in LDS ([k][row], row stride 144 doubles): the fragment of a k-step is then 16 consecutive doubles per lane group -- the four lane
+// groups of a ds_read_b64 fall on two disjoint halves of the banks, which is the two LDS cycles a 512-byte read costs anyway (the [row][k]
+// layout of round 1's SYRK put sixteen rows on two bank groups).  Row-major operands whose K runs along the row are transposed on the way in
+// (each thread reads 64 contiguous bytes of one row and writes eight ds_write_b64 into eight k-rows, consecutive lanes = consecutive rows).
+// Global loads of chunk t+1 are in flight while chunk t is multiplied; one barrier per chunk.
+// Skinny products (M = one panel) are cut along K over gridDim.z workgroups; the partial tiles go to a workspace and k_gemm_reduce adds them
+// in split order -- no atomics, so every result is reproducible bit for bit (every rank regenerates the key from the seed).
+#pragma once
+#include "psf_kernels.hpp"
+
+namespace psf {
+
+constexpr int GM_T = 128;        // tile edge
+constexpr int GM_BK = 16;        // K chunk
+constexpr int GM_LD = 144;       // LDS row stride (doubles) of a k-major tile
+constexpr size_t GM_LDS_BYTES = 2 * 2 * GM_BK * GM_LD * sizeof(double);   // two stages x (A | B) = 73 728 B
+
+struct GemmArgs {
+  const double* A; size_t lda;
+  const double* B; size_t ldb;
+  double* C; size_t ldc;
+  size_t M, N, K;
+  double alpha, beta;
+  const double* colscale;        // optional, length N: the product's column j is multiplied by colscale[j]
+  double* ws;                    // split-K workspace (gridDim.z x M_pad x N_pad), or nullptr when gridDim.z == 1
+  size_t klen;                   // K range per split (a multiple of GM_BK)
+};
+
+__device__ inline void gemm_epilogue(const GemmArgs& g, size_t row, size_t col, double v) {
+  if (g.colscale) v *= g.colscale[col];
+  double out = g.alpha * v;
+  if (g.beta != 0.0) out = fma(g.beta, g.C[row * g.ldc + col], out);
+  g.C[row * g.ldc + col] = out;
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256, 2) void k_gemm_f64(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double gm_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const size_t m0 = (size_t)blockIdx.y * GM_T, n0 = (size_t)blockIdx.x * GM_T;
+  const size_t kbeg = (size_t)blockIdx.z * g.klen;
+  const size_t kend = kbeg + g.klen < g.K ? kbeg + g.klen : g.K;
+  const int nk = kbeg < kend ? (int)((kend - kbeg + GM_BK - 1) / GM_BK) : 0;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // operand staging: A (and an NT B) -- thread = (row t / 2, k half t % 2), eight consecutive k; an NN B -- thread = (k row t / 16, eight columns)
+  const int a_row = tid >> 1, a_kh = (tid & 1) * 8;
+  const int b_kr = tid >> 4, b_seg = (tid & 15) * 8;
+  const bool a_ok = m0 + a_row < g.M;
+  const bool bt_ok = n0 + a_row < g.N;
+  const double* pa = g.A + (m0 + (a_ok ? a_row : 0)) * g.lda;
+  const double* pbt = g.B + (n0 + (bt_ok ? a_row : 0)) * g.ldb;
+  double ra[8], rb[8];
+  auto fetch = [&](int kt) {
+    const size_t k0 = kbeg + (size_t)kt * GM_BK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const size_t kk = k0 + a_kh + i;
+      ra[i] = (a_ok && kk < kend) ? pa[kk] : 0.0;
+    }
+    if (NT) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const size_t kk = k0 + a_kh + i;
+        rb[i] = (bt_ok && kk < kend) ? pbt[kk] : 0.0;
+      }
+    } else {
+      const size_t kk = k0 + b_kr;
+      const double* pb = g.B + (kk < kend ? kk : kbeg) * g.ldb + n0 + b_seg;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rb[i] = (kk < kend && n0 + b_seg + i < g.N) ? pb[i] : 0.0;
+    }
+  };
+  auto stash = [&](int buf) {
+    double* sA = gm_smem + buf * (2 * GM_BK * GM_LD);
+    double* sB = sA + GM_BK * GM_LD;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sA[(a_kh + i) * GM_LD + a_row] = ra[i];
+    if (NT) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sB[(a_kh + i) * GM_LD + a_row] = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sB[b_kr * GM_LD + b_seg + i] = rb[i];
+    }
+  };
+  const int r16 = lane & 15, gq = lane >> 4;
+  if (nk > 0) {
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) fetch(kt + 1);
+      const double* sA = gm_smem + cur * (2 * GM_BK * GM_LD);
+      const double* sB = sA + GM_BK * GM_LD;
+#pragma unroll
+      for (int ks = 0; ks < GM_BK / 4; ++ks) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = sA[(ks * 4 + gq) * GM_LD + wr * 64 + i * 16 + r16];
+          b[i] = sB[(ks * 4 + gq) * GM_LD + wc * 64 + i * 16 + r16];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < nk) stash(cur ^ 1);
+      __syncthreads();
+    }
+  }
+  // C/D map of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 reg
+  const size_t Mp = (size_t)gridDim.y * GM_T, Np = (size_t)gridDim.x * GM_T;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = m0 + wr * 64 + i * 16 + gq + 4 * r, col = n0 + wc * 64 + j * 16 + r16;
+        if (g.ws) g.ws[((size_t)blockIdx.z * Mp + row) * Np + col] = acc[i][j][r];
+        else if (row < g.M && col < g.N) gemm_epilogue(g, row, col, acc[i][j][r]);
+      }
+}
+
+// adds the partial products of the K splits in split order and applies the epilogue
+__global__ void k_gemm_reduce(GemmArgs g, int splits, size_t Mp, size_t Np) {
+  const size_t total = g.M * g.N;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = e / g.N, col = e % g.N;
+    double s = 0.0;
+    for (int z = 0; z < splits; ++z) s += g.ws[((size_t)z * Mp + row) * Np + col];
+    gemm_epilogue(g, row, col, s);
+  }
+}
+
+// ---- in-panel step of the blocked Gram-Schmidt: G = L D L^t (unit lower L, no pivoting), out = L^-1 ---------------------------------------------
+// One workgroup; the p x p Gram matrix of the panel (p <= 128) lives in LDS.  Applying L^-1 to the panel's rows IS Gram-Schmidt on them in
+// exact arithmetic (rows of L^-1 W are W's rows minus their components along the earlier ones); the caller runs the (Gram, LDL, apply) round
+// twice, which brings the rows to orthogonality at rounding level for a panel whose condition is below ~1e7 ("CholQR2").
+__global__ __launch_bounds__(256) void k_ldl_inverse(const double* __restrict__ Gm, size_t ldg, int p, double* __restrict__ Linv, size_t ldl, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double ldl_smem[];   // G: 128 x 129 (132 KiB) | one column (1 KiB)
+  constexpr int LD = GM_T + 1;
+  double* sG = ldl_smem;
+  double* sCol = ldl_smem + GM_T * LD;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < p * p; e += 256) { const int r = e / p, c = e % p; sG[r * LD + c] = Gm[(size_t)r * ldg + c]; }
+  __syncthreads();
+  for (int j = 0; j < p; ++j) {
+    const double dj = sG[j * LD + j];
+    if (!(dj > 0.0)) { if (tid == 0) atomicCAS(info, 0, j + 1); }        // a dependent "basis": reported, the row is left as it is
+    const double inv = dj > 0.0 ? 1.0 / dj : 0.0;
+    // trailing update with the unscaled column: G[i][c] -= (G[i][j] / d_j) G[c][j],  j < c <= i
+    const int rem = p - j - 1;
+    for (int e = tid; e < rem * rem; e += 256) {
+      const int i = j + 1 + e / rem, c = j + 1 + e % rem;
+      if (c <= i) sG[i * LD + c] = fma(-(sG[i * LD + j] * inv), sG[c * LD + j], sG[i * LD + c]);
+    }
+    __syncthreads();
+    for (int i = j + 1 + tid; i < p; i += 256) sG[i * LD + j] *= inv;    // column j of L
+    __syncthreads();
+  }
+  // X = L^-1 in place over the strictly lower part (unit diagonal implied), columns from the last to the first:
+  //   X[i][j] = -( L[i][j] + sum_{j < t < i} X[i][t] L[t][j] )     -- row i of X to the right of column j is final, column j of L is saved first
+  for (int j = p - 2; j >= 0; --j) {
+    for (int i = j + 1 + tid; i < p; i += 256) sCol[i] = sG[i * LD + j];
+    __syncthreads();
+    for (int i = j + 1 + tid; i < p; i += 256) {
+      double s = sCol[i];
+      for (int t = j + 1; t < i; ++t) s = fma(sG[i * LD + t], sCol[t], s);
+      sG[i * LD + j] = -s;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < p * p; e += 256) {
+    const int r = e / p, c = e % p;
+    Linv[(size_t)r * ldl + c] = c < r ? sG[r * LD + c] : (c == r ? 1.0 : 0.0);
+  }
+}
+
+// 1 / ||row||^2 of `rows` rows of length d (one wave per row, fixed summation order)
+__global__ __launch_bounds__(256) void k_rows_inv_norm2(const double* __restrict__ W, size_t ld, size_t d, int rows, double* __restrict__ inv) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (size_t j = lane; j < d; j += 64) acc = fma(W[(size_t)r * ld + j], W[(size_t)r * ld + j], acc);
+  acc = wave_xor_sum(acc);
+  if (lane == 0) inv[r] = acc > 0.0 ? 1.0 / acc : 0.0;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------------
+struct GemmWorkspace { double* ws = nullptr; size_t bytes = 0; };
+
+// launches C = beta C + alpha (A op(B)) diag(colscale); cuts K when the tile grid alone would leave most of the chip idle
+template <bool NT>
+inline void launch_gemm(hipStream_t st, GemmArgs g, GemmWorkspace& w) {
+  const unsigned tx = (unsigned)((g.N + GM_T - 1) / GM_T), ty = (unsigned)((g.M + GM_T - 1) / GM_T);
+  const size_t nchunks = (g.K + GM_BK - 1) / GM_BK;
+  unsigned splits = 1;
+  if ((size_t)tx * ty < 128) {
+    splits = (unsigned)(256 / ((size_t)tx * ty));
+    const size_t max_by_k = nchunks / 8 ? nchunks / 8 : 1;               // at least 8 chunks (128 coordinates) per split
+    if (splits > max_by_k) splits = (unsigned)max_by_k;
+    if (splits > 64) splits = 64;
+    const size_t need = (size_t)splits * ty * GM_T * tx * GM_T * sizeof(double);
+    if (splits > 1 && need > w.bytes) splits = 1;                        // (the caller sizes the workspace; never hit in this library)
+  }
+  g.klen = ((nchunks + splits - 1) / splits) * GM_BK;
+  splits = (unsigned)((g.K + g.klen - 1) / g.klen);
+  if (splits < 1) splits = 1;
+  double* ws = splits > 1 ? w.ws : nullptr;
+  GemmArgs k = g;
+  k.ws = ws;
+  hipLaunchKernelGGL((k_gemm_f64<NT>), dim3(tx, ty, splits), dim3(256), GM_LDS_BYTES, st, k);
+  if (splits > 1) {
+    const size_t total = g.M * g.N;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks), dim3(256), 0, st, k, (int)splits, (size_t)ty * GM_T, (size_t)tx * GM_T);
+  }
+}
+
+inline hipError_t gemm_prepare() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM_LDS_BYTES);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM_LDS_BYTES);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldl_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GM_T * (GM_T + 1) + GM_T) * sizeof(double)));
+}
+
+// Gram-Schmidt on the rows of Gt (nrows x d, row i = basis vector i as doubles on entry, b~_i on exit), panels of 128 rows:
+// twice per panel ("BCGS with re-orthogonalisation"):
+//   1. the panel minus its components along every finished vector (C = W B~^t D^-1; W -= C B~);
+//   2. Gram matrix of the panel, L D L^t, W <- L^-1 W -- Gram-Schmidt inside the panel.
+// Every vector is a row of B minus a combination of EARLIER vectors (unit lower triangular transform), and the rows come out orthogonal at
+// rounding level (tests/test_gpu_gpv_scale.py: < 1e-10 relative at d = 6208, where the vector-by-vector loop of round 2 -- projection
+// coefficients from the original b_j, one pass -- had lost them to 1.6e-6).  *info != 0: a Gram-Schmidt vector vanished (dependent rows).
+inline hipError_t gso_blocked(hipStream_t st, double* Gt, size_t nrows, size_t d, int* d_info) {
+  hipError_t e = gemm_prepare();
+  if (e != hipSuccess) return e;
+  double *dInv = nullptr, *dC = nullptr, *dG = nullptr, *dLi = nullptr;
+  GemmWorkspace w;
+  const size_t dpad = (d + GM_T - 1) / GM_T * GM_T, rpad = (nrows + GM_T - 1) / GM_T * GM_T;
+  w.bytes = (size_t)64 * GM_T * GM_T * sizeof(double);                       // a single 128 x 128 tile cut 64 ways ...
+  const size_t alt = (size_t)256 * GM_T * GM_T * sizeof(double) + (dpad > rpad ? dpad : rpad) * GM_T * sizeof(double);   // ... or <= 256 tiles over (splits x column tiles)
+  if (alt > w.bytes) w.bytes = alt;
+  auto fail = [&](hipError_t err) { hipFree(dInv); hipFree(dC); hipFree(dG); hipFree(dLi); hipFree(w.ws); return err; };
+  if ((e = hipMalloc(&dInv, rpad * sizeof(double))) != hipSuccess) return fail(e);
+  if ((e = hipMalloc(&dC, GM_T * rpad * sizeof(double))) != hipSuccess) return fail(e);
+  if ((e = hipMalloc(&dG, GM_T * GM_T * sizeof(double))) != hipSuccess) return fail(e);
+  if ((e = hipMalloc(&dLi, GM_T * GM_T * sizeof(double))) != hipSuccess) return fail(e);
+  if ((e = hipMalloc(&w.ws, w.bytes)) != hipSuccess) return fail(e);
+  for (size_t i0 = 0; i0 < nrows; i0 += GM_T) {
+    const size_t p = nrows - i0 < (size_t)GM_T ? nrows - i0 : (size_t)GM_T;
+    double* W = Gt + i0 * d;
+    // (project against the finished vectors, orthogonalise inside the panel) twice, in THIS order: the in-panel step can shorten a row by orders of
+    // magnitude (|b| / |b~| ~ 4000 at C2), which magnifies whatever the first projection left along the finished vectors relative to the row's final
+    // length; the second projection sees the short rows and removes it.
+    for (int pass = 0; pass < 2; ++pass) {
+      if (i0 > 0) {
+        launch_gemm<true>(st, GemmArgs{W, d, Gt, d, dC, rpad, p, i0, d, 1.0, 0.0, dInv, nullptr, 0}, w);          // C = W B~^t D^-1
+        launch_gemm<false>(st, GemmArgs{dC, rpad, Gt, d, W, d, p, d, i0, -1.0, 1.0, nullptr, nullptr, 0}, w);     // W -= C B~
+      }
+      launch_gemm<true>(st, GemmArgs{W, d, W, d, dG, GM_T, p, p, d, 1.0, 0.0, nullptr, nullptr, 0}, w);           // G = W W^t
+      hipLaunchKernelGGL(k_ldl_inverse, dim3(1), dim3(256), (GM_T * (GM_T + 1) + GM_T) * sizeof(double), st, dG, (size_t)GM_T, (int)p, dLi, (size_t)GM_T, d_info);
+      // W <- L^-1 W in place: the panel is ONE row tile, a workgroup reads rows 0..p-1 of its own 128 columns (K = p) and nothing else before it writes them
+      launch_gemm<false>(st, GemmArgs{dLi, GM_T, W, d, W, d, p, d, p, 1.0, 0.0, nullptr, nullptr, 0}, w);
+    }
+    hipLaunchKernelGGL(k_rows_inv_norm2, dim3((unsigned)((p + 3) / 4)), dim3(256), 0, st, W, d, d, (int)p, dInv + i0);
+  }
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  return fail(e);
+}
+
+}  // namespace psf

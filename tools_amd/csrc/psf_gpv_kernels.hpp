@@ -90,45 +90,11 @@ __global__ void k_gpv_basis_t_tail(const int8_t* __restrict__ BT, size_t ldw, si
   }
 }
 
-// ---- Gram-Schmidt (MatQ::gso, gpv.rs:91) on the rows of St, right-looking: after b~_i is final, its component is removed
-// from every later row, so row t receives its subtractions in ascending i -- the oracle's order.
+// ---- Gram-Schmidt (MatQ::gso, gpv.rs:91) on the rows of St: the blocked, re-orthogonalised form lives in psf_gemm_kernels.hpp (gso_blocked);
+// here only the conversion of the basis to doubles and the contract's norms.
 __global__ void k_i32_to_f64(const int32_t* __restrict__ s, double* __restrict__ d, size_t total) {
   for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) d[g] = (double)s[g];
 }
-__device__ inline double block_sum_256(double v, double* scratch) {
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-  __syncthreads();
-  const double r = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
-  __syncthreads();
-  return r;
-}
-__global__ __launch_bounds__(256) void k_gs_norm(const double* __restrict__ Gt, size_t m, size_t i, double* __restrict__ norm2) {
-  __shared__ double scratch[4];
-  double acc = 0.0;
-  for (size_t j = threadIdx.x; j < m; j += 256) acc = fma(Gt[i * m + j], Gt[i * m + j], acc);
-  const double s = block_sum_256(acc, scratch);
-  if (threadIdx.x == 0) norm2[i] = s;
-}
-// mu[t] = <b_t, b~_i> / ||b~_i||^2 for t > i; one wave per row t
-__global__ __launch_bounds__(256) void k_gs_project(const int32_t* __restrict__ St, const double* __restrict__ Gt, const double* __restrict__ norm2,
-                                                    size_t m, size_t i, double* __restrict__ mu) {
-  const size_t t = i + 1 + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= m) return;
-  const int lane = threadIdx.x & 63;
-  double acc = 0.0;
-  for (size_t j = lane; j < m; j += 64) acc = fma((double)St[t * m + j], Gt[i * m + j], acc);
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) mu[t] = acc / norm2[i];
-}
-// Gt[t][j] -= mu[t] Gt[i][j] for t > i
-__global__ __launch_bounds__(256) void k_gs_update(double* __restrict__ Gt, const double* __restrict__ mu, size_t m, size_t i) {
-  const size_t t = i + 1 + blockIdx.y;
-  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= m || j >= m) return;
-  Gt[t * m + j] = fma(-mu[t], Gt[i * m + j], Gt[t * m + j]);
-}
-
 // ||b~_i||^2 as the contract's ascending fma chain (one thread per row; setup only)
 __global__ void k_row_norm2_chain(const double* __restrict__ Gt, size_t m, double* __restrict__ norm2) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

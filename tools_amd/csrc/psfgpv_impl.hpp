@@ -44,17 +44,16 @@ static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
   const size_t d = g->dim;
   if (compute_gso) {
     hipLaunchKernelGGL(k_i32_to_f64, dim3(grid_for(d * d)), dim3(256), 0, 0, g->dSt, g->dGt, d * d);
-    double* dmu = nullptr;
-    HIP_TRY(hipMalloc(&dmu, d * sizeof(double)));
-    for (size_t i = 0; i + 1 < d; ++i) {
-      const size_t rest = d - 1 - i;
-      hipLaunchKernelGGL(k_gs_norm, dim3(1), dim3(256), 0, 0, g->dGt, d, i, g->dNorm2);
-      hipLaunchKernelGGL(k_gs_project, dim3((unsigned)((rest + 3) / 4)), dim3(256), 0, 0, g->dSt, g->dGt, g->dNorm2, d, i, dmu);
-      hipLaunchKernelGGL(k_gs_update, dim3((unsigned)((d + 255) / 256), (unsigned)rest), dim3(256), 0, 0, g->dGt, dmu, d, i);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    hipFree(dmu);
+    // blocked Gram-Schmidt with re-orthogonalisation on the FP64 matrix cores (psf_gemm_kernels.hpp)
+    int* dinfo = nullptr;
+    HIP_TRY(hipMalloc(&dinfo, sizeof(int)));
+    HIP_TRY(hipMemset(dinfo, 0, sizeof(int)));
+    const hipError_t ge = gso_blocked(nullptr, g->dGt, d, d, dinfo);
+    int info = 0;
+    if (ge == hipSuccess) hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost);
+    hipFree(dinfo);
+    if (ge != hipSuccess) return PSF_ERR_HIP;
+    if (info != 0) return PSF_ERR_PARAM;                                 // linearly dependent "basis"
   }
   hipLaunchKernelGGL(k_row_norm2_chain, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, 0, g->dGt, d, g->dNorm2);
   HIP_TRY(hipGetLastError());
@@ -560,6 +559,26 @@ psf_status psf_poly_mul_negacyclic_method(int device, uint64_t q, size_t n, size
 psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out) {
   const bool ntt = q < (1ull << 31) && n >= 2 && n <= 8192 && make_ntt_plan(q, (uint32_t)n).ok;
   return psf_poly_mul_negacyclic_method(device, q, n, count, a, b, out, ntt ? 1 : 0);
+}
+
+// MatQ::gso (gpv.rs:88-91) as a free function: rows of an integer matrix -> their Gram-Schmidt vectors
+psf_status psf_gso_rows(int device, const int32_t* basis_t, size_t rows, size_t width, double* out) {
+  if (!basis_t || !out || rows < 1 || width < 1) return PSF_ERR_PARAM;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return PSF_ERR_HIP;
+  HIP_TRY(hipSetDevice(device));
+  int32_t* dS = nullptr; double* dG = nullptr; int* dinfo = nullptr;
+  auto done = [&](psf_status st) { hipFree(dS); hipFree(dG); hipFree(dinfo); return st; };
+  if (hipMalloc(&dS, rows * width * sizeof(int32_t)) != hipSuccess || hipMalloc(&dG, rows * width * sizeof(double)) != hipSuccess ||
+      hipMalloc(&dinfo, sizeof(int)) != hipSuccess) return done(PSF_ERR_HIP);
+  if (hipMemcpy(dS, basis_t, rows * width * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess || hipMemset(dinfo, 0, sizeof(int)) != hipSuccess) return done(PSF_ERR_HIP);
+  hipLaunchKernelGGL(k_i32_to_f64, dim3(grid_for(rows * width)), dim3(256), 0, 0, dS, dG, rows * width);
+  if (gso_blocked(nullptr, dG, rows, width, dinfo) != hipSuccess) return done(PSF_ERR_HIP);
+  int info = 0;
+  if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return done(PSF_ERR_HIP);
+  if (info != 0) return done(PSF_ERR_PARAM);
+  if (hipMemcpy(out, dG, rows * width * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return done(PSF_ERR_HIP);
+  return done(PSF_OK);
 }
 
 // gen_trapdoor_ring_lwe (gadget_ring.rs:62-81) with r, e <- SampleZ(s) (trapdoor_distribution.rs:112-122) drawn from `seed`:

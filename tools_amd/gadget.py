@@ -168,3 +168,12 @@ def shard_range(total, world, rank):
     first, count = C.c_size_t(0), C.c_size_t(0)
     check(lib().psf_shard_range(C.c_size_t(total), C.c_int(world), C.c_int(rank), C.byref(first), C.byref(count)), "shard_range")
     return first.value, count.value
+
+
+def gso_rows(basis_t, device=0):
+    """MatQ::gso (gpv.rs:88-91) on the device: Gram-Schmidt vectors of the rows of an integer matrix (rows x width)."""
+    bt = np.ascontiguousarray(basis_t, dtype=np.int32)
+    rows, width = bt.shape
+    out = np.zeros((rows, width), dtype=np.float64)
+    check(lib().psf_gso_rows(C.c_int(device), _p(bt, C.c_int32), C.c_size_t(rows), C.c_size_t(width), _p(out, C.c_double)), "gso_rows")
+    return out
