@@ -232,6 +232,14 @@ psf_status psfp_get_timing(psfp_handle*, char* names, size_t names_len, double* 
  *   batched blocked form of tools_amd/csrc/psf_np_kernels.hpp (any lattice dimension that fits the device memory).
  *   The elimination is factored once per key (pivot columns + n x n operator); it returns the same particular
  *   solution as eliminating [A | u] per call with unit pivots and free variables 0.
+ *   Precision of the centres.  The reference holds the centre in exact rationals (MatQ, gpv.rs:158-160); the walk here keeps its running
+ *   projections in doubles.  With the centre -sol (entries up to q on n coordinates) the error of a centre, in units of that draw's width
+ *   s / |b~_i|, is about 2^-53 q sqrt(n) / s whatever the basis.  Keys with q sqrt(n) <= 2^13 s (C2, C4: 2^-47) are sampled in one pass at
+ *   a relative centre error <= 2^-40; for larger moduli -- every q < 2^62 -- samp_p runs TWO passes: the first finds a short element e1 of
+ *   the coset A e = u, the second samples e1 + D_{Lambda, s, -e1}, whose centres are of ordinary size (|e1| ~ s sqrt(m)): the output
+ *   distribution is that of gpv.rs:160 for any e1 (GPV08), so the first pass's imprecision cannot reach it, and the relative centre error
+ *   of the pass that matters is <= 2^-35 (asserted against 100-digit arithmetic in tests/test_oracle_centre_precision.py; the floor is
+ *   the double-precision Gram-Schmidt data, 1e-13 relative).  psfgpv_two_pass() says which form a handle uses.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct psfgpv_handle psfgpv_handle;
 typedef struct {
@@ -265,6 +273,8 @@ psf_status psfgpv_get_timing(psfgpv_handle*, double* solve_ms, double* nearest_p
  * e = sum z_i b_i was recombined by the 64-bit integer kernel (1) instead of the int8 matrix-core planes (0) -- the former when a
  * basis entry or a drawn z_i does not fit two balanced base-256 digits (|.| > 32639); the result is the same either way */
 psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle*, size_t* blocks, size_t* generic_recombination);
+/* 1 if samp_p of this handle draws in two passes (large moduli, see "Precision of the centres" above), else 0 */
+int psfgpv_two_pass(const psfgpv_handle*);
 
 /* ------------------------------------------------------------------------------------------------
  * PSFGPVRing (gpv_ring.rs:62-67, impl PSF :69-284) over R_q = Z_q[X]/(X^n + 1)

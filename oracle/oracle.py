@@ -488,6 +488,25 @@ class PSFGPV:
                                     _p(e, C.c_int64), C.c_int(1 if percall else 0), C.c_int(nthreads)))
         return e
 
+    def set_two_pass(self, mode):
+        """-1: by the rule q sqrt(n) > 2^13 s; 0 / 1: forced"""
+        lib().orc_gpv_set_two_pass(self._h, C.c_int(mode))
+
+    @property
+    def two_pass(self):
+        return bool(lib().orc_gpv_two_pass(self._h))
+
+    def samp_p_trace(self, seed, u, index=0):
+        """one preimage: (e, integer centre vector the final pass started from, centres c'_i as doubles, coefficients z_i)"""
+        u = _u64(u).reshape(self.n)
+        e = np.zeros(self.m, dtype=np.int64)
+        c0 = np.zeros(self.m, dtype=np.int64)
+        cen = np.zeros(self.m, dtype=np.float64)
+        z = np.zeros(self.m, dtype=np.int64)
+        _check(lib().orc_gpv_samp_p_trace(self._h, C.c_uint64(seed), C.c_uint64(index), _p(u, C.c_uint64), _p(e, C.c_int64),
+                                          _p(c0, C.c_int64), _p(cen, C.c_double), _p(z, C.c_int64)))
+        return e, c0, cen, z
+
     def samp_d(self, seed, B=1, first_index=0):
         e = np.zeros((B, self.m), dtype=np.int64)
         _check(lib().orc_gpv_samp_d(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(e, C.c_int64)))

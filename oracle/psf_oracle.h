@@ -32,14 +32,15 @@ enum {
   ORC_ERR_NOT_PD = 2,       /* mp_perturbation.rs:109-110 "panics if Sigma_2 is not positive definite" */
   ORC_ERR_DOMAIN = 3,       /* f_a on sigma outside D_n: mp_perturbation.rs:367 */
   ORC_ERR_MODULUS = 4,      /* gadget_classical.rs:170-172 base^k < q */
-  ORC_ERR_NO_SOLUTION = 5   /* solve_gaussian_elimination -> None -> unwrap panic (gpv.rs:153-155) */
+  ORC_ERR_NO_SOLUTION = 5,  /* solve_gaussian_elimination -> None -> unwrap panic (gpv.rs:153-155) */
+  ORC_ERR_SAMPLER = 6       /* a value left the range the restatement covers (mirrors PSF_ERR_SAMPLER of the product) */
 };
 
 /* randomness streams (c3 tag of the Philox counter) */
 enum {
   ORC_TAG_ABAR = 1, ORC_TAG_R = 2, ORC_TAG_NORMAL = 3, ORC_TAG_PERTURB = 4,
   ORC_TAG_GADGET = 5, ORC_TAG_SAMPD = 6, ORC_TAG_TARGET = 7, ORC_TAG_GPV = 8,
-  ORC_TAG_RING_R = 9, ORC_TAG_RING_E = 10, ORC_TAG_RING_A = 11
+  ORC_TAG_RING_R = 9, ORC_TAG_RING_E = 10, ORC_TAG_RING_A = 11, ORC_TAG_GPV2 = 12
 };
 
 /* ---- primitives of the randomness contract ---- */
@@ -135,6 +136,12 @@ void orc_np_gram(const int32_t* basis_t, const double* gso_t, size_t dim, double
 void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double* G, const double* norm2, size_t dim, double s,
                        uint64_t seed, uint32_t tag, uint64_t index, int64_t* c);
 /* Gram-Schmidt on the ROWS of St (MatQ::gso on the columns of the reference's matrix) */
+void orc_nearest_plane_trace(const int32_t* basis_t, const double* gso_t, const double* G, const double* norm2, size_t dim, double s,
+                             uint64_t seed, uint32_t tag, uint64_t index, int64_t* c, double* centres, int64_t* z_out);
+int orc_np_two_pass(uint64_t q, size_t n, double s);      /* q sqrt(n) > 2^13 s: sample in two passes (psf_oracle_gpv.c) */
+void orc_gpv_set_two_pass(void*, int mode);               /* -1 auto, 0 / 1 forced */
+int orc_gpv_two_pass(const void*);
+int orc_gpv_samp_p_trace(const void*, uint64_t seed, uint64_t index, const uint64_t* u, int64_t* e, int64_t* c_start, double* centres, int64_t* z);
 void orc_gso_rows(const int32_t* St, size_t m, double* Gt);
 void orc_gso_rows_leading(const int32_t* St, size_t nrows, size_t width, double* Gt);
 void* orc_gpv_new(const orc_gadget_params* gp, double s);

@@ -139,8 +139,15 @@ void orc_np_gram(const int32_t* basis_t, const double* gso_t, size_t dim, double
   }
 }
 
+void orc_nearest_plane_trace(const int32_t* basis_t, const double* gso_t, const double* G, const double* norm2, size_t dim, double s,
+                             uint64_t seed, uint32_t tag, uint64_t index, int64_t* c, double* centres, int64_t* z_out);
 void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double* G, const double* norm2, size_t dim, double s,
                        uint64_t seed, uint32_t tag, uint64_t index, int64_t* c) {
+  orc_nearest_plane_trace(basis_t, gso_t, G, norm2, dim, s, seed, tag, index, c, NULL, NULL);
+}
+/* the same walk; `centres` (dim doubles) receives c'_i as the sampler saw it, `z_out` the drawn coefficients (either may be NULL) */
+void orc_nearest_plane_trace(const int32_t* basis_t, const double* gso_t, const double* G, const double* norm2, size_t dim, double s,
+                             uint64_t seed, uint32_t tag, uint64_t index, int64_t* c, double* centres, int64_t* z_out) {
   double* t = (double*)malloc(dim * sizeof(double));
   int64_t* z = (int64_t*)calloc(dim, sizeof(int64_t));
   for (size_t i = 0; i < dim; ++i) {
@@ -156,6 +163,7 @@ void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double
     for (size_t i = j1; i-- > j0;) {
       const double inv = 1.0 / norm2[i];
       const double cen = t[i] * inv;
+      if (centres) centres[i] = cen;
       z[i] = orc_sample_z(seed, tag, index, (uint32_t)i, cen, s / sqrt(norm2[i]));
       const double nz = -(double)z[i];
       const double* gi = G + i * dim;
@@ -168,6 +176,7 @@ void orc_nearest_plane(const int32_t* basis_t, const double* gso_t, const double
     }
   }
   for (size_t i = 0; i < dim; ++i) {
+    if (z_out) z_out[i] = z[i];
     if (!z[i]) continue;
     const int32_t* bi = basis_t + i * dim;
     for (size_t j = 0; j < dim; ++j) c[j] -= z[i] * (int64_t)bi[j];
@@ -191,12 +200,13 @@ typedef struct {
   size_t* piv;        /* n pivot columns */
   uint64_t* T;        /* n x n solve operator */
   int has_solver;
+  int two_pass_mode;  /* -1: by orc_np_two_pass(q, n, s); 0 / 1: forced (tests) */
 } orc_gpv;
 
 static orc_gpv* gpv_new_impl(const orc_gadget_params* gp, double s) {
   if (!gp || gp->n < 1 || gp->q <= 1 || !(s > 0)) return NULL;
   orc_gpv* h = (orc_gpv*)calloc(1, sizeof(orc_gpv));
-  h->gp = *gp; h->s = s;
+  h->gp = *gp; h->s = s; h->two_pass_mode = -1;
   size_t w = gp->n * gp->k;
   h->m = gp->m_bar + w;
   h->A = (uint64_t*)calloc(gp->n * h->m, sizeof(uint64_t));
@@ -298,6 +308,21 @@ int orc_gpv_load_key(void* hv, const uint64_t* A, const int32_t* basis_t, const 
   return gpv_finish_key(h);
 }
 
+/* Large moduli.  The walk keeps its running projections in doubles; their first values <c0, b~_i> are as large as q sqrt(n) |b~_i| for the
+ * centre c0 = -sol of gpv.rs:158 (sol has entries up to q on the n pivot columns), so the centre c' = t / |b~|^2 carries an absolute error of
+ * about 2^-53 q sqrt(n) / |b~_i| -- in units of the sampler's width s / |b~_i|: 2^-53 q sqrt(n) / s, whatever the basis.  The reference keeps
+ * the centre in exact rationals (MatQ, gpv.rs:158-160).  When that relative error would exceed 2^-40, i.e. q sqrt(n) > 2^13 s, the sample is
+ * drawn in TWO passes: the first walk (stream ORC_TAG_GPV, centre -sol) only serves to find a SHORT element e1 of the coset (A e1 = u, |e1| ~ s
+ * sqrt(m)); the second walk (stream ORC_TAG_GPV2) samples v ~ D_{Lambda, s, -e1} with centres of ordinary size and the result is e = e1 + v ~
+ * D_{Lambda_u^perp, s}: exactly the distribution of gpv.rs:160, for ANY coset representative e1 (GPV08 SampleD is correct for every centre), so
+ * the imprecision of the first pass cannot reach the output distribution.  C2 / C4 (q = 3329) are single-pass. */
+int orc_np_two_pass(uint64_t q, size_t n, double s) { return (double)q * sqrt((double)n) > s * 8192.0; }
+void orc_gpv_set_two_pass(void* hv, int mode) { ((orc_gpv*)hv)->two_pass_mode = mode; }
+int orc_gpv_two_pass(const void* hv) {
+  const orc_gpv* h = (const orc_gpv*)hv;
+  return h->two_pass_mode >= 0 ? h->two_pass_mode : orc_np_two_pass(h->gp.q, h->gp.n, h->s);
+}
+
 /* gpv.rs:152-161.  percall != 0: run the elimination on [A | u] for every call exactly as the reference does;
  * otherwise use the factored solver (same solution, see orc_solve_precompute). */
 int orc_gpv_samp_p(const void* hv, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e,
@@ -328,9 +353,41 @@ int orc_gpv_samp_p(const void* hv, uint64_t seed, uint64_t first_index, size_t B
     orc_nearest_plane(h->St, h->Gt, h->G, h->norm2, m, h->s, seed, ORC_TAG_GPV, first_index + b, c);
     /* :160  sol + sample, sample = (-sol) - c_final */
     for (size_t j = 0; j < m; ++j) e[b * m + j] = -c[j];
+    if (orc_gpv_two_pass(h)) {                                                      /* second pass from the short representative e1 = -c */
+      for (size_t j = 0; j < m; ++j)
+        if (c[j] >= (1ll << 53) || c[j] <= -(1ll << 53)) status = ORC_ERR_SAMPLER;
+      orc_nearest_plane(h->St, h->Gt, h->G, h->norm2, m, h->s, seed, ORC_TAG_GPV2, first_index + b, c);
+      for (size_t j = 0; j < m; ++j) e[b * m + j] = -c[j];
+    }
     free(sol); free(c);
   }
   return status;
+}
+
+/* one preimage with the walk's own view of it (tests/test_oracle_centre_precision.py): the integer centre vector the FINAL pass started from
+ * (-sol, or -e1 in two-pass mode), the centres c'_i it computed in doubles and the coefficients z_i it drew */
+int orc_gpv_samp_p_trace(const void* hv, uint64_t seed, uint64_t index, const uint64_t* u, int64_t* e, int64_t* c_start, double* centres, int64_t* z) {
+  const orc_gpv* h = (const orc_gpv*)hv;
+  size_t n = h->gp.n, m = h->m;
+  uint64_t q = h->gp.q;
+  if (!h->has_solver) return ORC_ERR_NO_SOLUTION;
+  int64_t* c = (int64_t*)calloc(m, sizeof(int64_t));
+  for (size_t r = 0; r < n; ++r) {
+    u128 acc = 0;
+    for (size_t t = 0; t < n; ++t) acc = (acc + (u128)h->T[r * n + t] * (u[t] % q)) % q;
+    c[h->piv[r]] = -(int64_t)(uint64_t)acc;
+  }
+  if (orc_gpv_two_pass(h)) {
+    orc_nearest_plane(h->St, h->Gt, h->G, h->norm2, m, h->s, seed, ORC_TAG_GPV, index, c);
+    memcpy(c_start, c, m * sizeof(int64_t));
+    orc_nearest_plane_trace(h->St, h->Gt, h->G, h->norm2, m, h->s, seed, ORC_TAG_GPV2, index, c, centres, z);
+  } else {
+    memcpy(c_start, c, m * sizeof(int64_t));
+    orc_nearest_plane_trace(h->St, h->Gt, h->G, h->norm2, m, h->s, seed, ORC_TAG_GPV, index, c, centres, z);
+  }
+  for (size_t j = 0; j < m; ++j) e[j] = -c[j];
+  free(c);
+  return ORC_OK;
 }
 
 /* gpv.rs:113-116: D_{Z^m, s} centred at 0 */

@@ -100,17 +100,43 @@ def test_sampler_gives_the_same_bits_for_every_lane_split(T, oracle, monkeypatch
     assert psf.nearest_plane_stats() == ((psf.m + 63) // 64, 0)
 
 
-def test_large_modulus(T, oracle):
-    """q = 2^45: |c0| up to 2^45 enters the initial projection as doubles (exact), the walk itself never carries c."""
-    n, q, s = 3, 2**45, 60.0
+@pytest.mark.parametrize("n,q,s", [(3, 2**45, 60.0), (2, 2**60, 50.0), (2, 2**61 - 1, 50.0), (3, 2**31 - 1, 40.0)])
+def test_large_modulus(T, oracle, n, q, s):
+    """q sqrt(n) > 2^13 s: |c0| up to q would leave the centres of a single walk with an error of 2^-53 q sqrt(n) / s draw widths (2^-9 at
+    2^45, garbage at 2^60: tests/test_oracle_centre_precision.py), so both sides sample in two passes -- a short coset representative first, the
+    preimage around it second.  Bit-exact against the oracle, A e = u, check_domain, and short (a merely valid e could be as long as q)."""
     gp = T.GadgetParameters.init_default(n, q)
     psf = T.PSFGPV(gp, s)
+    assert psf.two_pass
     A, (bt, gt) = psf.trap_gen(9)
     u = oracle.uniform_targets(3, 5, n, q)
     e = psf.samp_p(u, seed=11, first_index=0)
     orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    assert orc.two_pass
     assert orc.load_key(A, bt, gt) == 0
     assert (e == orc.samp_p(11, u, first_index=0)).all()
+    assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
+    assert psf.check_domain(e).all()
+    assert ((e.astype(np.float64) ** 2).sum(axis=1) < 2.0 * s * s / (2 * np.pi) * psf.m).all()
+    assert (psf.f_a(e) == u).all()
+    assert (psf.samp_p(u[2:4], seed=11, first_index=2) == e[2:4]).all()               # sharding independence holds for both passes
+
+
+@pytest.mark.parametrize("force", [0, 1])
+def test_both_forms_of_the_walk_stay_reachable(T, oracle, monkeypatch, force):
+    """PSF_NP_TWO_PASS forces one form: two passes at a small modulus (the second projection runs over all d coordinates, K = d, several
+    blocks) and one pass at a large one (the pre-round-3 behaviour, kept only as the comparison arm); bitwise against the oracle forced alike."""
+    n, q, s = (40, 256, 300.0) if force else (3, 2**45, 60.0)
+    monkeypatch.setenv("PSF_NP_TWO_PASS", str(force))
+    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+    assert psf.two_pass == bool(force)
+    A, (bt, gt) = psf.trap_gen(4)
+    u = oracle.uniform_targets(6, 7, n, q)
+    e = psf.samp_p(u, seed=5, first_index=1)
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    orc.set_two_pass(force)
+    assert orc.load_key(A, bt, gt) == 0
+    assert (e == orc.samp_p(5, u, first_index=1)).all()
     assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
 
 

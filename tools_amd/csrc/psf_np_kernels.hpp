@@ -124,7 +124,7 @@ __global__ void k_np_pack_next(const double* __restrict__ Gd, size_t d, size_t n
     Gnx[g] = (j < d && i < d) ? Gd[j * d + i] : 0.0;
   }
 }
-// A operand of the initial projection: chunk (rb, kc) holds b~_i[piv[16 kc + kk]] for i = 128 rb + r, zero padded
+// A operand of the initial projection: chunk (rb, kc) holds b~_i[piv[16 kc + kk]] for i = 128 rb + r, zero padded (piv == nullptr: every coordinate, n = d)
 __global__ void k_np_pack_bpiv(const double* __restrict__ Gt, const uint32_t* __restrict__ piv, size_t d, size_t n, size_t nrb, size_t nkc,
                                double* __restrict__ Bp) {
   const size_t total = nrb * nkc * TR_CHUNK;
@@ -133,7 +133,7 @@ __global__ void k_np_pack_bpiv(const double* __restrict__ Gt, const uint32_t* __
     const int pos = (int)(g % TR_CHUNK);
     const int ks = pos >> 9, tile = (pos >> 6) & 7, ln = pos & 63;
     const size_t i = rb * 128 + tile * 16 + (ln & 15), r = kc * 16 + ks * 4 + (ln >> 4);
-    Bp[g] = (i < d && r < n) ? Gt[i * d + piv[r]] : 0.0;
+    Bp[g] = (i < d && r < n) ? Gt[i * d + (piv ? piv[r] : r)] : 0.0;
   }
 }
 // balanced base-256 digit planes of the basis, transposed for the recombination: B8[plane][j][i] (row = coordinate j, K = step i),
@@ -845,6 +845,25 @@ __global__ void k_np_add_sol(const uint64_t* __restrict__ Sol, const uint32_t* _
     const size_t r = g / B, b = g % B;
     E[b * lde + piv[r]] += (int64_t)Sol[r * ld + b];
   }
+}
+
+// ---- second pass of the two-pass walk (large moduli, psfgpv_impl.hpp): centre c1 = -e1 over ALL d coordinates --------------------------------
+// C1 chunk (bj, kc), kc < nkd: (double)(-e1[b][16 kc + kk]) -- the B operand of the initial projection T = B~ C1 (K = d).  |e1| < 2^53 or flags[0].
+__global__ void k_np_center_from_e(const int64_t* __restrict__ E1, size_t d, size_t B, size_t ld, size_t nkd, double* __restrict__ C1, int* __restrict__ flags) {
+  const size_t K = nkd * 16, total = K * ld;
+  int bad = 0;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t j = g % K, b = g / K;
+    const int64_t v = (j < d && b < B) ? E1[b * d + j] : 0;
+    if (v >= (1ll << 53) || v <= -(1ll << 53)) bad = 1;
+    const size_t chunk = (b / TR_BN) * nkd + j / 16;
+    C1[chunk * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(j % 16))] = -(double)v;
+  }
+  if (bad) atomicOr(flags, 1);
+}
+// e = e1 + sum z'_i b_i
+__global__ void k_np_add_e1(const int64_t* __restrict__ E1, size_t total, int64_t* __restrict__ E) {
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) E[g] += E1[g];
 }
 
 // The same recombination in 64-bit integers, one output per thread: for a basis or a z that does not fit two int8 digits.

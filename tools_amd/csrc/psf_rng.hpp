@@ -13,7 +13,7 @@ namespace psf {
 
 enum StreamTag : uint32_t {
   TAG_ABAR = 1, TAG_R = 2, TAG_NORMAL = 3, TAG_PERTURB = 4, TAG_GADGET = 5, TAG_SAMPD = 6,
-  TAG_TARGET = 7, TAG_GPV = 8, TAG_RING_R = 9, TAG_RING_E = 10, TAG_RING_A = 11
+  TAG_TARGET = 7, TAG_GPV = 8, TAG_RING_R = 9, TAG_RING_E = 10, TAG_RING_A = 11, TAG_GPV2 = 12
 };
 
 constexpr uint32_t kMaxAttempts = 65536u;

@@ -28,7 +28,13 @@ struct psfgpv_handle {
   int8_t* dZ8 = nullptr; size_t zplane = 0;          // three digit planes of z, [dpad / 16][ld][16] each
   double* dC0p = nullptr;             // -sol on the pivots, chunk stream (ld / 128) x nkc
   uint64_t* dSol = nullptr;           // n x ld
-  int* dFlags = nullptr;              // [0] sampler failure [1] second digit of some z in use [2] third digit [3] |z| beyond three digits
+  int* dFlags = nullptr;              // [0] sampler failure [1] second digit of some z in use [2] third digit [3] |z| beyond three digits; [4..7]: the same for the second pass
+  // two-pass walk for large moduli (q sqrt(n) > 2^13 s): the first pass only finds a short coset representative e1, the second samples around it
+  bool two_pass = false;
+  size_t nkd = 0;                     // K chunks of all d coordinates
+  double* dBfull = nullptr;           // b~_i on every coordinate, fragment order (A operand of the second projection)
+  double* dC1 = nullptr;              // -e1, chunk stream (ld / 128) x nkd
+  int64_t* dE1 = nullptr;             // e1, bcap x dim
   int np_g = 0;                       // PSF_NP_G: preimages per wave of the sampler (0 = by batch size)
   int np_immediate = -1;              // PSF_NP_IMMEDIATE: 1 = every block updates all the rows below it in the launch that follows, 0 = panel-deferred far update, -1 = by batch size
   bool has_key = false;
@@ -119,14 +125,16 @@ static psf_status gpv_build_solver(psfgpv_handle* g) {
   HIP_TRY(hipMemcpy(g->dPiv, piv.data(), piv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   // b~_i restricted to the pivot columns: the A operand of the initial projection T = B~ C0 (c0 = -sol is zero elsewhere)
   hipLaunchKernelGGL(k_np_pack_bpiv, dim3(grid_for(g->nrb * g->nkc * TR_CHUNK, 256, 256 * 64)), dim3(256), 0, 0, g->dGt, g->dPiv, g->dim, g->n, g->nrb, g->nkc, g->dBpiv);
+  if (g->two_pass)
+    hipLaunchKernelGGL(k_np_pack_bpiv, dim3(grid_for(g->nrb * g->nkd * TR_CHUNK, 256, 256 * 64)), dim3(256), 0, 0, g->dGt, (const uint32_t*)nullptr, g->dim, g->dim, g->nrb, g->nkd, g->dBfull);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   return PSF_OK;
 }
 
 static void free_np_batch(psfgpv_handle* g) {
-  hipFree(g->dTm); hipFree(g->dZf); hipFree(g->dZ8); hipFree(g->dC0p); hipFree(g->dSol);
-  g->dTm = g->dZf = g->dC0p = nullptr; g->dZ8 = nullptr; g->dSol = nullptr;
+  hipFree(g->dTm); hipFree(g->dZf); hipFree(g->dZ8); hipFree(g->dC0p); hipFree(g->dSol); hipFree(g->dC1); hipFree(g->dE1);
+  g->dTm = g->dZf = g->dC0p = g->dC1 = nullptr; g->dZ8 = nullptr; g->dSol = nullptr; g->dE1 = nullptr;
   g->bcap = 0;
 }
 static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
@@ -141,6 +149,10 @@ static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
   HIP_TRY(hipMalloc(&g->dZ8, 3 * g->zplane));
   HIP_TRY(hipMalloc(&g->dC0p, ld * g->nkc * 16 * sizeof(double)));
   HIP_TRY(hipMalloc(&g->dSol, g->n * ld * sizeof(uint64_t)));
+  if (g->two_pass) {
+    HIP_TRY(hipMalloc(&g->dC1, ld * g->nkd * 16 * sizeof(double)));
+    HIP_TRY(hipMalloc(&g->dE1, B * g->dim * sizeof(int64_t)));
+  }
   HIP_TRY(hipMemset(g->dTm, 0, g->dpad * ld * sizeof(double)));
   HIP_TRY(hipMemset(g->dZf, 0, ld * g->nkb * 16 * sizeof(double)));      // padding rows / columns of the operands stay zero for good
   HIP_TRY(hipMemset(g->dZ8, 0, 3 * g->zplane));
@@ -149,14 +161,17 @@ static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
 }
 
 // MatZ::sample_d_precomputed_gso for the whole batch (gpv.rs:160): the launch sequence of psf_np_kernels.hpp, one stream
-static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e) {
+// pass 0: centre -sol on the pivot columns (K = n), e = sum z b + sol; pass 1 (two-pass mode): centre -e1 on every coordinate (K = d), e = sum z b + e1
+static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e, int pass = 0) {
   const size_t ld = g->ld, nbj = round_up(B, TR_BN) / TR_BN;
   const size_t lds_gemm = 4 * TR_CHUNK * sizeof(double);
   // T = B~[:, pivots] C0[pivots]
-  hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, g->dC0p, g->nkc, (int)g->nkc, g->dTm, ld);
+  int* const flags = g->dFlags + 4 * pass;
+  if (pass == 0) hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, g->dC0p, g->nkc, (int)g->nkc, g->dTm, ld);
+  else hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBfull, g->nkd, g->dC1, g->nkd, (int)g->nkd, g->dTm, ld);
   int G = g->np_g;
   if (G != 1 && G != 2) G = B <= 1536 ? 1 : 2;      // one or two wave pairs per SIMD of the chip (1024 SIMDs)
-  NpSampleArgs a{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, g->dFlags};
+  NpSampleArgs a{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, flags};
   const unsigned nS = (unsigned)((B + 4 * (size_t)G - 1) / (4 * (size_t)G));
   const size_t W = NP_PANEL;
   // small batches: a rank-64 update of every row below costs less than the sampler's 64 steps, and the T matrix stays in the Infinity Cache (measured
@@ -199,7 +214,7 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
   if (!g->basis_generic) {
     // z = z0 + 256 z1 + 65536 z2, b = b0 + 256 b1: one pass per digit pair in use (the z digits beyond the first are gated on the device)
     const int8_t* zp[3] = {g->dZ8, g->dZ8 + g->zplane, g->dZ8 + 2 * g->zplane};
-    const int* gate[3] = {nullptr, g->dFlags + 1, g->dFlags + 2};
+    const int* gate[3] = {nullptr, flags + 1, flags + 2};
     bool first = true;
     for (int zi = 0; zi < 3; ++zi)
       for (int bi = 0; bi < (g->basis_hi ? 2 : 1); ++bi) {
@@ -208,11 +223,12 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
         else hipLaunchKernelGGL((k_np_combine8<true>), cgrid, dim3(256), 65536, st, g->dB8 + bi * plane, g->dpad, g->dim, nk128, zp[zi], ld, B, scale, gate[zi], d_e, g->dim);
         first = false;
       }
-    hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dSol, g->dPiv, g->n, B, ld, d_e, g->dim);
+    if (pass == 0) hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dSol, g->dPiv, g->n, B, ld, d_e, g->dim);
   }
   // integer fallback: always for a basis beyond two int8 digits, otherwise only if a z left the three-digit range (decided on the device)
-  hipLaunchKernelGGL(k_np_combine_generic, dim3(grid_for(g->dim * B, 256, 256 * 64)), dim3(256), 0, st, g->dSt, g->dim, g->dZf, g->nkb, g->dSol, g->dPiv, g->n, B, ld,
-                     g->basis_generic ? (const int*)nullptr : (const int*)(g->dFlags + 3), d_e, g->dim);
+  hipLaunchKernelGGL(k_np_combine_generic, dim3(grid_for(g->dim * B, 256, 256 * 64)), dim3(256), 0, st, g->dSt, g->dim, g->dZf, g->nkb, g->dSol, g->dPiv, pass == 0 ? g->n : (size_t)0, B, ld,
+                     g->basis_generic ? (const int*)nullptr : (const int*)(flags + 3), d_e, g->dim);
+  if (pass == 1) hipLaunchKernelGGL(k_np_add_e1, dim3(grid_for(g->dim * B, 256, 256 * 64)), dim3(256), 0, st, g->dE1, g->dim * B, d_e);
   (void)b;
   return PSF_OK;
 }
@@ -277,8 +293,13 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipMalloc(&g->dRows, g->nblk * NP_NB * sizeof(NpRow)));
   HIP_TRY(hipMalloc(&g->dBpiv, g->nrb * g->nkc * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipMalloc(&g->dB8, 2 * g->dpad * g->dpad));
-  HIP_TRY(hipMalloc(&g->dFlags, 4 * sizeof(int)));
-  HIP_TRY(hipMemset(g->dFlags, 0, 4 * sizeof(int)));
+  HIP_TRY(hipMalloc(&g->dFlags, 8 * sizeof(int)));
+  HIP_TRY(hipMemset(g->dFlags, 0, 8 * sizeof(int)));
+  // large moduli: q sqrt(n) > 2^13 s (relative centre error of a single pass above 2^-40, see oracle/psf_oracle_gpv.c "Large moduli"); PSF_NP_TWO_PASS=0/1 forces
+  g->two_pass = (double)g->base->q * std::sqrt((double)g->n) > g->s * 8192.0;
+  { const char* ev = getenv("PSF_NP_TWO_PASS"); if (ev) g->two_pass = atoi(ev) != 0; }
+  g->nkd = round_up(d, 16) / 16;
+  if (g->two_pass) HIP_TRY(hipMalloc(&g->dBfull, g->nrb * g->nkd * TR_CHUNK * sizeof(double)));
   { const char* ev = getenv("PSF_NP_G"); g->np_g = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("PSF_NP_IMMEDIATE"); g->np_immediate = ev ? (atoi(ev) != 0 ? 1 : 0) : -1; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_project), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
@@ -295,7 +316,7 @@ void psfgpv_destroy(psfgpv_handle* g) {
   hipSetDevice(g->base->prm.device);
   free_np_batch(g);
   hipFree(g->dSt); hipFree(g->dGt); hipFree(g->dNorm2); hipFree(g->dSz); hipFree(g->dT); hipFree(g->dPiv);
-  hipFree(g->dGp); hipFree(g->dGin); hipFree(g->dGnx); hipFree(g->dRows); hipFree(g->dBpiv); hipFree(g->dB8); hipFree(g->dFlags);
+  hipFree(g->dGp); hipFree(g->dGin); hipFree(g->dGnx); hipFree(g->dRows); hipFree(g->dBpiv); hipFree(g->dB8); hipFree(g->dFlags); hipFree(g->dBfull);
   for (auto& e : g->ev) if (e) hipEventDestroy(e);
   psfp_destroy(g->base);
   delete g;
@@ -374,13 +395,19 @@ psf_status psfgpv_samp_p_dev(psfgpv_handle* g, uint64_t seed, uint64_t first_ind
   psf_status rcb = ensure_np_batch(g, B);
   if (rcb != PSF_OK) return rcb;
   HIP_TRY(hipMemsetAsync(b->dFail, 0, 2 * sizeof(int), st));
-  HIP_TRY(hipMemsetAsync(g->dFlags, 0, 4 * sizeof(int), st));
+  HIP_TRY(hipMemsetAsync(g->dFlags, 0, 8 * sizeof(int), st));
   if (g->timing) hipEventRecord(g->ev[0], st);
   // :153-158  sol = A.solve(u), centre = -sol
   hipLaunchKernelGGL(k_np_solve, dim3(grid_for(g->nkc * 16 * g->ld)), dim3(256), 0, st, g->dT, g->n, g->nkc * 16, b->q, b->two64, d_u, B, g->ld, g->dSol, g->dC0p);
   if (g->timing) hipEventRecord(g->ev[1], st);
   // :160  sol + sample_d_precomputed_gso(basis, gso, centre, s)
-  const psf_status rc = launch_nearest_plane(g, st, seed, TAG_GPV, first_index, B, d_e);
+  psf_status rc;
+  if (!g->two_pass) rc = launch_nearest_plane(g, st, seed, TAG_GPV, first_index, B, d_e);
+  else {
+    rc = launch_nearest_plane(g, st, seed, TAG_GPV, first_index, B, g->dE1, 0);          // a short representative e1 of the coset (A e1 = u)
+    hipLaunchKernelGGL(k_np_center_from_e, dim3(grid_for(g->nkd * 16 * g->ld, 256, 256 * 64)), dim3(256), 0, st, g->dE1, g->dim, B, g->ld, g->nkd, g->dC1, g->dFlags);
+    if (rc == PSF_OK) rc = launch_nearest_plane(g, st, seed, TAG_GPV2, first_index, B, d_e, 1);   // v ~ D_{Lambda, s, -e1}; e = e1 + v
+  }
   if (g->timing) hipEventRecord(g->ev[2], st);
   if (rc != PSF_OK) return rc;
   HIP_TRY(hipGetLastError());
@@ -393,10 +420,10 @@ psf_status psfgpv_last_status(psfgpv_handle* g) {
   if (!g) return PSF_ERR_PARAM;
   const psf_status rc = psfp_last_status(g->base);        // synchronises the stream of the last call
   if (rc != PSF_OK) return rc;
-  int fl[4] = {0, 0, 0, 0};
+  int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpy(fl, g->dFlags, sizeof(fl), hipMemcpyDeviceToHost));
-  g->last_generic = g->basis_generic || fl[3] != 0;
-  return fl[0] ? PSF_ERR_SAMPLER : PSF_OK;
+  g->last_generic = g->basis_generic || fl[g->two_pass ? 7 : 3] != 0;
+  return (fl[0] || fl[4]) ? PSF_ERR_SAMPLER : PSF_OK;
 }
 
 psf_status psfgpv_samp_p(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
@@ -448,13 +475,14 @@ psf_status psfgpv_get_timing(psfgpv_handle* g, double* solve_ms, double* nearest
   if (nearest_plane_ms) *nearest_plane_ms = c;
   return PSF_OK;
 }
+int psfgpv_two_pass(const psfgpv_handle* g) { return (g && g->two_pass) ? 1 : 0; }
 psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle* g, size_t* blocks, size_t* generic_recombination) {
   if (!g) return PSF_ERR_PARAM;
   HIP_TRY(hipStreamSynchronize(g->last_stream));
-  int fl[4] = {0, 0, 0, 0};
+  int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpy(fl, g->dFlags, sizeof(fl), hipMemcpyDeviceToHost));
   if (blocks) *blocks = g->nblk;
-  if (generic_recombination) *generic_recombination = (g->basis_generic || fl[3]) ? 1 : 0;
+  if (generic_recombination) *generic_recombination = (g->basis_generic || fl[g->two_pass ? 7 : 3]) ? 1 : 0;
   return PSF_OK;
 }
 

@@ -318,6 +318,11 @@ class PSFGPV:
     def enable_timing(self, on=True):
         check(lib().psfgpv_enable_timing(self._h, C.c_int(1 if on else 0)), "enable_timing")
 
+    @property
+    def two_pass(self):
+        """large moduli (q sqrt(n) > 2^13 s): samp_p draws in two passes, see include/psf_mi355x.h"""
+        return bool(lib().psfgpv_two_pass(self._h))
+
     def nearest_plane_stats(self):
         """(64-row blocks walked by the nearest plane, 1 if the last samp_p call recombined in 64-bit integers instead of int8 planes)."""
         a, b = C.c_size_t(0), C.c_size_t(0)
