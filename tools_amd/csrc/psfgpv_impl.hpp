@@ -295,7 +295,7 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipMalloc(&g->dB8, 2 * g->dpad * g->dpad));
   HIP_TRY(hipMalloc(&g->dFlags, 8 * sizeof(int)));
   HIP_TRY(hipMemset(g->dFlags, 0, 8 * sizeof(int)));
-  // large moduli: q sqrt(n) > 2^13 s (relative centre error of a single pass above 2^-40, see oracle/psf_oracle_gpv.c "Large moduli"); PSF_NP_TWO_PASS=0/1 forces
+  // large moduli: q sqrt(n) > 2^13 s (relative centre error of a single pass above 2^-40, see include/psf_mi355x.h "Precision of the centres"); PSF_NP_TWO_PASS=0/1 forces
   g->two_pass = (double)g->base->q * std::sqrt((double)g->n) > g->s * 8192.0;
   { const char* ev = getenv("PSF_NP_TWO_PASS"); if (ev) g->two_pass = atoi(ev) != 0; }
   g->nkd = round_up(d, 16) / 16;
