@@ -9,7 +9,7 @@ ranks the batch is sharded by global preimage index (weak scaling: 4096 per GPU)
 to rank 0 over RCCL inside the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
-(k_trmm_f64: x = sqrt(Sigma_2) d on the f64 MFMA pipe) and `cpu_baseline` (the CPU oracle timed on this
+(k_trmm_f64_big: x = sqrt(Sigma_2) d on the f64 MFMA pipe) and `cpu_baseline` (the CPU oracle timed on this
 host's cores, rank 0, N=1 only).
 """
 import argparse
@@ -30,6 +30,7 @@ CONFIGS = {
     "bench64": ("PSFPerturbation", 64, 128, 6.0, 100.0, 4096),     # benches/psf.rs:78-93
     "c1": ("PSFPerturbation", 8, 64, 3.0, 25.0, 1),                 # README.md:62-66
     "c2": ("PSFGPV", 256, 3329, None, 1024.0, 1024),                # BASELINE.json configs[1]
+    "c2s240": ("PSFGPV", 256, 3329, None, 240.0, 1024),             # the same at the reference bench's own rule s = 30 log2 n (benches/psf.rs:32), SURVEY.md 8d
     "c4": ("PSFGPVRing", 256, 3329, None, 0.0, 4096),               # BASELINE.json configs[3]; s = compute_s(256), gpv_ring.rs:296-298
     "c5": ("PSFPerturbation", 1024, 2**60, 10.0, 1024.0, 8192),     # BASELINE.json configs[4]: batch 65536 over 8 GPUs = 8192 per GPU
 }                                                                   # (60.6 GB key per GPU, trap_gen ~30 s; run with --gpus 8 --config c5)
@@ -273,7 +274,7 @@ def cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, seed, sample):
     O.build()
     threads, quota_note = effective_cpus(O.num_threads())
     if scheme == "PSFPerturbation":
-        S = sample or min(u.shape[0], 1024)          # four groups of 256 preimages x 241 row panels: enough tasks for every thread
+        S = sample or min(u.shape[0], 512)           # two groups of 256 preimages x 241 row panels: enough tasks for every thread, ~3 s on 16 cores
         A, (R, Lp, _) = psf.export_key()
         orc = O.PSFPerturbation(O.gadget_params_default(n, q), r, s)
         orc.load_key(A, R, Lp)
@@ -298,7 +299,7 @@ def cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, seed, sample):
     dt = time.perf_counter() - t0
     same = bool((e_cpu.reshape(S, -1) == e[:S].cpu().numpy()).all())
     # single-thread leg on a smaller sample (about 10-20 s of work)
-    S1 = max(1, min(S, 256 if scheme == "PSFPerturbation" else 8))
+    S1 = max(1, min(S, 64 if scheme == "PSFPerturbation" else 8))      # ~5 s: the CPU legs together stay a minor share of the run
     t0 = time.perf_counter()
     e_one = orc.samp_p(seed, uh[:S1], first_index=first_index, nthreads=1)
     dt1 = time.perf_counter() - t0

@@ -75,6 +75,28 @@ def test_gpv_preimages_have_the_right_scale():
     assert np.abs(corr).max() < 6 / math.sqrt(B)
 
 
+def test_ring_preimages_have_the_right_scale():
+    """PSFGPVRing (gpv_ring.rs:160-212) at a small degree: one fixed syndrome, many preimages; the coefficient embedding of the preimage is a
+    spherical Gaussian of parameter s over its coset (s = 4 x compute_s is above the smoothing parameter of the embedded short basis)."""
+    import tools_amd as T
+    n, q, B = 8, 257, 12000
+    s = 4 * ((2 * 2 * 1.005 * math.sqrt(n) + 1) * 2) * 4                   # 4 x compute_s(n), gpv_ring.rs:296-298
+    psf = T.PSFGPVRing(T.GadgetParametersRing.init_default(n, q), s, 1.005)
+    psf.trap_gen(6)
+    u = np.tile(np.array([[1, 200, 7, 64, 0, 127, 256, 33]], dtype=np.uint64), (B, 1))
+    sg = psf.samp_p(u, seed=5)
+    assert (psf.f_a(sg) == u).all() and psf.check_domain(sg).all()
+    e = sg.reshape(B, -1).astype(np.float64)
+    sigma = s / math.sqrt(2 * math.pi)
+    std = e.std(axis=0)
+    assert np.abs(std / sigma - 1).max() < 0.05, (std.min(), std.max(), sigma)          # 1 / sqrt(2 B) = 0.65 %, d coordinates
+    assert abs((std**2).mean() / sigma**2 - 1) < 0.006
+    assert np.abs(e.mean(axis=0)).max() < 5.5 * sigma / math.sqrt(B) + 1.0
+    corr = np.corrcoef(e.T)
+    np.fill_diagonal(corr, 0)
+    assert np.abs(corr).max() < 6 / math.sqrt(B), np.abs(corr).max()
+
+
 def test_samp_d_marginals():
     import tools_amd as T
     psf = T.PSFPerturbation(T.GadgetParameters.init_default(5, 32), 2.0, 20.0)
