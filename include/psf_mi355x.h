@@ -189,8 +189,14 @@ psf_status psfp_check_domain(psfp_handle*, size_t B, const int64_t* e, size_t le
 
 /* One job over `count` handles, one per GPU of the node, each holding the same key (psfp_trap_gen with the same seed, or psfp_load_key):
  * the B rows are cut into contiguous shares (psf_shard_range), share i is computed by handles[i] on its own device, all devices at once.
- * Row b uses global index first_index + b, so the result equals psfp_samp_p on one handle bit for bit.  Host buffers. */
+ * Row b uses global index first_index + b, so the result equals psfp_samp_p on one handle bit for bit.  Host buffers (pageable is fine):
+ * one worker thread per handle drives its device for the call (upload, samp_p, download), because HIP copies from / to pageable memory
+ * block the issuing thread.  A handle may appear once in `handles`.  Every worker finishes and synchronises its stream before the call
+ * returns, also after an error on another device; the first non-OK status in handle order is returned. */
 psf_status psfp_samp_p_multi(psfp_handle* const* handles, int count, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
+/* this handle's window inside the last psfp_samp_p_multi call, in ms since that call began (host clock): its first samp_p launch
+ * sequence enqueued / its last row landed in e; -1 if it had no rows.  Overlapping windows = the devices worked at the same time. */
+psf_status psfp_get_multi_timing(const psfp_handle*, double* launched_ms, double* done_ms);
 
 /* device-resident variants: d_u, d_e are HIP device pointers, stream is a hipStream_t (NULL = default).
  * Asynchronous with respect to the host; errors detected on device are reported by psfp_last_status. */

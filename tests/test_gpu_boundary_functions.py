@@ -126,3 +126,28 @@ def test_samp_p_multi_equals_single_handle(T, oracle):
     # fewer rows than handles: the empty shares are skipped
     few = samp_p_multi(handles, u[:2], seed=77, first_index=1000)
     assert (few == single[:2]).all()
+
+
+def test_samp_p_multi_drives_its_handles_concurrently(T, oracle):
+    """One worker thread per handle: handle 1 must have ENQUEUED its launch sequence before handle 0's last row has landed in the caller's
+    (pageable) buffer -- with the single-threaded form of round 2 every handle's window began after the previous one's had ended.  All handles sit on
+    one GPU here, so the device work itself still serialises; what the windows show is that nothing on the host waits for the neighbour.  On a
+    node with several GPUs the same windows overlap for their whole length."""
+    from tools_amd.psf import samp_p_multi, multi_timing
+    n, q, r, s, B = 64, 128, 6.0, 100.0, 6144                    # benches/psf.rs:78-93 parameters; 2048 rows per handle, ~50 MB of output each
+    gp = T.GadgetParameters.init_default(n, q)
+    handles = [T.PSFPerturbation(gp, r, s) for _ in range(3)]
+    for h in handles:
+        h.trap_gen(5, export=False)
+    u = oracle.uniform_targets(2, B, n, q)
+    samp_p_multi(handles, u, seed=1)                              # warm-up: buffers, first-touch of the output pages
+    multi = samp_p_multi(handles, u, seed=77, first_index=10)
+    win = [multi_timing(h) for h in handles]
+    assert all(0 <= a <= b for a, b in win), win
+    latest_launch = max(a for a, _ in win)
+    earliest_done = min(b for _, b in win)
+    assert latest_launch < earliest_done, win                    # every handle was launched before ANY handle had finished
+    single = handles[0].samp_p(u, seed=77, first_index=10)
+    assert (multi == single).all()
+    with pytest.raises(T.PsfError):                               # a handle may appear once
+        samp_p_multi([handles[0], handles[0]], u[:4], seed=1)

@@ -4,7 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/psf_mi355x.h"
 #include "psf_host.hpp"
@@ -88,6 +90,9 @@ struct psfp_handle {
   // timing
   bool timing = false;
   std::vector<TimingSlot> slots;
+  // psfp_samp_p_multi: this handle's window inside the last call (host clock, ms since the call began)
+  const std::chrono::steady_clock::time_point* multi_t0 = nullptr;
+  double multi_launched_ms = -1.0, multi_done_ms = -1.0;
 };
 
 static size_t gadget_lds_bytes(size_t k) { return k * k * 8 + k * 8 + k * sizeof(SampleZParams) + k * k * 4 + k * 256 * 4; }
@@ -704,6 +709,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   }
   HIP_TRY(hipGetLastError());
   h->last_stream = user_st;
+  if (h->multi_t0 && h->multi_launched_ms < 0.0)
+    h->multi_launched_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - *h->multi_t0).count();
   return PSF_OK;
 }
 
@@ -788,43 +795,55 @@ psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size
 }
 
 // One job over several handles (one per GPU of the node, each with the same key): rows are cut into contiguous shares
-// (psf_shard_range), share i is computed by handles[i] on its own device and stream, all of them at once; row b draws from the global
-// index first_index + b, so the result equals the single-handle one bit for bit.  Host buffers; no collective is involved -- the
-// "gather" of SURVEY.md 8e is each device's copy into its slice of e.
+// (psf_shard_range), share i is computed by handles[i] on its own device and stream; row b draws from the global index first_index + b,
+// so the result equals the single-handle one bit for bit.  Host buffers; no collective is involved -- the "gather" of SURVEY.md 8e is
+// each device's copy into its slice of e.
+// Concurrency: ONE WORKER THREAD PER HANDLE.  The caller's u / e are pageable memory, and HIP's "asynchronous" copies to or from pageable
+// memory block the calling host thread until the device has drained -- issued from one thread (round 2) the devices ran one after another.
+// Each worker owns its device for the call: upload, the samp_p launch sequence, download (through the handle's own slicing, so the rows of
+// the first half cross PCIe while the second half is computed), status.  A failure on one device does not leave work of another in flight:
+// every worker runs to completion and synchronises its own stream before the call returns; the first non-OK status in handle order is returned.
+// Per handle the call records, relative to its own start (host clock, ms): when the worker had enqueued its first samp_p launch sequence and when its
+// last byte had landed in e -- psfp_get_multi_timing; overlap between the handles' [launched, done] windows is what a test can assert even with
+// every handle on one GPU.
 psf_status psfp_samp_p_multi(psfp_handle* const* handles, int count, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
   if (!handles || count < 1 || (B && (!u || !e))) return PSF_ERR_PARAM;
   for (int i = 0; i < count; ++i) {
     if (!handles[i]) return PSF_ERR_PARAM;
     if (!handles[i]->has_key) return PSF_ERR_NO_KEY;
     if (handles[i]->n != handles[0]->n || handles[i]->m != handles[0]->m || handles[i]->q != handles[0]->q) return PSF_ERR_PARAM;
+    for (int j = 0; j < i; ++j) if (handles[j] == handles[i]) return PSF_ERR_PARAM;      // one worker per handle: a handle may appear once
   }
   if (B == 0) return PSF_OK;
   std::vector<size_t> first(count), cnt(count);
   for (int i = 0; i < count; ++i) psf_shard_range(B, count, i, &first[i], &cnt[i]);
-  psf_status worst = PSF_OK;
-  // enqueue everything first (uploads, the samp_p launch sequence, downloads: all asynchronous on the handle's own stream) ...
-  for (int i = 0; i < count && worst == PSF_OK; ++i) {
+  std::vector<psf_status> rc(count, PSF_OK);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(t - t0).count(); };
+  auto work = [&](int i) {
     psfp_handle* h = handles[i];
-    if (!cnt[i]) continue;
-    HIP_TRY(hipSetDevice(h->prm.device));
-    psf_status rc = ensure_batch(h, cnt[i]);
-    if (rc != PSF_OK) { worst = rc; break; }
-    if (h->timing) clear_slots(h);
-    HIP_TRY(hipMemcpyAsync(h->dU, u + first[i] * h->n, cnt[i] * h->n * sizeof(uint64_t), hipMemcpyHostToDevice, h->s1));
-    rc = run_samp_p(h, seed, first_index + first[i], cnt[i], h->dU, h->dE, h->s1);
-    if (rc != PSF_OK) { worst = rc; break; }
-    HIP_TRY(hipMemcpyAsync(e + first[i] * h->m, h->dE, cnt[i] * h->m * sizeof(int64_t), hipMemcpyDeviceToHost, h->s1));
-  }
-  // ... then wait for every device
-  for (int i = 0; i < count; ++i) {
-    psfp_handle* h = handles[i];
-    if (!cnt[i]) continue;
-    HIP_TRY(hipSetDevice(h->prm.device));
-    h->last_stream = h->s1;
-    const psf_status rc = psfp_last_status(h);
-    if (rc != PSF_OK && worst == PSF_OK) worst = rc;
-  }
-  return worst;
+    h->multi_launched_ms = h->multi_done_ms = -1.0;
+    if (!cnt[i]) return;
+    h->multi_t0 = &t0;
+    rc[i] = psfp_samp_p(h, seed, first_index + first[i], cnt[i], u + first[i] * h->n, e + first[i] * h->m);
+    h->multi_t0 = nullptr;
+    h->multi_done_ms = ms_since(std::chrono::steady_clock::now());
+  };
+  std::vector<std::thread> pool;
+  pool.reserve(count > 1 ? count - 1 : 0);
+  for (int i = 1; i < count; ++i) pool.emplace_back(work, i);
+  work(0);                                               // the calling thread serves the first handle
+  for (auto& t : pool) t.join();
+  for (int i = 0; i < count; ++i) if (rc[i] != PSF_OK) return rc[i];
+  return PSF_OK;
+}
+
+// [launched, done] window of this handle inside the last psfp_samp_p_multi call, in ms since that call began (-1: the handle had no rows)
+psf_status psfp_get_multi_timing(const psfp_handle* h, double* launched_ms, double* done_ms) {
+  if (!h) return PSF_ERR_PARAM;
+  if (launched_ms) *launched_ms = h->multi_launched_ms;
+  if (done_ms) *done_ms = h->multi_done_ms;
+  return PSF_OK;
 }
 
 psf_status psfp_samp_p_stages(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, double* d, double* x,

@@ -216,6 +216,13 @@ def samp_p_multi(psfs, u, seed=0, first_index=0):
     return e
 
 
+def multi_timing(psf):
+    """(launched_ms, done_ms) of this handle inside the last samp_p_multi call, measured from the start of that call; (-1, -1) if it had no rows."""
+    a, b = C.c_double(0), C.c_double(0)
+    check(lib().psfp_get_multi_timing(psf._h, C.byref(a), C.byref(b)), "multi_timing")
+    return a.value, b.value
+
+
 class PSFGPV:
     """gpv.rs:53-57 / impl PSF :59-225 on one MI355X.  The trapdoor (short basis, GSO) is exchanged TRANSPOSED:
     row i = basis vector i = column i of the reference's matrices."""

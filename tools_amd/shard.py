@@ -58,9 +58,10 @@ class AsyncRowGather:
 
     def __init__(self, rows, cols, device, dst=0, depth=2, force=False):
         self.enabled = dist.is_initialized() and (dist.get_world_size() > 1 or force)   # force: exercise the path on one rank
-        self.dst, self.depth = dst, depth
         self.rank = dist.get_rank() if self.enabled else 0
         self.world = dist.get_world_size() if self.enabled else 1
+        depth = self.fit_depth(rows, cols, device, depth, self.world, self.rank == dst) if self.enabled else depth
+        self.dst, self.depth = dst, depth
         self.stage = [torch.empty((rows, cols), dtype=torch.int32, device=device) for _ in range(depth)] if self.enabled else []
         self.recv = None
         if self.enabled and self.rank == dst:
@@ -68,6 +69,20 @@ class AsyncRowGather:
         self.work = [None] * depth
         self.step = 0
         self.overflow = torch.zeros((), dtype=torch.int32, device=device) if self.enabled else None
+
+    @staticmethod
+    def bytes_per_depth(rows, cols, world, is_dst):
+        """device memory one level of the ring costs on this rank: its own int32 staging block, plus one receive block per rank on dst"""
+        return rows * cols * 4 * (1 + (world if is_dst else 0))
+
+    @staticmethod
+    def fit_depth(rows, cols, device, depth, world, is_dst, free_bytes=None):
+        """Largest ring depth <= `depth` (at least 1) whose buffers fit into 80 % of the free device memory.  At C5 (8192 x 122 980 rows per rank,
+        8 ranks) one level is 4.03 GB on a worker and 36.3 GB on rank 0; depth 2 = 72.5 GB beside the 60.6 GB key and ~33 GB of batch buffers."""
+        if free_bytes is None:
+            free_bytes = torch.cuda.mem_get_info(device)[0] if (isinstance(device, torch.device) and device.type == "cuda") else 1 << 62
+        per = AsyncRowGather.bytes_per_depth(rows, cols, world, is_dst)
+        return max(1, min(depth, int(0.8 * free_bytes) // max(per, 1)))
 
     def submit(self, e_int64):
         """Queue the gather of this step's rows; returns immediately."""
