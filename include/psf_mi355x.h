@@ -93,10 +93,17 @@ psf_status psf_gen_short_basis_for_trapdoor(const psf_gadget_params* gp, const u
  * PSF_ERR_MODULUS if base^k < q. */
 psf_status psf_gen_trapdoor(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const uint64_t* tag, uint64_t seed,
                             uint64_t* A /*n x m*/, int8_t* R /*m_bar x nk*/);
+/* the same with the caller's own R (m_bar x nk, row-major) -- the draw of whatever TrapdoorDistribution the caller uses: the reference samples R through
+ * the trait object `params.distribution` (gadget_classical.rs:62-64, gadget_parameters.rs:51, trapdoor_distribution.rs:21-48).  |R_ij| <= 127
+ * (the trapdoor is an int8 operand of the matrix cores on the device), PSF_ERR_UNSUPPORTED otherwise.  Install the pair with psfp_load_key(A, R, NULL). */
+psf_status psf_gen_trapdoor_with_r(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const uint64_t* tag, const int64_t* R,
+                                   uint64_t* A /*n x m*/);
 /* gen_trapdoor_ring_lwe (gadget_ring.rs:62-81): r, e <- SampleZ(s) from `seed`, a = [1 | a_bar | g^t - (a_bar r + e)] in R_q
- * (gp from psf_gadget_params_ring_default; q < 2^31).  a_bar: n coefficients; a: (k+2) x n; r, e: k x n */
+ * (gp from psf_gadget_params_ring_default; q < 2^62).  a_bar: n coefficients; a: (k+2) x n; r, e: k x n */
 psf_status psf_gen_trapdoor_ring_lwe(int device, const psf_gadget_params* gp, const uint64_t* a_bar, double s, uint64_t seed,
                                      uint64_t* a, int64_t* r, int64_t* e);
+/* the same with the caller's own r, e (gadget_ring.rs:69-70 draw them through `params.distribution`); |coefficients| <= 2^30 */
+psf_status psf_gen_trapdoor_ring_lwe_with(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const int64_t* r, const int64_t* e, uint64_t* a);
 /* gen_gadget_ring (gadget_ring.rs:103-109): the k constant polynomials base^j, out[j] = constant term */
 psf_status psf_gen_gadget_ring(uint64_t k, uint64_t base, int64_t* out);
 /* find_solution_gadget_ring (gadget_ring.rs:145-166): u (n coefficients of an element of R_q) -> out[k x n], polynomial i = i-th digit
@@ -168,7 +175,14 @@ psf_status psfp_trap_gen(psfp_handle*, uint64_t seed);
 /* PSFPerturbation::compute_sqrt_sigma_2 (mp_perturbation.rs:111-139) for Sigma = s_cov^2 * I using the
  * handle's R; replaces the handle's sqrt(Sigma_2) (the doctest at :89-107). */
 psf_status psfp_compute_sqrt_sigma_2(psfp_handle*, double s_cov);
-/* install / read back key material (host buffers).  Any of the out pointers may be NULL. */
+/* The general form: `mat_sigma: &MatQ` of mp_perturbation.rs:111 is any symmetric m x m matrix (used as a full matrix at :125-126).
+ * sigma_lower_packed: its lower triangle, row i holding i + 1 entries (m(m+1)/2 doubles).  PSF_ERR_NOT_PD if Sigma_2 is not positive
+ * definite; PSF_ERR_UNSUPPORTED on a PSFP_FLAG_STRUCTURED_SQRT handle (that factor exists for Sigma = s^2 I only). */
+psf_status psfp_compute_sqrt_sigma_2_dense(psfp_handle*, const double* sigma_lower_packed);
+/* install / read back key material (host buffers).  Any of the out pointers may be NULL.
+ * psfp_load_key(A, NULL, NULL): the PUBLIC key only -- what a verifier holds; f_a, check_domain and samp_d work (PSF::f_a takes `a` alone,
+ *   mp_perturbation.rs:366), samp_p returns PSF_ERR_NO_KEY.
+ * psfp_load_key(A, R, NULL): sqrt(Sigma_2) is recomputed from R with the handle's s, as trap_gen does (mp_perturbation.rs:227-231). */
 psf_status psfp_load_key(psfp_handle*, const uint64_t* A, const int8_t* R, const double* sqrt_sigma2_packed);
 psf_status psfp_export_key(const psfp_handle*, uint64_t* A, int8_t* R, double* sqrt_sigma2_packed);
 /* rows [row0, row0 + nrows) of sqrt(Sigma_2) in the same packed form (row i holds i + 1 entries): the factor of BASELINE's
@@ -288,6 +302,8 @@ int psfgpv_two_pass(const psfgpv_handle*);
  *   Trapdoor = (r, e), two 1 x k MatPolyOverZ  -> int64_t[k * n] each (gadget_ring.rs:62-81)
  *   Domain   = MatPolyOverZ (k+2) x 1          -> int64_t[(k+2) * n] per call
  *   Range    = one element of R_q               -> uint64_t[n] per call
+ * Any modulus 1 < q < 2^62 (GadgetParametersRing carries an arbitrary ModulusPolynomialRingZq, gadget_parameters.rs:73-81): R_q products by the NTT
+ * kernel where q allows and by the exact schoolbook kernel elsewhere, the walk in two passes where q sqrt(n) > 2^13 s (see PSFGPV above).
  * samp_p (gpv_ring.rs:160-212) works on the coefficient embedding: the short basis
  * (gen_short_basis_for_trapdoor_ring, short_basis_ring.rs:64-79), rot^-(iota(a)) (rotation_matrix.rs:85-96), the
  * elimination and the Gram-Schmidt vectors are built ONCE per key here, where the reference rebuilds them per call.

@@ -70,6 +70,10 @@ class PSFPerturbation {
     return {std::move(A), std::move(td)};
   }
   void load_key(const MatZq& A, const Trapdoor& td) { check(psfp_load_key(h_, A.data(), td.R.data(), td.sqrt_sigma_2.data()), "load_key"); }
+  void load_public_key(const MatZq& A) { check(psfp_load_key(h_, A.data(), nullptr, nullptr), "load_key"); }      // a verifier's handle: f_a / check_domain only
+  // compute_sqrt_sigma_2 (:111-139): Sigma = s_cov^2 I, or any symmetric covariance as its packed lower triangle (row i: i + 1 entries)
+  void compute_sqrt_sigma_2(double s_cov) { check(psfp_compute_sqrt_sigma_2(h_, s_cov), "compute_sqrt_sigma_2"); }
+  void compute_sqrt_sigma_2(const std::vector<double>& sigma_lower_packed) { check(psfp_compute_sqrt_sigma_2_dense(h_, sigma_lower_packed.data()), "compute_sqrt_sigma_2"); }
   MatZ samp_d(uint64_t seed, size_t B = 1, uint64_t first_index = 0) {                           // :264-267
     MatZ e(B * m());
     check(psfp_samp_d(h_, seed, first_index, B, e.data()), "samp_d");

@@ -339,6 +339,15 @@ class PSFPerturbation:
         rc = lib().orc_psfp_compute_sqrt_sigma_2(self._h, _p(R, C.c_int8), C.c_double(s_cov), _p(Lp, C.c_double))
         return rc, Lp
 
+    def compute_sqrt_sigma_2_dense(self, R, sigma_packed):
+        """mp_perturbation.rs:111-139 for a general covariance: sigma_packed = lower triangle of mat_sigma, row i holding i + 1 entries"""
+        R = _i8(R)
+        sg = np.ascontiguousarray(sigma_packed, dtype=np.float64)
+        assert sg.size == self.m * (self.m + 1) // 2
+        Lp = np.zeros(self.m * (self.m + 1) // 2)
+        rc = lib().orc_psfp_compute_sqrt_sigma_2_dense(self._h, _p(R, C.c_int8), _p(sg, C.c_double), _p(Lp, C.c_double))
+        return rc, Lp
+
     def samp_p(self, seed, u, first_index=0, nthreads=0):
         u = _u64(u).reshape(-1, self.n)
         B = u.shape[0]

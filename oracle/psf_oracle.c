@@ -503,18 +503,22 @@ void orc_psfp_free(orc_psfp* h) {
 
 /* mp_perturbation.rs:111-139 with Sigma = s_cov^2 I (the form trap_gen passes at :227-231):
  *   Sigma_2 = (1/2pi) r^2 ((Sigma - (b^2+1) T T^t) - I),  T = [R; I_w];  returns its lower Cholesky factor. */
-static int sqrt_sigma_2_rows(const orc_psfp* h, const int8_t* R, double s_cov, size_t m, double* Lp);
+static int sqrt_sigma_2_rows(const orc_psfp* h, const int8_t* R, double s_cov, const double* sigma, size_t m, double* Lp);
 int orc_psfp_compute_sqrt_sigma_2(const orc_psfp* h, const int8_t* R, double s_cov, double* Lp) {
-  return sqrt_sigma_2_rows(h, R, s_cov, h->gp.m_bar + h->gp.n * h->gp.k, Lp);
+  return sqrt_sigma_2_rows(h, R, s_cov, NULL, h->gp.m_bar + h->gp.n * h->gp.k, Lp);
+}
+/* the general form of mp_perturbation.rs:111: any symmetric mat_sigma, given as its packed lower triangle (row i: i + 1 entries) */
+int orc_psfp_compute_sqrt_sigma_2_dense(const orc_psfp* h, const int8_t* R, const double* sigma_packed, double* Lp) {
+  return sqrt_sigma_2_rows(h, R, 0.0, sigma_packed, h->gp.m_bar + h->gp.n * h->gp.k, Lp);
 }
 /* The first m0 rows of the same factor.  Row i of the Cholesky-Banachiewicz recurrence only reads rows <= i, so this is the
  * factor of the leading m0 x m0 block of Sigma_2 and at the same time rows 0..m0-1 of the full factor: a cheap check of a
  * device factor that spans many panels at sizes where the whole recurrence (m^3/3) is out of reach for a scalar CPU loop. */
 int orc_psfp_sqrt_sigma_2_leading(const orc_psfp* h, const int8_t* R, double s_cov, size_t m0, double* Lp) {
   if (m0 > h->gp.m_bar + h->gp.n * h->gp.k) return ORC_ERR_PARAM;
-  return sqrt_sigma_2_rows(h, R, s_cov, m0, Lp);
+  return sqrt_sigma_2_rows(h, R, s_cov, NULL, m0, Lp);
 }
-static int sqrt_sigma_2_rows(const orc_psfp* h, const int8_t* R, double s_cov, size_t m, double* Lp) {
+static int sqrt_sigma_2_rows(const orc_psfp* h, const int8_t* R, double s_cov, const double* sigma, size_t m, double* Lp) {
   const orc_gadget_params* gp = &h->gp;
   size_t mb = gp->m_bar, w = gp->n * gp->k;
   const double TWO_PI = 6.283185307179586476925;
@@ -535,7 +539,8 @@ static int sqrt_sigma_2_rows(const orc_psfp* h, const int8_t* R, double s_cov, s
         tt = acc;
       } else if (j < mb) tt = R[j * w + (i - mb)];
       else tt = (i == j);
-      double sp = (i == j ? s2 : 0.0) - (double)(b2p1 * tt);   /* Sigma_p entry, :125-126 */
+      const double sg = sigma ? sigma[i * (i + 1) / 2 + j] : (i == j ? s2 : 0.0);
+      double sp = sg - (double)(b2p1 * tt);                     /* Sigma_p entry, :125-126 */
       if (i == j) sp = sp - 1.0;                                /* - I, :134-135 */
       row[j] = nf_r2 * sp;
     }

@@ -101,6 +101,7 @@ int orc_psfp_trap_gen(orc_psfp*, uint64_t seed);
 int orc_psfp_load_key(orc_psfp*, const uint64_t* A, const int8_t* R, const double* L_packed);
 /* mp_perturbation.rs:111-139 ; sigma given as scalar*I (the only form trap_gen uses) */
 int orc_psfp_compute_sqrt_sigma_2(const orc_psfp*, const int8_t* R, double s_cov, double* L_packed);
+int orc_psfp_compute_sqrt_sigma_2_dense(const orc_psfp*, const int8_t* R, const double* sigma_packed, double* L_packed);
 /* rows 0..m0-1 of the same factor (= the factor of the leading m0 x m0 block of Sigma_2); Lp: m0(m0+1)/2 */
 int orc_psfp_sqrt_sigma_2_leading(const orc_psfp*, const int8_t* R, double s_cov, size_t m0, double* L_packed);
 /* x = sqrt(Sigma_2) d restricted to a packed row block of the factor (streamed verification of large keys) */

@@ -208,6 +208,14 @@ fn matpolyring_to_rows(a: &MatPolynomialRingZq, n: i64) -> Vec<u64> {
     matpoly_to_rows(&repr, n).into_iter().map(|v| u64::try_from(v).unwrap()).collect()
 }
 
+/// 64 bits from the operating system's generator (/dev/urandom), for `from_entropy`.
+fn os_seed() -> u64 {
+    use std::io::Read;
+    let mut b = [0u8; 8];
+    std::fs::File::open("/dev/urandom").and_then(|mut f| f.read_exact(&mut b)).expect("no /dev/urandom");
+    u64::from_le_bytes(b)
+}
+
 /// Call counter -> seed of the next sampling call: seeds of different calls never coincide for one wrapper.
 fn next_seed(seed: &Cell<u64>, calls: &Cell<u64>) -> u64 {
     let c = calls.get();
@@ -228,6 +236,8 @@ pub struct GpuPSFPerturbation {
     calls: Cell<u64>,
     /// the (A, R, sqrt(Sigma_2)) the handle currently holds, to skip the upload when samp_p is called again with the same key
     installed: RefCell<Option<(MatZq, MatZ, MatQ)>>,
+    /// the public matrix the handle holds when it was installed WITHOUT a trapdoor (f_a of a verifier)
+    public_only: RefCell<Option<MatZq>>,
 }
 
 impl GpuPSFPerturbation {
@@ -236,7 +246,14 @@ impl GpuPSFPerturbation {
         let c = ffi::psfp_params { gp: gp_to_c(&params.gp), r: f64::from(&params.r), s: f64::from(&params.s), device, flags: 0 };
         let mut handle = std::ptr::null_mut();
         check(unsafe { ffi::psfp_create(&c, &mut handle) }, "psfp_create");
-        Self { params, handle, seed: Cell::new(seed), calls: Cell::new(0), installed: RefCell::new(None) }
+        Self { params, handle, seed: Cell::new(seed), calls: Cell::new(0), installed: RefCell::new(None), public_only: RefCell::new(None) }
+    }
+
+    /// Like `new`, with the seed drawn from the operating system (the reference samples through the OS-seeded thread-local RNG of qfall-math).
+    /// A caller-chosen 64-bit seed (`new`, `reseed`) makes runs reproducible and is meant for tests and benches: it bounds the entropy of every
+    /// key and preimage at 64 bits.
+    pub fn from_entropy(params: PSFPerturbation, device: i32) -> Self {
+        Self::new(params, device, os_seed())
     }
 
     pub fn reseed(&self, seed: u64) {
@@ -260,6 +277,24 @@ impl GpuPSFPerturbation {
         let (av, rv, lv) = (matzq_to_rows(a), matz_to_rows_i8(r), matq_lower_to_packed(sqrt_sigma_2));
         check(unsafe { ffi::psfp_load_key(self.handle, av.as_ptr(), rv.as_ptr(), lv.as_ptr()) }, "psfp_load_key");
         *self.installed.borrow_mut() = Some((a.clone(), r.clone(), sqrt_sigma_2.clone()));
+        *self.public_only.borrow_mut() = None;
+    }
+
+    /// `PSFPerturbation::compute_sqrt_sigma_2` (mp_perturbation.rs:111-139) on the device for ANY symmetric covariance `mat_sigma`
+    /// (the reference's signature; its doctest at :89-107 passes s'^2 I).  Needs the handle to hold (A, R): call after `trap_gen` or `samp_p`.
+    pub fn compute_sqrt_sigma_2(&self, mat_r: &MatZ, mat_sigma: &MatQ) -> MatQ {
+        let (_, _, _, m) = self.dims();
+        let (a, _r_old, _) = self.installed.borrow().as_ref().expect("compute_sqrt_sigma_2 needs an installed key (trap_gen / samp_p first)").clone();
+        // install (A, R) -- the factor is recomputed below, so none is uploaded
+        let (av, rv) = (matzq_to_rows(&a), matz_to_rows_i8(mat_r));
+        check(unsafe { ffi::psfp_load_key(self.handle, av.as_ptr(), rv.as_ptr(), std::ptr::null()) }, "psfp_load_key");
+        let sg = matq_lower_to_packed(mat_sigma);
+        check(unsafe { ffi::psfp_compute_sqrt_sigma_2_dense(self.handle, sg.as_ptr()) }, "psfp_compute_sqrt_sigma_2_dense");
+        let mut l = vec![0f64; (m * (m + 1) / 2) as usize];
+        check(unsafe { ffi::psfp_export_key(self.handle, std::ptr::null_mut(), std::ptr::null_mut(), l.as_mut_ptr()) }, "psfp_export_key");
+        let l_mat = matq_lower_from_packed(m, &l);
+        *self.installed.borrow_mut() = Some((a, mat_r.clone(), l_mat.clone()));
+        l_mat
     }
 
     /// B independent `samp_p` calls with one key: the batched form the library is built for (row b of `targets` = one syndrome).
@@ -340,17 +375,14 @@ impl PSF for GpuPSFPerturbation {
     fn f_a(&self, a: &MatZq, sigma: &MatZ) -> MatZq {
         let (n, _, _, m) = self.dims();
         assert!(sigma.get_num_rows() == m && sigma.get_num_columns() == 1, "sigma must be a column vector of length m");
-        // only A matters for f_a: if the caller's A is not the installed one, upload it with the trapdoor part the handle holds
-        let upload = match self.installed.borrow().as_ref() {
-            Some((ia, _, _)) if ia == a => None,
-            Some((_, ir, il)) => Some((matzq_to_rows(a), matz_to_rows_i8(ir), matq_lower_to_packed(il))),
-            None => panic!("f_a before trap_gen / samp_p: the handle holds no key"),
-        };
-        if let Some((av, rv, lv)) = upload {
-            check(unsafe { ffi::psfp_load_key(self.handle, av.as_ptr(), rv.as_ptr(), lv.as_ptr()) }, "psfp_load_key");
-            if let Some(inst) = self.installed.borrow_mut().as_mut() {
-                inst.0 = a.clone();
-            }
+        // PSF::f_a takes the public matrix alone (mp_perturbation.rs:366): a verifier that never saw a trapdoor can call it.  If the caller's A is
+        // not the one the handle holds, it is installed as a public-key-only key (psfp_load_key(A, NULL, NULL)); a later samp_p re-installs its tuple.
+        let same = matches!(self.installed.borrow().as_ref(), Some((ia, _, _)) if ia == a) || matches!(self.public_only.borrow().as_ref(), Some(ia) if ia == a);
+        if !same {
+            let av = matzq_to_rows(a);
+            check(unsafe { ffi::psfp_load_key(self.handle, av.as_ptr(), std::ptr::null(), std::ptr::null()) }, "psfp_load_key");
+            *self.installed.borrow_mut() = None;
+            *self.public_only.borrow_mut() = Some(a.clone());
         }
         let e = matz_to_rows_i64(sigma);
         let mut u = vec![0u64; n as usize];

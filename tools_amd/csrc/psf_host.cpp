@@ -1,4 +1,5 @@
 // psf_host.cpp -- host-side mirror of the reference's deterministic gadget helpers (see psf_host.hpp).
+#include <climits>
 #include "psf_host.hpp"
 #include <algorithm>
 #include <cstring>
@@ -317,10 +318,14 @@ psf_status ring_short_basis_t(const psf_gadget_params& gp, const uint64_t* a, co
     }
   basis_t.assign(d * d, 0);
   std::vector<int64_t> col(K * n), prod(n), shifted(n);
+  bool overflow = false;
   auto emit = [&](size_t column, size_t shift) {
     for (size_t row = 0; row < K; ++row) {
       poly_shift_negacyclic(col.data() + row * n, n, shift, shifted.data());
-      for (size_t c = 0; c < n; ++c) basis_t[column * d + row * n + c] = (int32_t)shifted[c];
+      for (size_t c = 0; c < n; ++c) {
+        if (shifted[c] > INT32_MAX || shifted[c] < -INT32_MAX) overflow = true;     // caller-supplied (r, e) of unusual size: the basis is held in int32
+        basis_t[column * d + row * n + c] = (int32_t)shifted[c];
+      }
     }
   };
   for (size_t c = 0; c < k; ++c) {                                       // left block
@@ -347,6 +352,7 @@ psf_status ring_short_basis_t(const psf_gadget_params& gp, const uint64_t* a, co
     }
     for (size_t i = 0; i < n; ++i) emit(k * n + 2 * i + c, i);
   }
+  if (overflow) return PSF_ERR_UNSUPPORTED;
   return PSF_OK;
 }
 

@@ -1583,10 +1583,11 @@ __global__ void k_sample_R(uint64_t seed, size_t mbar, size_t w, size_t ldr, int
   }
 }
 
-// Sigma_2 = (r^2/2pi) ((s^2 I - (b^2+1) T T^t) - I), T = [R; I]  (mp_perturbation.rs:111-136), lower triangle of a
-// dense row-major m x m matrix.  The R R^t block is a dot4 product of 64 x 64 row pairs.
+// Sigma_2 = (r^2/2pi) ((Sigma - (b^2+1) T T^t) - I), T = [R; I]  (mp_perturbation.rs:111-136), lower triangle of a
+// dense row-major m x m matrix.  Sigma = s^2 I (Sig == nullptr: the form trap_gen passes, :227-231) or any symmetric matrix given as its
+// packed lower triangle (row i: i + 1 entries).  The R R^t block is a dot4 product of 64 x 64 row pairs.
 __global__ __launch_bounds__(256) void k_sigma2(const int8_t* __restrict__ R, size_t ldr, size_t mbar, size_t w, size_t m,
-                                                double nf_r2, double s2, double b2p1, double* __restrict__ S, size_t lds) {
+                                                double nf_r2, double s2, double b2p1, const double* __restrict__ Sig, double* __restrict__ S, size_t lds) {
   __shared__ uint32_t sRi[64][17];
   __shared__ uint32_t sRj[64][17];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -1636,7 +1637,8 @@ __global__ __launch_bounds__(256) void k_sigma2(const int8_t* __restrict__ R, si
       if (i < mbar) tt = (double)acc[r][c];
       else if (j < mbar) tt = (double)R[j * ldr + (i - mbar)];
       else tt = (i == j) ? 1.0 : 0.0;
-      double sp = ((i == j) ? s2 : 0.0) - b2p1 * tt;
+      const double sg = Sig ? Sig[i * (i + 1) / 2 + j] : ((i == j) ? s2 : 0.0);
+      double sp = sg - b2p1 * tt;
       if (i == j) sp = sp - 1.0;
       S[i * lds + j] = nf_r2 * sp;
     }

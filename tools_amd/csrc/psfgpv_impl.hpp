@@ -349,7 +349,7 @@ psf_status psfgpv_trap_gen(psfgpv_handle* g, uint64_t seed) {
   if (rc != PSF_OK) return rc;
   rc = gpv_build_solver(g);
   if (rc != PSF_OK) return rc;
-  b->has_key = true;
+  b->has_key = true; b->has_pub = true;
   g->has_key = true;
   return PSF_OK;
 }
@@ -367,7 +367,7 @@ psf_status psfgpv_load_key(psfgpv_handle* g, const uint64_t* A, const int32_t* b
   if (rc != PSF_OK) return rc;
   rc = gpv_build_solver(g);
   if (rc != PSF_OK) return rc;
-  b->has_key = true;
+  b->has_key = true; b->has_pub = true;
   g->has_key = true;
   return PSF_OK;
 }
@@ -517,7 +517,7 @@ static psf_status ring_install(psfring_handle* h) {
   if (rc2 != PSF_OK) return rc2;
   rc2 = gpv_build_solver(g);                            // gpv_ring.rs:180-185
   if (rc2 != PSF_OK) return rc2;
-  b->has_key = true;
+  b->has_key = true; b->has_pub = true;
   g->has_key = true;
   return PSF_OK;
 }
@@ -527,7 +527,7 @@ extern "C" {
 psf_status psfring_create(const psfring_params* prm, psfring_handle** out) {
   if (!prm || !out || !(prm->s > 0.0) || !(prm->s_td > 0.0)) return PSF_ERR_PARAM;
   const psf_gadget_params& gp = prm->gp;
-  if (gp.n < 1 || gp.k < 1 || gp.q <= 1 || gp.q >= (1ull << 31)) return gp.q >= (1ull << 31) ? PSF_ERR_UNSUPPORTED : PSF_ERR_PARAM;
+  if (gp.n < 1 || gp.k < 1 || gp.q <= 1 || gp.q >= (1ull << 62)) return gp.q >= (1ull << 62) ? PSF_ERR_UNSUPPORTED : PSF_ERR_PARAM;
   psfgpv_params gpvp;
   gpvp.gp = psf_gadget_params{gp.n, gp.k, 2 * gp.n, gp.base, gp.q};
   gpvp.s = prm->s; gpvp.device = prm->device; gpvp.flags = 0;
@@ -609,21 +609,12 @@ psf_status psf_gso_rows(int device, const int32_t* basis_t, size_t rows, size_t 
   return done(PSF_OK);
 }
 
-// gen_trapdoor_ring_lwe (gadget_ring.rs:62-81) with r, e <- SampleZ(s) (trapdoor_distribution.rs:112-122) drawn from `seed`:
-// A = [1 | a_bar | g_j - (a_bar r_j + e_j)] mod (X^n + 1, q); the k products a_bar * r_j run on the device (NTT kernel when q allows)
-psf_status psf_gen_trapdoor_ring_lwe(int device, const psf_gadget_params* gp, const uint64_t* a_bar, double s, uint64_t seed, uint64_t* a, int64_t* r, int64_t* e) {
-  if (!gp || !a_bar || !a || !r || !e || !(s > 0.0) || gp->n < 1 || gp->k < 1 || gp->q <= 1) return PSF_ERR_PARAM;
-  if (gp->q >= (1ull << 31)) return PSF_ERR_UNSUPPORTED;
+// gen_trapdoor_ring_lwe (gadget_ring.rs:62-81): A = [1 | a_bar | g_j - (a_bar r_j + e_j)] mod (X^n + 1, q); the k products a_bar * r_j run on the
+// device (NTT kernel when q allows, the exact schoolbook kernel for every other q < 2^62).  r, e: SampleZ(s) from `seed`
+// (trapdoor_distribution.rs:112-122), or the caller's own draw (`params.distribution.sample(...)`, gadget_ring.rs:69-70).
+static psf_status ring_lwe_assemble(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const int64_t* r, const int64_t* e, uint64_t* a) {
   const size_t n = gp->n, k = gp->k;
   const uint64_t q = gp->q;
-  const SampleZParams sp = make_sample_z_params(s);
-  int fail = 0;
-  for (size_t j = 0; j < k; ++j)
-    for (size_t c = 0; c < n; ++c) {
-      r[j * n + c] = sample_z(seed, TAG_RING_R, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);      // :69
-      e[j * n + c] = sample_z(seed, TAG_RING_E, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);      // :70
-    }
-  if (fail) return PSF_ERR_SAMPLER;
   std::vector<uint64_t> abar_rep(k * n), prod(k * n);
   for (size_t j = 0; j < k; ++j)
     for (size_t c = 0; c < n; ++c) abar_rep[j * n + c] = a_bar[c] % q;
@@ -643,6 +634,27 @@ psf_status psf_gen_trapdoor_ring_lwe(int device, const psf_gadget_params* gp, co
     gpow = mulmod_u64(gpow, gp->base % q, q);
   }
   return PSF_OK;
+}
+psf_status psf_gen_trapdoor_ring_lwe(int device, const psf_gadget_params* gp, const uint64_t* a_bar, double s, uint64_t seed, uint64_t* a, int64_t* r, int64_t* e) {
+  if (!gp || !a_bar || !a || !r || !e || !(s > 0.0) || gp->n < 1 || gp->k < 1 || gp->q <= 1) return PSF_ERR_PARAM;
+  if (gp->q >= (1ull << 62)) return PSF_ERR_UNSUPPORTED;
+  const size_t n = gp->n, k = gp->k;
+  const SampleZParams sp = make_sample_z_params(s);
+  int fail = 0;
+  for (size_t j = 0; j < k; ++j)
+    for (size_t c = 0; c < n; ++c) {
+      r[j * n + c] = sample_z(seed, TAG_RING_R, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);      // :69
+      e[j * n + c] = sample_z(seed, TAG_RING_E, 0, (uint32_t)(j * n + c), 0.0, sp, &fail);      // :70
+    }
+  if (fail) return PSF_ERR_SAMPLER;
+  return ring_lwe_assemble(device, gp, a_bar, r, e, a);
+}
+psf_status psf_gen_trapdoor_ring_lwe_with(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const int64_t* r, const int64_t* e, uint64_t* a) {
+  if (!gp || !a_bar || !a || !r || !e || gp->n < 1 || gp->k < 1 || gp->q <= 1) return PSF_ERR_PARAM;
+  if (gp->q >= (1ull << 62)) return PSF_ERR_UNSUPPORTED;
+  for (size_t i = 0; i < gp->k * gp->n; ++i)
+    if (r[i] > (1ll << 30) || r[i] < -(1ll << 30) || e[i] > (1ll << 30) || e[i] < -(1ll << 30)) return PSF_ERR_UNSUPPORTED;   // the embedded short basis is int32
+  return ring_lwe_assemble(device, gp, a_bar, r, e, a);
 }
 
 // gen_gadget_ring (gadget_ring.rs:103-109): k constant polynomials base^j; out[j] = the constant term

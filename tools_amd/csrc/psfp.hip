@@ -44,7 +44,9 @@ struct psfp_handle {
   size_t n, k, mb, w, m;
   uint64_t q, two64, two31;
   bool wide;            // q >= 2^31: two 31-bit limbs
-  bool has_key = false;
+  bool has_key = false;      // A, R and sqrt(Sigma_2) installed
+  bool has_pub = false;      // A installed (f_a, check_domain, samp_d work; samp_p needs has_key)
+  bool has_R = false;        // A and R installed (compute_sqrt_sigma_2 can complete the key)
   // key material
   uint64_t* dA = nullptr;      // n x m
   int8_t* dR = nullptr;        // mb x ldr
@@ -409,7 +411,7 @@ size_t psfp_m(const psfp_handle* h) { return h ? h->m : 0; }
 // Structured mode factors Sigma_2 = c [[alpha I - kappa R R^t, -kappa R], [-kappa R^t, beta I]]  (c = r^2 / 2 pi, kappa = b^2 + 1, alpha = s^2 - 1,
 // beta = alpha - kappa) as B B^t with B = [[L_1 / sqrt c, -kappa R / sqrt beta], [0, sqrt beta I]] sqrt c, where L_1 is the Cholesky factor of
 // c (alpha I - kappa (alpha / beta) R R^t): only that m_bar x m_bar block is assembled, factored and stored.
-static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov) {
+static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* d_sigma_packed = nullptr) {
   const double TWO_PI = 6.283185307179586476925;
   const double nf_r2 = (1.0 / TWO_PI) * (h->prm.r * h->prm.r);
   const double s2 = s_cov * s_cov;
@@ -427,7 +429,7 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov) {
   HIP_TRY(hipMalloc(&dS, m * m * sizeof(double)));
   HIP_TRY(hipMemset(dS, 0, m * m * sizeof(double)));
   const unsigned tiles = (unsigned)((m + 63) / 64);
-  hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, dS, m);
+  hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sigma_packed, dS, m);
   HIP_TRY(hipGetLastError());
   // blocked right-looking Cholesky of the lower triangle, panel width 128 (psf_chol_kernels.hpp)
   int* dinfo = nullptr;
@@ -499,10 +501,12 @@ static psf_status gen_A_R(psfp_handle* h, uint64_t seed) {
   return PSF_OK;
 }
 
-// gen_trapdoor (gadget_classical.rs:56-68) as a free function: caller-supplied A_bar and tag H, R <- PlusMinusOneZero from `seed`
-// (the stream psfp_trap_gen uses), A = [A_bar | H G - A_bar R] on the device
-psf_status psf_gen_trapdoor(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const uint64_t* tag, uint64_t seed, uint64_t* A, int8_t* R) {
-  if (!gp || !a_bar || !A || !R) return PSF_ERR_PARAM;
+// gen_trapdoor (gadget_classical.rs:56-68) as a free function: caller-supplied A_bar and tag H; R <- PlusMinusOneZero from `seed` (the stream
+// psfp_trap_gen uses) or, with R_in, the caller's own draw from whatever TrapdoorDistribution it uses (`params.distribution.sample(...)`,
+// gadget_classical.rs:62-64 -- a trait object in the reference, trapdoor_distribution.rs:21-48); A = [A_bar | H G - A_bar R] on the device
+static psf_status gen_trapdoor_core(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const uint64_t* tag, uint64_t seed, const int64_t* R_in,
+                                    uint64_t* A, int8_t* R_out) {
+  if (!gp || !a_bar || !A) return PSF_ERR_PARAM;
   psfp_params prm;
   prm.gp = *gp; prm.r = 1.0; prm.s = 1.0; prm.device = device; prm.flags = PSFP_FLAG_NO_PERTURB;
   psfp_handle* h = nullptr;
@@ -516,12 +520,31 @@ psf_status psf_gen_trapdoor(int device, const psf_gadget_params* gp, const uint6
     if (hipMalloc(&dtag, h->n * h->n * sizeof(uint64_t)) != hipSuccess) return fail(PSF_ERR_HIP);
     if (hipMemcpy(dtag, tag, h->n * h->n * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return fail(PSF_ERR_HIP);
   }
-  hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);      // gadget_classical.rs:62-64
+  if (R_in) {
+    // the trapdoor lives in int8 on the device (operand of the int8 matrix cores in e = p + [R; I] z and of the dot4 assembly of Sigma_2)
+    std::vector<int8_t> r8(h->mb * h->w);
+    for (size_t i = 0; i < r8.size(); ++i) {
+      if (R_in[i] > 127 || R_in[i] < -127) return fail(PSF_ERR_UNSUPPORTED);
+      r8[i] = (int8_t)R_in[i];
+    }
+    if (hipMemset(h->dR, 0, h->mb_pad * h->ldr) != hipSuccess) return fail(PSF_ERR_HIP);
+    if (hipMemcpy2D(h->dR, h->ldr, r8.data(), h->w, h->w, h->mb, hipMemcpyHostToDevice) != hipSuccess) return fail(PSF_ERR_HIP);
+  } else {
+    hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);    // gadget_classical.rs:62-64
+  }
   launch_zq_trapdoor(h, dtag);                                                                                            // :66
   if (hipGetLastError() != hipSuccess) return fail(PSF_ERR_HIP);
   if (hipMemcpy(A, h->dA, h->n * h->m * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return fail(PSF_ERR_HIP);
-  if (hipMemcpy2D(R, h->w, h->dR, h->ldr, h->w, h->mb, hipMemcpyDeviceToHost) != hipSuccess) return fail(PSF_ERR_HIP);
+  if (R_out && hipMemcpy2D(R_out, h->w, h->dR, h->ldr, h->w, h->mb, hipMemcpyDeviceToHost) != hipSuccess) return fail(PSF_ERR_HIP);
   return fail(PSF_OK);
+}
+psf_status psf_gen_trapdoor(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const uint64_t* tag, uint64_t seed, uint64_t* A, int8_t* R) {
+  if (!R) return PSF_ERR_PARAM;
+  return gen_trapdoor_core(device, gp, a_bar, tag, seed, nullptr, A, R);
+}
+psf_status psf_gen_trapdoor_with_r(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const uint64_t* tag, const int64_t* R, uint64_t* A) {
+  if (!R) return PSF_ERR_PARAM;
+  return gen_trapdoor_core(device, gp, a_bar, tag, 0, R, A, nullptr);
 }
 
 // contiguous shares of `total` rows for `world` workers: the first total % world workers get one row more
@@ -539,6 +562,7 @@ psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
   HIP_TRY(hipSetDevice(h->prm.device));
   const psf_status rcg = gen_A_R(h, seed);
   if (rcg != PSF_OK) return rcg;
+  h->has_pub = h->has_R = true;
   const psf_status rc = build_sqrt_sigma2(h, h->prm.s);            // mp_perturbation.rs:227-231
   if (rc != PSF_OK) { h->has_key = false; return rc; }
   h->has_key = true;
@@ -547,18 +571,48 @@ psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
 
 psf_status psfp_compute_sqrt_sigma_2(psfp_handle* h, double s_cov) {
   if (!h || !(s_cov > 0.0)) return PSF_ERR_PARAM;
-  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (!h->has_R || (h->prm.flags & PSFP_FLAG_NO_PERTURB)) return PSF_ERR_NO_KEY;
   HIP_TRY(hipSetDevice(h->prm.device));
-  return build_sqrt_sigma2(h, s_cov);
+  const psf_status rc = build_sqrt_sigma2(h, s_cov);
+  h->has_key = rc == PSF_OK;
+  return rc;
+}
+
+// compute_sqrt_sigma_2 with a general covariance (mp_perturbation.rs:111: `mat_sigma: &MatQ` is any symmetric matrix, used as a full matrix at :125-126)
+psf_status psfp_compute_sqrt_sigma_2_dense(psfp_handle* h, const double* sigma_lower_packed) {
+  if (!h || !sigma_lower_packed) return PSF_ERR_PARAM;
+  if (!h->has_R || (h->prm.flags & PSFP_FLAG_NO_PERTURB)) return PSF_ERR_NO_KEY;
+  if (h->structured) return PSF_ERR_UNSUPPORTED;           // the structured factor exists for Sigma = s^2 I only
+  HIP_TRY(hipSetDevice(h->prm.device));
+  double* dsg = nullptr;
+  const size_t np = h->m * (h->m + 1) / 2;
+  HIP_TRY(hipMalloc(&dsg, np * sizeof(double)));
+  if (hipMemcpy(dsg, sigma_lower_packed, np * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { hipFree(dsg); return PSF_ERR_HIP; }
+  const psf_status rc = build_sqrt_sigma2(h, 0.0, dsg);
+  hipFree(dsg);
+  h->has_key = rc == PSF_OK;
+  return rc;
 }
 
 psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, const double* Lp) {
-  if (!h || !A || !R || !Lp) return PSF_ERR_PARAM;
+  if (!h || !A || (!R && Lp)) return PSF_ERR_PARAM;
   HIP_TRY(hipSetDevice(h->prm.device));
+  h->has_key = h->has_R = h->has_pub = false;
   HIP_TRY(hipMemcpy(h->dA, A, h->n * h->m * sizeof(uint64_t), hipMemcpyHostToDevice));
+  split_A(h);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  h->has_pub = true;
+  if (!R) return PSF_OK;                                    // public key only: the verifier's handle (f_a, check_domain, samp_d)
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
-  split_A(h);
+  h->has_R = true;
+  if (h->prm.flags & PSFP_FLAG_NO_PERTURB) return PSF_OK;
+  if (!Lp) {                                                // trapdoor without its factor: recompute it as trap_gen does (mp_perturbation.rs:227-231)
+    const psf_status rc = build_sqrt_sigma2(h, h->prm.s);
+    h->has_key = rc == PSF_OK;
+    return rc;
+  }
   double* dp = nullptr;
   const size_t np = h->mL * (h->mL + 1) / 2;
   HIP_TRY(hipMalloc(&dp, np * sizeof(double)));
@@ -581,7 +635,7 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
 
 psf_status psfp_export_key(const psfp_handle* h, uint64_t* A, int8_t* R, double* Lp) {
   if (!h) return PSF_ERR_PARAM;
-  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (!h->has_pub || ((R || Lp) && !h->has_R) || (Lp && !h->has_key)) return PSF_ERR_NO_KEY;
   HIP_TRY(hipSetDevice(h->prm.device));
   if (A) HIP_TRY(hipMemcpy(A, h->dA, h->n * h->m * sizeof(uint64_t), hipMemcpyDeviceToHost));
   if (R) HIP_TRY(hipMemcpy2D(R, h->w, h->dR, h->ldr, h->w, h->mb, hipMemcpyDeviceToHost));
@@ -931,7 +985,7 @@ psf_status psfp_check_domain(psfp_handle* h, size_t B, const int64_t* e, size_t 
 
 psf_status psfp_f_a_dev(psfp_handle* h, size_t B, const int64_t* d_e, uint64_t* d_u, uint8_t* d_ok, void* stream) {
   if (!h || (B && (!d_e || !d_u || !d_ok))) return PSF_ERR_PARAM;
-  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (!h->has_pub) return PSF_ERR_NO_KEY;                     // f_a needs the public matrix only (mp_perturbation.rs:366-369)
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
   psf_status rc = ensure_batch(h, B);
@@ -948,7 +1002,7 @@ psf_status psfp_f_a_dev(psfp_handle* h, size_t B, const int64_t* d_e, uint64_t* 
 
 psf_status psfp_f_a(psfp_handle* h, size_t B, const int64_t* e, uint64_t* u) {
   if (!h || (B && (!e || !u))) return PSF_ERR_PARAM;
-  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (!h->has_pub) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
   psf_status rc = ensure_batch(h, B);

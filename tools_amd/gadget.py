@@ -122,6 +122,36 @@ def gen_trapdoor(gp, a_bar, tag=None, seed=0, device=0):
     return A, R
 
 
+def gen_trapdoor_with_r(gp, a_bar, R, tag=None, device=0):
+    """gen_trapdoor (gadget_classical.rs:56-68) with the caller's own R -- any TrapdoorDistribution's draw (:62-64); returns A."""
+    c = gp.c if hasattr(gp, "c") else gp
+    a_bar = np.ascontiguousarray(a_bar, dtype=np.uint64)
+    w = c.n * c.k
+    R = np.ascontiguousarray(R, dtype=np.int64)
+    assert a_bar.shape == (c.n, c.m_bar) and R.shape == (c.m_bar, w)
+    A = np.zeros((c.n, c.m_bar + w), dtype=np.uint64)
+    tagp = None
+    if tag is not None:
+        tag = np.ascontiguousarray(tag, dtype=np.uint64)
+        assert tag.shape == (c.n, c.n)
+        tagp = _p(tag, C.c_uint64)
+    check(lib().psf_gen_trapdoor_with_r(C.c_int(device), C.byref(c), _p(a_bar, C.c_uint64), tagp, _p(R, C.c_int64), _p(A, C.c_uint64)), "gen_trapdoor_with_r")
+    return A
+
+
+def gen_trapdoor_ring_lwe_with(gp, a_bar, r, e, device=0):
+    """gen_trapdoor_ring_lwe (gadget_ring.rs:62-81) with the caller's own r, e (:69-70); returns a [(k+2) x n]."""
+    c = gp.c if hasattr(gp, "c") else gp
+    a_bar = np.ascontiguousarray(a_bar, dtype=np.uint64).reshape(c.n)
+    r = np.ascontiguousarray(r, dtype=np.int64)
+    e = np.ascontiguousarray(e, dtype=np.int64)
+    assert r.shape == (c.k, c.n) and e.shape == (c.k, c.n)
+    a = np.zeros((c.k + 2, c.n), dtype=np.uint64)
+    check(lib().psf_gen_trapdoor_ring_lwe_with(C.c_int(device), C.byref(c), _p(a_bar, C.c_uint64), _p(r, C.c_int64), _p(e, C.c_int64), _p(a, C.c_uint64)),
+          "gen_trapdoor_ring_lwe_with")
+    return a
+
+
 def gen_trapdoor_ring_lwe(gp, a_bar, s, seed=0, device=0):
     """gen_trapdoor_ring_lwe (gadget_ring.rs:62-81): returns (a [(k+2) x n], r [k x n], e [k x n])."""
     c = gp.c if hasattr(gp, "c") else gp

@@ -152,17 +152,35 @@ class PSFPerturbation:
         check(lib().psfp_export_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8), None), "export_key")
         return A, R
 
-    def load_key(self, A, R, sqrt_sigma2_packed):
+    def load_key(self, A, R=None, sqrt_sigma2_packed=None):
+        """(A, R, factor): the whole trapdoor tuple; (A, R): the factor is recomputed from R with the handle's s (mp_perturbation.rs:227-231);
+        (A,): the public key alone -- a verifier's handle (f_a, check_domain, samp_d)."""
         A = np.ascontiguousarray(A, dtype=np.uint64)
-        R = np.ascontiguousarray(R, dtype=np.int8)
-        Lp = np.ascontiguousarray(sqrt_sigma2_packed, dtype=np.float64)
-        mL = self.m_bar if self.structured else self.m
-        assert A.shape == (self.n, self.m) and R.shape == (self.m_bar, self.w) and Lp.size == mL * (mL + 1) // 2
-        check(lib().psfp_load_key(self._h, _p(A, C.c_uint64), _p(R, C.c_int8), _p(Lp, C.c_double)), "load_key")
+        assert A.shape == (self.n, self.m)
+        Rp = Lpp = None
+        if R is not None:
+            R = np.ascontiguousarray(R, dtype=np.int8)
+            assert R.shape == (self.m_bar, self.w)
+            Rp = _p(R, C.c_int8)
+        if sqrt_sigma2_packed is not None:
+            Lp = np.ascontiguousarray(sqrt_sigma2_packed, dtype=np.float64)
+            mL = self.m_bar if self.structured else self.m
+            assert R is not None and Lp.size == mL * (mL + 1) // 2
+            Lpp = _p(Lp, C.c_double)
+        check(lib().psfp_load_key(self._h, _p(A, C.c_uint64), Rp, Lpp), "load_key")
 
-    def compute_sqrt_sigma_2(self, s_cov):
-        """mp_perturbation.rs:111-139 for Sigma = s_cov^2 I."""
-        check(lib().psfp_compute_sqrt_sigma_2(self._h, C.c_double(s_cov)), "compute_sqrt_sigma_2")
+    def compute_sqrt_sigma_2(self, s_cov=None, sigma=None):
+        """mp_perturbation.rs:111-139: Sigma = s_cov^2 I, or any symmetric m x m covariance `sigma` (a full matrix or its packed lower triangle)."""
+        if sigma is None:
+            check(lib().psfp_compute_sqrt_sigma_2(self._h, C.c_double(s_cov)), "compute_sqrt_sigma_2")
+            return
+        sg = np.asarray(sigma, dtype=np.float64)
+        if sg.ndim == 2:
+            assert sg.shape == (self.m, self.m)
+            sg = sg[np.tril_indices(self.m)]                  # row-major lower triangle: row i holds i + 1 entries
+        sg = np.ascontiguousarray(sg)
+        assert sg.size == self.m * (self.m + 1) // 2
+        check(lib().psfp_compute_sqrt_sigma_2_dense(self._h, _p(sg, C.c_double)), "compute_sqrt_sigma_2_dense")
 
     # ---- stage-level access (parity tests) ---------------------------------------------------------------
     def samp_p_stages(self, u, seed=0, first_index=0):
