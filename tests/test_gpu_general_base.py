@@ -74,9 +74,9 @@ def test_documented_limits_are_reported_not_crashed():
         with pytest.raises(T.PsfError) as ei:
             T.PSFPerturbation(GP.init_default(4, 64), r, s)
         assert ei.value.status == _ffi.ERR_PARAM
-    # ring modulus at or above 2^31
+    # ring modulus at or above 2^62 (round 3 lifted the 2^31 limit: tests/test_gpu_boundary_completion.py runs 2^31 + 11 ... 2^61 - 1)
     with pytest.raises(T.PsfError) as ei:
-        T.PSFGPVRing(T.GadgetParametersRing.init_default(8, 2**31 + 11), 100.0, 1.005)
+        T.PSFGPVRing(T.GadgetParametersRing(8, 62, 64, 2, 2**62), 100.0, 1.005)
     assert ei.value.status == _ffi.ERR_UNSUPPORTED
     # a gadget too short for q (gadget_classical.rs:170-172 panics there)
     psf = T.PSFPerturbation(GP(4, 5, 5 * 4 + 4, 2, 64), 3.0, 50.0)

@@ -1,16 +1,20 @@
-// psf_chol_kernels.hpp -- blocked right-looking Cholesky of Sigma_2 (mp_perturbation.rs:138, cholesky_decomposition_flint)
-// on a dense row-major matrix whose LOWER triangle is significant.  Panel width 128:
-//   k_chol_diag : factor the 128 x 128 diagonal block in LDS (one workgroup); reports a non-positive pivot (:109-110)
-//   k_chol_trsm : rows below the block, x L11^t = p by forward substitution, one row per thread, row and L11 in LDS
-//   k_chol_syrk : trailing update C[i][j] -= L[i] L[j]^t on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), K = 128:
-//                 the 128-term product is accumulated from +0 and subtracted from C once
+// psf_chol_kernels.hpp -- blocked Cholesky of Sigma_2 (mp_perturbation.rs:138, cholesky_decomposition_flint) on a dense row-major
+// matrix whose LOWER triangle is significant.  Round 3: LEFT-looking, panel width 128, on the FP64 product of psf_gemm_kernels.hpp:
+//   panel j   -=  L[j.., 0..j) L[j..j+128, 0..j)^t          one GEMM, K = j (split along K when few row tiles are left); every finished column
+//                                                            of L is READ once per panel and nothing but the panel is written -- the right-looking
+//                                                            form of rounds 1-2 re-wrote the whole trailing matrix per panel (0.9 TB at C3, K = 128)
+//   k_chol_diag_inv : factor the 128 x 128 diagonal block in LDS (one workgroup), write L11, invert it in place (reports a non-positive pivot, :109-110)
+//   rows below      =  panel L11^-t                          one GEMM, K = 128, against the inverse
+// The right-looking kernels (k_chol_diag / k_chol_trsm / k_chol_syrk) stay as the PSF_CHOL=right comparison arm.
 // Setup path only (once per key); the factor is compared with the oracle's unblocked one within a tolerance.
 #pragma once
 #include "psf_kernels.hpp"
+#include "psf_gemm_kernels.hpp"
 
 namespace psf {
 
 constexpr int CH_NB = 128;
+
 
 // ---- diagonal block ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ A, size_t ld, size_t off, int nb, int* __restrict__ info) {
@@ -43,6 +47,68 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ A, size_
   for (int e = tid; e < nb * nb; e += 256) {
     const int r = e / nb, c = e % nb;
     if (c <= r) A[(off + r) * ld + off + c] = ch_smem[r * LD + c];
+  }
+}
+
+// ---- diagonal block + its inverse (left-looking form) ----------------------------------------------------------------------------------
+// 256 threads; the block lives in LDS as [128][129].  Step j: pivot, column j scaled by the threads i > j, then the rank-1 update of the rows
+// below -- thread (i = t % 128, h = t / 128) takes the columns j < c <= i with c = j + 1 + h (mod 2): lanes walk rows (stride 129: no bank
+// conflict), the pivot column is a broadcast.  L11 goes back to A; the inverse (lower triangular, written to Linv row-major, zeros above the
+// diagonal) is formed in place from the last column to the first: X[i][j] = -(sum_{j < t <= i} X[i][t] L[t][j]) / L[j][j].
+__global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, size_t ld, size_t off, int nb, double* __restrict__ Linv, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double ch_smem[];   // nb x (CH_NB + 1) | one column
+  constexpr int LD = CH_NB + 1;
+  double* __restrict__ sG = ch_smem;
+  double* __restrict__ sCol = ch_smem + CH_NB * LD;
+  const int tid = threadIdx.x, ti = tid & 127, th = tid >> 7;
+  if (*info != 0) return;
+  for (int e = tid; e < nb * CH_NB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    if (c < nb) sG[r * LD + c] = (c <= r) ? A[(off + r) * ld + off + c] : 0.0;
+  }
+  __syncthreads();
+  double* __restrict__ myrow = sG + ti * LD;
+  for (int j = 0; j < nb; ++j) {
+    const double d = sG[j * LD + j];
+    if (!(d > 0.0)) {                       // not positive definite (uniform: every thread reads the same word)
+      if (tid == 0) atomicCAS(info, 0, (int)(off + j + 1));
+      return;
+    }
+    const double sd = sqrt(d);
+    __syncthreads();
+    if (th == 0 && ti >= j && ti < nb) {      // column j of L, kept a second time in sCol: the update below reads it from there (no aliasing with the rows it writes)
+      const double v = (ti == j) ? sd : myrow[j] / sd;
+      myrow[j] = v;
+      sCol[ti] = v;
+    }
+    __syncthreads();
+    if (ti > j && ti < nb) {
+      const double nl = -sCol[ti];
+      int c = j + 1 + th;
+      // eight columns at a time: loads first, then the fmas, then the stores -- written out so that the LDS round trips overlap whatever the compiler
+      // can or cannot prove about the pointers
+      for (; c + 14 <= ti; c += 16) {
+        double p[8], g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { p[u] = sCol[c + 2 * u]; g[u] = myrow[c + 2 * u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g[u] = fma(nl, p[u], g[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) myrow[c + 2 * u] = g[u];
+      }
+      for (; c <= ti; c += 2) myrow[c] = fma(nl, sCol[c], myrow[c]);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < nb * CH_NB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    if (c <= r && c < nb) A[(off + r) * ld + off + c] = sG[r * LD + c];
+  }
+  __syncthreads();
+  tri_inverse_inplace(sG, sCol, nb, tid);                  // X = L11^-1 in place (psf_gemm_kernels.hpp)
+  for (int e = tid; e < nb * CH_NB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    if (r < nb && c < nb) Linv[(size_t)r * CH_NB + c] = (c <= r) ? sG[r * LD + c] : 0.0;
   }
 }
 

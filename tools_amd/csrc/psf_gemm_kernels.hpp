@@ -3,10 +3,9 @@
 // and the blocked Gram-Schmidt orthogonalisation built on it (MatQ::gso, gpv.rs:91; inside MatPolyOverZ::sample_d, gpv_ring.rs:205).
 //
 // Workgroup tile 128 x 128, four waves (2 x 2) with 64 x 64 wave tiles of v_mfma_f64_16x16x4_f64, K chunks of 16.  Both operand tiles are kept
-// K-MAJOR in LDS ([k][row], row stride 144 doubles): the fragment of a k-step is then 16 consecutive doubles per lane group -- the four lane
-// groups of a ds_read_b64 fall on two disjoint halves of the banks, which is the two LDS cycles a 512-byte read costs anyway (the [row][k]
-// layout of round 1's SYRK put sixteen rows on two bank groups).  Row-major operands whose K runs along the row are transposed on the way in
-// (each thread reads 64 contiguous bytes of one row and writes eight ds_write_b64 into eight k-rows, consecutive lanes = consecutive rows).
+// K-MAJOR in LDS ([k][row], row stride 144 doubles, rows rotated by 2 (k >> 1)): the fragment of a k-step is 16 consecutive doubles per lane
+// group, conflict free, and so is the transposing write of row-major operands whose K runs along the row (the [row][k] layout of round 1's SYRK
+// put sixteen rows on two bank groups).  Sixteen consecutive lanes load the 128 contiguous bytes one row contributes to a chunk.
 // Global loads of chunk t+1 are in flight while chunk t is multiplied; one barrier per chunk.
 // Skinny products (M = one panel) are cut along K over gridDim.z workgroups; the partial tiles go to a workspace and k_gemm_reduce adds them
 // in split order -- no atomics, so every result is reproducible bit for bit (every rank regenerates the key from the seed).
@@ -55,71 +54,95 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
-  // operand staging: A (and an NT B) -- thread = (row t / 2, k half t % 2), eight consecutive k; an NN B -- thread = (k row t / 16, eight columns)
-  const int a_row = tid >> 1, a_kh = (tid & 1) * 8;
-  const int b_kr = tid >> 4, b_seg = (tid & 15) * 8;
-  const bool a_ok = m0 + a_row < g.M;
-  const bool bt_ok = n0 + a_row < g.N;
-  const double* pa = g.A + (m0 + (a_ok ? a_row : 0)) * g.lda;
-  const double* pbt = g.B + (n0 + (bt_ok ? a_row : 0)) * g.ldb;
+  // operand staging.  A (and an NT B): load i of thread t brings element (row (t >> 4) + 16 i, k = t & 15) -- sixteen consecutive lanes read the 128
+  // contiguous bytes a row contributes to the chunk, so every cache line is touched by ONE instruction (first version: eight 8-byte loads per lane
+  // along its own row -- each line fetched through the L1 eight times, 15 k cycles per chunk).  An NN B: (k row t >> 4, column (t & 15) + 16 i).
+  // In LDS element (kk, x) of a tile sits at kk * GM_LD + ((x + 2 (kk >> 1)) & 127): with GM_LD = 16 (mod 32) both the transposing ds_write_b64 of
+  // a half wave (kk = 0..15, two rows) and the fragment ds_read_b64 (sixteen rows, two kk) fall on 32 distinct 8-byte slots.
+  // The loads are UNCONDITIONAL (addresses clamped into the matrix): a select on a loaded value makes the compiler wait for the load where it is
+  // issued, i.e. in front of the MFMAs it should hide behind.  Rows beyond M / columns beyond N only feed outputs that are never stored, so their
+  // (finite) stand-in values are harmless; the K tail of a split is zeroed on ONE operand, A, after the loads have landed (0 x finite = 0).
+  const int t_hi = tid >> 4, t_lo = tid & 15;
+  const double* pa[8];
+  const double* pb[8];
+  size_t bcol[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const size_t ar = m0 + t_hi + 16 * i, br = n0 + t_hi + 16 * i;
+    pa[i] = g.A + (ar < g.M ? ar : g.M - 1) * g.lda;
+    if (NT) pb[i] = g.B + (br < g.N ? br : g.N - 1) * g.ldb;
+    else { const size_t c = n0 + t_lo + 16 * i; bcol[i] = c < g.N ? c : g.N - 1; }
+  }
+  const size_t klast = g.K - 1;
   double ra[8], rb[8];
   auto fetch = [&](int kt) {
     const size_t k0 = kbeg + (size_t)kt * GM_BK;
+    size_t ka = k0 + t_lo, kb = k0 + t_hi;             // this thread's k for A / NT-B, and for an NN B
+    if (k0 + GM_BK > g.K) { ka = ka < klast ? ka : klast; kb = kb < klast ? kb : klast; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const size_t kk = k0 + a_kh + i;
-      ra[i] = (a_ok && kk < kend) ? pa[kk] : 0.0;
-    }
+    for (int i = 0; i < 8; ++i) ra[i] = pa[i][ka];
     if (NT) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const size_t kk = k0 + a_kh + i;
-        rb[i] = (bt_ok && kk < kend) ? pbt[kk] : 0.0;
-      }
+      for (int i = 0; i < 8; ++i) rb[i] = pb[i][ka];
     } else {
-      const size_t kk = k0 + b_kr;
-      const double* pb = g.B + (kk < kend ? kk : kbeg) * g.ldb + n0 + b_seg;
+      const double* prow = g.B + kb * g.ldb;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) rb[i] = (kk < kend && n0 + b_seg + i < g.N) ? pb[i] : 0.0;
+      for (int i = 0; i < 8; ++i) rb[i] = prow[bcol[i]];
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int kt, int buf) {
     double* sA = gm_smem + buf * (2 * GM_BK * GM_LD);
     double* sB = sA + GM_BK * GM_LD;
+    const size_t k0 = kbeg + (size_t)kt * GM_BK;
+    const bool a_dead = k0 + t_lo >= kend;              // K tail of this split: its A entries count as zero
+    const int rot_a = 2 * (t_lo >> 1), rot_b = 2 * (t_hi >> 1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sA[(a_kh + i) * GM_LD + a_row] = ra[i];
+    for (int i = 0; i < 8; ++i) sA[t_lo * GM_LD + ((t_hi + 16 * i + rot_a) & 127)] = a_dead ? 0.0 : ra[i];
     if (NT) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sB[(a_kh + i) * GM_LD + a_row] = rb[i];
+      for (int i = 0; i < 8; ++i) sB[t_lo * GM_LD + ((t_hi + 16 * i + rot_a) & 127)] = rb[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sB[b_kr * GM_LD + b_seg + i] = rb[i];
+      for (int i = 0; i < 8; ++i) sB[t_hi * GM_LD + ((t_lo + 16 * i + rot_b) & 127)] = rb[i];
     }
   };
   const int r16 = lane & 15, gq = lane >> 4;
   if (nk > 0) {
     fetch(0);
-    stash(0);
+    stash(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
+#if !defined(GM_PROBE) || GM_PROBE != 1     /* tools/probe_gemm.hip: GM_PROBE=1 leaves the operands in LDS */
       if (kt + 1 < nk) fetch(kt + 1);
+#endif
       const double* sA = gm_smem + cur * (2 * GM_BK * GM_LD);
       const double* sB = sA + GM_BK * GM_LD;
-#pragma unroll
-      for (int ks = 0; ks < GM_BK / 4; ++ks) {
-        double a[4], b[4];
+      // fragments of k-step ks + 1 are read from LDS while the MFMAs of k-step ks run (two register sets): with a single set every k-step paid an LDS
+      // round trip in front of its 16 MFMAs -- 5.8 k cycles per chunk for 4.1 k of matrix work (tools/probe_gemm.hip, GM_PROBE=1)
+      double fa[2][4], fb[2][4];
+      auto frags = [&](int ks, double (&a)[4], double (&b)[4]) {
+        const int kk = ks * 4 + gq, rot = 2 * (kk >> 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          a[i] = sA[(ks * 4 + gq) * GM_LD + wr * 64 + i * 16 + r16];
-          b[i] = sB[(ks * 4 + gq) * GM_LD + wc * 64 + i * 16 + r16];
+          a[i] = sA[kk * GM_LD + ((wr * 64 + i * 16 + r16 + rot) & 127)];
+          b[i] = sB[kk * GM_LD + ((wc * 64 + i * 16 + r16 + rot) & 127)];
         }
+      };
+      frags(0, fa[0], fb[0]);
+#pragma unroll
+      for (int ks = 0; ks < GM_BK / 4; ++ks) {
+        if (ks + 1 < GM_BK / 4) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+#if defined(GM_PROBE) && GM_PROBE == 2      /* no MFMAs: loads, LDS traffic, barriers */
+          for (int j = 0; j < 4; ++j) acc[i][j][0] += fa[ks & 1][i] * fb[ks & 1][j];
+#else
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+#endif
       }
-      if (kt + 1 < nk) stash(cur ^ 1);
+      if (kt + 1 < nk) stash(kt + 1, cur ^ 1);
       __syncthreads();
     }
   }
@@ -152,43 +175,79 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits, size_t Mp, size_t Np) {
 // One workgroup; the p x p Gram matrix of the panel (p <= 128) lives in LDS.  Applying L^-1 to the panel's rows IS Gram-Schmidt on them in
 // exact arithmetic (rows of L^-1 W are W's rows minus their components along the earlier ones); the caller runs the (Gram, LDL, apply) round
 // twice, which brings the rows to orthogonality at rounding level for a panel whose condition is below ~1e7 ("CholQR2").
-__global__ __launch_bounds__(256) void k_ldl_inverse(const double* __restrict__ Gm, size_t ldg, int p, double* __restrict__ Linv, size_t ldl, int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double ldl_smem[];   // G: 128 x 129 (132 KiB) | one column (1 KiB)
+// X = T^-1 in place for a lower triangular T held as rows of stride 129 in LDS (256 threads: thread (ti = t & 127, th = t >> 7)), columns from the
+// last to the first:  X[i][j] = -( sum_{j < t <= i} X[i][t] T[t][j] ) / T[j][j],  X[j][j] = 1 / T[j][j].  Both halves of the workgroup share a row's
+// dot product (even / odd t), four partial sums each.  sCol: 2 x 128 doubles of scratch.
+__device__ inline void tri_inverse_inplace(double* __restrict__ sG, double* __restrict__ sCol, int nb, int tid) {
   constexpr int LD = GM_T + 1;
-  double* sG = ldl_smem;
-  double* sCol = ldl_smem + GM_T * LD;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < p * p; e += 256) { const int r = e / p, c = e % p; sG[r * LD + c] = Gm[(size_t)r * ldg + c]; }
+  const int ti = tid & 127, th = tid >> 7;
+  double* __restrict__ myrow = sG + ti * LD;
+  for (int j = nb - 1; j >= 0; --j) {
+    if (th == 0 && ti >= j && ti < nb) sCol[ti] = myrow[j];
+    __syncthreads();
+    double part = 0.0;
+    if (ti > j && ti < nb) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int t = j + 1 + th;
+      for (; t + 6 <= ti; t += 8) {
+        s0 = fma(myrow[t], sCol[t], s0);
+        s1 = fma(myrow[t + 2], sCol[t + 2], s1);
+        s2 = fma(myrow[t + 4], sCol[t + 4], s2);
+        s3 = fma(myrow[t + 6], sCol[t + 6], s3);
+      }
+      for (; t <= ti; t += 2) s0 = fma(myrow[t], sCol[t], s0);      // includes t = ti: X[i][i] is final (inverted when column i was processed)
+      part = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();                          // every read of column j's old values and of the rows is done
+    if (th == 1 && ti > j && ti < nb) sCol[GM_T + ti] = part;        // the second half hands its partial sum over
+    __syncthreads();
+    if (th == 0 && ti >= j && ti < nb) {
+      const double inv = 1.0 / sCol[j];
+      myrow[j] = (ti == j) ? inv : -(part + sCol[GM_T + ti]) * inv;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ldl_inverse(const double* __restrict__ Gm, size_t ldg, int p, double* __restrict__ Linv, size_t ldl, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double ldl_smem[];   // G: 128 x 129 (132 KiB) | two columns (2 KiB)
+  constexpr int LD = GM_T + 1;
+  double* __restrict__ sG = ldl_smem;
+  double* __restrict__ sCol = ldl_smem + GM_T * LD;
+  const int tid = threadIdx.x, ti = tid & 127, th = tid >> 7;
+  for (int e = tid; e < p * GM_T; e += 256) { const int r = e >> 7, c = e & 127; if (c < p) sG[r * LD + c] = Gm[(size_t)r * ldg + c]; }
   __syncthreads();
+  double* __restrict__ myrow = sG + ti * LD;
   for (int j = 0; j < p; ++j) {
-    const double dj = sG[j * LD + j];
-    if (!(dj > 0.0)) { if (tid == 0) atomicCAS(info, 0, j + 1); }        // a dependent "basis": reported, the row is left as it is
+    // column j as it stands (u = L[.][j] d_j) is copied to sCol; the update G[i][c] -= (u_i / d_j) u_c reads it from there
+    if (th == 0 && ti >= j && ti < p) sCol[ti] = myrow[j];
+    __syncthreads();
+    const double dj = sCol[j];
+    if (!(dj > 0.0) && tid == 0) atomicCAS(info, 0, j + 1);              // a dependent "basis": reported, the row is left as it is
     const double inv = dj > 0.0 ? 1.0 / dj : 0.0;
-    // trailing update with the unscaled column: G[i][c] -= (G[i][j] / d_j) G[c][j],  j < c <= i
-    const int rem = p - j - 1;
-    for (int e = tid; e < rem * rem; e += 256) {
-      const int i = j + 1 + e / rem, c = j + 1 + e % rem;
-      if (c <= i) sG[i * LD + c] = fma(-(sG[i * LD + j] * inv), sG[c * LD + j], sG[i * LD + c]);
-    }
-    __syncthreads();
-    for (int i = j + 1 + tid; i < p; i += 256) sG[i * LD + j] *= inv;    // column j of L
-    __syncthreads();
-  }
-  // X = L^-1 in place over the strictly lower part (unit diagonal implied), columns from the last to the first:
-  //   X[i][j] = -( L[i][j] + sum_{j < t < i} X[i][t] L[t][j] )     -- row i of X to the right of column j is final, column j of L is saved first
-  for (int j = p - 2; j >= 0; --j) {
-    for (int i = j + 1 + tid; i < p; i += 256) sCol[i] = sG[i * LD + j];
-    __syncthreads();
-    for (int i = j + 1 + tid; i < p; i += 256) {
-      double s = sCol[i];
-      for (int t = j + 1; t < i; ++t) s = fma(sG[i * LD + t], sCol[t], s);
-      sG[i * LD + j] = -s;
+    if (ti > j && ti < p) {
+      const double nl = -(sCol[ti] * inv);
+      int c = j + 1 + th;
+      for (; c + 14 <= ti; c += 16) {
+        double u[8], gg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { u[k] = sCol[c + 2 * k]; gg[k] = myrow[c + 2 * k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gg[k] = fma(nl, u[k], gg[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) myrow[c + 2 * k] = gg[k];
+      }
+      for (; c <= ti; c += 2) myrow[c] = fma(nl, sCol[c], myrow[c]);
+      if (th == 0) myrow[j] = sCol[ti] * inv;                            // column j of L
     }
     __syncthreads();
   }
-  for (int e = tid; e < p * p; e += 256) {
-    const int r = e / p, c = e % p;
-    Linv[(size_t)r * ldl + c] = c < r ? sG[r * LD + c] : (c == r ? 1.0 : 0.0);
+  if (th == 0 && ti < p) myrow[ti] = 1.0;                                // unit diagonal for the inversion
+  __syncthreads();
+  tri_inverse_inplace(sG, sCol, p, tid);
+  for (int e = tid; e < p * GM_T; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    if (c < p) Linv[(size_t)r * ldl + c] = c <= r ? sG[r * LD + c] : 0.0;
   }
 }
 
@@ -212,8 +271,8 @@ inline void launch_gemm(hipStream_t st, GemmArgs g, GemmWorkspace& w) {
   const unsigned tx = (unsigned)((g.N + GM_T - 1) / GM_T), ty = (unsigned)((g.M + GM_T - 1) / GM_T);
   const size_t nchunks = (g.K + GM_BK - 1) / GM_BK;
   unsigned splits = 1;
-  if ((size_t)tx * ty < 128) {
-    splits = (unsigned)(256 / ((size_t)tx * ty));
+  if ((size_t)tx * ty < 384) {                                           // two workgroups per CU hide each other's barriers and load latency (measured:
+    splits = (unsigned)((512 + (size_t)tx * ty - 1) / ((size_t)tx * ty));  // 39 -> see profiles/r03_notes.md TFLOP/s on the Cholesky update shape with one per CU)
     const size_t max_by_k = nchunks / 8 ? nchunks / 8 : 1;               // at least 8 chunks (128 coordinates) per split
     if (splits > max_by_k) splits = (unsigned)max_by_k;
     if (splits > 64) splits = 64;
@@ -240,7 +299,7 @@ inline hipError_t gemm_prepare() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GM_LDS_BYTES);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldl_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GM_T * (GM_T + 1) + GM_T) * sizeof(double)));
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldl_inverse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((GM_T * (GM_T + 1) + 2 * GM_T) * sizeof(double)));
 }
 
 // Gram-Schmidt on the rows of Gt (nrows x d, row i = basis vector i as doubles on entry, b~_i on exit), panels of 128 rows:
@@ -257,7 +316,7 @@ inline hipError_t gso_blocked(hipStream_t st, double* Gt, size_t nrows, size_t d
   GemmWorkspace w;
   const size_t dpad = (d + GM_T - 1) / GM_T * GM_T, rpad = (nrows + GM_T - 1) / GM_T * GM_T;
   w.bytes = (size_t)64 * GM_T * GM_T * sizeof(double);                       // a single 128 x 128 tile cut 64 ways ...
-  const size_t alt = (size_t)256 * GM_T * GM_T * sizeof(double) + (dpad > rpad ? dpad : rpad) * GM_T * sizeof(double);   // ... or <= 256 tiles over (splits x column tiles)
+  const size_t alt = (size_t)900 * GM_T * GM_T * sizeof(double) + (dpad > rpad ? dpad : rpad) * GM_T * sizeof(double);   // ... or < 384 + 512 (tile, split) pairs
   if (alt > w.bytes) w.bytes = alt;
   auto fail = [&](hipError_t err) { hipFree(dInv); hipFree(dC); hipFree(dG); hipFree(dLi); hipFree(w.ws); return err; };
   if ((e = hipMalloc(&dInv, rpad * sizeof(double))) != hipSuccess) return fail(e);
@@ -277,7 +336,7 @@ inline hipError_t gso_blocked(hipStream_t st, double* Gt, size_t nrows, size_t d
         launch_gemm<false>(st, GemmArgs{dC, rpad, Gt, d, W, d, p, d, i0, -1.0, 1.0, nullptr, nullptr, 0}, w);     // W -= C B~
       }
       launch_gemm<true>(st, GemmArgs{W, d, W, d, dG, GM_T, p, p, d, 1.0, 0.0, nullptr, nullptr, 0}, w);           // G = W W^t
-      hipLaunchKernelGGL(k_ldl_inverse, dim3(1), dim3(256), (GM_T * (GM_T + 1) + GM_T) * sizeof(double), st, dG, (size_t)GM_T, (int)p, dLi, (size_t)GM_T, d_info);
+      hipLaunchKernelGGL(k_ldl_inverse, dim3(1), dim3(256), (GM_T * (GM_T + 1) + 2 * GM_T) * sizeof(double), st, dG, (size_t)GM_T, (int)p, dLi, (size_t)GM_T, d_info);
       // W <- L^-1 W in place: the panel is ONE row tile, a workgroup reads rows 0..p-1 of its own 128 columns (K = p) and nothing else before it writes them
       launch_gemm<false>(st, GemmArgs{dLi, GM_T, W, d, W, d, p, d, p, 1.0, 0.0, nullptr, nullptr, 0}, w);
     }

@@ -431,19 +431,64 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
   const unsigned tiles = (unsigned)((m + 63) / 64);
   hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sigma_packed, dS, m);
   HIP_TRY(hipGetLastError());
-  // blocked right-looking Cholesky of the lower triangle, panel width 128 (psf_chol_kernels.hpp)
+  // blocked Cholesky of the lower triangle, panel width 128 (psf_chol_kernels.hpp): left-looking on the FP64 GEMM; PSF_CHOL=right: the right-looking
+  // kernels of rounds 1-2 (comparison arm)
   int* dinfo = nullptr;
   HIP_TRY(hipMalloc(&dinfo, sizeof(int)));
   HIP_TRY(hipMemset(dinfo, 0, sizeof(int)));
-  for (size_t off = 0; off < m; off += CH_NB) {
-    const int nb = (int)(m - off < (size_t)CH_NB ? m - off : (size_t)CH_NB);
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), (size_t)nb * (CH_NB + 1) * sizeof(double), 0, dS, m, off, nb, dinfo);
-    const size_t rest = m - off - nb;
-    if (rest == 0) break;
-    const size_t trsm_lds = ((size_t)nb * (nb + 1) / 2 + (size_t)nb * 64) * sizeof(double);
-    hipLaunchKernelGGL(k_chol_trsm, dim3((unsigned)((rest + 63) / 64)), dim3(64), trsm_lds, 0, dS, m, off, nb, m, dinfo);
-    const size_t nt = (rest + 127) / 128;
-    hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 2 * 4096 * sizeof(double), 0, dS, m, off, m, (int)nt, dinfo);
+  const char* chol_env = std::getenv("PSF_CHOL");
+  if (chol_env && !std::strcmp(chol_env, "right")) {
+    for (size_t off = 0; off < m; off += CH_NB) {
+      const int nb = (int)(m - off < (size_t)CH_NB ? m - off : (size_t)CH_NB);
+      hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), (size_t)nb * (CH_NB + 1) * sizeof(double), 0, dS, m, off, nb, dinfo);
+      const size_t rest = m - off - nb;
+      if (rest == 0) break;
+      const size_t trsm_lds = ((size_t)nb * (nb + 1) / 2 + (size_t)nb * 64) * sizeof(double);
+      hipLaunchKernelGGL(k_chol_trsm, dim3((unsigned)((rest + 63) / 64)), dim3(64), trsm_lds, 0, dS, m, off, nb, m, dinfo);
+      const size_t nt = (rest + 127) / 128;
+      hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 2 * 4096 * sizeof(double), 0, dS, m, off, m, (int)nt, dinfo);
+    }
+  } else {
+    if (gemm_prepare() != hipSuccess) { hipFree(dinfo); hipFree(dS); return PSF_ERR_HIP; }
+    const size_t diag_lds = ((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+    GemmWorkspace w;
+    w.bytes = (size_t)900 * GM_T * GM_T * sizeof(double);              // < 384 + 512 (tile, split) pairs per launch, see launch_gemm
+    double* dLi = nullptr;
+    hipStream_t sm = nullptr, sd = nullptr;                            // products / diagonal blocks
+    hipEvent_t evTile = nullptr, evDiag = nullptr;
+    auto cleanup = [&]() { if (sm) hipStreamDestroy(sm); if (sd) hipStreamDestroy(sd); if (evTile) hipEventDestroy(evTile); if (evDiag) hipEventDestroy(evDiag); hipFree(w.ws); hipFree(dLi); };
+    if (hipMalloc(&w.ws, w.bytes) != hipSuccess || hipMalloc(&dLi, CH_NB * CH_NB * sizeof(double)) != hipSuccess ||
+        hipStreamCreateWithFlags(&sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&evTile, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDiag, hipEventDisableTiming) != hipSuccess) {
+      cleanup(); hipFree(dinfo); hipFree(dS); return PSF_ERR_HIP;
+    }
+    HIP_TRY(hipDeviceSynchronize());                                   // k_sigma2 ran on the default stream
+    // Look-ahead: the factorisation of a diagonal block is one workgroup walking 128 dependent steps (~0.2-0.35 ms, pure latency).  The update of
+    // panel j is therefore cut in two: its first row tile (the diagonal block) goes first, its factorisation + inversion then runs on a second
+    // stream BESIDE the update of the rows below, and the triangular solve of those rows (a product with the inverse) joins the two.
+    for (size_t off = 0; off < m; off += CH_NB) {
+      const size_t nb = m - off < (size_t)CH_NB ? m - off : (size_t)CH_NB;
+      const size_t rest = m - off - nb;
+      double* P = dS + off * m + off;                                  // the panel: rows off.., columns off..off+nb
+      double* P2 = P + nb * m;                                         // its rows below the diagonal block
+      if (off > 0) {                                                   // P -= L[off.., 0..off) L[off..off+nb, 0..off)^t
+        launch_gemm<true>(sm, GemmArgs{dS + off * m, m, dS + off * m, m, P, m, nb, nb, off, -1.0, 1.0, nullptr, nullptr, 0}, w);
+        hipEventRecord(evTile, sm);
+        if (rest) launch_gemm<true>(sm, GemmArgs{dS + (off + nb) * m, m, dS + off * m, m, P2, m, rest, nb, off, -1.0, 1.0, nullptr, nullptr, 0}, w);
+        hipStreamWaitEvent(sd, evTile, 0);
+      }
+      hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sd, dS, m, off, (int)nb, dLi, dinfo);
+      hipEventRecord(evDiag, sd);
+      hipStreamWaitEvent(sm, evDiag, 0);
+      if (rest == 0) break;
+      // rows below = panel L11^-t; in place: one column tile, a workgroup reads only its own rows
+      launch_gemm<true>(sm, GemmArgs{P2, m, dLi, (size_t)CH_NB, P2, m, rest, nb, nb, 1.0, 0.0, nullptr, nullptr, 0}, w);
+    }
+    const hipError_t ce = hipStreamSynchronize(sm);
+    hipStreamSynchronize(sd);
+    cleanup();
+    if (ce != hipSuccess) { hipFree(dinfo); hipFree(dS); return PSF_ERR_HIP; }
   }
   HIP_TRY(hipGetLastError());
   int info = -1;
