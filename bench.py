@@ -186,8 +186,9 @@ def main():
             flops = 2.0 * float(m) * float(m) * B
             ach = flops / (npl * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "nearest plane: k_np_project + d/64 x k_np_step + k_np_combine8", "achieved": round(ach, 3),
-                    "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": None,
-                    "traffic_note": "not measured: rocprofv3 --pmc FETCH_SIZE segfaults on this launch sequence at C2 and did not finish within 45 minutes at C4 (profiles/r02_notes.md)",
+                    "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4),
+                    "traffic": load_traffic(args.config, B, "np_traffic.json", ("psf_np_kernels.hpp",)),
+                    "traffic_source": "profiles/np_traffic.json: rocprofv3 PMC passes over tools/bin/np_harness (C++ over the C ABI), every k_np_* launch of one samp_p call; null when psf_np_kernels.hpp changed since",
                     "launch_ms": round(npl, 3), "flops_per_launch": flops, "serial_steps": int(m),
                     "us_per_serial_step": round(npl * 1e3 / m, 4),
                     "note": "latency bound: d sequential SampleZ draws per preimage (one launch per 64 of them); frac is the FP64 share of the phase"}
@@ -236,11 +237,11 @@ def main():
         sys.exit(4)
 
 
-def load_traffic(config, B):
+def load_traffic(config, B, fname="trmm_traffic.json", sources=("psf_kernels.hpp",)):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/trmm_traffic.json), or None.  The figure is a
     committed measurement, not a counter read during this run: it is only returned while the kernel source it was measured on is unchanged
     (sha256 of the kernel headers recorded beside it), otherwise the line says null rather than carry a stale number."""
-    path = os.path.join(ROOT, "profiles", "trmm_traffic.json")
+    path = os.path.join(ROOT, "profiles", fname)
     try:
         with open(path) as fh:
             rec = json.load(fh)
@@ -248,17 +249,17 @@ def load_traffic(config, B):
         if not ent:
             return None
         want = ent.get("kernel_source_sha256")
-        if want and want != kernel_source_hash():
+        if want and want != kernel_source_hash(sources):
             return None
-        return ent["hbm_bytes_per_launch"]
+        return ent.get("hbm_bytes_per_launch", ent.get("hbm_bytes_per_call"))
     except Exception:
         return None
 
 
-def kernel_source_hash():
+def kernel_source_hash(sources=("psf_kernels.hpp",)):
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("psf_kernels.hpp",):
+    for f in sources:
         with open(os.path.join(ROOT, "tools_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]

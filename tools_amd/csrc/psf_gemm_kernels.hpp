@@ -270,14 +270,22 @@ template <bool NT>
 inline void launch_gemm(hipStream_t st, GemmArgs g, GemmWorkspace& w) {
   const unsigned tx = (unsigned)((g.N + GM_T - 1) / GM_T), ty = (unsigned)((g.M + GM_T - 1) / GM_T);
   const size_t nchunks = (g.K + GM_BK - 1) / GM_BK;
+  // K splits: the chip holds 512 workgroups of this kernel at once (2 per CU); a launch of T tiles x s splits runs in ceil(T s / 512) rounds, so s is
+  // chosen to fill the rounds it occupies (120 tiles: s = 4 -> 480 workgroups in one round; s = 5 would leave a second round 17 % full).  Every split
+  // keeps at least 8 chunks (128 coordinates); ties go to the smaller s (less workspace traffic).
   unsigned splits = 1;
-  if ((size_t)tx * ty < 384) {                                           // two workgroups per CU hide each other's barriers and load latency (measured:
-    splits = (unsigned)((512 + (size_t)tx * ty - 1) / ((size_t)tx * ty));  // 39 -> see profiles/r03_notes.md TFLOP/s on the Cholesky update shape with one per CU)
-    const size_t max_by_k = nchunks / 8 ? nchunks / 8 : 1;               // at least 8 chunks (128 coordinates) per split
-    if (splits > max_by_k) splits = (unsigned)max_by_k;
-    if (splits > 64) splits = 64;
-    const size_t need = (size_t)splits * ty * GM_T * tx * GM_T * sizeof(double);
-    if (splits > 1 && need > w.bytes) splits = 1;                        // (the caller sizes the workspace; never hit in this library)
+  {
+    const size_t T = (size_t)tx * ty;
+    size_t smax = nchunks / 8 ? nchunks / 8 : 1;
+    if (smax > 64) smax = 64;
+    double best_fill = 0.0;
+    for (size_t sc = 1; sc <= smax; ++sc) {
+      const size_t wg = T * sc, rounds = (wg + 511) / 512;
+      if ((size_t)sc * ty * GM_T * tx * GM_T * sizeof(double) > w.bytes && sc > 1) break;
+      const double fill = (double)wg / (double)(rounds * 512);
+      if (fill > best_fill + 0.02) { best_fill = fill; splits = (unsigned)sc; }
+      if (wg >= 4 * 512) break;                                            // several full rounds anyway
+    }
   }
   g.klen = ((nchunks + splits - 1) / splits) * GM_BK;
   splits = (unsigned)((g.K + g.klen - 1) / g.klen);
