@@ -597,6 +597,91 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
   if (f) atomicOr(fail, 1);
 }
 
+// The same rounding with a lean refill (round 3; narrow SampleZ words, i.e. ceil(6 r) + floor(6 r) + 1 <= 4096 -- every PSFPerturbation of BASELINE).
+// What the wave-compacted kernel above pays per iteration beside its Philox block and four screens -- sz_range in f64 for every lane, two 64-bit
+// cross-lane shuffles of the window registers, 64-bit sample ids -- is moved to where it is needed: the constants of a sample (range start, fp32
+// offset, Lemire threshold) are computed once when a lane TAKES the sample, the window of upcoming centres lives in a wave-private LDS ring of 256
+// doubles (one ds_read per refill; the ring is topped up 64 centres at a time from a register loaded one slide earlier), ids are 32-bit offsets into
+// the wave's segment.  Values are those of k_perturb_round_wave bit for bit: a sample's value is the first accepted attempt of its own stream.
+constexpr int PRL_SEG = 8192;
+constexpr int PRL_WIN = 256;
+__global__ __launch_bounds__(256) void k_perturb_round_lean(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
+                                                            const double* __restrict__ X, SampleZParams sp, int32_t* __restrict__ P,
+                                                            int* __restrict__ fail) {
+  __shared__ double s_win[4][PRL_WIN];
+  const int lane = threadIdx.x & 63;
+  double* win = s_win[threadIdx.x >> 6];
+  const size_t total = m * B;
+  const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PRL_SEG;
+  if (seg0 >= total) return;                                   // (no workgroup barrier below: a wave may leave alone)
+  const uint32_t nseg = (uint32_t)(total - seg0 < (size_t)PRL_SEG ? total - seg0 : (size_t)PRL_SEG);
+  const uint32_t coord0 = (uint32_t)(seg0 / B), b00 = (uint32_t)(seg0 % B), B32 = (uint32_t)B;
+  const bool few_wraps = B32 >= (uint32_t)PRL_SEG;             // then an offset wraps at most once
+  auto locate = [&](uint32_t off, uint32_t* coord, uint32_t* bb) {
+    const uint32_t o = b00 + off;
+    if (few_wraps) { const bool wrap = o >= B32; *coord = coord0 + (wrap ? 1u : 0u); *bb = wrap ? o - B32 : o; }
+    else { *coord = coord0 + o / B32; *bb = o % B32; }
+  };
+  auto gload = [&](uint32_t off) -> double {
+    if (off >= nseg) return 0.0;
+    uint32_t cc, bb;
+    locate(off, &cc, &bb);
+    return X[(size_t)cc * ld + bb];
+  };
+  // ring: offsets [loaded - 256, loaded) sit at index (offset & 255); pf holds the block [loaded, loaded + 64)
+  win[lane] = gload(lane); win[64 + lane] = gload(64 + lane); win[128 + lane] = gload(128 + lane);
+  uint32_t loaded = 192;
+  double pf = gload(192 + lane);
+  uint32_t my = (uint32_t)lane, next_free = 64;
+  bool active = my < nseg;
+  const float inv_s_f = (float)sp.inv_s;
+  double c = 0.0; float c_rel = 0.f; uint32_t coord = 0, b = 0, idx_lo = 0, tw = 0, t = 0;
+  SzRange rg{0, 1, 0, 16};
+  bool generic = false;
+  auto take = [&](uint32_t off) {                               // a lane adopts sample `off`: everything that depends on the sample only
+    c = win[off & (PRL_WIN - 1)];
+    locate(off, &coord, &b);
+    const uint64_t index = first_index + b;
+    idx_lo = (uint32_t)index;
+    tw = tag_word(TAG_PERTURB, index);
+    rg = sz_range(c, sp);
+    c_rel = (float)((double)rg.lo - c);
+    generic = !(fabs(c) < 0x1.0p40);
+    t = 0;
+  };
+  if (active) take(my);
+  int f = 0;
+  while (__ballot(active)) {
+    bool accept = false;
+    long long x = 0;
+    if (active) {
+      accept = generic ? sz_group4(seed, coord, idx_lo, tw, t, rg, c, sp.inv_s, &x)
+                       : sz_group4_narrow(seed, coord, idx_lo, tw, t, rg, c, sp.inv_s, c_rel, inv_s_f, &x);
+      if (!accept && ++t >= kMaxAttempts / 4) { accept = true; f = 1; x = (long long)floor(c + 0.5); }
+      if (accept) {
+        if (x > kDigitRangeP || x < -kDigitRangeP) f = 1;       // the syndrome product needs |p| < 2^23 (k_split_P)
+        P[(size_t)coord * ld + b] = (int32_t)x;
+      }
+    }
+    const uint64_t mask = __ballot(accept);
+    if (mask) {
+      const uint32_t nid = next_free + (uint32_t)lane_rank(mask);
+      next_free += (uint32_t)__popcll(mask);
+      while (loaded < next_free + 64 && loaded < nseg) {        // uniform: keep every offset below next_free + 64 in the ring
+        win[(loaded + lane) & (PRL_WIN - 1)] = pf;
+        loaded += 64;
+        pf = gload(loaded + lane);
+      }
+      if (accept) {
+        my = nid;
+        active = nid < nseg;
+        if (active) take(nid);
+      }
+    }
+  }
+  if (f) atomicOr(fail, 1);
+}
+
 // ---- integer products over Z_q ---------------------------------------------------------------------------
 // S[i][c] = sum_t a[i][t] * p[t][c]  (a in [0,q) as u64, p small signed), reduced mod q, then an epilogue:
 //   ZQ_SYNDROME : out[i][c] = (u[c][i] - S) mod q      out n x ld   (mp_perturbation.rs:318)

@@ -252,6 +252,34 @@ __device__ inline bool sz_group4(uint64_t seed, uint32_t coord, uint32_t idx_lo,
   *x_out = x;
   return accept;
 }
+// sz_group4 for narrow words with the per-SAMPLE part of the screen (c_rel = fp32(lo - c), fp32(1/s)) supplied by the caller, who computes it once per
+// sample instead of once per group of attempts.  Same classes, same exact decisions, same value.
+__device__ inline bool sz_group4_narrow(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t g, const SzRange rg, double center,
+                                        double inv_s, float c_rel, float inv_s_f, long long* x_out) {
+  const U4 w = philox(seed, coord, idx_lo, g, tw);
+  const uint32_t word[4] = {w.x, w.y, w.z, w.w};
+  int tm = -1, cls = 0;
+  uint32_t idxm = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t idx = 0;
+    const int cj = sz_screen16(word[j], rg, c_rel, inv_s_f, &idx);
+    if (tm < 0 && cj) { tm = j; idxm = idx; cls = cj; }
+  }
+  if (tm < 0) return false;
+  long long x = rg.lo + (long long)idxm;
+  *x_out = x;
+  if (cls == 1) return true;                       // the first surviving attempt is a certain accept: no f64 evaluation at all
+  const uint32_t wbm = word[tm] & 0xffffu;
+  bool accept = sz_decide(seed, coord, idx_lo, tw, 4 * g + (uint32_t)tm, x, wbm, center, inv_s, 16);
+  if (!accept) {
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      if (!accept && j > tm) accept = sz_attempt(seed, coord, idx_lo, tw, 4 * g + (uint32_t)j, word[j] >> 16, word[j] & 0xffffu, rg, center, inv_s, &x);
+    *x_out = x;
+  }
+  return accept;
+}
 #endif
 
 __host__ __device__ inline long long sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center,

@@ -775,8 +775,14 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   }
   {  // p_i <- D_{Z,r,x_i}
     ScopedTimer t(h, s2, "k_perturb_round");
-    const size_t waves = (m * B + PR_SEG - 1) / PR_SEG;
-    hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
+    const char* renv = std::getenv("PSF_ROUND");                 // "wave": the round-2 kernel (comparison arm; same bits)
+    if (h->szR.sh == 16 && !(renv && !std::strcmp(renv, "wave"))) {
+      const size_t waves = (m * B + PRL_SEG - 1) / PRL_SEG;
+      hipLaunchKernelGGL(k_perturb_round_lean, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
+    } else {
+      const size_t waves = (m * B + PR_SEG - 1) / PR_SEG;
+      hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
+    }
   }
   {  // mp_perturbation.rs:318 -- v = u - A p
     ScopedTimer t(h, s2, "k_zq_matmul(syndrome)");
