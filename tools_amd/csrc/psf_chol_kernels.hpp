@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ A, size_
 // below -- thread (i = t % 128, h = t / 128) takes the columns j < c <= i with c = j + 1 + h (mod 2): lanes walk rows (stride 129: no bank
 // conflict), the pivot column is a broadcast.  L11 goes back to A; the inverse (lower triangular, written to Linv row-major, zeros above the
 // diagonal) is formed in place from the last column to the first: X[i][j] = -(sum_{j < t <= i} X[i][t] L[t][j]) / L[j][j].
-__global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, size_t ld, size_t off, int nb, double* __restrict__ Linv, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, size_t ld, size_t off, int nb, double* __restrict__ Linv, int* __restrict__ info, size_t report_base) {
   extern __shared__ __attribute__((aligned(16))) double ch_smem[];   // nb x (CH_NB + 1) | one column
   constexpr int LD = CH_NB + 1;
   double* __restrict__ sG = ch_smem;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, s
   for (int j = 0; j < nb; ++j) {
     const double d = sG[j * LD + j];
     if (!(d > 0.0)) {                       // not positive definite (uniform: every thread reads the same word)
-      if (tid == 0) atomicCAS(info, 0, (int)(off + j + 1));
+      if (tid == 0) atomicCAS(info, 0, (int)(report_base + j + 1));
       return;
     }
     const double sd = sqrt(d);
@@ -109,6 +109,120 @@ __global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, s
   for (int e = tid; e < nb * CH_NB; e += 256) {
     const int r = e >> 7, c = e & 127;
     if (r < nb && c < nb) Linv[(size_t)r * CH_NB + c] = (c <= r) ? sG[r * LD + c] : 0.0;
+  }
+}
+
+// ---- Cholesky directly on the key's chunk stream (round 3, the default) ---------------------------------------------------------------------
+// sqrt(Sigma_2) is stored as the fragment-ordered chunk stream k_trmm_f64_big reads (psf_kernels.hpp: chunk (bi, c) = 128 rows x 16 columns).  A row block
+// of that stream is at the same time the A operand AND -- its rows in the role of columns -- the B operand of an MFMA product, so the update of panel j,
+//     P(bi, j)  =  Sigma_2(bi, j)  -  sum_{c < 8 j} L(bi, c) L(j, c)^t            for every row block bi >= j,
+// is the register-streaming loop of k_trmm_f64_big run on two row blocks of the SAME stream (no LDS, no barrier, 256 AccVGPRs of accumulators, four
+// k-steps in flight; the K loop below is that kernel's, statement for statement).  The dense m x m matrix of rounds 1-2 (7.6 GB at C3, 121 GB at C5)
+// no longer exists: Sigma_2 is assembled panel by panel into a dense (m - 128 j) x 128 buffer, the product is subtracted from it, the diagonal block is
+// factored and inverted (k_chol_diag_inv), the rows below are multiplied by the inverse (k_gemm_f64), and the finished panel is written into the
+// stream (k_chol_pack_panel).  A panel has at most nbi / 2 workgroup tiles (256 rows x 128 columns), fewer than the chip has CUs, so K is cut over
+// gridDim.y workgroups in units of two chunks; the partial tiles go to a workspace and k_chol_panel_reduce subtracts them in split order (no atomics).
+__global__ __launch_bounds__(256, 1) void k_chol_update_big(const double* __restrict__ Lt, int j, int nbi, int bt0, int units_total,
+                                                            double* __restrict__ Pbuf, double* __restrict__ ws, size_t ws_stride) {
+  const int bt = bt0 + (int)blockIdx.x;                               // row tile of 256 rows, counted from the panel's first row block
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int bi = j + 2 * bt + wr;
+  // K range of this split, in units of two chunks (8 k-steps of 4 coordinates): [u0, u1) of units_total = 4 j
+  const int nz = (int)gridDim.y, z = (int)blockIdx.y;
+  const int u0 = (int)(((long long)units_total * z) / nz), u1 = (int)(((long long)units_total * (z + 1)) / nz);
+  const int nsteps = (u1 - u0) * 8;
+  if (bi >= nbi) return;                                              // (no barrier in this kernel)
+  d4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = d4{0.0, 0.0, 0.0, 0.0};
+  if (nsteps > 0) {
+    const double* gA = Lt + (tr_rowblock_base((size_t)bi) + (size_t)u0 * 2) * TR_CHUNK;                          // wave-uniform
+    const double* gB = Lt + (tr_rowblock_base((size_t)j) + (size_t)u0 * 2) * TR_CHUNK + (size_t)(wc * 4) * 64;
+    const uint32_t voff = (uint32_t)lane * 8u;
+    double a[TR_BIG_PD][8], b[TR_BIG_PD][4];
+    auto issue = [&](double (&av)[8], double (&bv)[4], int s) {
+      const double* pa = gA + (size_t)s * 512;
+      const double* pb = gB + (size_t)s * 512;
+      TR_LOAD8(av[0], voff, pa, 0); TR_LOAD8(av[1], voff, pa, 512); TR_LOAD8(av[2], voff, pa, 1024); TR_LOAD8(av[3], voff, pa, 1536);
+      TR_LOAD8(av[4], voff, pa, 2048); TR_LOAD8(av[5], voff, pa, 2560); TR_LOAD8(av[6], voff, pa, 3072); TR_LOAD8(av[7], voff, pa, 3584);
+      TR_LOAD8(bv[0], voff, pb, 0); TR_LOAD8(bv[1], voff, pb, 512); TR_LOAD8(bv[2], voff, pb, 1024); TR_LOAD8(bv[3], voff, pb, 1536);
+    };
+#define CH_MFMA(i, jj) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i][jj]) : "v"(av[i]), "v"(bv[jj]))
+    auto step = [&](double (&av)[8], double (&bv)[4], int sn) {
+      const double* pa = gA + (size_t)sn * 512;
+      const double* pb = gB + (size_t)sn * 512;
+      CH_MFMA(0, 0); CH_MFMA(0, 1); CH_MFMA(0, 2); CH_MFMA(0, 3); TR_LOAD8(av[0], voff, pa, 0);
+      CH_MFMA(1, 0); CH_MFMA(1, 1); CH_MFMA(1, 2); CH_MFMA(1, 3); TR_LOAD8(av[1], voff, pa, 512);
+      CH_MFMA(2, 0); CH_MFMA(2, 1); CH_MFMA(2, 2); CH_MFMA(2, 3); TR_LOAD8(av[2], voff, pa, 1024);
+      CH_MFMA(3, 0); CH_MFMA(3, 1); CH_MFMA(3, 2); CH_MFMA(3, 3); TR_LOAD8(av[3], voff, pa, 1536);
+      CH_MFMA(4, 0); CH_MFMA(4, 1); CH_MFMA(4, 2); CH_MFMA(4, 3); TR_LOAD8(av[4], voff, pa, 2048);
+      CH_MFMA(5, 0); CH_MFMA(5, 1); CH_MFMA(5, 2); CH_MFMA(5, 3); TR_LOAD8(av[5], voff, pa, 2560);
+      CH_MFMA(6, 3); CH_MFMA(7, 3); TR_LOAD8(bv[3], voff, pb, 1536);
+      CH_MFMA(6, 2); CH_MFMA(7, 2); TR_LOAD8(bv[2], voff, pb, 1024);
+      CH_MFMA(6, 1); CH_MFMA(7, 1); TR_LOAD8(bv[1], voff, pb, 512);
+      CH_MFMA(6, 0); CH_MFMA(7, 0); TR_LOAD8(bv[0], voff, pb, 0);
+      TR_LOAD8(av[6], voff, pa, 3072); TR_LOAD8(av[7], voff, pa, 3584);
+    };
+#pragma unroll
+    for (int u = 0; u < TR_BIG_PD; ++u) issue(a[u], b[u], u);
+    for (int s0 = 0; s0 < nsteps; s0 += TR_BIG_PD * 2) {                // nsteps is a multiple of 8
+#pragma unroll
+      for (int rnd = 0; rnd < 2; ++rnd)
+#pragma unroll
+        for (int u = 0; u < TR_BIG_PD; ++u) {
+          TR_WAIT12(36, a[u], b[u]);
+          static_assert(TR_BIG_PD == 4, "the wait count above is 12 (TR_BIG_PD - 1)");
+          int sn = s0 + rnd * TR_BIG_PD + u + TR_BIG_PD;
+          sn = sn < nsteps ? sn : nsteps - 1;                           // past the end: re-read the last step (never consumed)
+          step(a[u], b[u], sn);
+        }
+    }
+#undef CH_MFMA
+#pragma unroll
+    for (int u = 0; u < TR_BIG_PD; ++u) TR_WAIT12(0, a[u], b[u]);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMA retires before an accumulator is read (see k_trmm_f64_big)
+  }
+  // C/D map of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 reg.  Row r of the panel buffer = row (j * 128 + r) of the matrix.
+  const size_t prow0 = (size_t)(2 * bt + wr) * TR_BM;
+  double* dst = ws ? ws + (size_t)z * ws_stride : Pbuf;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t at = (prow0 + i * 16 + (lane >> 4) + 4 * r) * TR_BM + wc * 64 + jj * 16 + (lane & 15);
+        if (ws) dst[at] = acc[i][jj][r];
+        else dst[at] -= acc[i][jj][r];
+      }
+}
+
+// Pbuf[rows x 128] -= sum_z ws[z] (split order)
+__global__ void k_chol_panel_reduce(double* __restrict__ Pbuf, const double* __restrict__ ws, size_t ws_stride, int splits, size_t first, size_t count) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * ws_stride + first + e];
+    Pbuf[first + e] -= s;
+  }
+}
+
+// the finished panel j (dense, rows = matrix rows j * 128 .., 128 columns) -> chunks (bi, 8 j + kc) of the stream; above the diagonal and beyond m: zero
+__global__ void k_chol_pack_panel(const double* __restrict__ Pbuf, int j, int nbi, size_t m, double* __restrict__ Lt) {
+  const size_t total = (size_t)(nbi - j) * 8 * TR_CHUNK;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t cidx = g / TR_CHUNK;
+    const int pos = (int)(g % TR_CHUNK);
+    const size_t bl = cidx / 8, kc = cidx % 8;                       // row block (from j), chunk inside the panel
+    const int ks = pos >> 9, tile = (pos >> 6) & 7, ln = pos & 63;
+    const size_t r = tile * 16 + (ln & 15), kk = kc * 16 + ks * 4 + (ln >> 4);
+    const size_t row = ((size_t)j + bl) * TR_BM + r, col = (size_t)j * TR_BM + kk;
+    double v = 0.0;
+    if (row < m && col <= row) v = Pbuf[(bl * TR_BM + r) * TR_BM + kk];
+    Lt[(tr_rowblock_base((size_t)j + bl) + (size_t)j * 8 + kc) * TR_CHUNK + pos] = v;
   }
 }
 

@@ -1672,11 +1672,13 @@ __global__ void k_sample_R(uint64_t seed, size_t mbar, size_t w, size_t ldr, int
 // dense row-major m x m matrix.  Sigma = s^2 I (Sig == nullptr: the form trap_gen passes, :227-231) or any symmetric matrix given as its
 // packed lower triangle (row i: i + 1 entries).  The R R^t block is a dot4 product of 64 x 64 row pairs.
 __global__ __launch_bounds__(256) void k_sigma2(const int8_t* __restrict__ R, size_t ldr, size_t mbar, size_t w, size_t m,
-                                                double nf_r2, double s2, double b2p1, const double* __restrict__ Sig, double* __restrict__ S, size_t lds) {
+                                                double nf_r2, double s2, double b2p1, const double* __restrict__ Sig, double* __restrict__ S, size_t lds,
+                                                size_t row_off, size_t col_off) {
   __shared__ uint32_t sRi[64][17];
   __shared__ uint32_t sRj[64][17];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const size_t i0 = (size_t)blockIdx.y * 64, j0 = (size_t)blockIdx.x * 64;
+  // (row_off, col_off): the tile grid covers rows row_off.. and columns col_off.. of Sigma_2 and S holds that window (the panel-wise Cholesky)
+  const size_t i0 = row_off + (size_t)blockIdx.y * 64, j0 = col_off + (size_t)blockIdx.x * 64;
   if (j0 > i0 + 63) return;  // strictly upper tile
   int32_t acc[4][4];
 #pragma unroll
@@ -1725,7 +1727,7 @@ __global__ __launch_bounds__(256) void k_sigma2(const int8_t* __restrict__ R, si
       const double sg = Sig ? Sig[i * (i + 1) / 2 + j] : ((i == j) ? s2 : 0.0);
       double sp = sg - b2p1 * tt;
       if (i == j) sp = sp - 1.0;
-      S[i * lds + j] = nf_r2 * sp;
+      S[(i - row_off) * lds + (j - col_off)] = nf_r2 * sp;
     }
 }
 

@@ -411,6 +411,84 @@ size_t psfp_m(const psfp_handle* h) { return h ? h->m : 0; }
 // Structured mode factors Sigma_2 = c [[alpha I - kappa R R^t, -kappa R], [-kappa R^t, beta I]]  (c = r^2 / 2 pi, kappa = b^2 + 1, alpha = s^2 - 1,
 // beta = alpha - kappa) as B B^t with B = [[L_1 / sqrt c, -kappa R / sqrt beta], [0, sqrt beta I]] sqrt c, where L_1 is the Cholesky factor of
 // c (alpha I - kappa (alpha / beta) R R^t): only that m_bar x m_bar block is assembled, factored and stored.
+// Cholesky of Sigma_2 directly on the key's chunk stream (psf_chol_kernels.hpp, "Cholesky directly on the key's chunk stream"): no dense m x m matrix.
+static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double s2, double b2p1, const double* d_sig) {
+  const size_t m = h->mL;
+  const int nbi = (int)h->nbiL;
+  const size_t prow = (size_t)nbi * TR_BM;                            // rows of the panel buffer (panel 0 needs them all)
+  // K splits of the update: about one workgroup per CU (the kernel is a one-workgroup-per-CU design), each split at least one unit of two chunks
+  auto splits_for = [](int tiles, int units) { int sp = tiles > 0 ? (256 + tiles - 1) / tiles : 1; if (sp > units) sp = units; if (sp > 64) sp = 64; return sp < 1 ? 1 : sp; };
+  size_t ws_doubles = 0;
+  for (int j = 1; j < nbi; ++j) {
+    const int T = (nbi - j + 1) / 2;
+    const size_t a = (size_t)splits_for(1, 4 * j) * 2 * TR_BM * TR_BM;
+    const size_t b = T > 1 ? (size_t)splits_for(T - 1, 4 * j) * (size_t)(T - 1) * 2 * TR_BM * TR_BM : 0;
+    if (a > ws_doubles) ws_doubles = a;
+    if (b > ws_doubles) ws_doubles = b;
+  }
+  double *dPn = nullptr, *dLi = nullptr, *dWs = nullptr; int* dinfo = nullptr;
+  hipStream_t sm = nullptr, sd = nullptr;
+  hipEvent_t evTile = nullptr, evDiag = nullptr;
+  GemmWorkspace w;                                                    // the solve against the inverse never cuts K (K = 128)
+  auto cleanup = [&]() { if (sm) hipStreamDestroy(sm); if (sd) hipStreamDestroy(sd); if (evTile) hipEventDestroy(evTile); if (evDiag) hipEventDestroy(evDiag);
+                         hipFree(dPn); hipFree(dLi); hipFree(dWs); hipFree(dinfo); };
+  const size_t diag_lds = ((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double);
+  if (gemm_prepare() != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds) != hipSuccess ||
+      hipMalloc(&dPn, prow * TR_BM * sizeof(double)) != hipSuccess || hipMalloc(&dLi, CH_NB * CH_NB * sizeof(double)) != hipSuccess ||
+      (ws_doubles && hipMalloc(&dWs, ws_doubles * sizeof(double)) != hipSuccess) || hipMalloc(&dinfo, sizeof(int)) != hipSuccess ||
+      hipMemset(dinfo, 0, sizeof(int)) != hipSuccess || hipMemset(dPn, 0, prow * TR_BM * sizeof(double)) != hipSuccess ||
+      hipStreamCreateWithFlags(&sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&evTile, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDiag, hipEventDisableTiming) != hipSuccess) {
+    cleanup();
+    return PSF_ERR_HIP;
+  }
+  HIP_TRY(hipDeviceSynchronize());                                    // R (and k_pack_R8) were produced on the default stream
+  for (int j = 0; j < nbi; ++j) {
+    const size_t off = (size_t)j * TR_BM;
+    const size_t nb = m - off < (size_t)TR_BM ? m - off : (size_t)TR_BM;
+    const size_t rest = m - off - nb;
+    const int T = (nbi - j + 1) / 2;                                  // 256-row workgroup tiles of the panel
+    // Sigma_2 restricted to the panel (rows off.., columns off..off+127), dense with leading dimension 128
+    hipLaunchKernelGGL(k_sigma2, dim3(2, (unsigned)((m - off + 63) / 64)), dim3(256), 0, sm, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sig, dPn, (size_t)TR_BM, off, off);
+    if (j > 0) {
+      auto update = [&](int bt0, int count) {
+        const int sp = splits_for(count, 4 * j);
+        const size_t stride = (size_t)count * 2 * TR_BM * TR_BM;      // doubles per split in the workspace
+        double* P0 = dPn + (size_t)bt0 * 2 * TR_BM * TR_BM;
+        hipLaunchKernelGGL(k_chol_update_big, dim3((unsigned)count, (unsigned)sp), dim3(256), 0, sm, h->dLt, j, nbi, bt0, 4 * j, P0 - (size_t)bt0 * 2 * TR_BM * TR_BM,
+                           sp > 1 ? dWs - (size_t)bt0 * 2 * TR_BM * TR_BM : (double*)nullptr, stride);
+        if (sp > 1) {
+          size_t cnt = stride;
+          const size_t first = (size_t)bt0 * 2 * TR_BM * TR_BM;
+          if (first + cnt > prow * TR_BM) cnt = prow * TR_BM - first; // an odd number of row blocks leaves the last tile's lower half outside the buffer
+          hipLaunchKernelGGL(k_chol_panel_reduce, dim3(grid_for(cnt, 256, 2048)), dim3(256), 0, sm, dPn + first, dWs, stride, sp, (size_t)0, cnt);
+        }
+      };
+      update(0, 1);                                                   // the tile that holds the diagonal block goes first ...
+      hipEventRecord(evTile, sm);
+      if (T > 1) update(1, T - 1);                                    // ... the rows below are updated while the diagonal block is factored on the other stream
+    } else {
+      hipEventRecord(evTile, sm);
+    }
+    hipStreamWaitEvent(sd, evTile, 0);
+    hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sd, dPn, (size_t)TR_BM, (size_t)0, (int)nb, dLi, dinfo, off);
+    hipEventRecord(evDiag, sd);
+    hipStreamWaitEvent(sm, evDiag, 0);
+    if (rest)                                                         // rows below = panel L11^-t (in place: one column tile, a workgroup reads only its own rows)
+      launch_gemm<true>(sm, GemmArgs{dPn + TR_BM * TR_BM, (size_t)TR_BM, dLi, (size_t)CH_NB, dPn + TR_BM * TR_BM, (size_t)TR_BM, rest, nb, nb, 1.0, 0.0, nullptr, nullptr, 0}, w);
+    hipLaunchKernelGGL(k_chol_pack_panel, dim3(grid_for((size_t)(nbi - j) * 8 * TR_CHUNK, 256, 4096)), dim3(256), 0, sm, dPn, j, nbi, m, h->dLt);
+  }
+  hipError_t ce = hipStreamSynchronize(sm);
+  if (ce == hipSuccess) ce = hipStreamSynchronize(sd);
+  if (ce == hipSuccess) ce = hipGetLastError();
+  int info = -1;
+  if (ce == hipSuccess) ce = hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost);
+  cleanup();
+  if (ce != hipSuccess) return PSF_ERR_HIP;
+  return info != 0 ? PSF_ERR_NOT_PD : PSF_OK;                         // mp_perturbation.rs:109-110
+}
+
 static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* d_sigma_packed = nullptr) {
   const double TWO_PI = 6.283185307179586476925;
   const double nf_r2 = (1.0 / TWO_PI) * (h->prm.r * h->prm.r);
@@ -425,11 +503,15 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     h->h_const = std::sqrt(nf_r2 * beta);
     hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(round_up(h->mb, 64) * h->ldr, 256, 256 * 64)), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, round_up(h->mb, 64), h->ldr, h->dR8);
   }
+  {
+    const char* ce = std::getenv("PSF_CHOL");                        // default: on the chunk stream; "gemm": left-looking on a dense matrix; "right": rounds 1-2
+    if (!ce || !std::strcmp(ce, "stream")) return build_sqrt_sigma2_stream(h, nf_r2, s2, b2p1, d_sigma_packed);
+  }
   double* dS = nullptr;
   HIP_TRY(hipMalloc(&dS, m * m * sizeof(double)));
   HIP_TRY(hipMemset(dS, 0, m * m * sizeof(double)));
   const unsigned tiles = (unsigned)((m + 63) / 64);
-  hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sigma_packed, dS, m);
+  hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sigma_packed, dS, m, (size_t)0, (size_t)0);
   HIP_TRY(hipGetLastError());
   // blocked Cholesky of the lower triangle, panel width 128 (psf_chol_kernels.hpp): left-looking on the FP64 GEMM; PSF_CHOL=right: the right-looking
   // kernels of rounds 1-2 (comparison arm)
@@ -478,7 +560,7 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
         if (rest) launch_gemm<true>(sm, GemmArgs{dS + (off + nb) * m, m, dS + off * m, m, P2, m, rest, nb, off, -1.0, 1.0, nullptr, nullptr, 0}, w);
         hipStreamWaitEvent(sd, evTile, 0);
       }
-      hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sd, dS, m, off, (int)nb, dLi, dinfo);
+      hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sd, dS, m, off, (int)nb, dLi, dinfo, off);
       hipEventRecord(evDiag, sd);
       hipStreamWaitEvent(sm, evDiag, 0);
       if (rest == 0) break;
