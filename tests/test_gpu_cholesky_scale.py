@@ -134,3 +134,28 @@ def test_full_size_preimages_have_the_right_variance_in_every_panel(c3):
     corr = np.corrcoef(sub.T)
     np.fill_diagonal(corr, 0)
     assert np.abs(corr).max() < 5.5 / math.sqrt(B), np.abs(corr).max()
+
+
+@pytest.mark.parametrize("n,q", [(8, 64), (20, 257), (40, 2**20)])
+def test_the_three_cholesky_forms_agree(monkeypatch, oracle, n, q):
+    """PSF_CHOL selects the factorisation: on the key's chunk stream (the default for large keys: no dense matrix), left-looking on a dense matrix with
+    the LDS-staged GEMM (the default below 16 GB), right-looking (rounds 1-2).  Same key seed: A and R are bitwise equal, the factors agree with each
+    other and with the oracle's unblocked recurrence within rounding, and each reproduces Sigma_2; m runs from one partial panel to several panels."""
+    import tools_amd as T
+    r, s = 4.0, 120.0
+    gp = T.GadgetParameters.init_default(n, q)
+    got = {}
+    for form in ("stream", "gemm", "right"):
+        monkeypatch.setenv("PSF_CHOL", form)
+        psf = T.PSFPerturbation(gp, r, s)
+        A, (R, Lp, _) = psf.trap_gen(6)
+        got[form] = (A, R, Lp)
+        psf.close()
+    A, R, L0 = got["stream"]
+    for form in ("gemm", "right"):
+        assert (got[form][0] == A).all() and (got[form][1] == R).all()
+        np.testing.assert_allclose(got[form][2], L0, rtol=0, atol=1e-10 * np.abs(L0).max())
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s)
+    rc, Lref = orc.compute_sqrt_sigma_2(R, s)
+    assert rc == 0
+    np.testing.assert_allclose(L0, Lref, rtol=0, atol=1e-10 * np.abs(Lref).max())

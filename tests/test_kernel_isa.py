@@ -1,4 +1,4 @@
-"""The default FP64 product k_trmm_f64_big relies on orderings the compiler cannot see (asm-statement MFMAs, loads whose results are
+"""The default FP64 product k_trmm_f64_big -- and k_chol_update_big, the same K loop run on two row blocks of the key's chunk stream -- rely on orderings the compiler cannot see (asm-statement MFMAs, loads whose results are
 in flight, a hand-written drain before the accumulators are read).  This test compiles the device code for gfx950 (no GPU needed) and
 checks the EMITTED instruction stream, so that a toolchain bump which breaks one of the assumptions fails here and not as a silent
 wrong bit on the GPU (psf_kernels.hpp).  If it fails: PSF_TRMM_VARIANT=1 (k_trmm_f64_reg, builtin MFMAs) is the fallback."""
@@ -13,21 +13,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+KERNELS = {"k_trmm_f64_big": r"_ZN3psf14k_trmm_f64_big\w+", "k_chol_update_big": r"_ZN3psf17k_chol_update_big\w+"}
+
+
+@pytest.fixture(scope="module", params=sorted(KERNELS))
+def big_isa(request, device_asm):
+    m = re.search(r"^(" + KERNELS[request.param] + r"):.*?^\s*\.end_amdhsa_kernel", device_asm, re.S | re.M)
+    assert m, request.param + " not found in the device assembly"
+    body = m.group(0)
+    ins = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith(";") and not ln.strip().startswith(".")
+           or ln.strip().startswith(".LBB")]
+    return body, ins
+
+
 @pytest.fixture(scope="module")
-def big_isa(tmp_path_factory):
+def device_asm(tmp_path_factory):
     if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
         pytest.skip("no hipcc on this host")
     out = tmp_path_factory.mktemp("isa") / "psfp.s"
     src = os.path.join(ROOT, "tools_amd", "csrc", "psfp.hip")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
                            "--cuda-device-only", "-S", "-o", str(out), "-x", "hip", src], stderr=subprocess.DEVNULL)
-    text = out.read_text()
-    m = re.search(r"^(_ZN3psf14k_trmm_f64_big\w+):.*?^\s*\.end_amdhsa_kernel", text, re.S | re.M)
-    assert m, "k_trmm_f64_big not found in the device assembly"
-    body = m.group(0)
-    ins = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith(";") and not ln.strip().startswith(".")
-           or ln.strip().startswith(".LBB")]
-    return body, ins
+    return out.read_text()
 
 
 def _inner_loop(ins):

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, s
 // stream (k_chol_pack_panel).  A panel has at most nbi / 2 workgroup tiles (256 rows x 128 columns), fewer than the chip has CUs, so K is cut over
 // gridDim.y workgroups in units of two chunks; the partial tiles go to a workspace and k_chol_panel_reduce subtracts them in split order (no atomics).
 __global__ __launch_bounds__(256, 1) void k_chol_update_big(const double* __restrict__ Lt, int j, int nbi, int bt0, int units_total,
-                                                            double* __restrict__ Pbuf, double* __restrict__ ws, size_t ws_stride) {
+                                                            double* __restrict__ ws, size_t ws_stride) {
   const int bt = bt0 + (int)blockIdx.x;                               // row tile of 256 rows, counted from the panel's first row block
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,18 +186,20 @@ __global__ __launch_bounds__(256, 1) void k_chol_update_big(const double* __rest
     for (int u = 0; u < TR_BIG_PD; ++u) TR_WAIT12(0, a[u], b[u]);
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMA retires before an accumulator is read (see k_trmm_f64_big)
   }
-  // C/D map of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 reg.  Row r of the panel buffer = row (j * 128 + r) of the matrix.
-  const size_t prow0 = (size_t)(2 * bt + wr) * TR_BM;
-  double* dst = ws ? ws + (size_t)z * ws_stride : Pbuf;
+  // C/D map of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 reg.  The product goes to the workspace with plain stores, exactly the epilogue of
+  // k_trmm_f64_big (a read-modify-write of the panel here cost the register allocation its shape: spills of loads in flight, accumulators shuttled out of
+  // the AccVGPRs inside the loop); k_chol_panel_reduce subtracts it from the panel also when K is not cut.
+  const size_t row0 = (size_t)(2 * bt + wr) * TR_BM, col0 = (size_t)wc * 64;
+  double* __restrict__ Xo = ws + (size_t)z * ws_stride;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const size_t at = (prow0 + i * 16 + (lane >> 4) + 4 * r) * TR_BM + wc * 64 + jj * 16 + (lane & 15);
-        if (ws) dst[at] = acc[i][jj][r];
-        else dst[at] -= acc[i][jj][r];
+      for (int r = 0; r < 4; ++r)
+      {
+        const size_t row = row0 + i * 16 + (lane >> 4) + 4 * r;
+        Xo[row * TR_BM + col0 + jj * 16 + (lane & 15)] = acc[i][jj][r];
       }
 }
 

@@ -415,9 +415,9 @@ size_t psfp_m(const psfp_handle* h) { return h ? h->m : 0; }
 static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double s2, double b2p1, const double* d_sig) {
   const size_t m = h->mL;
   const int nbi = (int)h->nbiL;
-  const size_t prow = (size_t)nbi * TR_BM;                            // rows of the panel buffer (panel 0 needs them all)
-  // K splits of the update: about one workgroup per CU (the kernel is a one-workgroup-per-CU design), each split at least one unit of two chunks
-  auto splits_for = [](int tiles, int units) { int sp = tiles > 0 ? (256 + tiles - 1) / tiles : 1; if (sp > units) sp = units; if (sp > 64) sp = 64; return sp < 1 ? 1 : sp; };
+  const size_t prow = (size_t)nbi * TR_BM;                            // rows of a panel buffer (panel 0 needs them all)
+  // K splits of the update: at most one workgroup per CU (the kernel is a one-workgroup-per-CU design), each split at least one unit of two chunks
+  auto splits_for = [](int tiles, int units) { int sp = tiles > 0 ? 256 / tiles : 1; if (sp > units) sp = units; if (sp > 64) sp = 64; return sp < 1 ? 1 : sp; };
   size_t ws_doubles = 0;
   for (int j = 1; j < nbi; ++j) {
     const int T = (nbi - j + 1) / 2;
@@ -426,44 +426,54 @@ static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double 
     if (a > ws_doubles) ws_doubles = a;
     if (b > ws_doubles) ws_doubles = b;
   }
-  double *dPn = nullptr, *dLi = nullptr, *dWs = nullptr; int* dinfo = nullptr;
-  hipStream_t sm = nullptr, sd = nullptr;
-  hipEvent_t evTile = nullptr, evDiag = nullptr;
+  double *dPn[2] = {nullptr, nullptr}, *dLi = nullptr, *dWs = nullptr; int* dinfo = nullptr;
+  hipStream_t sm = nullptr, sd = nullptr, ss = nullptr;               // products / diagonal blocks / Sigma_2 panels (one panel ahead)
+  hipEvent_t evTile = nullptr, evDiag = nullptr, evSig[2] = {nullptr, nullptr}, evPack[2] = {nullptr, nullptr};
   GemmWorkspace w;                                                    // the solve against the inverse never cuts K (K = 128)
-  auto cleanup = [&]() { if (sm) hipStreamDestroy(sm); if (sd) hipStreamDestroy(sd); if (evTile) hipEventDestroy(evTile); if (evDiag) hipEventDestroy(evDiag);
-                         hipFree(dPn); hipFree(dLi); hipFree(dWs); hipFree(dinfo); };
+  auto cleanup = [&]() {
+    for (hipStream_t st : {sm, sd, ss}) if (st) hipStreamDestroy(st);
+    for (hipEvent_t ev : {evTile, evDiag, evSig[0], evSig[1], evPack[0], evPack[1]}) if (ev) hipEventDestroy(ev);
+    hipFree(dPn[0]); hipFree(dPn[1]); hipFree(dLi); hipFree(dWs); hipFree(dinfo);
+  };
   const size_t diag_lds = ((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double);
-  if (gemm_prepare() != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds) != hipSuccess ||
-      hipMalloc(&dPn, prow * TR_BM * sizeof(double)) != hipSuccess || hipMalloc(&dLi, CH_NB * CH_NB * sizeof(double)) != hipSuccess ||
-      (ws_doubles && hipMalloc(&dWs, ws_doubles * sizeof(double)) != hipSuccess) || hipMalloc(&dinfo, sizeof(int)) != hipSuccess ||
-      hipMemset(dinfo, 0, sizeof(int)) != hipSuccess || hipMemset(dPn, 0, prow * TR_BM * sizeof(double)) != hipSuccess ||
-      hipStreamCreateWithFlags(&sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&evTile, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDiag, hipEventDisableTiming) != hipSuccess) {
-    cleanup();
-    return PSF_ERR_HIP;
-  }
+  bool ok = gemm_prepare() == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds) == hipSuccess &&
+            hipMalloc(&dPn[0], prow * TR_BM * sizeof(double)) == hipSuccess && hipMalloc(&dPn[1], prow * TR_BM * sizeof(double)) == hipSuccess &&
+            hipMalloc(&dLi, CH_NB * CH_NB * sizeof(double)) == hipSuccess && (!ws_doubles || hipMalloc(&dWs, ws_doubles * sizeof(double)) == hipSuccess) &&
+            hipMalloc(&dinfo, sizeof(int)) == hipSuccess && hipMemset(dinfo, 0, sizeof(int)) == hipSuccess &&
+            hipMemset(dPn[0], 0, prow * TR_BM * sizeof(double)) == hipSuccess && hipMemset(dPn[1], 0, prow * TR_BM * sizeof(double)) == hipSuccess;
+  for (hipStream_t* st : {&sm, &sd, &ss}) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t* ev : {&evTile, &evDiag, &evSig[0], &evSig[1], &evPack[0], &evPack[1]}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { cleanup(); return PSF_ERR_HIP; }
   HIP_TRY(hipDeviceSynchronize());                                    // R (and k_pack_R8) were produced on the default stream
+  // Sigma_2 restricted to panel j (rows off.., columns off..off+127), dense with leading dimension 128; it does not depend on the factorisation, so it
+  // is assembled one panel ahead on its own stream into the other of two panel buffers
+  auto sigma_panel = [&](int j) {
+    const size_t off = (size_t)j * TR_BM;
+    hipLaunchKernelGGL(k_sigma2, dim3(2, (unsigned)((m - off + 63) / 64)), dim3(256), 0, ss, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sig, dPn[j & 1], (size_t)TR_BM, off, off);
+    hipEventRecord(evSig[j & 1], ss);
+  };
+  sigma_panel(0);
   for (int j = 0; j < nbi; ++j) {
     const size_t off = (size_t)j * TR_BM;
     const size_t nb = m - off < (size_t)TR_BM ? m - off : (size_t)TR_BM;
     const size_t rest = m - off - nb;
     const int T = (nbi - j + 1) / 2;                                  // 256-row workgroup tiles of the panel
-    // Sigma_2 restricted to the panel (rows off.., columns off..off+127), dense with leading dimension 128
-    hipLaunchKernelGGL(k_sigma2, dim3(2, (unsigned)((m - off + 63) / 64)), dim3(256), 0, sm, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sig, dPn, (size_t)TR_BM, off, off);
+    double* P = dPn[j & 1];
+    if (j + 1 < nbi) {
+      if (j >= 1) hipStreamWaitEvent(ss, evPack[(j + 1) & 1], 0);     // the buffer's previous panel (j - 1) has been packed
+      sigma_panel(j + 1);
+    }
+    hipStreamWaitEvent(sm, evSig[j & 1], 0);
     if (j > 0) {
       auto update = [&](int bt0, int count) {
         const int sp = splits_for(count, 4 * j);
         const size_t stride = (size_t)count * 2 * TR_BM * TR_BM;      // doubles per split in the workspace
-        double* P0 = dPn + (size_t)bt0 * 2 * TR_BM * TR_BM;
-        hipLaunchKernelGGL(k_chol_update_big, dim3((unsigned)count, (unsigned)sp), dim3(256), 0, sm, h->dLt, j, nbi, bt0, 4 * j, P0 - (size_t)bt0 * 2 * TR_BM * TR_BM,
-                           sp > 1 ? dWs - (size_t)bt0 * 2 * TR_BM * TR_BM : (double*)nullptr, stride);
-        if (sp > 1) {
-          size_t cnt = stride;
-          const size_t first = (size_t)bt0 * 2 * TR_BM * TR_BM;
-          if (first + cnt > prow * TR_BM) cnt = prow * TR_BM - first; // an odd number of row blocks leaves the last tile's lower half outside the buffer
-          hipLaunchKernelGGL(k_chol_panel_reduce, dim3(grid_for(cnt, 256, 2048)), dim3(256), 0, sm, dPn + first, dWs, stride, sp, (size_t)0, cnt);
-        }
+        const size_t first = (size_t)bt0 * 2 * TR_BM * TR_BM;
+        hipLaunchKernelGGL(k_chol_update_big, dim3((unsigned)count, (unsigned)sp), dim3(256), 0, sm, h->dLt, j, nbi, bt0, 4 * j, dWs - first, stride);
+        size_t cnt = stride;
+        if (first + cnt > prow * TR_BM) cnt = prow * TR_BM - first;   // an odd number of row blocks leaves the last tile's lower half outside the buffer
+        hipLaunchKernelGGL(k_chol_panel_reduce, dim3(grid_for(cnt, 256, 2048)), dim3(256), 0, sm, P + first, dWs, stride, sp, (size_t)0, cnt);
       };
       update(0, 1);                                                   // the tile that holds the diagonal block goes first ...
       hipEventRecord(evTile, sm);
@@ -472,15 +482,17 @@ static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double 
       hipEventRecord(evTile, sm);
     }
     hipStreamWaitEvent(sd, evTile, 0);
-    hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sd, dPn, (size_t)TR_BM, (size_t)0, (int)nb, dLi, dinfo, off);
+    hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sd, P, (size_t)TR_BM, (size_t)0, (int)nb, dLi, dinfo, off);
     hipEventRecord(evDiag, sd);
     hipStreamWaitEvent(sm, evDiag, 0);
     if (rest)                                                         // rows below = panel L11^-t (in place: one column tile, a workgroup reads only its own rows)
-      launch_gemm<true>(sm, GemmArgs{dPn + TR_BM * TR_BM, (size_t)TR_BM, dLi, (size_t)CH_NB, dPn + TR_BM * TR_BM, (size_t)TR_BM, rest, nb, nb, 1.0, 0.0, nullptr, nullptr, 0}, w);
-    hipLaunchKernelGGL(k_chol_pack_panel, dim3(grid_for((size_t)(nbi - j) * 8 * TR_CHUNK, 256, 4096)), dim3(256), 0, sm, dPn, j, nbi, m, h->dLt);
+      launch_gemm<true>(sm, GemmArgs{P + TR_BM * TR_BM, (size_t)TR_BM, dLi, (size_t)CH_NB, P + TR_BM * TR_BM, (size_t)TR_BM, rest, nb, nb, 1.0, 0.0, nullptr, nullptr, 0}, w);
+    hipLaunchKernelGGL(k_chol_pack_panel, dim3(grid_for((size_t)(nbi - j) * 8 * TR_CHUNK, 256, 4096)), dim3(256), 0, sm, P, j, nbi, m, h->dLt);
+    hipEventRecord(evPack[j & 1], sm);
   }
   hipError_t ce = hipStreamSynchronize(sm);
   if (ce == hipSuccess) ce = hipStreamSynchronize(sd);
+  if (ce == hipSuccess) ce = hipStreamSynchronize(ss);
   if (ce == hipSuccess) ce = hipGetLastError();
   int info = -1;
   if (ce == hipSuccess) ce = hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost);
@@ -504,8 +516,14 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(round_up(h->mb, 64) * h->ldr, 256, 256 * 64)), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, round_up(h->mb, 64), h->ldr, h->dR8);
   }
   {
-    const char* ce = std::getenv("PSF_CHOL");                        // default: on the chunk stream; "gemm": left-looking on a dense matrix; "right": rounds 1-2
-    if (!ce || !std::strcmp(ce, "stream")) return build_sqrt_sigma2_stream(h, nf_r2, s2, b2p1, d_sigma_packed);
+    // "stream": left-looking on the key's chunk stream, no dense matrix (C5: 14.9 s against 21.1 s, and 121 GB less memory); "gemm": left-looking on a
+    // dense m x m matrix with the LDS-staged GEMM (C3: 0.29 s against 0.30 s); "right": the right-looking kernels of rounds 1-2.  Default by size: the
+    // dense form while the matrix stays below 16 GB (m < 46 341), the stream form above.  (The diagonal blocks are factored beside the updates on a
+    // second stream in both; beside k_chol_update_big that overlap returns nothing -- FP64 MFMAs and the vector work of the triangular kernel share
+    // one pipe, profiles/r03_notes.md -- but the single-workgroup kernel is 0.3 s of C5's 14.9 s either way.)
+    const char* ce = std::getenv("PSF_CHOL");
+    const bool stream = ce ? !std::strcmp(ce, "stream") : m * m * sizeof(double) > (16ull << 30);
+    if (stream) return build_sqrt_sigma2_stream(h, nf_r2, s2, b2p1, d_sigma_packed);
   }
   double* dS = nullptr;
   HIP_TRY(hipMalloc(&dS, m * m * sizeof(double)));
