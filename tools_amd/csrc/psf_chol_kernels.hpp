@@ -120,53 +120,61 @@ __global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, s
 // k-steps in flight; the K loop below is that kernel's, statement for statement).  The dense m x m matrix of rounds 1-2 (7.6 GB at C3, 121 GB at C5)
 // no longer exists: Sigma_2 is assembled panel by panel into a dense (m - 128 j) x 128 buffer, the product is subtracted from it, the diagonal block is
 // factored and inverted (k_chol_diag_inv), the rows below are multiplied by the inverse (k_gemm_f64), and the finished panel is written into the
-// stream (k_chol_pack_panel).  A panel has at most nbi / 2 workgroup tiles (256 rows x 128 columns), fewer than the chip has CUs, so K is cut over
-// gridDim.y workgroups in units of two chunks; the partial tiles go to a workspace and k_chol_panel_reduce subtracts them in split order (no atomics).
-__global__ __launch_bounds__(256, 1) void k_chol_update_big(const double* __restrict__ Lt, int j, int nbi, int bt0, int units_total,
+// stream (k_chol_pack_panel).  When a panel has fewer row blocks than the chip has CUs, K is cut over gridDim.y workgroups in units of two chunks; the
+// partial tiles go to a workspace and k_chol_panel_reduce subtracts them in split order (no atomics).
+// Panels are TWO column blocks (256 columns) wide: a workgroup owns one row block (128 rows) and both column blocks, wave (wr, wc) the rows 64 wr .. of it
+// against column block 2 J + wc -- 4 A fragments (its own rows: read once per panel, from HBM) and 8 B fragments (the panel's row blocks: shared by every
+// workgroup, from L2) per k-step for the same 32 MFMAs.  The A stream comes straight from HBM (nothing shares it), and four k-steps in flight do not
+// cover that latency the way they cover L2's: 46 TFLOP/s at C5 with 128-wide panels (32 flop per unshared byte), 52 with 256 columns per pass over L.
+__global__ __launch_bounds__(256, 1) void k_chol_update_big(const double* __restrict__ Lt, int J, int nbi, int rb0, int units_total,
                                                             double* __restrict__ ws, size_t ws_stride) {
-  const int bt = bt0 + (int)blockIdx.x;                               // row tile of 256 rows, counted from the panel's first row block
+  const int bl = rb0 + (int)blockIdx.x;                                // row block, counted from the panel's first one
+  const int bi = 2 * J + bl;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int bi = j + 2 * bt + wr;
-  // K range of this split, in units of two chunks (8 k-steps of 4 coordinates): [u0, u1) of units_total = 4 j
+  const int cb = 2 * J + wc;                                           // this wave's column block
+  // K range of this split, in units of two chunks (8 k-steps of 4 coordinates): [u0, u1) of units_total = 8 J
   const int nz = (int)gridDim.y, z = (int)blockIdx.y;
   const int u0 = (int)(((long long)units_total * z) / nz), u1 = (int)(((long long)units_total * (z + 1)) / nz);
   const int nsteps = (u1 - u0) * 8;
-  if (bi >= nbi) return;                                              // (no barrier in this kernel)
-  d4 acc[8][4];
+  if (cb >= nbi) return;                                               // an odd number of column blocks: the last panel has one (no barrier in this kernel)
+  d4 acc[4][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int jj = 0; jj < 8; ++jj) acc[i][jj] = d4{0.0, 0.0, 0.0, 0.0};
   if (nsteps > 0) {
-    const double* gA = Lt + (tr_rowblock_base((size_t)bi) + (size_t)u0 * 2) * TR_CHUNK;                          // wave-uniform
-    const double* gB = Lt + (tr_rowblock_base((size_t)j) + (size_t)u0 * 2) * TR_CHUNK + (size_t)(wc * 4) * 64;
+    const double* gA = Lt + (tr_rowblock_base((size_t)bi) + (size_t)u0 * 2) * TR_CHUNK + (size_t)(wr * 4) * 64;        // wave-uniform
+    const double* gB = Lt + (tr_rowblock_base((size_t)cb) + (size_t)u0 * 2) * TR_CHUNK;
     const uint32_t voff = (uint32_t)lane * 8u;
-    double a[TR_BIG_PD][8], b[TR_BIG_PD][4];
-    auto issue = [&](double (&av)[8], double (&bv)[4], int s) {
+    double a[TR_BIG_PD][4], b[TR_BIG_PD][8];
+    auto issue = [&](double (&av)[4], double (&bv)[8], int s) {
       const double* pa = gA + (size_t)s * 512;
       const double* pb = gB + (size_t)s * 512;
       TR_LOAD8(av[0], voff, pa, 0); TR_LOAD8(av[1], voff, pa, 512); TR_LOAD8(av[2], voff, pa, 1024); TR_LOAD8(av[3], voff, pa, 1536);
-      TR_LOAD8(av[4], voff, pa, 2048); TR_LOAD8(av[5], voff, pa, 2560); TR_LOAD8(av[6], voff, pa, 3072); TR_LOAD8(av[7], voff, pa, 3584);
       TR_LOAD8(bv[0], voff, pb, 0); TR_LOAD8(bv[1], voff, pb, 512); TR_LOAD8(bv[2], voff, pb, 1024); TR_LOAD8(bv[3], voff, pb, 1536);
+      TR_LOAD8(bv[4], voff, pb, 2048); TR_LOAD8(bv[5], voff, pb, 2560); TR_LOAD8(bv[6], voff, pb, 3072); TR_LOAD8(bv[7], voff, pb, 3584);
     };
 #define CH_MFMA(i, jj) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i][jj]) : "v"(av[i]), "v"(bv[jj]))
-    auto step = [&](double (&av)[8], double (&bv)[4], int sn) {
+    // one k-step: every operand register is reloaded right behind its last reader (as in k_trmm_f64_big, with the roles of A and B swapped)
+    auto step = [&](double (&av)[4], double (&bv)[8], int sn) {
       const double* pa = gA + (size_t)sn * 512;
       const double* pb = gB + (size_t)sn * 512;
-      CH_MFMA(0, 0); CH_MFMA(0, 1); CH_MFMA(0, 2); CH_MFMA(0, 3); TR_LOAD8(av[0], voff, pa, 0);
-      CH_MFMA(1, 0); CH_MFMA(1, 1); CH_MFMA(1, 2); CH_MFMA(1, 3); TR_LOAD8(av[1], voff, pa, 512);
-      CH_MFMA(2, 0); CH_MFMA(2, 1); CH_MFMA(2, 2); CH_MFMA(2, 3); TR_LOAD8(av[2], voff, pa, 1024);
-      CH_MFMA(3, 0); CH_MFMA(3, 1); CH_MFMA(3, 2); CH_MFMA(3, 3); TR_LOAD8(av[3], voff, pa, 1536);
-      CH_MFMA(4, 0); CH_MFMA(4, 1); CH_MFMA(4, 2); CH_MFMA(4, 3); TR_LOAD8(av[4], voff, pa, 2048);
-      CH_MFMA(5, 0); CH_MFMA(5, 1); CH_MFMA(5, 2); CH_MFMA(5, 3); TR_LOAD8(av[5], voff, pa, 2560);
-      CH_MFMA(6, 3); CH_MFMA(7, 3); TR_LOAD8(bv[3], voff, pb, 1536);
-      CH_MFMA(6, 2); CH_MFMA(7, 2); TR_LOAD8(bv[2], voff, pb, 1024);
-      CH_MFMA(6, 1); CH_MFMA(7, 1); TR_LOAD8(bv[1], voff, pb, 512);
-      CH_MFMA(6, 0); CH_MFMA(7, 0); TR_LOAD8(bv[0], voff, pb, 0);
-      TR_LOAD8(av[6], voff, pa, 3072); TR_LOAD8(av[7], voff, pa, 3584);
+      CH_MFMA(0, 0); CH_MFMA(1, 0); CH_MFMA(2, 0); CH_MFMA(3, 0); TR_LOAD8(bv[0], voff, pb, 0);
+      CH_MFMA(0, 1); CH_MFMA(1, 1); CH_MFMA(2, 1); CH_MFMA(3, 1); TR_LOAD8(bv[1], voff, pb, 512);
+      CH_MFMA(0, 2); CH_MFMA(1, 2); CH_MFMA(2, 2); CH_MFMA(3, 2); TR_LOAD8(bv[2], voff, pb, 1024);
+      CH_MFMA(0, 3); CH_MFMA(1, 3); CH_MFMA(2, 3); CH_MFMA(3, 3); TR_LOAD8(bv[3], voff, pb, 1536);
+      CH_MFMA(0, 4); CH_MFMA(1, 4); CH_MFMA(2, 4); CH_MFMA(3, 4); TR_LOAD8(bv[4], voff, pb, 2048);
+      CH_MFMA(0, 5); CH_MFMA(1, 5); CH_MFMA(2, 5); CH_MFMA(3, 5); TR_LOAD8(bv[5], voff, pb, 2560);
+      CH_MFMA(3, 6); CH_MFMA(3, 7); TR_LOAD8(av[3], voff, pa, 1536);
+      CH_MFMA(2, 6); CH_MFMA(2, 7); TR_LOAD8(av[2], voff, pa, 1024);
+      CH_MFMA(1, 6); CH_MFMA(1, 7); TR_LOAD8(av[1], voff, pa, 512);
+      CH_MFMA(0, 6); CH_MFMA(0, 7); TR_LOAD8(av[0], voff, pa, 0);
+      TR_LOAD8(bv[6], voff, pb, 3072); TR_LOAD8(bv[7], voff, pb, 3584);
     };
+#define CH_WAIT12(n, A, Bv) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(Bv[0]), "+v"(Bv[1]), "+v"(Bv[2]), "+v"(Bv[3]), \
+                                         "+v"(Bv[4]), "+v"(Bv[5]), "+v"(Bv[6]), "+v"(Bv[7]))
 #pragma unroll
     for (int u = 0; u < TR_BIG_PD; ++u) issue(a[u], b[u], u);
     for (int s0 = 0; s0 < nsteps; s0 += TR_BIG_PD * 2) {                // nsteps is a multiple of 8
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void k_chol_update_big(const double* __rest
       for (int rnd = 0; rnd < 2; ++rnd)
 #pragma unroll
         for (int u = 0; u < TR_BIG_PD; ++u) {
-          TR_WAIT12(36, a[u], b[u]);
+          CH_WAIT12(36, a[u], b[u]);                                    // 12 (TR_BIG_PD - 1): all but the three newest k-steps have landed
           static_assert(TR_BIG_PD == 4, "the wait count above is 12 (TR_BIG_PD - 1)");
           int sn = s0 + rnd * TR_BIG_PD + u + TR_BIG_PD;
           sn = sn < nsteps ? sn : nsteps - 1;                           // past the end: re-read the last step (never consumed)
@@ -183,27 +191,28 @@ __global__ __launch_bounds__(256, 1) void k_chol_update_big(const double* __rest
     }
 #undef CH_MFMA
 #pragma unroll
-    for (int u = 0; u < TR_BIG_PD; ++u) TR_WAIT12(0, a[u], b[u]);
+    for (int u = 0; u < TR_BIG_PD; ++u) CH_WAIT12(0, a[u], b[u]);
+#undef CH_WAIT12
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMA retires before an accumulator is read (see k_trmm_f64_big)
   }
-  // C/D map of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 reg.  The product goes to the workspace with plain stores, exactly the epilogue of
-  // k_trmm_f64_big (a read-modify-write of the panel here cost the register allocation its shape: spills of loads in flight, accumulators shuttled out of
-  // the AccVGPRs inside the loop); k_chol_panel_reduce subtracts it from the panel also when K is not cut.
-  const size_t row0 = (size_t)(2 * bt + wr) * TR_BM, col0 = (size_t)wc * 64;
+  // C/D map of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 reg.  Plain stores into the workspace (panel layout: rows from the panel's first
+  // row, 256 columns), exactly the epilogue form of k_trmm_f64_big -- a read-modify-write of the panel here cost the register allocation its shape
+  // (spills of loads in flight, accumulators shuttled out of the AccVGPRs inside the loop); k_chol_panel_reduce subtracts it also when K is not cut.
+  const size_t row0 = (size_t)bl * TR_BM + wr * 64, col0 = (size_t)wc * TR_BM;
   double* __restrict__ Xo = ws + (size_t)z * ws_stride;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int jj = 0; jj < 8; ++jj)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
       {
         const size_t row = row0 + i * 16 + (lane >> 4) + 4 * r;
-        Xo[row * TR_BM + col0 + jj * 16 + (lane & 15)] = acc[i][jj][r];
+        Xo[row * (2 * TR_BM) + col0 + jj * 16 + (lane & 15)] = acc[i][jj][r];
       }
 }
 
-// Pbuf[rows x 128] -= sum_z ws[z] (split order)
+// Pbuf -= sum_z ws[z] (split order) over `count` doubles from `first`
 __global__ void k_chol_panel_reduce(double* __restrict__ Pbuf, const double* __restrict__ ws, size_t ws_stride, int splits, size_t first, size_t count) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
     double s = 0.0;
@@ -212,19 +221,22 @@ __global__ void k_chol_panel_reduce(double* __restrict__ Pbuf, const double* __r
   }
 }
 
-// the finished panel j (dense, rows = matrix rows j * 128 .., 128 columns) -> chunks (bi, 8 j + kc) of the stream; above the diagonal and beyond m: zero
-__global__ void k_chol_pack_panel(const double* __restrict__ Pbuf, int j, int nbi, size_t m, double* __restrict__ Lt) {
-  const size_t total = (size_t)(nbi - j) * 8 * TR_CHUNK;
+// the finished panel J (dense, leading dimension 256, rows = matrix rows 256 J ..) -> chunks (bi, 16 J + kc) of the stream, kc < 8 `ncb`; above the
+// diagonal and beyond m: zero
+__global__ void k_chol_pack_panel(const double* __restrict__ Pbuf, int J, int ncb, int nbi, size_t m, double* __restrict__ Lt) {
+  const size_t per_rb = (size_t)ncb * 8 * TR_CHUNK;
+  const size_t total = (size_t)(nbi - 2 * J) * per_rb;
   for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t cidx = g / TR_CHUNK;
+    const size_t bl = g / per_rb, kc = (g % per_rb) / TR_CHUNK;       // row block (from 2 J), chunk inside the panel
     const int pos = (int)(g % TR_CHUNK);
-    const size_t bl = cidx / 8, kc = cidx % 8;                       // row block (from j), chunk inside the panel
     const int ks = pos >> 9, tile = (pos >> 6) & 7, ln = pos & 63;
     const size_t r = tile * 16 + (ln & 15), kk = kc * 16 + ks * 4 + (ln >> 4);
-    const size_t row = ((size_t)j + bl) * TR_BM + r, col = (size_t)j * TR_BM + kk;
+    const size_t bi = (size_t)2 * J + bl;
+    const size_t row = bi * TR_BM + r, col = (size_t)2 * J * TR_BM + kk;
+    if ((size_t)2 * J * 8 + kc >= 8 * (bi + 1)) continue;            // the stream has no chunk there (second column block of the panel's first row block)
     double v = 0.0;
-    if (row < m && col <= row) v = Pbuf[(bl * TR_BM + r) * TR_BM + kk];
-    Lt[(tr_rowblock_base((size_t)j + bl) + (size_t)j * 8 + kc) * TR_CHUNK + pos] = v;
+    if (row < m && col <= row) v = Pbuf[(bl * TR_BM + r) * (2 * TR_BM) + kk];
+    Lt[(tr_rowblock_base(bi) + (size_t)2 * J * 8 + kc) * TR_CHUNK + pos] = v;
   }
 }
 

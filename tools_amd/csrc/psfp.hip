@@ -415,83 +415,89 @@ size_t psfp_m(const psfp_handle* h) { return h ? h->m : 0; }
 static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double s2, double b2p1, const double* d_sig) {
   const size_t m = h->mL;
   const int nbi = (int)h->nbiL;
-  const size_t prow = (size_t)nbi * TR_BM;                            // rows of a panel buffer (panel 0 needs them all)
+  const int nP = (nbi + 1) / 2;                                       // panels of two column blocks (256 columns)
+  const size_t PW = 2 * TR_BM;                                        // leading dimension of a panel buffer
+  const size_t prow = (size_t)nbi * TR_BM;                            // its rows (panel 0 needs them all)
   // K splits of the update: at most one workgroup per CU (the kernel is a one-workgroup-per-CU design), each split at least one unit of two chunks
-  auto splits_for = [](int tiles, int units) { int sp = tiles > 0 ? 256 / tiles : 1; if (sp > units) sp = units; if (sp > 64) sp = 64; return sp < 1 ? 1 : sp; };
+  auto splits_for = [](int wgs, int units) { int sp = wgs > 0 ? 256 / wgs : 1; if (sp > units) sp = units; if (sp > 64) sp = 64; return sp < 1 ? 1 : sp; };
   size_t ws_doubles = 0;
-  for (int j = 1; j < nbi; ++j) {
-    const int T = (nbi - j + 1) / 2;
-    const size_t a = (size_t)splits_for(1, 4 * j) * 2 * TR_BM * TR_BM;
-    const size_t b = T > 1 ? (size_t)splits_for(T - 1, 4 * j) * (size_t)(T - 1) * 2 * TR_BM * TR_BM : 0;
+  for (int J = 1; J < nP; ++J) {
+    const int nrb = nbi - 2 * J, head = nrb < 2 ? nrb : 2;
+    const size_t a = (size_t)splits_for(head, 8 * J) * head * TR_BM * PW;
+    const size_t b = nrb > 2 ? (size_t)splits_for(nrb - 2, 8 * J) * (size_t)(nrb - 2) * TR_BM * PW : 0;
     if (a > ws_doubles) ws_doubles = a;
     if (b > ws_doubles) ws_doubles = b;
   }
   double *dPn[2] = {nullptr, nullptr}, *dLi = nullptr, *dWs = nullptr; int* dinfo = nullptr;
-  hipStream_t sm = nullptr, sd = nullptr, ss = nullptr;               // products / diagonal blocks / Sigma_2 panels (one panel ahead)
-  hipEvent_t evTile = nullptr, evDiag = nullptr, evSig[2] = {nullptr, nullptr}, evPack[2] = {nullptr, nullptr};
-  GemmWorkspace w;                                                    // the solve against the inverse never cuts K (K = 128)
+  hipStream_t sm = nullptr, ss = nullptr;                             // factorisation / Sigma_2 panels (one panel ahead)
+  hipEvent_t evSig[2] = {nullptr, nullptr}, evPack[2] = {nullptr, nullptr};
+  GemmWorkspace w;                                                    // the in-panel products have K = 128: never cut
   auto cleanup = [&]() {
-    for (hipStream_t st : {sm, sd, ss}) if (st) hipStreamDestroy(st);
-    for (hipEvent_t ev : {evTile, evDiag, evSig[0], evSig[1], evPack[0], evPack[1]}) if (ev) hipEventDestroy(ev);
+    for (hipStream_t st : {sm, ss}) if (st) hipStreamDestroy(st);
+    for (hipEvent_t ev : {evSig[0], evSig[1], evPack[0], evPack[1]}) if (ev) hipEventDestroy(ev);
     hipFree(dPn[0]); hipFree(dPn[1]); hipFree(dLi); hipFree(dWs); hipFree(dinfo);
   };
   const size_t diag_lds = ((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double);
   bool ok = gemm_prepare() == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds) == hipSuccess &&
-            hipMalloc(&dPn[0], prow * TR_BM * sizeof(double)) == hipSuccess && hipMalloc(&dPn[1], prow * TR_BM * sizeof(double)) == hipSuccess &&
+            hipMalloc(&dPn[0], prow * PW * sizeof(double)) == hipSuccess && hipMalloc(&dPn[1], prow * PW * sizeof(double)) == hipSuccess &&
             hipMalloc(&dLi, CH_NB * CH_NB * sizeof(double)) == hipSuccess && (!ws_doubles || hipMalloc(&dWs, ws_doubles * sizeof(double)) == hipSuccess) &&
             hipMalloc(&dinfo, sizeof(int)) == hipSuccess && hipMemset(dinfo, 0, sizeof(int)) == hipSuccess &&
-            hipMemset(dPn[0], 0, prow * TR_BM * sizeof(double)) == hipSuccess && hipMemset(dPn[1], 0, prow * TR_BM * sizeof(double)) == hipSuccess;
-  for (hipStream_t* st : {&sm, &sd, &ss}) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
-  for (hipEvent_t* ev : {&evTile, &evDiag, &evSig[0], &evSig[1], &evPack[0], &evPack[1]}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+            hipMemset(dPn[0], 0, prow * PW * sizeof(double)) == hipSuccess && hipMemset(dPn[1], 0, prow * PW * sizeof(double)) == hipSuccess;
+  for (hipStream_t* st : {&sm, &ss}) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t* ev : {&evSig[0], &evSig[1], &evPack[0], &evPack[1]}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
   if (!ok) { cleanup(); return PSF_ERR_HIP; }
   HIP_TRY(hipDeviceSynchronize());                                    // R (and k_pack_R8) were produced on the default stream
-  // Sigma_2 restricted to panel j (rows off.., columns off..off+127), dense with leading dimension 128; it does not depend on the factorisation, so it
+  // Sigma_2 restricted to panel J (rows off.., columns off..off+255), dense with leading dimension 256; it does not depend on the factorisation, so it
   // is assembled one panel ahead on its own stream into the other of two panel buffers
-  auto sigma_panel = [&](int j) {
-    const size_t off = (size_t)j * TR_BM;
-    hipLaunchKernelGGL(k_sigma2, dim3(2, (unsigned)((m - off + 63) / 64)), dim3(256), 0, ss, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sig, dPn[j & 1], (size_t)TR_BM, off, off);
-    hipEventRecord(evSig[j & 1], ss);
+  auto sigma_panel = [&](int J) {
+    const size_t off = (size_t)J * PW;
+    const size_t cols = m - off < PW ? m - off : PW;
+    hipLaunchKernelGGL(k_sigma2, dim3((unsigned)((cols + 63) / 64), (unsigned)((m - off + 63) / 64)), dim3(256), 0, ss, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sig,
+                       dPn[J & 1], PW, off, off);
+    hipEventRecord(evSig[J & 1], ss);
   };
   sigma_panel(0);
-  for (int j = 0; j < nbi; ++j) {
-    const size_t off = (size_t)j * TR_BM;
-    const size_t nb = m - off < (size_t)TR_BM ? m - off : (size_t)TR_BM;
-    const size_t rest = m - off - nb;
-    const int T = (nbi - j + 1) / 2;                                  // 256-row workgroup tiles of the panel
-    double* P = dPn[j & 1];
-    if (j + 1 < nbi) {
-      if (j >= 1) hipStreamWaitEvent(ss, evPack[(j + 1) & 1], 0);     // the buffer's previous panel (j - 1) has been packed
-      sigma_panel(j + 1);
+  for (int J = 0; J < nP; ++J) {
+    const size_t off = (size_t)J * PW;
+    const int ncb = 2 * J + 1 < nbi ? 2 : 1;                          // column blocks of this panel
+    const int nrb = nbi - 2 * J;                                      // its row blocks
+    const size_t nb0 = m - off < (size_t)TR_BM ? m - off : (size_t)TR_BM;
+    const size_t below0 = m - off - nb0;                              // rows under the first diagonal block
+    const size_t nb1 = ncb == 2 ? (below0 < (size_t)TR_BM ? below0 : (size_t)TR_BM) : 0;
+    const size_t below1 = ncb == 2 ? below0 - nb1 : 0;                // rows under the second diagonal block
+    double* P = dPn[J & 1];
+    if (J + 1 < nP) {
+      if (J >= 1) hipStreamWaitEvent(ss, evPack[(J + 1) & 1], 0);     // the buffer's previous panel (J - 1) has been packed
+      sigma_panel(J + 1);
     }
-    hipStreamWaitEvent(sm, evSig[j & 1], 0);
-    if (j > 0) {
-      auto update = [&](int bt0, int count) {
-        const int sp = splits_for(count, 4 * j);
-        const size_t stride = (size_t)count * 2 * TR_BM * TR_BM;      // doubles per split in the workspace
-        const size_t first = (size_t)bt0 * 2 * TR_BM * TR_BM;
-        hipLaunchKernelGGL(k_chol_update_big, dim3((unsigned)count, (unsigned)sp), dim3(256), 0, sm, h->dLt, j, nbi, bt0, 4 * j, dWs - first, stride);
-        size_t cnt = stride;
-        if (first + cnt > prow * TR_BM) cnt = prow * TR_BM - first;   // an odd number of row blocks leaves the last tile's lower half outside the buffer
-        hipLaunchKernelGGL(k_chol_panel_reduce, dim3(grid_for(cnt, 256, 2048)), dim3(256), 0, sm, P + first, dWs, stride, sp, (size_t)0, cnt);
+    hipStreamWaitEvent(sm, evSig[J & 1], 0);
+    if (J > 0) {                                                      // P -= L[rows of the panel, columns < off] L[panel's row blocks, columns < off]^t
+      auto update = [&](int rb0, int count) {
+        const int sp = splits_for(count, 8 * J);
+        const size_t stride = (size_t)count * TR_BM * PW;             // doubles per split in the workspace
+        const size_t first = (size_t)rb0 * TR_BM * PW;
+        hipLaunchKernelGGL(k_chol_update_big, dim3((unsigned)count, (unsigned)sp), dim3(256), 0, sm, h->dLt, J, nbi, rb0, 8 * J, dWs - first, stride);
+        hipLaunchKernelGGL(k_chol_panel_reduce, dim3(grid_for(stride, 256, 2048)), dim3(256), 0, sm, P + first, dWs, stride, sp, (size_t)0, stride);
       };
-      update(0, 1);                                                   // the tile that holds the diagonal block goes first ...
-      hipEventRecord(evTile, sm);
-      if (T > 1) update(1, T - 1);                                    // ... the rows below are updated while the diagonal block is factored on the other stream
-    } else {
-      hipEventRecord(evTile, sm);
+      const int head = nrb < 2 ? nrb : 2;
+      update(0, head);                                                // the two row blocks that hold the diagonal blocks (cut finely along K), then the rest
+      if (nrb > 2) update(2, nrb - 2);
     }
-    hipStreamWaitEvent(sd, evTile, 0);
-    hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sd, P, (size_t)TR_BM, (size_t)0, (int)nb, dLi, dinfo, off);
-    hipEventRecord(evDiag, sd);
-    hipStreamWaitEvent(sm, evDiag, 0);
-    if (rest)                                                         // rows below = panel L11^-t (in place: one column tile, a workgroup reads only its own rows)
-      launch_gemm<true>(sm, GemmArgs{P + TR_BM * TR_BM, (size_t)TR_BM, dLi, (size_t)CH_NB, P + TR_BM * TR_BM, (size_t)TR_BM, rest, nb, nb, 1.0, 0.0, nullptr, nullptr, 0}, w);
-    hipLaunchKernelGGL(k_chol_pack_panel, dim3(grid_for((size_t)(nbi - j) * 8 * TR_CHUNK, 256, 4096)), dim3(256), 0, sm, P, j, nbi, m, h->dLt);
-    hipEventRecord(evPack[j & 1], sm);
+    // inside the panel: factor + invert the first diagonal block, solve its rows below, take its contribution out of the second column block, the same again
+    hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sm, P, PW, (size_t)0, (int)nb0, dLi, dinfo, off);
+    if (below0)
+      launch_gemm<true>(sm, GemmArgs{P + TR_BM * PW, PW, dLi, (size_t)CH_NB, P + TR_BM * PW, PW, below0, nb0, nb0, 1.0, 0.0, nullptr, nullptr, 0}, w);
+    if (ncb == 2) {
+      launch_gemm<true>(sm, GemmArgs{P + TR_BM * PW, PW, P + TR_BM * PW, PW, P + TR_BM * PW + TR_BM, PW, below0, nb1, (size_t)TR_BM, -1.0, 1.0, nullptr, nullptr, 0}, w);
+      hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sm, P, PW, (size_t)TR_BM, (int)nb1, dLi, dinfo, off + TR_BM);
+      if (below1)
+        launch_gemm<true>(sm, GemmArgs{P + 2 * TR_BM * PW + TR_BM, PW, dLi, (size_t)CH_NB, P + 2 * TR_BM * PW + TR_BM, PW, below1, nb1, nb1, 1.0, 0.0, nullptr, nullptr, 0}, w);
+    }
+    hipLaunchKernelGGL(k_chol_pack_panel, dim3(grid_for((size_t)nrb * ncb * 8 * TR_CHUNK, 256, 4096)), dim3(256), 0, sm, P, J, ncb, nbi, m, h->dLt);
+    hipEventRecord(evPack[J & 1], sm);
   }
   hipError_t ce = hipStreamSynchronize(sm);
-  if (ce == hipSuccess) ce = hipStreamSynchronize(sd);
   if (ce == hipSuccess) ce = hipStreamSynchronize(ss);
   if (ce == hipSuccess) ce = hipGetLastError();
   int info = -1;
@@ -516,11 +522,11 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(round_up(h->mb, 64) * h->ldr, 256, 256 * 64)), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, round_up(h->mb, 64), h->ldr, h->dR8);
   }
   {
-    // "stream": left-looking on the key's chunk stream, no dense matrix (C5: 14.9 s against 21.1 s, and 121 GB less memory); "gemm": left-looking on a
-    // dense m x m matrix with the LDS-staged GEMM (C3: 0.29 s against 0.30 s); "right": the right-looking kernels of rounds 1-2.  Default by size: the
-    // dense form while the matrix stays below 16 GB (m < 46 341), the stream form above.  (The diagonal blocks are factored beside the updates on a
-    // second stream in both; beside k_chol_update_big that overlap returns nothing -- FP64 MFMAs and the vector work of the triangular kernel share
-    // one pipe, profiles/r03_notes.md -- but the single-workgroup kernel is 0.3 s of C5's 14.9 s either way.)
+    // "stream": left-looking on the key's chunk stream, no dense matrix (C5: 13.4 s against 21.1 s, and 121 GB less memory; C3: 0.32 s against 0.29 s); "gemm": left-looking on a
+    // dense m x m matrix with the LDS-staged GEMM; "right": the right-looking kernels of rounds 1-2.  Default by size: the
+    // dense form while the matrix stays below 16 GB (m < 46 341), the stream form above.  (The dense form factors the diagonal blocks beside the updates on a
+    // second stream; beside k_chol_update_big that overlap returns nothing -- FP64 MFMAs and the vector work of the triangular kernel share
+    // one pipe, profiles/r03_notes.md -- so the stream form runs them in line: 0.3 s of C5's total.)
     const char* ce = std::getenv("PSF_CHOL");
     const bool stream = ce ? !std::strcmp(ce, "stream") : m * m * sizeof(double) > (16ull << 30);
     if (stream) return build_sqrt_sigma2_stream(h, nf_r2, s2, b2p1, d_sigma_packed);
