@@ -841,13 +841,15 @@ __global__ void k_split_A(const uint64_t* __restrict__ A, size_t lda, size_t n, 
   }
 }
 
-// P (K x ld int32) -> three digit planes [K_pad/16][ld][16]; thread = (16-coordinate group, preimage)
-__global__ void k_split_P(const int32_t* __restrict__ P, size_t K, size_t ld, size_t ngroups, int8_t* __restrict__ P8, int* __restrict__ fail) {
-  const size_t total = ngroups * ld;
-  const size_t plane = total * 16;
+// P (K x ld int32) -> three digit planes [K_pad/16][ld][16]; thread = (16-coordinate group, preimage).  Only the columns [col0, col0 + cw) are
+// converted (the two halves of a batch run their stages on two streams: a half must not touch the other half's columns).
+__global__ void k_split_P(const int32_t* __restrict__ P, size_t K, size_t ld, size_t ngroups, int8_t* __restrict__ P8, int* __restrict__ fail, size_t col0, size_t cw) {
+  const size_t total = ngroups * cw;
+  const size_t plane = ngroups * ld * 16;
   int f = 0;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t kg = g / ld, b = g % ld;
+  for (size_t g0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < total; g0 += (size_t)gridDim.x * blockDim.x) {
+    const size_t kg = g0 / cw, b = col0 + g0 % cw;
+    const size_t g = kg * ld + b;
     v4i o0, o1, o2;
     int32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -891,14 +893,14 @@ __device__ inline uint64_t zq_term(int32_t T, uint64_t pw, uint64_t q, uint64_t 
 // `part[split][i][c]` and k_zq_combine adds them.  (Folding inside the K loop made hipcc spill accumulators to scratch.)
 template <int NA>
 __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, size_t n_pad, size_t K_pad, const int8_t* __restrict__ P8, size_t ld,
-                                                 int ks_per_split, ZqConsts zc, int wide, uint64_t* __restrict__ part) {
+                                                 int ks_per_split, ZqConsts zc, int wide, uint64_t* __restrict__ part, size_t col0) {
   constexpr int STAGE = (NA + 3) * 4096;
   constexpr int NC = NA + 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char zq_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const size_t b0 = (size_t)blockIdx.x * 64, i0 = (size_t)blockIdx.y * 64;
+  const size_t b0 = col0 + (size_t)blockIdx.x * 64, i0 = (size_t)blockIdx.y * 64;
   const size_t planeA = n_pad * K_pad, planeP = (K_pad / 16) * ld * 16;
   const int nks_all = (int)(K_pad / 64);
   const int ks0 = (int)blockIdx.z * ks_per_split;
@@ -987,11 +989,11 @@ __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, 
 
 // out = (u - sum_z part[z]) mod q  (syndrome, mp_perturbation.rs:318)  or  sum_z part[z] mod q written row-per-preimage (f_a, :368)
 __global__ void k_zq_combine(int mode, const uint64_t* __restrict__ part, int splits, size_t n, size_t n_pad, size_t ld, size_t ncols, uint64_t q,
-                             const uint64_t* __restrict__ U, uint64_t* __restrict__ out, size_t ldo) {
-  const size_t total = n * ld;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t i = g / ld, cc = g % ld;
-    if (cc >= ncols) continue;
+                             const uint64_t* __restrict__ U, uint64_t* __restrict__ out, size_t ldo, size_t col0) {
+  const size_t total = n * ncols;                  // columns [col0, col0 + ncols)
+  for (size_t g0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < total; g0 += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g0 / ncols, cc = col0 + g0 % ncols;
+    const size_t g = i * ld + cc;
     uint64_t s = 0;
     for (int z = 0; z < splits; ++z) {
       s += part[(size_t)z * n_pad * ld + g];

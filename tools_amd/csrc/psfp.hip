@@ -623,19 +623,21 @@ static void split_A(psfp_handle* h) {
   hipLaunchKernelGGL(k_split_A, dim3(grid_for(h->n_pad * h->K_pad)), dim3(256), 0, 0, h->dA, h->m, h->n, h->m, h->n_pad, h->K_pad, h->NA, h->dA8);
 }
 
-// out = (mode syndrome) U - A P  or  (mode f_a) A P, with P (K x ld int32) first cut into digit planes
-static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32_t* P, int8_t* P8, size_t ncols, const uint64_t* U, uint64_t* out, size_t ldo) {
+// out = (mode syndrome) U - A P  or  (mode f_a) A P for the columns [col0, col0 + ncols), with P (K x ld int32) first cut into digit planes
+static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32_t* P, int8_t* P8, size_t ncols, const uint64_t* U, uint64_t* out, size_t ldo, size_t col0 = 0) {
   const size_t ld = h->ld;
-  hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * ld, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, P8, h->dFail);
+  size_t cw = round_up(ncols, 64);                                    // the product works on 64-column tiles
+  if (col0 + cw > ld) cw = ld - col0;
+  hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * cw, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, P8, h->dFail, col0, cw);
   dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64), (unsigned)h->zq_splits);
 #define ZQM(NA_)                                                                                                        \
   case NA_:                                                                                                             \
     hipLaunchKernelGGL((k_zq_mfma<NA_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, h->zq_ks, h->zc,  \
-                       (int)h->wide, h->dPart);                                                                         \
+                       (int)h->wide, h->dPart, col0);                                                                   \
     break;
   switch (h->NA) { ZQM(1) ZQM(2) ZQM(3) ZQM(4) ZQM(5) ZQM(6) ZQM(7) ZQM(8) default: break; }
-  hipLaunchKernelGGL(k_zq_combine, dim3(grid_for(h->n * ld, 256, 256 * 32)), dim3(256), 0, st, mode, h->dPart, h->zq_splits, h->n, h->n_pad, ld, ncols,
-                     h->q, U, out, ldo);
+  hipLaunchKernelGGL(k_zq_combine, dim3(grid_for(h->n * ncols, 256, 256 * 32)), dim3(256), 0, st, mode, h->dPart, h->zq_splits, h->n, h->n_pad, ld, ncols,
+                     h->q, U, out, ldo, col0);
 #undef ZQM
 }
 
@@ -879,40 +881,62 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     HIP_TRY(hipStreamWaitEvent(s2, h->evT[cur], 0));
     HIP_TRY(hipStreamWaitEvent(s2, h->evIn, 0));
   }
-  {  // p_i <- D_{Z,r,x_i}
-    ScopedTimer t(h, s2, "k_perturb_round");
-    const char* renv = std::getenv("PSF_ROUND");                 // "wave": the round-2 kernel (comparison arm; same bits)
-    if (h->szR.sh == 16 && !(renv && !std::strcmp(renv, "wave"))) {
-      const size_t waves = (m * B + PRL_SEG - 1) / PRL_SEG;
-      hipLaunchKernelGGL(k_perturb_round_lean, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
-    } else {
-      const size_t waves = (m * B + PR_SEG - 1) / PR_SEG;
-      hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, seed, first_index, m, B, ld, h->dX, h->szR, h->dP, h->dFail);
+  // The stages behind the product, for the columns [b0, b0 + Bh) of the batch on stream sx.  Column offsets: [coord][b] matrices move by b0 elements,
+  // digit planes ([group][b][16]) by 16 b0 bytes, row-major API matrices by b0 rows; the Z_q product takes its window as (col0, ncols).
+  auto tail = [&](hipStream_t sx, size_t b0, size_t Bh) {
+    {  // p_i <- D_{Z,r,x_i}
+      ScopedTimer t(h, sx, "k_perturb_round");
+      const char* renv = std::getenv("PSF_ROUND");                 // "wave": the round-2 kernel (comparison arm; same bits)
+      if (h->szR.sh == 16 && !(renv && !std::strcmp(renv, "wave"))) {
+        const size_t waves = (m * Bh + PRL_SEG - 1) / PRL_SEG;
+        hipLaunchKernelGGL(k_perturb_round_lean, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, m, Bh, ld, h->dX + b0, h->szR, h->dP + b0, h->dFail);
+      } else {
+        const size_t waves = (m * Bh + PR_SEG - 1) / PR_SEG;
+        hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, m, Bh, ld, h->dX + b0, h->szR, h->dP + b0, h->dFail);
+      }
     }
-  }
-  {  // mp_perturbation.rs:318 -- v = u - A p
-    ScopedTimer t(h, s2, "k_zq_matmul(syndrome)");
-    launch_zq_mfma(h, s2, ZQ_SYNDROME, h->dP, h->dP8, B, d_u, h->dV, ld);
-  }
-  {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
-    ScopedTimer t(h, s2, "k_gadget");
-    if (h->gadget_queue) {
-      GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
-      const size_t per_wg = (size_t)GQ_WAVES * gq_problems_per_wave((uint32_t)h->k);
-      hipLaunchKernelGGL(k_gadget_queue, dim3((unsigned)((h->n * B + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k), s2, seed,
-                         first_index, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, B, ld, h->dV, tq, h->dZlo, h->dZhi, h->dFail);
-    } else {
-      GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
-      hipLaunchKernelGGL(k_gadget, dim3((unsigned)((B + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(h->k), s2, seed, first_index,
-                         (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, B, ld, h->dV, tb, h->dZlo, h->dZhi, h->dFail);
+    {  // mp_perturbation.rs:318 -- v = u - A p
+      ScopedTimer t(h, sx, "k_zq_matmul(syndrome)");
+      launch_zq_mfma(h, sx, ZQ_SYNDROME, h->dP, h->dP8, Bh, d_u, h->dV, ld, b0);
     }
-  }
-  {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
-    ScopedTimer t(h, s2, "k_recombine");
-    hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((B + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), RC_LDS, s2, h->dR,
-                       h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo, h->dZhi, ld, h->dFail, h->dP, B, d_e, m);
-    hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((B + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, s2, h->mb, h->w,
-                       h->dZlo, h->dZhi, ld, h->dP, B, d_e, m);
+    {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
+      ScopedTimer t(h, sx, "k_gadget");
+      if (h->gadget_queue) {
+        GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
+        const size_t per_wg = (size_t)GQ_WAVES * gq_problems_per_wave((uint32_t)h->k);
+        hipLaunchKernelGGL(k_gadget_queue, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k), sx, seed,
+                           first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+      } else {
+        GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
+        hipLaunchKernelGGL(k_gadget, dim3((unsigned)((Bh + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(h->k), sx, seed, first_index + b0,
+                           (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, Bh, ld, h->dV + b0, tb, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+      }
+    }
+    {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
+      ScopedTimer t(h, sx, "k_recombine");
+      hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bh + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), RC_LDS, sx, h->dR,
+                         h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m);
+      hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bh + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, sx, h->mb, h->w,
+                         h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
+    }
+  };
+  // PSF_HALVES=1: the batch's two halves run these stages on two streams, so that the int8 matrix-core kernels of one half (Z_q product, recombination)
+  // can share the chip with the vector-bound samplers of the other (vector work hides behind int8 / bf16 MFMAs, unlike behind FP64 ones: profiles/r03_notes.md)
+  const char* henv = std::getenv("PSF_HALVES");
+  const bool halves = !pipe && henv && std::atoi(henv) != 0 && B >= 512 && B % 256 == 0;
+  if (!halves) {
+    tail(s2, 0, B);
+  } else {
+    const size_t Bh = B / 2;
+    HIP_TRY(hipEventRecord(h->evT[0], st));
+    HIP_TRY(hipStreamWaitEvent(h->s1, h->evT[0], 0));
+    HIP_TRY(hipStreamWaitEvent(h->aux, h->evT[0], 0));
+    tail(h->s1, 0, Bh);
+    tail(h->aux, Bh, B - Bh);
+    HIP_TRY(hipEventRecord(h->evP[0], h->s1));
+    HIP_TRY(hipEventRecord(h->evP[1], h->aux));
+    HIP_TRY(hipStreamWaitEvent(user_st, h->evP[0], 0));
+    HIP_TRY(hipStreamWaitEvent(user_st, h->evP[1], 0));
   }
   if (pipe) {
     HIP_TRY(hipEventRecord(h->evP[cur], h->aux));
