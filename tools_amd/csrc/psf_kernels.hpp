@@ -1675,19 +1675,20 @@ __global__ void k_sample_R(uint64_t seed, size_t mbar, size_t w, size_t ldr, int
 // packed lower triangle (row i: i + 1 entries).  The R R^t block is a dot4 product of 64 x 64 row pairs.
 __global__ __launch_bounds__(256) void k_sigma2(const int8_t* __restrict__ R, size_t ldr, size_t mbar, size_t w, size_t m,
                                                 double nf_r2, double s2, double b2p1, const double* __restrict__ Sig, double* __restrict__ S, size_t lds,
-                                                size_t row_off, size_t col_off) {
+                                                size_t row_off, size_t col_off, int skip_rrt) {
   __shared__ uint32_t sRi[64][17];
   __shared__ uint32_t sRj[64][17];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   // (row_off, col_off): the tile grid covers rows row_off.. and columns col_off.. of Sigma_2 and S holds that window (the panel-wise Cholesky)
   const size_t i0 = row_off + (size_t)blockIdx.y * 64, j0 = col_off + (size_t)blockIdx.x * 64;
   if (j0 > i0 + 63) return;  // strictly upper tile
+  if (skip_rrt && i0 + 63 < mbar) return;                // skip_rrt: the entries with i, j < m_bar come from k_sigma2_rrt (int8 matrix cores)
   int32_t acc[4][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[r][c] = 0;
-  if (i0 < mbar && j0 < mbar) {
+  if (!skip_rrt && i0 < mbar && j0 < mbar) {
     const uint32_t* R32 = reinterpret_cast<const uint32_t*>(R);
     const size_t ldr4 = ldr / 4, w4 = (w + 3) / 4;
     for (size_t q0 = 0; q0 < w4; q0 += 16) {
@@ -1722,6 +1723,7 @@ __global__ __launch_bounds__(256) void k_sigma2(const int8_t* __restrict__ R, si
     for (int c = 0; c < 4; ++c) {
       const size_t i = i0 + ty * 4 + r, j = j0 + tx * 4 + c;
       if (i >= m || j > i) continue;
+      if (skip_rrt && i < mbar) continue;
       double tt;
       if (i < mbar) tt = (double)acc[r][c];
       else if (j < mbar) tt = (double)R[j * ldr + (i - mbar)];
@@ -1731,6 +1733,74 @@ __global__ __launch_bounds__(256) void k_sigma2(const int8_t* __restrict__ R, si
       if (i == j) sp = sp - 1.0;
       S[(i - row_off) * lds + (j - col_off)] = nf_r2 * sp;
     }
+}
+
+// The R R^t block of Sigma_2 (rows and columns below m_bar: at C3 half the entries and all of the arithmetic, m_bar^2 w / 2 = 1.8e12 MAC; C5: 1.2e14) on
+// the int8 matrix cores: R is ternary, so v_mfma_i32_16x16x64_i8 sums exactly.  Both operands are row tiles of R itself -- a row of R is 16 consecutive k for
+// the A fragment and for the B fragment alike.  64 x 64 output tile per workgroup (4 waves, 2 x 2 of 32 x 32), K steps of 64 staged straight from the
+// row-major R by LDS-DMA (each lane moves one 16-byte k group; the groups of a row are stored rotated by row / 4, i8_slot, so that the fragment reads are
+// conflict free), ring of three stages.  Writes the same window and the same expression as k_sigma2.
+__global__ __launch_bounds__(256, 2) void k_sigma2_rrt(const int8_t* __restrict__ R, size_t ldr, size_t mbar, size_t m, double nf_r2, double s2, double b2p1,
+                                                       const double* __restrict__ Sig, double* __restrict__ S, size_t lds, size_t row_off, size_t col_off) {
+  constexpr int STAGE = 2 * 4096, NS = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char rr_smem[];
+  const size_t i0 = row_off + (size_t)blockIdx.y * 64, j0 = col_off + (size_t)blockIdx.x * 64;
+  if (j0 > i0 + 63 || i0 >= mbar || j0 >= mbar) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nks = (int)(ldr / 64);
+  v4i acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = v4i{0, 0, 0, 0};
+  // piece p = tid of a 64 x 64-byte tile: LDS slot (row p / 4, position p % 4) takes k group (position - row / 4) mod 4
+  const size_t koff = (size_t)(((tid & 3) - (tid >> 4)) & 3) * 16;
+  const int8_t* srcA = R + (i0 + (size_t)(tid >> 2)) * ldr + koff;
+  const int8_t* srcB = R + (j0 + (size_t)(tid >> 2)) * ldr + koff;
+  auto stage_load = [&](int ks, int buf) {
+    unsigned char* base = rr_smem + buf * STAGE + wave * 1024;
+    __builtin_amdgcn_global_load_lds(srcA + (size_t)ks * 64, (lds_void_ptr)base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(srcB + (size_t)ks * 64, (lds_void_ptr)(base + 4096), 16, 0, 0);
+  };
+  for (int s0 = 0; s0 < NS - 1 && s0 < nks; ++s0) stage_load(s0, s0);
+  const int r16 = lane & 15, gq = lane >> 4;
+  int cur = 0;
+  for (int ks = 0; ks < nks; ++ks) {
+    // stage ks has landed when at most the NS - 2 younger stages (2 DMA instructions each) are outstanding
+    if (nks - 1 - ks >= NS - 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // everybody's part of stage ks is in LDS; everybody is done with stage ks - 1
+    const int nxt = ks + NS - 1;
+    if (nxt < nks) stage_load(nxt, cur == 0 ? NS - 1 : cur - 1);
+    const unsigned char* sb = rr_smem + cur * STAGE;
+    v4i fa[2], fb[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      fa[x] = *reinterpret_cast<const v4i*>(sb + ((wr * 32 + x * 16 + r16) * 64 + i8_slot(wr * 32 + x * 16 + r16, gq) * 16));
+      fb[x] = *reinterpret_cast<const v4i*>(sb + 4096 + ((wc * 32 + x * 16 + r16) * 64 + i8_slot(wc * 32 + x * 16 + r16, gq) * 16));
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[x], fb[y], acc[x][y], 0, 0, 0);
+    cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  // C/D map: column (here j) = lane & 15, row (here i) = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t i = i0 + wr * 32 + x * 16 + 4 * gq + r, j = j0 + wc * 32 + y * 16 + r16;
+        if (i >= mbar || j > i || i >= m) continue;
+        const double sg = Sig ? Sig[i * (i + 1) / 2 + j] : ((i == j) ? s2 : 0.0);
+        double sp = sg - b2p1 * (double)acc[x][y][r];
+        if (i == j) sp = sp - 1.0;
+        S[(i - row_off) * lds + (j - col_off)] = nf_r2 * sp;
+      }
 }
 
 }  // namespace psf

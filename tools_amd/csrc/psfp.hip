@@ -453,8 +453,9 @@ static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double 
   auto sigma_panel = [&](int J) {
     const size_t off = (size_t)J * PW;
     const size_t cols = m - off < PW ? m - off : PW;
-    hipLaunchKernelGGL(k_sigma2, dim3((unsigned)((cols + 63) / 64), (unsigned)((m - off + 63) / 64)), dim3(256), 0, ss, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sig,
-                       dPn[J & 1], PW, off, off);
+    const dim3 sg((unsigned)((cols + 63) / 64), (unsigned)((m - off + 63) / 64));
+    hipLaunchKernelGGL(k_sigma2_rrt, sg, dim3(256), 3 * 2 * 4096, ss, h->dR, h->ldr, h->mb, m, nf_r2, s2, b2p1, d_sig, dPn[J & 1], PW, off, off);
+    hipLaunchKernelGGL(k_sigma2, sg, dim3(256), 0, ss, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sig, dPn[J & 1], PW, off, off, 1);
     hipEventRecord(evSig[J & 1], ss);
   };
   sigma_panel(0);
@@ -535,7 +536,9 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
   HIP_TRY(hipMalloc(&dS, m * m * sizeof(double)));
   HIP_TRY(hipMemset(dS, 0, m * m * sizeof(double)));
   const unsigned tiles = (unsigned)((m + 63) / 64);
-  hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sigma_packed, dS, m, (size_t)0, (size_t)0);
+  // the R R^t block on the int8 matrix cores, everything else (the rows from m_bar on) in k_sigma2
+  hipLaunchKernelGGL(k_sigma2_rrt, dim3(tiles, tiles), dim3(256), 3 * 2 * 4096, 0, h->dR, h->ldr, h->mb, m, nf_r2, s2, b2p1, d_sigma_packed, dS, m, (size_t)0, (size_t)0);
+  hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sigma_packed, dS, m, (size_t)0, (size_t)0, 1);
   HIP_TRY(hipGetLastError());
   // blocked Cholesky of the lower triangle, panel width 128 (psf_chol_kernels.hpp): left-looking on the FP64 GEMM; PSF_CHOL=right: the right-looking
   // kernels of rounds 1-2 (comparison arm)
