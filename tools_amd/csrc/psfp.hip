@@ -418,8 +418,20 @@ static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double 
   const int nP = (nbi + 1) / 2;                                       // panels of two column blocks (256 columns)
   const size_t PW = 2 * TR_BM;                                        // leading dimension of a panel buffer
   const size_t prow = (size_t)nbi * TR_BM;                            // its rows (panel 0 needs them all)
-  // K splits of the update: at most one workgroup per CU (the kernel is a one-workgroup-per-CU design), each split at least one unit of two chunks
-  auto splits_for = [](int wgs, int units) { int sp = wgs > 0 ? 256 / wgs : 1; if (sp > units) sp = units; if (sp > 64) sp = 64; return sp < 1 ? 1 : sp; };
+  // K splits of the update.  One workgroup occupies a CU (356 registers per lane), so a launch runs in rounds of 256 workgroups, each as long as one split
+  // plus its epilogue (the 128 x 256 partial tile goes to the workspace and is read back by the reduce: about 1.5 units' worth of time, a unit being two
+  // chunks = 32 columns of L).  The split count minimises rounds x (units per split + 1.5) over at most 4096 workgroups: without it the middle panels of a large key, whose 257..511 row
+  // blocks are just over one round, leave up to half of the chip idle.
+  auto splits_for = [](int wgs, int units) {
+    if (wgs <= 0 || units <= 1) return 1;
+    int best = 1; double best_cost = 1e300;
+    for (int sp = 1; sp <= units && sp <= 64; ++sp) {
+      if (sp > 1 && (size_t)wgs * sp > 4096) break;                    // workspace: 256 KB per workgroup, 1 GB at most
+      const double cost = (double)(((size_t)wgs * sp + 255) / 256) * ((double)((units + sp - 1) / sp) + 1.5);
+      if (cost < best_cost * 0.999) { best_cost = cost; best = sp; }
+    }
+    return best;
+  };
   size_t ws_doubles = 0;
   for (int J = 1; J < nP; ++J) {
     const int nrb = nbi - 2 * J, head = nrb < 2 ? nrb : 2;
