@@ -85,6 +85,20 @@ __device__ inline void filler_body(int iters, unsigned lane_seed, unsigned* sink
     } else if (OP == 8) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) d[i] = det_exp(-0.5 * d[i]) + 0.25;
+    } else if (OP == 10) {     // the int8 matrix instruction of k_recombine_mfma / k_zq_mfma as the partner: four independent 16 x 16 accumulators in VGPRs
+      typedef int v4i_ __attribute__((ext_vector_type(4)));
+      static_assert(sizeof(v4i_) == 16, "");
+      v4i_ x = {(int)a[0], (int)a[1], (int)a[2], (int)a[3]}, y = {(int)a[4], (int)a[5], (int)a[6], (int)a[7]};
+      v4i_ c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(c0) : "v"(x), "v"(y));
+        asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(c1) : "v"(y), "v"(x));
+        asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(c2) : "v"(x), "v"(x));
+        asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(c3) : "v"(y), "v"(y));
+      }
+      asm volatile("s_nop 15" ::: "memory");
+      a[0] ^= (uint32_t)(c0[0] ^ c1[1] ^ c2[2] ^ c3[3]);
     }
   }
   uint32_t acc = 0;
@@ -264,9 +278,10 @@ int main(int argc, char** argv) {
       } break;
     }
   };
-  const char* names[10] = {"", "v_xor+v_add_u32", "v_mul_lo/hi_u32", "v_mad_u64_u32", "v_fma_f32", "v_fma_f64", "v_exp_f32", "Philox4x32-10", "det_exp (f64)", "k_perturb_round_wave (shipped)"};
+  const char* names[11] = {"", "v_xor+v_add_u32", "v_mul_lo/hi_u32", "v_mad_u64_u32", "v_fma_f32", "v_fma_f64", "v_exp_f32", "Philox4x32-10", "det_exp (f64)", "k_perturb_round_wave (shipped)", "v_mfma_i32_16x16x64_i8"};
 
-  const bool skip_s2 = argc > 3 && !strcmp(argv[3], "pmc");
+  const bool i8_mode = argc > 3 && !strcmp(argv[3], "i8");      // only the S1 case with the int8 matrix instruction as the partner
+  const bool skip_s2 = (argc > 3 && !strcmp(argv[3], "pmc")) || i8_mode;
   // warm-up + matrix kernel alone
   launch_big(sa); hipDeviceSynchronize();
   float t_big = 1e30f;
@@ -333,7 +348,7 @@ int main(int argc, char** argv) {
         hipEventRecord(a0, sa);
 #define S1CASE(OP_) case OP_: if (mop == 0) hipLaunchKernelGGL((k_two_roles<OP_, 0>), dim3(256), dim3(512), 0, sa, mi, fi, roles, out, sink, simd_hist); \
                               else hipLaunchKernelGGL((k_two_roles<OP_, 1>), dim3(256), dim3(512), 0, sa, mi, fi, roles, out, sink, simd_hist); break;
-        switch (op) { S1CASE(1) S1CASE(2) S1CASE(3) S1CASE(4) S1CASE(5) S1CASE(6) S1CASE(7) S1CASE(8) }
+        switch (op) { S1CASE(1) S1CASE(2) S1CASE(3) S1CASE(4) S1CASE(5) S1CASE(6) S1CASE(7) S1CASE(8) S1CASE(10) }
 #undef S1CASE
         hipEventRecord(a1, sa); hipEventSynchronize(a1);
         best = std::min(best, elapsed(a0, a1));
@@ -350,7 +365,8 @@ int main(int argc, char** argv) {
       hipDeviceSynchronize();
       continue;
     }
-    for (int op = 1; op <= 8; ++op) {
+    for (int op = i8_mode ? 10 : 1; op <= 10; ++op) {
+      if (op == 9) continue;
       const float tm = run_s1(op, mi, 0, 1);
       int fi = 1000;
       float tf = 0;

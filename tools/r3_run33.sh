@@ -1,5 +1,9 @@
 #!/bin/bash
 O=gpurun_out/r3_run33; mkdir -p $O
-timeout 900 python3 -m pytest tests/test_gpu_psfp_parity.py tests/test_gpu_pipeline_mode.py tests/test_gpu_structured.py tests/test_gpu_general_base.py tests/test_gpu_boundary_functions.py -q -m gpu 2>&1 | tail -5
-PSF_HALVES=1 timeout 900 python3 -m pytest tests/test_gpu_psfp_parity.py tests/test_gpu_pipeline_mode.py tests/test_gpu_structured.py tests/test_gpu_distribution.py -q -m gpu 2>&1 | tail -5
-for r in 1 2 3; do for v in 0 1; do PSF_HALVES=$v timeout 300 python3 bench.py --config c3 --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('halves=$v', d['ms_per_step'], d['valid'], d['kernels_ms'])"; done; done
+for g in "8 4" "4 8" "2 16" "16 2"; do
+  set -- $g
+  export PSF_TRMM_GR=$1 PSF_TRMM_GC=$2
+  echo "== GR=$1 GC=$2" | tee -a $O/log.txt
+  timeout 300 python3 bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['kernels_ms'])" | tee -a $O/log.txt
+  timeout 600 tools/pmc_traffic.sh c3 k_trmm_f64_big | tee -a $O/log.txt
+done

@@ -118,28 +118,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(GemmArgs g) {
 #endif
       const double* sA = gm_smem + cur * (2 * GM_BK * GM_LD);
       const double* sB = sA + GM_BK * GM_LD;
-      // fragments of k-step ks + 1 are read from LDS while the MFMAs of k-step ks run (two register sets): with a single set every k-step paid an LDS
-      // round trip in front of its 16 MFMAs -- 5.8 k cycles per chunk for 4.1 k of matrix work (tools/probe_gemm.hip, GM_PROBE=1)
-      double fa[2][4], fb[2][4];
-      auto frags = [&](int ks, double (&a)[4], double (&b)[4]) {
-        const int kk = ks * 4 + gq, rot = 2 * (kk >> 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a[i] = sA[kk * GM_LD + ((wr * 64 + i * 16 + r16 + rot) & 127)];
-          b[i] = sB[kk * GM_LD + ((wc * 64 + i * 16 + r16 + rot) & 127)];
-        }
-      };
-      frags(0, fa[0], fb[0]);
+      // one fragment set: reading k-step ks + 1 into a second set while the MFMAs of k-step ks run measured no faster at two workgroups per CU (the other
+      // workgroup's MFMAs cover the LDS round trip) and spills at the 256-register budget (profiles/r03_notes.md)
 #pragma unroll
       for (int ks = 0; ks < GM_BK / 4; ++ks) {
-        if (ks + 1 < GM_BK / 4) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+        const int kk = ks * 4 + gq, rot = 2 * (kk >> 1);
+        double fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fa[i] = sA[kk * GM_LD + ((wr * 64 + i * 16 + r16 + rot) & 127)];
+          fb[i] = sB[kk * GM_LD + ((wc * 64 + i * 16 + r16 + rot) & 127)];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
 #if defined(GM_PROBE) && GM_PROBE == 2      /* no MFMAs: loads, LDS traffic, barriers */
-          for (int j = 0; j < 4; ++j) acc[i][j][0] += fa[ks & 1][i] * fb[ks & 1][j];
+          for (int j = 0; j < 4; ++j) acc[i][j][0] += fa[i] * fb[j];
 #else
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
 #endif
       }
       if (kt + 1 < nk) stash(kt + 1, cur ^ 1);
