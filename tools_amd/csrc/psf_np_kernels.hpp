@@ -328,7 +328,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
   uint4 (*s_ring)[8 * 64] = reinterpret_cast<uint4 (*)[8 * 64]>(smem_raw + 16384 + 2048 + 8192);         // per pair: records of two groups of four steps
   double (*s_zs)[128] = reinterpret_cast<double (*)[128]>(smem_raw + 16384 + 2048 + 8192 + 32768);       // sampler: z of the block above, [sg][k]
   int (*s_cnt)[2] = reinterpret_cast<int (*)[2]>(smem_raw + 16384 + 2048 + 8192 + 32768 + 4096);         // per pair: groups produced, groups consumed
-  const SampleZParams* g_sz = a.sz + j0_of(J);                                              // full SampleZ tables: rare paths only, read from L2
+  double* s_invs = reinterpret_cast<double*>(smem_raw + 16384 + 2048 + 8192 + 32768 + 4096 + 64);        // 1 / s' of the block's rows in full precision (NP_NB)
+  const SampleZParams* g_sz = a.sz + j0_of(J);                                              // full SampleZ tables, in L2: only 1 / s' is not in the LDS record
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool helper = wave >= 4;
@@ -361,6 +362,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
     }
     if (tid < NP_NB) {
       s_row[tid] = tid < nrows ? a.rows[j0 + tid] : NpRow{0.0, 0.f, 0, 1, 0, 0, 16};
+      s_invs[tid] = tid < nrows ? g_sz[tid].inv_s : 1.0;
     }
     if (tid < 8) s_cnt[tid >> 1][tid & 1] = 0;
   }
@@ -560,7 +562,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
               if (pending && !sure && lane == fl) {               // keep every bit of the exact decision (incl. its tie-break Philox block) inside the branch
                 uint32_t ta = (uint32_t)lam;
                 asm volatile("" : "+v"(ta));
-                acc = sz_decide(seed, coord, (uint32_t)index, tw, ta, (long long)lo + (long long)idx, rec.w, cen, g_sz[l].inv_s, rw.sh);
+                acc = sz_decide(seed, coord, (uint32_t)index, tw, ta, (long long)lo + (long long)idx, rec.w, cen, s_invs[l], rw.sh);
               }
               const uint64_t accm = __ballot(acc);
               const int xi = __shfl((int)idx, fl);
@@ -576,7 +578,15 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
             NP_EVENT(2);
             // (an "accepted for certain" class here as in the first round was measured: C2 3.5 % slower, C4 unchanged -- the rounds are rare and the
             // extra live values cost the hot path registers)
-            const SampleZParams sp2 = g_sz[l];
+            // the row's SampleZ parameters rebuilt from LDS (an L2 round trip here cost ~2 k cycles of every generic phase; at C4, where 32 first-round
+            // attempts leave 12 % of the wave-steps without a candidate, these phases are what the slowest wave of a launch is made of)
+            SampleZParams sp2;
+            if (rw.sh != 0) {
+              sp2.inv_s = s_invs[l]; sp2.c6 = (long long)rw.c6; sp2.n_int = rw.n_int; sp2.f6 = (long long)rw.n_int - 1 - (long long)rw.c6;
+              sp2.thr_int = rw.thr_int; sp2.thr_frac = rw.thr_frac; sp2.sh = rw.sh;
+            } else {
+              sp2 = g_sz[l];                                         // rows without a fast path (more than 2^24 candidates): the record does not carry c6
+            }
             const SzRange rg = sz_range(cen, sp2);
             for (; t0 < kMaxAttempts; t0 += LPD) {
               if (!__ballot(!got)) break;
