@@ -7,7 +7,8 @@ for cfg in c3 c2 c4 c3prime c2s240; do
   timeout 600 python3 bench.py --config $cfg --steps 20 --warmup 2 > $O/bench_$cfg.log 2>&1; tail -1 $O/bench_$cfg.log > $O/bench_$cfg.json
 done
 timeout 300 python3 bench.py --config c3 --structured --steps 20 --warmup 2 > $O/bench_c3s.log 2>&1; tail -1 $O/bench_c3s.log > $O/bench_c3_structured.json
-python3 tools/keygen_time.py c3 c3prime c2 c4 > $O/keygen.log 2>&1
+timeout 900 python3 bench.py --config c5 --steps 2 --warmup 1 > $O/bench_c5.log 2>&1; tail -1 $O/bench_c5.log > $O/bench_c5_one_gpu.json
+python3 tools/keygen_time.py c3 c3prime c2 c4 c5 > $O/keygen.log 2>&1
 cd /tmp
 for cfg in c3 c2 c4; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$cfg -o t --output-format csv -- python3 $R/bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline > $O/rocprof_$cfg.log 2>&1

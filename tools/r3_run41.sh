@@ -1,0 +1,9 @@
+#!/bin/bash
+O=gpurun_out/r3_run41; mkdir -p $O
+R=$GRAFT_REPO_ROOT
+timeout 600 python3 -m pytest tests/test_gpu_psfp_parity.py -q -m gpu -x 2>&1 | tail -3
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o t --output-format csv -- python3 $R/bench.py --config c3 --steps 5 --warmup 1 --no-cpu-baseline > $R/$O/rocprof.log 2>&1
+cd $R
+f=$(find $O/prof -name "*kernel_stats.csv" | head -1); grep -E "recombine|zq_mfma" $f | cut -c1-40,150-300
+rm -f $O/prof/*kernel_trace.csv

@@ -1381,13 +1381,14 @@ constexpr int RC_LDS = 3 * RC_STAGE;      // 72 KiB: three 24 KiB stages, or fou
 __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int nks,
                                                            const int8_t* __restrict__ Zlo, const int8_t* __restrict__ Zhi, size_t ld,
                                                            const int* __restrict__ flags, const int32_t* __restrict__ P, size_t B,
-                                                           int64_t* __restrict__ E, size_t m) {
+                                                           int64_t* __restrict__ E, size_t m, int only_hi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const size_t b0 = (size_t)blockIdx.x * 128, i0 = (size_t)blockIdx.y * 128;
   const bool use_hi = flags[1] != 0;
+  if (only_hi && !use_hi) return;                     // k_recombine_mfma_big (launched in front) has done the lo-plane-only case
 
   v4i alo[4][4], ahi[4][4];
 #pragma unroll
@@ -1524,6 +1525,144 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
         if (bb < B && ii < mbar)
           E[bb * m + ii] = (int64_t)sP[il * 129 + bl] + (int64_t)alo[bt][it][r] + 256 * (int64_t)ahi[bt][it][r];
       }
+}
+
+// The common case (no |z| > 127: one digit plane) on 256 x 256 workgroup tiles: eight waves, wave (wr, wc) the 128 (b) x 64 (i) piece in 32 accumulator
+// tiles = 128 registers; one workgroup per CU; two 64 KiB stages (R tile [k half 2][row 256][64 B, k groups rotated by i8_slot] | Z tile [k group 8][preimage 256]
+// [16 B]) filled by LDS-DMA, K = 128 (64 MFMAs per wave) between two barriers.  p is added straight from global memory: the four preimages of a lane's
+// accumulator tile are one 16-byte run of a row of P.
+// Measured at C3 (profiles/r03_notes.md): 1.064 ms against 1.081 ms for the 128 x 128 kernel above -- half the bytes staged (7.6 instead of 15 GB) buy 1.6 %.
+// What bounds both is instruction ISSUE on the SIMD, not the L2 -> LDS stream that round 2 blamed: per v_mfma_i32_16x16x64_i8 (16 cycles) a wave here also issues
+// 1/8 of an LDS-DMA piece (~125 cycles each inside such a phase, MI355X_MICROARCH.md) and 3/8 of a ds_read_b128 (~25): 16 + 15.6 + 9.4 = 41 cycles per
+// MFMA, 5.3 k per K step and CU, which is the measured time; the same sum gives the 128 x 128 kernel's.  Reading the fragments of the next sub-step while the
+// MFMAs of the current one run (two register sets) changed nothing (1.077 ms), as it must if issue slots are the bound.
+constexpr int RCB_STAGE = 65536;
+constexpr int RCB_LDS = 2 * RCB_STAGE;
+__global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int n2,
+                                                               const int8_t* __restrict__ Zlo, size_t ld, const int* __restrict__ flags,
+                                                               const int32_t* __restrict__ P, size_t B, int64_t* __restrict__ E, size_t m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rcb_smem[];
+  if (flags[1] != 0) return;                          // a second digit plane is in use: k_recombine_mfma (launched behind) takes the call
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const size_t b0 = (size_t)blockIdx.x * 256, i0 = (size_t)blockIdx.y * 256;
+  v4i acc[8][4];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = v4i{0, 0, 0, 0};
+  // 16-byte pieces of a stage: 2048 of R and 2048 of Z, four of each per thread; piece p of R = (k half p / 1024, row (p / 4) % 256, position p % 4) and
+  // holds k group (position - row / 4) mod 4; piece p of Z = (k group p / 256, preimage p % 256)
+  const int8_t* srcR[4]; const int8_t* srcZ[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = (wave * 4 + j) * 64 + lane;
+    const int kk = p >> 10, row = (p >> 2) & 255, col = ((p & 3) - (row >> 2)) & 3;
+    srcR[j] = R + (i0 + (size_t)row) * ldr + (size_t)(kk * 64 + col * 16);
+    srcZ[j] = Zlo + ((size_t)(p >> 8) * ld + b0 + (size_t)(p & 255)) * 16;
+  }
+  auto stage_load = [&](int ks2, int buf) {
+    unsigned char* base = rcb_smem + buf * RCB_STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds(srcR[j] + (size_t)ks2 * 128, (lds_void_ptr)(base + (wave * 4 + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(srcZ[j] + (size_t)ks2 * 8 * ld * 16, (lds_void_ptr)(base + 32768 + (wave * 4 + j) * 1024), 16, 0, 0);
+    }
+  };
+  const int r16 = lane & 15, g = lane >> 4;
+  stage_load(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#ifdef RCB_NO_LOOP
+  n2 = 1;
+#endif
+  for (int ks2 = 0; ks2 < n2; ++ks2) {
+    const int cb = ks2 & 1;
+#ifdef RCB_REG_STAGE
+    v4i stR[4], stZ[4];
+    if (ks2 + 1 < n2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        stR[j] = *reinterpret_cast<const v4i*>(srcR[j] + (size_t)(ks2 + 1) * 128);
+        stZ[j] = *reinterpret_cast<const v4i*>(srcZ[j] + (size_t)(ks2 + 1) * 8 * ld * 16);
+      }
+    }
+#elif defined(RCB_NO_DMA)
+    if (ks2 + 1 < 2) stage_load(ks2 + 1, cb ^ 1);
+#else
+    if (ks2 + 1 < n2) stage_load(ks2 + 1, cb ^ 1);
+#endif
+#ifdef RCB_NO_READ
+    const unsigned char* sR = rcb_smem + (ks2 > 1 ? 0 : cb) * RCB_STAGE;
+    if (ks2 > 1) {
+      v4i fa = {tid, 1, 2, 3}, fb = {lane, 5, 6, 7};
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+      for (int bt = 0; bt < 8; ++bt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, acc[bt][it], 0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      continue;
+    }
+#else
+    const unsigned char* sR = rcb_smem + cb * RCB_STAGE;
+#endif
+    const unsigned char* sL = sR + 32768;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      v4i fr[4], fl[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ri = wc * 64 + t * 16 + r16;
+        fr[t] = *reinterpret_cast<const v4i*>(sR + kk * 16384 + (ri * 64 + i8_slot(ri, g) * 16));
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fl[t] = *reinterpret_cast<const v4i*>(sL + (((kk * 4 + g) * 256 + wr * 128 + t * 16 + r16) * 16));
+#pragma unroll
+      for (int bt = 0; bt < 8; ++bt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fl[bt], fr[it], acc[bt][it], 0, 0, 0);
+    }
+#ifdef RCB_REG_STAGE
+    if (ks2 + 1 < n2) {
+      unsigned char* nb = rcb_smem + (cb ^ 1) * RCB_STAGE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<v4i*>(nb + ((wave * 4 + j) * 64 + lane) * 16) = stR[j];
+        *reinterpret_cast<v4i*>(nb + 32768 + ((wave * 4 + j) * 64 + lane) * 16) = stZ[j];
+      }
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // C/D map: column (here i) = lane & 15, row (here b) = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int bt = 0; bt < 8; ++bt) {
+    const size_t bb = b0 + (size_t)(wr * 128 + bt * 16 + 4 * g);
+    int4 pv[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const size_t ii = i0 + (size_t)(wc * 64 + it * 16 + r16);
+      pv[it] = (ii < mbar && bb < B) ? *reinterpret_cast<const int4*>(P + ii * ld + bb) : int4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const size_t ii = i0 + (size_t)(wc * 64 + it * 16 + r16);
+      if (ii >= mbar) continue;
+      const int pr[4] = {pv[it].x, pv[it].y, pv[it].z, pv[it].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#ifdef RCB_NO_STORE
+        if (bb + r < B && acc[bt][it][r] == 0x7fffffff) E[(bb + r) * m + ii] = (int64_t)pr[r] + (int64_t)acc[bt][it][r];
+#else
+        if (bb + r < B) E[(bb + r) * m + ii] = (int64_t)pr[r] + (int64_t)acc[bt][it][r];
+#endif
+    }
+  }
 }
 
 // bottom part: e[b][mbar + c] = p[mbar + c][b] + z[c][b]

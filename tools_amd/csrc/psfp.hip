@@ -310,7 +310,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   h->mL = h->structured ? h->mb : h->m;
   h->nbiL = round_up(h->mL, TR_BM) / TR_BM;
   h->ldr = round_up(h->w, 64);          // K of the int8 MFMA product, zero padded
-  h->mb_pad = round_up(h->mb, 128);
+  h->mb_pad = round_up(h->mb, 256);        // rows of R as allocated (zero below m_bar): the 256-row tiles of k_recombine_mfma_big read them all
   h->n_pad = round_up(h->n, 64);
   h->K_pad = round_up(h->m, 64);
   {  // number of balanced base-256 digits so that the top digit of any a < q fits an int8
@@ -380,6 +380,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB * (CH_NB + 1) / 2 + CH_NB * 64) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_mfma_big), hipFuncAttributeMaxDynamicSharedMemorySize, RCB_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rd2_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (1 + kFixPlanes) * 4096));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
@@ -929,8 +930,13 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
     {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
       ScopedTimer t(h, sx, "k_recombine");
-      hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bh + 127) / 128), (unsigned)(h->mb_pad / 128)), dim3(256), RC_LDS, sx, h->dR,
-                         h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m);
+      // one digit plane (decided on the device by the gadget kernel): 256 x 256 tiles; otherwise, or for shapes the big tile does not fit, the 128 x 128 kernel
+      const bool big = Bh % 256 == 0 && b0 % 256 == 0 && h->mb >= 512 && (h->ldr / 64) % 2 == 0;
+      if (big)
+        hipLaunchKernelGGL(k_recombine_mfma_big, dim3((unsigned)(Bh / 256), (unsigned)(h->mb_pad / 256)), dim3(512), RCB_LDS, sx, h->dR, h->ldr, h->mb,
+                           (int)(h->ldr / 128), h->dZlo + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m);
+      hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bh + 127) / 128), (unsigned)((h->mb + 127) / 128)), dim3(256), RC_LDS, sx, h->dR,
+                         h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m, big ? 1 : 0);
       hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bh + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, sx, h->mb, h->w,
                          h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
     }
