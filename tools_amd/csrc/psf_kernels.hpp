@@ -1531,11 +1531,11 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
 // tiles = 128 registers; one workgroup per CU; two 64 KiB stages (R tile [k half 2][row 256][64 B, k groups rotated by i8_slot] | Z tile [k group 8][preimage 256]
 // [16 B]) filled by LDS-DMA, K = 128 (64 MFMAs per wave) between two barriers.  p is added straight from global memory: the four preimages of a lane's
 // accumulator tile are one 16-byte run of a row of P.
-// Measured at C3 (profiles/r03_notes.md): 1.064 ms against 1.081 ms for the 128 x 128 kernel above -- half the bytes staged (7.6 instead of 15 GB) buy 1.6 %.
-// What bounds both is instruction ISSUE on the SIMD, not the L2 -> LDS stream that round 2 blamed: per v_mfma_i32_16x16x64_i8 (16 cycles) a wave here also issues
-// 1/8 of an LDS-DMA piece (~125 cycles each inside such a phase, MI355X_MICROARCH.md) and 3/8 of a ds_read_b128 (~25): 16 + 15.6 + 9.4 = 41 cycles per
-// MFMA, 5.3 k per K step and CU, which is the measured time; the same sum gives the 128 x 128 kernel's.  Reading the fragments of the next sub-step while the
-// MFMAs of the current one run (two register sets) changed nothing (1.077 ms), as it must if issue slots are the bound.
+// Measured at C3 (profiles/r03_notes.md, "int8 recombination: what bounds it"): 1.064 ms against 1.081 ms for the 128 x 128 kernel above -- half the bytes
+// staged (7.6 instead of 15 GB) buy 1.6 %, so the L2 -> LDS stream round 2 blamed is not the bound.  Ablation of this kernel (stores off, 0.93 ms): without the
+// LDS fragment reads 0.96, without the LDS-DMA 0.65, without both 0.51 (the MFMAs alone: 0.41 at 16 cycles each); the epilogue alone 0.19.  The eight DMA
+// pieces a wave issues per K step are what the step waits for, however they are placed (in front of the MFMAs, spread over them by the scheduler, or replaced by
+// global loads into registers + ds_write_b128: 1.08 / 1.08 / 1.13 ms); double-buffered fragment reads change nothing (1.08).
 constexpr int RCB_STAGE = 65536;
 constexpr int RCB_LDS = 2 * RCB_STAGE;
 __global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int n2,
@@ -1574,42 +1574,10 @@ __global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __r
   stage_load(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-#ifdef RCB_NO_LOOP
-  n2 = 1;
-#endif
   for (int ks2 = 0; ks2 < n2; ++ks2) {
     const int cb = ks2 & 1;
-#ifdef RCB_REG_STAGE
-    v4i stR[4], stZ[4];
-    if (ks2 + 1 < n2) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        stR[j] = *reinterpret_cast<const v4i*>(srcR[j] + (size_t)(ks2 + 1) * 128);
-        stZ[j] = *reinterpret_cast<const v4i*>(srcZ[j] + (size_t)(ks2 + 1) * 8 * ld * 16);
-      }
-    }
-#elif defined(RCB_NO_DMA)
-    if (ks2 + 1 < 2) stage_load(ks2 + 1, cb ^ 1);
-#else
     if (ks2 + 1 < n2) stage_load(ks2 + 1, cb ^ 1);
-#endif
-#ifdef RCB_NO_READ
-    const unsigned char* sR = rcb_smem + (ks2 > 1 ? 0 : cb) * RCB_STAGE;
-    if (ks2 > 1) {
-      v4i fa = {tid, 1, 2, 3}, fb = {lane, 5, 6, 7};
-#pragma unroll
-      for (int rep = 0; rep < 2; ++rep)
-#pragma unroll
-      for (int bt = 0; bt < 8; ++bt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) acc[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, acc[bt][it], 0, 0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      continue;
-    }
-#else
     const unsigned char* sR = rcb_smem + cb * RCB_STAGE;
-#endif
     const unsigned char* sL = sR + 32768;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -1626,16 +1594,6 @@ __global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __r
 #pragma unroll
         for (int it = 0; it < 4; ++it) acc[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fl[bt], fr[it], acc[bt][it], 0, 0, 0);
     }
-#ifdef RCB_REG_STAGE
-    if (ks2 + 1 < n2) {
-      unsigned char* nb = rcb_smem + (cb ^ 1) * RCB_STAGE;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<v4i*>(nb + ((wave * 4 + j) * 64 + lane) * 16) = stR[j];
-        *reinterpret_cast<v4i*>(nb + 32768 + ((wave * 4 + j) * 64 + lane) * 16) = stZ[j];
-      }
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -1656,11 +1614,7 @@ __global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __r
       const int pr[4] = {pv[it].x, pv[it].y, pv[it].z, pv[it].w};
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-#ifdef RCB_NO_STORE
-        if (bb + r < B && acc[bt][it][r] == 0x7fffffff) E[(bb + r) * m + ii] = (int64_t)pr[r] + (int64_t)acc[bt][it][r];
-#else
         if (bb + r < B) E[(bb + r) * m + ii] = (int64_t)pr[r] + (int64_t)acc[bt][it][r];
-#endif
     }
   }
 }
