@@ -1540,13 +1540,21 @@ constexpr int RCB_STAGE = 65536;
 constexpr int RCB_LDS = 2 * RCB_STAGE;
 __global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int n2,
                                                                const int8_t* __restrict__ Zlo, size_t ld, const int* __restrict__ flags,
-                                                               const int32_t* __restrict__ P, size_t B, int64_t* __restrict__ E, size_t m) {
+                                                               const int32_t* __restrict__ P, size_t B, int64_t* __restrict__ E, size_t m,
+                                                               unsigned nbx, unsigned nby) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rcb_smem[];
   if (flags[1] != 0) return;                          // a second digit plane is in use: k_recombine_mfma (launched behind) takes the call
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const size_t b0 = (size_t)blockIdx.x * 256, i0 = (size_t)blockIdx.y * 256;
+  // the 32 workgroups an XCD holds at a time (blockIdx % 8 = XCD, one workgroup per CU) form a super-tile of 4 preimage tiles x 8 coordinate tiles: every R
+  // tile is fetched into that XCD's L2 once for four workgroups, every Z tile once for eight
+  const unsigned nbg = (nbx + 3) / 4, nig = (nby + 7) / 8;
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const unsigned sup = (slot >> 5) * 8u + xcd, tt = slot & 31u;
+  const unsigned bx = (sup % nbg) * 4u + (tt & 3u), by = (sup / nbg) * 8u + (tt >> 2);
+  if (sup >= nbg * nig || bx >= nbx || by >= nby) return;
+  const size_t b0 = (size_t)bx * 256, i0 = (size_t)by * 256;
   v4i acc[8][4];
 #pragma unroll
   for (int x = 0; x < 8; ++x)

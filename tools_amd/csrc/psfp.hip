@@ -932,9 +932,12 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       ScopedTimer t(h, sx, "k_recombine");
       // one digit plane (decided on the device by the gadget kernel): 256 x 256 tiles; otherwise, or for shapes the big tile does not fit, the 128 x 128 kernel
       const bool big = Bh % 256 == 0 && b0 % 256 == 0 && h->mb >= 512 && (h->ldr / 64) % 2 == 0;
-      if (big)
-        hipLaunchKernelGGL(k_recombine_mfma_big, dim3((unsigned)(Bh / 256), (unsigned)(h->mb_pad / 256)), dim3(512), RCB_LDS, sx, h->dR, h->ldr, h->mb,
-                           (int)(h->ldr / 128), h->dZlo + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m);
+      if (big) {
+        const unsigned nbx = (unsigned)(Bh / 256), nby = (unsigned)(h->mb_pad / 256);
+        const unsigned nsup = ((nbx + 3) / 4) * ((nby + 7) / 8);                 // super-tiles of 4 x 8 tiles, dealt to the XCDs in rounds of eight
+        hipLaunchKernelGGL(k_recombine_mfma_big, dim3(((nsup + 7) / 8) * 8 * 32), dim3(512), RCB_LDS, sx, h->dR, h->ldr, h->mb,
+                           (int)(h->ldr / 128), h->dZlo + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m, nbx, nby);
+      }
       hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bh + 127) / 128), (unsigned)((h->mb + 127) / 128)), dim3(256), RC_LDS, sx, h->dR,
                          h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m, big ? 1 : 0);
       hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bh + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, sx, h->mb, h->w,
