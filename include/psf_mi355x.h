@@ -173,7 +173,8 @@ size_t     psfp_m(const psfp_handle*);
  * PSF_ERR_NOT_PD if Sigma_2 is not positive definite (s too small). */
 psf_status psfp_trap_gen(psfp_handle*, uint64_t seed);
 /* PSFPerturbation::compute_sqrt_sigma_2 (mp_perturbation.rs:111-139) for Sigma = s_cov^2 * I using the
- * handle's R; replaces the handle's sqrt(Sigma_2) (the doctest at :89-107). */
+ * handle's R; replaces the handle's sqrt(Sigma_2) (the doctest at :89-107).  With PSFP_FLAG_STRUCTURED_SQRT only s_cov == s is
+ * accepted (PSF_ERR_UNSUPPORTED otherwise): the structured factor's constants are rebuilt from s when a key is loaded. */
 psf_status psfp_compute_sqrt_sigma_2(psfp_handle*, double s_cov);
 /* The general form: `mat_sigma: &MatQ` of mp_perturbation.rs:111 is any symmetric m x m matrix (used as a full matrix at :125-126).
  * sigma_lower_packed: its lower triangle, row i holding i + 1 entries (m(m+1)/2 doubles).  PSF_ERR_NOT_PD if Sigma_2 is not positive

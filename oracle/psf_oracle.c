@@ -108,6 +108,7 @@ static int sz_attempt(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t t
   return (double)w2[0] < rfrac;
 }
 
+static unsigned long g_sample_z_cap_hits = 0;
 int64_t orc_sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center, double s) {
   double inv_s = 1.0 / s;
   int64_t c6 = (int64_t)ceil(6.0 * s), f6 = (int64_t)floor(6.0 * s);
@@ -133,8 +134,15 @@ int64_t orc_sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord
     for (uint32_t j = 0; j < 4; ++j)
       if (sz_attempt(seed, coord, (uint32_t)index, tw, 4 * g + j, wa[j], wb[j], lo, N, thr, sh, center, inv_s, &x)) return x;
   }
+  /* ORC_MAX_ATTEMPTS attempts without an accept (a width far below 1 with a half-integral centre: acceptance ~e^-25).  The reference would keep
+   * drawing; the contract ends the draw with the nearest integer AND reports it: the sampling entry points return ORC_ERR_SAMPLER when this counter
+   * moved during their call (the device raises its failure flag in the same place, PSF_ERR_SAMPLER). */
+  __atomic_fetch_add(&g_sample_z_cap_hits, 1ul, __ATOMIC_RELAXED);
   return (int64_t)floor(center + 0.5);
 }
+unsigned long orc_sample_z_cap_hits(void) { return __atomic_load_n(&g_sample_z_cap_hits, __ATOMIC_RELAXED); }
+/* status of a sampling entry point: ORC_ERR_SAMPLER when a draw of the call ended at the attempt cap (cap0 = the counter at entry) */
+static int cap_status(unsigned long cap0, int rc) { return (rc == ORC_OK && orc_sample_z_cap_hits() != cap0) ? ORC_ERR_SAMPLER : rc; }
 
 /* N(0,1) by Kinderman-Monahan ratio of uniforms: x = sqrt(2/e) v / u, accept iff u <= exp(-x^2/4). */
 double orc_sample_normal(uint64_t seed, uint64_t index, uint32_t coord) {
@@ -752,6 +760,7 @@ int orc_psfp_samp_p_from_x(const orc_psfp* h, uint64_t seed, uint64_t index, con
   const orc_gadget_params* gp = &h->gp;
   size_t n = gp->n, k = gp->k, mb = gp->m_bar, w = n * k, m = h->m;
   uint64_t q = gp->q;
+  const unsigned long cap0 = orc_sample_z_cap_hits();
   (void)k;
   for (size_t i = 0; i < m; ++i) p[i] = orc_sample_z(seed, ORC_TAG_PERTURB, index, (uint32_t)i, x[i], h->r);
   /* :318 v = u - A p */
@@ -772,7 +781,7 @@ int orc_psfp_samp_p_from_x(const orc_psfp* h, uint64_t seed, uint64_t index, con
     e[i] = p[i] + acc;
   }
   for (size_t c = 0; c < w; ++c) e[mb + c] = p[mb + c] + z[c];
-  return ORC_OK;
+  return cap_status(cap0, ORC_OK);
 }
 
 int orc_num_threads(void) {
@@ -840,6 +849,7 @@ int orc_psfp_samp_p(const orc_psfp* h, uint64_t seed, uint64_t first_index, size
   const uint64_t q = gp->q;
   const size_t ngroups = (B + GRP - 1) / GRP, npanels = (m + ORC_MC - 1) / ORC_MC;
   int status = ORC_OK;
+  const unsigned long cap0 = orc_sample_z_cap_hits();
   if (!h->L) return ORC_ERR_PARAM;
   if (B == 0) return ORC_OK;
   double* norm2 = (double*)malloc(2 * k * sizeof(double));
@@ -975,7 +985,7 @@ int orc_psfp_samp_p(const orc_psfp* h, uint64_t seed, uint64_t first_index, size
         for (size_t b = 0; b < nb; ++b) e[(b0 + b) * m + mb + c] = (int64_t)P[(mb + c) * GRP + b] + Z[c * GRP + b];
   }
   free(Dall); free(Pall); free(Zall); free(maxp_g); free(norm2);
-  return status;
+  return cap_status(cap0, status);
 }
 #undef GRP
 
@@ -983,9 +993,10 @@ int orc_psfp_samp_p(const orc_psfp* h, uint64_t seed, uint64_t first_index, size
 int orc_psfp_samp_d(const orc_psfp* h, uint64_t seed, uint64_t first_index, size_t B, int64_t* e) {
   size_t m = h->m;
   double sr = h->s * h->r;
+  const unsigned long cap0 = orc_sample_z_cap_hits();
   for (size_t b = 0; b < B; ++b)
     for (size_t i = 0; i < m; ++i) e[b * m + i] = orc_sample_z(seed, ORC_TAG_SAMPD, first_index + b, (uint32_t)i, 0.0, sr);
-  return ORC_OK;
+  return cap_status(cap0, ORC_OK);
 }
 
 /* mp_perturbation.rs:396-402: column vector of length m with ||sigma||^2 <= s^2 m r^2 */

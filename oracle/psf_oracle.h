@@ -48,6 +48,8 @@ void   orc_philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint
 double orc_det_exp(double y);
 /* D_{Z,s,c} by rejection from [ceil(c)-ceil(6s), floor(c)+floor(6s)] (CONTRIBUTING.md:35-45) */
 int64_t orc_sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center, double s);
+/* how many draws have ended at the attempt cap since the library was loaded (see orc_sample_z) */
+unsigned long orc_sample_z_cap_hits(void);
 double  orc_sample_normal(uint64_t seed, uint64_t index, uint32_t coord);
 uint64_t orc_uniform_mod(uint64_t seed, uint32_t tag, uint32_t c0, uint32_t c1, uint64_t q);
 

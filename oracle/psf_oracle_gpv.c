@@ -331,6 +331,7 @@ int orc_gpv_samp_p(const void* hv, uint64_t seed, uint64_t first_index, size_t B
   size_t n = h->gp.n, m = h->m;
   uint64_t q = h->gp.q;
   int status = ORC_OK;
+  const unsigned long cap0 = orc_sample_z_cap_hits();
   if (!percall && !h->has_solver) return ORC_ERR_NO_SOLUTION;
 #ifdef _OPENMP
   if (nthreads <= 0) nthreads = omp_get_max_threads();
@@ -361,7 +362,7 @@ int orc_gpv_samp_p(const void* hv, uint64_t seed, uint64_t first_index, size_t B
     }
     free(sol); free(c);
   }
-  return status;
+  return (status == ORC_OK && orc_sample_z_cap_hits() != cap0) ? ORC_ERR_SAMPLER : status;      /* a draw that ended at the attempt cap (orc_sample_z) */
 }
 
 /* one preimage with the walk's own view of it (tests/test_oracle_centre_precision.py): the integer centre vector the FINAL pass started from
@@ -371,6 +372,7 @@ int orc_gpv_samp_p_trace(const void* hv, uint64_t seed, uint64_t index, const ui
   size_t n = h->gp.n, m = h->m;
   uint64_t q = h->gp.q;
   if (!h->has_solver) return ORC_ERR_NO_SOLUTION;
+  const unsigned long cap0 = orc_sample_z_cap_hits();
   int64_t* c = (int64_t*)calloc(m, sizeof(int64_t));
   for (size_t r = 0; r < n; ++r) {
     u128 acc = 0;
@@ -387,15 +389,16 @@ int orc_gpv_samp_p_trace(const void* hv, uint64_t seed, uint64_t index, const ui
   }
   for (size_t j = 0; j < m; ++j) e[j] = -c[j];
   free(c);
-  return ORC_OK;
+  return orc_sample_z_cap_hits() != cap0 ? ORC_ERR_SAMPLER : ORC_OK;
 }
 
 /* gpv.rs:113-116: D_{Z^m, s} centred at 0 */
 int orc_gpv_samp_d(const void* hv, uint64_t seed, uint64_t first_index, size_t B, int64_t* e) {
   const orc_gpv* h = (const orc_gpv*)hv;
+  const unsigned long cap0 = orc_sample_z_cap_hits();
   for (size_t b = 0; b < B; ++b)
     for (size_t i = 0; i < h->m; ++i) e[b * h->m + i] = orc_sample_z(seed, ORC_TAG_SAMPD, first_index + b, (uint32_t)i, 0.0, h->s);
-  return ORC_OK;
+  return orc_sample_z_cap_hits() != cap0 ? ORC_ERR_SAMPLER : ORC_OK;
 }
 
 /* gpv.rs:219-224 */

@@ -97,3 +97,19 @@ def test_structured_not_pd_is_reported(T):
     with pytest.raises(T.PsfError) as ei:
         psf.trap_gen(1)
     assert ei.value.status == 2
+
+
+def test_structured_factor_for_another_covariance_is_refused(T):
+    """The structured factor's constants g, h follow from s and are rebuilt from the handle's s when a key is loaded (an exported key carries only L_1), so a
+    factor for another s_cov could not survive an export / load round trip: compute_sqrt_sigma_2 refuses it instead of pairing L_1(s_cov) with g, h(s)."""
+    from tools_amd import _ffi
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(8, 64), 3.0, 25.0, structured=True)
+    psf.trap_gen(3)
+    psf.compute_sqrt_sigma_2(25.0)                       # the handle's own s: allowed, same factor
+    with pytest.raises(T.PsfError) as ei:
+        psf.compute_sqrt_sigma_2(35.0)
+    assert ei.value.status == _ffi.ERR_UNSUPPORTED
+    u = np.zeros((3, 8), dtype=np.int64)
+    e = psf.samp_p(u, seed=4)                            # the key in the handle is still the one for s
+    assert (psf.f_a(e) == u).all() and psf.check_domain(e).all()
+    psf.close()

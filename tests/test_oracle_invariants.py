@@ -122,3 +122,24 @@ def test_streams_are_independent_of_batching(oracle):
     full = psf.samp_p(77, u, first_index=100)
     part = psf.samp_p(77, u[17:23], first_index=117)
     assert (part == full[17:23]).all()
+
+
+def test_a_draw_that_ends_at_the_attempt_cap_is_reported(oracle):
+    """The reference's sample_z loops until it accepts; the contract caps a draw at 65 536 attempts (psf_rng.hpp kMaxAttempts), ends it with the nearest integer
+    and REPORTS it: the device raises PSF_ERR_SAMPLER, and so must the oracle's sampling entry points (found by tests/test_gpu_random_configs.py: the oracle
+    used to return the same fallback value with status 0).  A width of 0.2 around a half-integer accepts with probability e^-19 per attempt."""
+    import ctypes as C
+    from oracle.oracle import lib
+    lib().orc_sample_z_cap_hits.restype = C.c_ulong
+    before = lib().orc_sample_z_cap_hits()
+    z = oracle.sample_z(1, 3, 0, 0, 0.5, 0.2)
+    assert z in (0, 1) and lib().orc_sample_z_cap_hits() == before + 1
+    assert oracle.sample_z(1, 3, 0, 0, 0.5, 3.0) is not None and lib().orc_sample_z_cap_hits() == before + 1      # an ordinary draw does not count
+    # through an entry point: a PSFGPV whose Gaussian is far below the smoothing parameter
+    n, q, s = 6, 257, 0.3
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    assert orc.trap_gen(1) == 0
+    u = oracle.uniform_targets(1, 2, n, q)
+    import pytest
+    with pytest.raises(RuntimeError, match="oracle status 6"):
+        orc.samp_p(5, u)

@@ -536,7 +536,7 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(round_up(h->mb, 64) * h->ldr, 256, 256 * 64)), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, round_up(h->mb, 64), h->ldr, h->dR8);
   }
   {
-    // "stream": left-looking on the key's chunk stream, no dense matrix (C5: 13.4 s against 21.1 s, and 121 GB less memory; C3: 0.32 s against 0.29 s); "gemm": left-looking on a
+    // "stream": left-looking on the key's chunk stream, no dense matrix (C5: 10.1 s against 21.1 s, and 121 GB less memory; C3: 0.28 s either way); "gemm": left-looking on a
     // dense m x m matrix with the LDS-staged GEMM; "right": the right-looking kernels of rounds 1-2.  Default by size: the
     // dense form while the matrix stays below 16 GB (m < 46 341), the stream form above.  (The dense form factors the diagonal blocks beside the updates on a
     // second stream; beside k_chol_update_big that overlap returns nothing -- FP64 MFMAs and the vector work of the triangular kernel share
@@ -741,6 +741,9 @@ psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
 psf_status psfp_compute_sqrt_sigma_2(psfp_handle* h, double s_cov) {
   if (!h || !(s_cov > 0.0)) return PSF_ERR_PARAM;
   if (!h->has_R || (h->prm.flags & PSFP_FLAG_NO_PERTURB)) return PSF_ERR_NO_KEY;
+  // The structured factor's constants g, h depend on the covariance parameter, and an exported key carries only L_1: psfp_load_key rebuilds them from
+  // the handle's s.  A factor for another s_cov would therefore be paired with the wrong constants after an export / load round trip, silently; refused.
+  if (h->structured && s_cov != h->prm.s) return PSF_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(h->prm.device));
   const psf_status rc = build_sqrt_sigma2(h, s_cov);
   h->has_key = rc == PSF_OK;
