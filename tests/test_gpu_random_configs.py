@@ -51,6 +51,9 @@ def test_perturbation_random_configuration(oracle, case):
     psf = T.PSFPerturbation(gp, r, s)
     A, (R, Lp, _) = psf.trap_gen(100 + case)
     orc = oracle.PSFPerturbation(oracle.GadgetParams(n, k, m_bar, base, q), r, s)
+    assert orc.trap_gen(100 + case) == 0                                  # key generation from the same seed: A, R bitwise, the factor within rounding
+    assert (A == orc.A).all() and (R == orc.R).all(), (n, q, base, k, m_bar)
+    np.testing.assert_allclose(Lp, orc.L_packed, rtol=0, atol=1e-9 * np.abs(orc.L_packed).max())
     orc.load_key(A, R, Lp)
     u = oracle.uniform_targets(case, B, n, q)
     first = int(rng.integers(0, 2**40))
@@ -58,6 +61,9 @@ def test_perturbation_random_configuration(oracle, case):
     assert psf.last_status() == 0
     assert (e == orc.samp_p(7 + case, u, first_index=first)).all(), (n, q, base, k, m_bar, r, s, B)
     assert (psf.f_a(e) == u).all() and psf.check_domain(e).all()
+    d = psf.samp_d(seed=3 + case, B=min(B, 9), first_index=first)          # mp_perturbation.rs:264-267
+    assert (d == orc.samp_d(3 + case, B=min(B, 9), first_index=first)).all()
+    assert psf.check_domain(d).all() and (psf.f_a(d) == orc.f_a(d)).all()
     psf.close()
 
 
@@ -75,6 +81,10 @@ def test_gpv_random_configuration(oracle, case):
     orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
     assert orc.load_key(A, bt, gt) == 0
     assert orc.two_pass == psf.two_pass                 # the same rule on both sides (q sqrt(n) > 2^13 s)
+    d = psf.samp_d(seed=4 + case, B=3, first_index=5)   # gpv.rs:113-116
+    assert (d == orc.samp_d(4 + case, B=3, first_index=5)).all()
+    if psf.check_domain(d).all():
+        assert (psf.f_a(d) == orc.f_a(d)).all()
     u = oracle.uniform_targets(case, B, n, q)
     first = int(rng.integers(0, 2**40))
     try:
