@@ -217,3 +217,21 @@ def test_one_launch_walk_is_bit_identical(T, oracle, monkeypatch, n, q, B):
     assert orc.load_key(A, bt, gt) == 0
     assert (e == orc.samp_p(13, u, first_index=3)).all()
     assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
+
+
+def test_one_launch_walk_falls_back_when_a_wait_times_out(T, oracle, monkeypatch):
+    """k_np_walk needs all its workgroups resident; every wait is bounded, and a wait that gives up abandons the launch and the call is repeated with a launch
+    per block (psfgpv_last_status).  PSF_NP_WALK_SPINS=0 makes the first unsatisfied wait give up at once: the result must still be the oracle's, and the handle
+    must not try the one-launch walk again."""
+    n, q, s, B = 40, 256, 300.0, 9
+    monkeypatch.setenv("PSF_NP_PERSIST", "1")
+    monkeypatch.setenv("PSF_NP_WALK_SPINS", "0")
+    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+    A, (bt, gt) = psf.trap_gen(6)
+    u = oracle.uniform_targets(8, B, n, q)
+    e = psf.samp_p(u, seed=13, first_index=3)
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    assert orc.load_key(A, bt, gt) == 0
+    assert (e == orc.samp_p(13, u, first_index=3)).all()
+    assert (psf.samp_p(u, seed=14, first_index=3) == orc.samp_p(14, u, first_index=3)).all()
+    psf.close()

@@ -815,7 +815,7 @@ __device__ unsigned long long g_walk_prof[8];
 
 template <int G>
 __global__ __launch_bounds__(512, 4) void k_np_walk(NpSampleArgs a, size_t dim, size_t nblk, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, unsigned nS,
-                                                    int nbj, int nrb, int S, const double* __restrict__ Gp, double* __restrict__ Tm, NpWalkSync sy) {
+                                                    int nbj, int nrb, int S, const double* __restrict__ Gp, double* __restrict__ Tm, NpWalkSync sy, unsigned spin_limit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char np_smem[];
   __shared__ int s_go;
   const int tid = threadIdx.x;
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(512, 4) void k_np_walk(NpSampleArgs a, size_t dim, 
       for (;;) {
         const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (at_most ? v <= bound : v >= bound) break;
-        if (++spins > (1u << 21) || __hip_atomic_load(sy.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (++spins > spin_limit || __hip_atomic_load(sy.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           __hip_atomic_store(sy.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = 0;
           break;

@@ -203,8 +203,10 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
       hipMemsetAsync(sy.tprog, 0x7f, nt * sizeof(int), st);
       hipMemsetAsync(sy.abort, 0, 16 * sizeof(int), st);
       const unsigned grid = nS + (unsigned)(nbj * (size_t)S);
-      if (G == 1) hipLaunchKernelGGL((k_np_walk<1>), dim3(grid), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, (int)nbj, (int)g->nrb, S, g->dGp, g->dTm, sy);
-      else hipLaunchKernelGGL((k_np_walk<2>), dim3(grid), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, (int)nbj, (int)g->nrb, S, g->dGp, g->dTm, sy);
+      unsigned spins = 1u << 21;                                       // ~0.5 s of polling before a wait gives up; PSF_NP_WALK_SPINS: tests force the fallback with 0
+      if (const char* ev = getenv("PSF_NP_WALK_SPINS")) spins = (unsigned)strtoul(ev, nullptr, 10);
+      if (G == 1) hipLaunchKernelGGL((k_np_walk<1>), dim3(grid), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, (int)nbj, (int)g->nrb, S, g->dGp, g->dTm, sy, spins);
+      else hipLaunchKernelGGL((k_np_walk<2>), dim3(grid), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, (int)nbj, (int)g->nrb, S, g->dGp, g->dTm, sy, spins);
       g->walk_used = true;
     }
   }
