@@ -18,3 +18,4 @@ nblk = (m + 63) // 64
 nS = B // 4
 print(f"per sampler workgroup and block: wait {out[0]/nS/nblk:.0f} ticks, body {out[1]/nS/nblk:.0f}")
 print(f"workers: wait {out[2]:.3e} ticks in total, tiles {out[3]:.3e} over {out[4]} tiles = {out[3]/max(out[4],1):.0f} per tile")
+print(f"sampler workgroup 0: {out[5]} shader ticks in {out[6]} ticks of the 100 MHz clock = {out[6] / 100.0:.1f} us -> {out[5] / max(out[6], 1) * 100.0:.0f} MHz")

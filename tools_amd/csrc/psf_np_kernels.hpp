@@ -844,6 +844,9 @@ __global__ __launch_bounds__(512, 4) void k_np_walk(NpSampleArgs a, size_t dim, 
   if (blockIdx.x < nS) {
     const unsigned wg = blockIdx.x;
     const int bj = (int)(((size_t)wg * 4 * G) / TR_BN);
+#ifdef NP_WALK_PROFILE
+    const unsigned long long pc0 = (unsigned long long)__builtin_readcyclecounter(), pw0 = wall_clock64();
+#endif
     for (size_t J = nblk; J-- > 0;) {
       bool okw = true;
       WALK_T(0, if (J + 2 < nblk) okw = wait_for(sy.tprog + (J / 2) * (size_t)nbj + bj, (int)J + 2, true));
@@ -853,6 +856,9 @@ __global__ __launch_bounds__(512, 4) void k_np_walk(NpSampleArgs a, size_t dim, 
       __syncthreads();
       if (tid == 0 && J >= 2) __hip_atomic_fetch_add(sy.zcnt + (size_t)bj * nblk + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef NP_WALK_PROFILE
+    if (tid == 0 && wg == 0) { g_walk_prof[5] = (unsigned long long)__builtin_readcyclecounter() - pc0; g_walk_prof[6] = wall_clock64() - pw0; }   // shader ticks / 100 MHz ticks of workgroup 0
+#endif
     return;
   }
   const unsigned w = blockIdx.x - nS;
