@@ -33,7 +33,7 @@ CONFIGS = {
     "c2s240": ("PSFGPV", 256, 3329, None, 240.0, 1024),             # the same at the reference bench's own rule s = 30 log2 n (benches/psf.rs:32), SURVEY.md 8d
     "c4": ("PSFGPVRing", 256, 3329, None, 0.0, 4096),               # BASELINE.json configs[3]; s = compute_s(256), gpv_ring.rs:296-298
     "c5": ("PSFPerturbation", 1024, 2**60, 10.0, 1024.0, 8192),     # BASELINE.json configs[4]: batch 65536 over 8 GPUs = 8192 per GPU
-}                                                                   # (60.6 GB key per GPU, trap_gen ~30 s; run with --gpus 8 --config c5)
+}                                                                   # (60.6 GB key per GPU, trap_gen ~10 s; run with --gpus 8 --config c5)
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix; measured 77.3 by tools/probe_mfma_f64.hip (profiles/r01_probe_mfma_f64.log)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
