@@ -263,8 +263,12 @@ __global__ __launch_bounds__(256, 2) void k_np_project(const double* __restrict_
 //   * per-row constants come from a 32-byte LDS record, the in-block triangle row g[l][.] from LDS;
 //   * the fp32 screen (sz_screen16) classifies each attempt as rejected / certainly accepted / to be settled; only a "to be
 //     settled" attempt that precedes every certain accept pays the exact f64 decision (sz_decide).
-// Anything else (wide words, huge centres, no accept among the first LPD attempts) runs the generic rounds: per-lane Philox,
+// Anything else (huge or integral centres, no accept among the fast attempts) runs the generic rounds: per-lane Philox,
 // sz_maybe / sz_decide.  Either way the outcome is that of the sequential sampler on the same Philox streams.
+// G == 2 (32 lanes per draw): the helper prepares TWO sets of 32 attempts per step (packed 8-byte records, same ring bytes); the sampler reads and screens
+// the second set only for a draw that is still open after the first ((11/12)^32 = 6 % of the draws have no candidate there), so 64 attempts are covered by the
+// fast screen as with G == 1.  Before, those draws went through the generic rounds (~3 k cycles each) and, two preimages per wave, 12 % of the wave-steps did:
+// at C4 39 % of a sampler wave's time and most of the launch's slowest-wave tail (profiles/r03_notes.md): 4.88 -> 4.59 ms.
 // Then the rows below in the block take t' = fma(-z, g[l][.], t').  Outputs: z as f64 in the operand layout of the update
 // product, and as three balanced base-256 int8 digit planes [i/16][b][16] for the recombination.
 #ifdef NP_PROFILE   /* cycle breakdown of k_np_sample (workgroup 0, wave 0): tools/np_profile.py */
@@ -424,10 +428,51 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           uint32_t low, idx;
           if (narrow) { const uint32_t prod = __umul24(wd.x, Nf); low = prod & 0xffffu; idx = prod >> 16; }
           else { low = wd.x * Nf; idx = __umulhi(wd.x, Nf); }
-          const float u = (float)idx * rw.inv_sk;
-          const float wbf = (float)wd.y * (narrow ? 0x1.0p-16f : 0x1.0p-32f);
           const bool okidx = live && low >= rw.thr_frac;            // Lemire's rejection of the lowest fractions
-          ring[((k & 1) * 4 + sp) * 64 + lane] = make_uint4(__float_as_uint(u), __float_as_uint(wbf), (idx & 0x7fffffffu) | (okidx ? 0x80000000u : 0u), wd.y);
+          if (G == 1) {
+            const float u = (float)idx * rw.inv_sk;
+            const float wbf = (float)wd.y * (narrow ? 0x1.0p-16f : 0x1.0p-32f);
+            ring[((k & 1) * 4 + sp) * 64 + lane] = make_uint4(__float_as_uint(u), __float_as_uint(wbf), (idx & 0x7fffffffu) | (okidx ? 0x80000000u : 0u), wd.y);
+          } else {                                                  // packed: the sampler converts (two sets of attempts share the ring's bytes)
+            reinterpret_cast<uint2*>(ring)[(((k & 1) * 4 + sp) * 2 + 0) * 64 + lane] = make_uint2((idx & 0x7fffffffu) | (okidx ? 0x80000000u : 0u), wd.y);
+          }
+        }
+        if (G == 2) {
+          // second set: attempts LPD .. 2 LPD - 1 of the same four steps (Philox blocks BPS .. 2 BPS - 1 of a narrow row, 2 BPS .. 4 BPS - 1 of a wide one).  With 32 lanes
+          // per draw (11/12)^32 = 6 % of the draws find no candidate in the first set; the sampler screens this set in the same fast way instead of entering the generic rounds.
+          const int s = lam / BPS, g = lam % BPS;
+          const int lstep = lbase + 3 - s;
+          const uint32_t shs = s_row[lstep].sh;
+          const uint32_t coord_s = (uint32_t)(j0 + lstep);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the first set's reads of the strip are done
+          uint2* dst = wstrip + (sg * 4 + s) * LPD;
+          if (shs != 32) {
+            const U4 w = philox(seed, coord_s, (uint32_t)index, (uint32_t)(BPS + g), tw);
+            uint4* d4p = reinterpret_cast<uint4*>(dst + 4 * g);
+            d4p[0] = make_uint4(w.x >> 16, w.x & 0xffffu, w.y >> 16, w.y & 0xffffu);
+            d4p[1] = make_uint4(w.z >> 16, w.z & 0xffffu, w.w >> 16, w.w & 0xffffu);
+          }
+          if (__ballot(shs == 32)) {
+            const U4 w1 = philox(seed, coord_s, (uint32_t)index, (uint32_t)(2 * BPS + g), tw), w2 = philox(seed, coord_s, (uint32_t)index, (uint32_t)(3 * BPS + g), tw);
+            if (shs == 32) {
+              *reinterpret_cast<uint4*>(dst + 2 * g) = make_uint4(w1.x, w1.y, w1.z, w1.w);
+              *reinterpret_cast<uint4*>(dst + 2 * (g + BPS)) = make_uint4(w2.x, w2.y, w2.z, w2.w);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp) {
+            const int l = lbase + 3 - sp;
+            const NpRow rw = s_row[l];
+            const uint2 wd = wstrip[(sg * 4 + sp) * LPD + lam];
+            const bool narrow = rw.sh == 16;
+            const uint32_t Nf = rw.n_int - 1u;
+            uint32_t low, idx;
+            if (narrow) { const uint32_t prod = __umul24(wd.x, Nf); low = prod & 0xffffu; idx = prod >> 16; }
+            else { low = wd.x * Nf; idx = __umulhi(wd.x, Nf); }
+            const bool okidx = live && low >= rw.thr_frac;
+            reinterpret_cast<uint2*>(ring)[(((k & 1) * 4 + sp) * 2 + 1) * 64 + lane] = make_uint2((idx & 0x7fffffffu) | (okidx ? 0x80000000u : 0u), wd.y);
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         ++k;
@@ -489,12 +534,15 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       NP_T(1);
       const uint4* rslot = ring + (k & 1) * 4 * 64 + lane;
+      const uint2* rslot2 = reinterpret_cast<const uint2*>(ring) + (k & 1) * 4 * 2 * 64 + lane;     // G == 2: [step][set][lane], 8-byte records
       // operands of the first step of the group; those of the following steps are fetched one step ahead
       NpRow rw = s_row[lbase + 3];
       double gl[G];
 #pragma unroll
       for (int s2 = 0; s2 <= slot; ++s2) gl[s2] = tri_at(lbase + 3, s2 * LPD + lam);
-      uint4 rec = rslot[0];
+      uint4 rec = make_uint4(0, 0, 0, 0);
+      if (G == 1) rec = rslot[0];
+      else { const uint2 r2 = rslot2[0]; rec.z = r2.x; rec.w = r2.y; }
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp) {
         const int l = lbase + 3 - sp;
@@ -507,7 +555,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           rwn = s_row[l - 1];
 #pragma unroll
           for (int s2 = 0; s2 <= slot; ++s2) gln[s2] = tri_at(l - 1, s2 * LPD + lam);
-          recn = rslot[(sp + 1) * 64];
+          if (G == 1) recn = rslot[(sp + 1) * 64];
+          else { const uint2 r2 = rslot2[(sp + 1) * 2 * 64]; recn.z = r2.x; recn.w = r2.y; }
         }
         if (l < nrows) {
           const int ls = l - slot * LPD;
@@ -519,9 +568,10 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           uint32_t t0 = 0;
           NP_T(2);
           const bool narrow = rw.sh == 16;
-          const float u = __uint_as_float(rec.x), wbf = __uint_as_float(rec.y);
           const uint32_t idx = rec.z & 0x7fffffffu;
           const bool okidx = (rec.z >> 31) != 0;
+          const float u = G == 1 ? __uint_as_float(rec.x) : (float)idx * rw.inv_sk;                                   // the helper's expressions, evaluated here for
+          const float wbf = G == 1 ? __uint_as_float(rec.y) : (float)rec.w * (narrow ? 0x1.0p-16f : 0x1.0p-32f);      // the packed records of G == 2
           const float wbe = wbf + (narrow ? 0x1.0p-16f : 1e-7f);
           // --- the dependent chain ----------------------------------------------------------------------------------
           const double cc = ceil(cen);
@@ -544,13 +594,61 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
             if (bad_w == 0 && ((m1_w >> fl) & 1)) { z = (long long)(lo + __builtin_amdgcn_readlane((int)idx, fl)); got = true; }
             else settle = live;
           } else {
-            const uint64_t cand = mc_w & sgmask;
-            const int fl = cand ? (__ffsll((long long)cand) - 1) : lane;
-            const int xi = __shfl((int)idx, fl);
-            if (live && !(bad_w & sgmask) && ((m1_w >> fl) & 1) && cand) { z = (long long)(lo + xi); got = true; }
-            else settle = live;
+            // G == 2: two sets of LPD attempts with the fast screen.  Set A as always; set B (attempts LPD .. 2 LPD - 1) is read and screened only when a
+            // draw is still open after set A -- no candidate in it (6 % of the draws) or all its candidates settled as rejects -- so the common step pays nothing.
+            const bool usable = !(bad_w & sgmask);
+            auto settle_set = [&](uint64_t m1, uint64_t m2, uint32_t idxv, uint32_t wbraw, uint32_t tbase) {
+              while (true) {
+                const uint64_t cnd = m1 | m2;
+                const bool pending = !got && cnd != 0;
+                if (!__ballot(pending)) break;
+                const int fl = pending ? (__ffsll((long long)cnd) - 1) : lane;
+                const bool sure = (m1 >> fl) & 1;
+                bool acc = false;
+                if (pending && !sure && lane == fl) {
+                  uint32_t ta = tbase + (uint32_t)lam;
+                  asm volatile("" : "+v"(ta));
+                  acc = sz_decide(seed, coord, (uint32_t)index, tw, ta, (long long)lo + (long long)idxv, wbraw, cen, s_invs[l], rw.sh);
+                }
+                const uint64_t accm = __ballot(acc);
+                const int xi = __shfl((int)idxv, fl);
+                if (pending) {
+                  if (sure || ((accm >> fl) & 1)) { z = (long long)(lo + xi); got = true; }
+                  else m2 &= ~(1ull << fl);
+                }
+              }
+            };
+            {
+              const uint64_t cand = mc_w & sgmask;
+              const int fl = cand ? (__ffsll((long long)cand) - 1) : lane;
+              const int xi = __shfl((int)idx, fl);
+              if (live && usable && cand && ((m1_w >> fl) & 1)) { z = (long long)(lo + xi); got = true; }
+              const bool pend = live && !got && usable && cand != 0;                 // the first candidate of set A is a "to be settled" one
+              if (__ballot(pend)) { NP_EVENT(1); settle_set(pend ? (m1_w & sgmask) : 0, pend ? ((mc_w & ~m1_w) & sgmask) : 0, idx, rec.w, 0u); }
+            }
+            const bool need_b = live && !got && usable;
+            if (__ballot(need_b)) {
+              const uint2 rb = rslot2[(sp * 2 + 1) * 64];
+              const uint32_t idx_b = rb.x & 0x7fffffffu;
+              const bool ok_b = (rb.x >> 31) != 0;
+              const float u_b = (float)idx_b * rw.inv_sk;
+              const float wbf_b = (float)rb.y * (narrow ? 0x1.0p-16f : 0x1.0p-32f);
+              const float wbe_b = wbf_b + (narrow ? 0x1.0p-16f : 1e-7f);
+              const float ak_b = fmaf(c_rel, rw.inv_sk, u_b);
+              const float rho_b = __builtin_amdgcn_exp2f(-(ak_b * ak_b));
+              const bool cand_bb = ok_b && wbf_b <= fmaf(rho_b, 1.001f, 1e-9f);
+              const bool sure_bb = ok_b && wbe_b <= rho_b * 0.999f;
+              const uint64_t mcb_w = __ballot(cand_bb), m1b_w = __ballot(sure_bb);
+              const uint64_t cand = mcb_w & sgmask;
+              const int fl = cand ? (__ffsll((long long)cand) - 1) : lane;
+              const int xi = __shfl((int)idx_b, fl);
+              if (need_b && cand && ((m1b_w >> fl) & 1)) { z = (long long)(lo + xi); got = true; }
+              const bool pend = need_b && !got && cand != 0;
+              if (__ballot(pend)) settle_set(pend ? (m1b_w & sgmask) : 0, pend ? ((mcb_w & ~m1b_w) & sgmask) : 0, idx_b, rb.y, (uint32_t)LPD);
+            }
+            t0 = usable ? 2u * (uint32_t)LPD : 0u;                  // special centres start over with the generic rounds
           }
-          if (__ballot(settle)) {
+          if (G == 1 && __ballot(settle)) {
             NP_EVENT(1);
             // rare: a "to be settled" attempt comes first, or there is no candidate among the first LPD attempts, or the centre is special
             const bool usable = !(bad_w & sgmask);
