@@ -110,6 +110,9 @@ static int sz_attempt(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t t
 
 static unsigned long g_sample_z_cap_hits = 0;
 int64_t orc_sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center, double s) {
+  /* a centre at or beyond 2^62 does not leave room for ceil(c) - ceil(6 s) and the candidates in 64-bit integers (the conversion below would be undefined
+   * behaviour): the draw ends with 0 and is reported like a draw that ended at the attempt cap; the device does the same (psf_np_kernels.hpp) */
+  if (!(fabs(center) < 0x1.0p62)) { __atomic_fetch_add(&g_sample_z_cap_hits, 1ul, __ATOMIC_RELAXED); return 0; }
   double inv_s = 1.0 / s;
   int64_t c6 = (int64_t)ceil(6.0 * s), f6 = (int64_t)floor(6.0 * s);
   int64_t lo = (int64_t)ceil(center) - c6;

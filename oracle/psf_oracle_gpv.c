@@ -175,11 +175,17 @@ void orc_nearest_plane_trace(const int32_t* basis_t, const double* gso_t, const 
       t[i2] = acc;
     }
   }
+  /* c -= sum z_i b_i.  The coefficients take part as the doubles the walk itself used: exact below 2^53, rounded above -- which only happens in the first pass
+   * of a two-pass walk at moduli near 2^60, where the result need only be SOME representative of the coset (a rounded z_i shifts it by the lattice vector
+   * (z_i - fl(z_i)) b_i), and it is what the device's 64-bit recombination reads (k_np_combine_generic).  Sums of products beyond 2^63 cancel back into range:
+   * the arithmetic is modulo 2^64 by definition here (unsigned), not by accident of the compiler.  (Found by tools/fuzz_configs.py: the exact integers used
+   * here before differed from the device at q = 2^57 .. 2^59.) */
   for (size_t i = 0; i < dim; ++i) {
     if (z_out) z_out[i] = z[i];
     if (!z[i]) continue;
+    const uint64_t zz = (uint64_t)(int64_t)(double)z[i];
     const int32_t* bi = basis_t + i * dim;
-    for (size_t j = 0; j < dim; ++j) c[j] -= z[i] * (int64_t)bi[j];
+    for (size_t j = 0; j < dim; ++j) c[j] = (int64_t)((uint64_t)c[j] - zz * (uint64_t)(int64_t)bi[j]);
   }
   free(t); free(z);
 }

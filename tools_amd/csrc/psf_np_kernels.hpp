@@ -675,6 +675,11 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
             t0 = usable ? LPD : 0;                                 // special centres start over with the generic rounds
           }
           NP_T(4);
+          // A centre at or beyond 2^62 (a modulus near 2^60 over a Gram-Schmidt vector of tiny norm): ceil(c) - ceil(6 s') and the candidates no longer fit the
+          // walk's 64-bit integers.  The draw ends with 0 and the call reports PSF_ERR_SAMPLER; the oracle does the same in orc_sample_z, where the conversion
+          // would otherwise be undefined behaviour (found by tools/fuzz_configs.py: x86 and gfx950 saturate differently, silently).  Every such centre comes
+          // through here: `bad` sends |c| >= 2^30 to the generic rounds.
+          if (!got && !(fabs(cen) < 0x1.0p62)) { f = 1; z = 0; got = true; }
           if (__ballot(!got)) {                                      // generic rounds: attempts t0 + lam, t0 + LPD + lam, ...
             NP_EVENT(2);
             // (an "accepted for certain" class here as in the first round was measured: C2 3.5 % slower, C4 unchanged -- the rounds are rare and the

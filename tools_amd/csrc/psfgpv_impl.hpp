@@ -2,6 +2,7 @@
 // the Z_q machinery (A, its digit planes, f_a, check_domain, samp_d) is shared with PSFPerturbation through an inner
 // psfp_handle created with r = 1 (then s*r = s and the domain bound s^2 m r^2 = s^2 m, gpv.rs:113-116, :219-224).
 
+#include <algorithm>
 struct psfgpv_handle {
   psfp_handle* base = nullptr;
   double s = 0;
@@ -119,6 +120,24 @@ static psf_status gpv_build_solver(psfgpv_handle* g) {
   std::vector<uint64_t> T;
   const psf_status rc = solve_precompute(A.data(), b->n, b->m, b->q, piv, T);
   if (rc != PSF_OK) return rc;                                         // gpv.rs:153-155: solve(...).unwrap() would panic
+  {
+    // The elimination finds its pivot columns row by row, and over a power-of-two modulus (a unit is needed) not always in ascending order.  The initial projection
+    // <c0, b~_i> is an fma chain over the pivot coordinates, and the contract's chain runs in ascending COORDINATE order (the oracle walks all m columns and skips the
+    // zeros): the pivots are therefore sorted, each with its row of the solve operator.  Unsorted, the two chains would differ in their last bits -- invisible while
+    // |c0| is small, a different sample at every step once |t| reaches 2^60.
+    const size_t nn = b->n;
+    std::vector<size_t> order(nn);
+    for (size_t r = 0; r < nn; ++r) order[r] = r;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return piv[x] < piv[y]; });
+    std::vector<uint32_t> piv2(nn);
+    std::vector<uint64_t> T2(T.size());
+    for (size_t r = 0; r < nn; ++r) {
+      piv2[r] = piv[order[r]];
+      for (size_t t = 0; t < nn; ++t) T2[r * nn + t] = T[order[r] * nn + t];
+    }
+    piv.swap(piv2);
+    T.swap(T2);
+  }
   {  // stored transposed: lane r of the solve kernel reads Tt[t][r], consecutive lanes consecutive addresses
     const size_t nn = b->n;
     std::vector<uint64_t> Tt(T.size());
@@ -528,6 +547,17 @@ psf_status psfgpv_get_timing(psfgpv_handle* g, double* solve_ms, double* nearest
   return PSF_OK;
 }
 int psfgpv_two_pass(const psfgpv_handle* g) { return (g && g->two_pass) ? 1 : 0; }
+// debugging / tests: the coefficients z_i the LAST walk of the last call drew for preimage b (d doubles; the second pass's in two-pass mode)
+extern "C" psf_status psfgpv_debug_last_z(psfgpv_handle* g, size_t b, double* z_out) {
+  if (!g || !z_out || !g->dZf || b >= g->ld) return PSF_ERR_PARAM;
+  HIP_TRY(hipSetDevice(g->base->prm.device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<double> zf(g->ld * g->nkb * 16);
+  HIP_TRY(hipMemcpy(zf.data(), g->dZf, zf.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < g->dim; ++i) z_out[i] = zf[((b / TR_BN) * g->nkb + i / 16) * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(i % 16))];
+  return PSF_OK;
+}
+
 psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle* g, size_t* blocks, size_t* generic_recombination) {
   if (!g) return PSF_ERR_PARAM;
   HIP_TRY(hipStreamSynchronize(g->last_stream));
