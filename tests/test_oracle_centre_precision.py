@@ -30,7 +30,7 @@ def exact_gso(bt):
     return G, n2
 
 
-def worst_relative_centre_error(orc, bt, G, n2, s, seed, u):
+def worst_relative_centre_error(orc, bt, G, n2, s, seed, u, exact_walk=True):
     e, c0, cen, z = orc.samp_p_trace(seed, u, index=3)
     d = bt.shape[0]
     c = [Decimal(int(v)) for v in c0]
@@ -42,7 +42,8 @@ def worst_relative_centre_error(orc, bt, G, n2, s, seed, u):
         zi = int(z[i])
         if zi:
             c = [x - zi * int(b) for x, b in zip(c, bt[i])]
-    assert [int(-x) for x in c] == [int(v) for v in e]                              # the trace is the preimage's own walk
+    if exact_walk:
+        assert [int(-x) for x in c] == [int(v) for v in e]                          # the trace is the preimage's own walk
     return float(worst), e
 
 
@@ -63,7 +64,10 @@ def test_large_moduli_are_sampled_in_two_passes_with_accurate_centres(oracle, n,
     assert float((e.astype(np.float64) ** 2).sum()) < 2.0 * s * s / (2 * np.pi) * len(e)      # a short preimage, not merely a valid one
     # the same key through ONE pass: the centres are off by many orders of magnitude more (what two passes are for)
     orc.set_two_pass(0)
-    single, _ = worst_relative_centre_error(orc, bt, G, n2, s, 11, u)
+    # (coefficients beyond 2^53 take part in the recombination as the doubles the walk used -- psf_oracle_gpv.c -- so a single pass at 2^60 ends on another
+    # representative of the coset than the exact integers would: still A e = u, no longer "c0 - sum z_i b_i" digit for digit)
+    single, e1p = worst_relative_centre_error(orc, bt, G, n2, s, 11, u, exact_walk=q < 2**50)
+    assert ((A.astype(object) @ e1p.astype(object)) % q == u.astype(object)).all()
     assert single > 1000 * worst and single > 2.0**-30, (single, worst)
     orc.set_two_pass(-1)
 
