@@ -45,7 +45,8 @@ enum {
   PSF_ERR_HIP = 7,             /* HIP runtime error (no device, out of memory, launch failure)           */
   PSF_ERR_UNSUPPORTED = 8,     /* parameter combination outside what the kernels cover                   */
   PSF_ERR_SAMPLER = 9          /* a draw did not accept within 65 536 attempts (Gaussian far below the smoothing parameter), or an
-                                  intermediate left its range (nearest-plane coefficient beyond 2^53, perturbation beyond 2^23);
+                                  intermediate left its range (nearest-plane centre beyond 2^62 or first-pass representative beyond 2^53,
+                                  perturbation beyond 2^23);
                                   the reference would keep computing -- DESIGN.md section 8, "Limits" */
 };
 
