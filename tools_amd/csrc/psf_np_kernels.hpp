@@ -679,8 +679,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           // walk's 64-bit integers.  The draw ends with 0 and the call reports PSF_ERR_SAMPLER; the oracle does the same in orc_sample_z, where the conversion
           // would otherwise be undefined behaviour (found by tools/fuzz_configs.py: x86 and gfx950 saturate differently, silently).  Every such centre comes
           // through here: `bad` sends |c| >= 2^30 to the generic rounds.
-          if (!got && !(fabs(cen) < 0x1.0p62)) { f = 1; z = 0; got = true; }
           if (__ballot(!got)) {                                      // generic rounds: attempts t0 + lam, t0 + LPD + lam, ...
+            if (!got && !(fabs(cen) < 0x1.0p62)) { f = 1; z = 0; got = true; }      // (inside the rare branch: as a test of its own in front of it the step cost 2 % more)
             NP_EVENT(2);
             // (an "accepted for certain" class here as in the first round was measured: C2 3.5 % slower, C4 unchanged -- the rounds are rare and the
             // extra live values cost the hot path registers)
