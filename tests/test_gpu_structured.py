@@ -113,3 +113,35 @@ def test_structured_factor_for_another_covariance_is_refused(T):
     e = psf.samp_p(u, seed=4)                            # the key in the handle is still the one for s
     assert (psf.f_a(e) == u).all() and psf.check_domain(e).all()
     psf.close()
+
+
+@pytest.mark.parametrize("case", range(64))
+def test_structured_random_configuration(T, oracle, case):
+    """seeded random shapes for the opt-in structured square root: odd n, moduli of every kind, widths from just above the positive-definiteness bound, ragged batches --
+    every stage of a few rows bitwise against the oracle's restatement, the whole batch through the invariants"""
+    rng = np.random.default_rng(8000 + case)
+    n = int(rng.integers(2, 40))
+    kind = int(rng.integers(0, 3))
+    q = int(2 ** rng.integers(4, 61)) if kind == 0 else (int(rng.choice([257, 3329, 12289, 1073741789, 2**61 - 1])) if kind == 1 else int(rng.integers(17, 2**20)) | 1)
+    k = int(math.ceil(math.log2(q)))
+    r = float(rng.choice([2.0, 3.0, 4.5, 30.0]))
+    m_bar = n * k + int(rng.integers(0, 40))
+    s = r * math.sqrt(5.0) * (math.sqrt(m_bar) + math.sqrt(n * k) + 4.0) * float(rng.choice([1.2, 2.0]))
+    if not s * r * math.sqrt(m_bar + n * k) < 2**23 * 0.9:
+        pytest.skip("outside the documented domain bound")
+    B = int(rng.choice([1, 5, 127, 129, 256, 300]))
+    gp = T.GadgetParameters(n, k, m_bar, 2, q)
+    psf = T.PSFPerturbation(gp, r, s, structured=True)
+    A, (R, L1, _) = psf.trap_gen(300 + case)
+    orc = oracle.PSFPerturbation(oracle.GadgetParams(n, k, m_bar, 2, q), r, s, with_L=False)
+    orc.load_key(A, R)
+    u = oracle.uniform_targets(case, B, n, q)
+    first = int(rng.integers(0, 2**40))
+    st = psf.samp_p_stages(u, seed=21 + case, first_index=first)
+    for b in sorted(set([0, B // 2, B - 1])):
+        tr = orc.samp_p_structured_trace(L1, s, 21 + case, first + b, u[b])
+        assert (st["x"][b].view(np.uint64) == tr["x"].view(np.uint64)).all(), (n, q, m_bar, r, s, B, b)
+        for key in ("p", "v", "z", "e"):
+            assert (st[key][b] == tr[key]).all(), (key, n, q, m_bar, r, s, B, b)
+    assert (psf.f_a(st["e"]) == u).all() and psf.check_domain(st["e"]).all()
+    psf.close()
