@@ -11,6 +11,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 PRIMES = [257, 3329, 7681, 12289, 65537, 1073741789, 2**31 - 1, 2**61 - 1]
+# the menus the draws choose from (tools/fuzz_configs.py --wide swaps in broader ones)
+R_MENU = [1.5, 2.0, 3.0, 4.5, 30.0]
+S_FACTOR_MENU = [1.1, 1.5, 3.0]
+BATCH_MENU = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]
+GPV_S_MENU = [8.0, 30.0, 240.0, 1000.0]
 
 
 def draw_modulus(rng):
@@ -23,8 +28,7 @@ def draw_modulus(rng):
 
 
 def draw_batch(rng):
-    edge = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]))
-    return edge
+    return int(rng.choice(BATCH_MENU))
 
 
 @pytest.mark.parametrize("case", range(64))
@@ -40,10 +44,10 @@ def test_perturbation_random_configuration(oracle, case):
     if k > 64:
         base, k = 2, int(math.ceil(math.log2(q)))
     m_bar = n * int(math.ceil(math.log2(q))) + int(rng.integers(0, 40))
-    r = float(rng.choice([1.5, 2.0, 3.0, 4.5, 30.0]))
+    r = float(rng.choice(R_MENU))
     # sigma_max(R) <= sqrt(m_bar) + sqrt(n k) + a few; s from 1.1x the positive-definiteness bound upwards
     bound = r * math.sqrt(base * base + 1) * (math.sqrt(m_bar) + math.sqrt(n * k) + 4.0)
-    s = bound * float(rng.choice([1.1, 1.5, 3.0]))
+    s = bound * float(rng.choice(S_FACTOR_MENU))
     B = draw_batch(rng)
     if not s * r * math.sqrt(m_bar + n * k) < 2**23 * 0.9:
         pytest.skip("outside the documented domain bound")
@@ -76,7 +80,7 @@ def test_gpv_random_configuration(oracle, case):
     rng = np.random.default_rng(2000 + case)
     q = draw_modulus(rng)
     n = int(rng.integers(2, 40 if q < 2**24 else 12))
-    s = float(rng.choice([8.0, 30.0, 240.0, 1000.0])) * (1.0 if q < 2**30 else 4.0)
+    s = float(rng.choice(GPV_S_MENU)) * (1.0 if q < 2**30 else 4.0)
     B = int(rng.choice([1, 3, 4, 5, 8, 9, 64, 130]))
     psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
     A, (bt, gt) = psf.trap_gen(200 + case)

@@ -8,6 +8,11 @@ import test_gpu_random_configs as R
 from oracle import oracle
 oracle.build()
 first, count = int(sys.argv[1]), int(sys.argv[2])
+if "--wide" in sys.argv:          # broader menus than the suite's: very wide and very narrow Gaussians, larger batches
+    R.R_MENU = [1.5, 3.0, 30.0, 100.0, 400.0]
+    R.S_FACTOR_MENU = [1.02, 1.5, 10.0]
+    R.BATCH_MENU = [1, 129, 300, 512, 777, 1024]
+    R.GPV_S_MENU = [3.0, 8.0, 240.0, 5000.0, 60000.0]
 bad = 0; skipped = 0
 t0 = time.time()
 for fn in (R.test_perturbation_random_configuration, R.test_gpv_random_configuration, R.test_ring_random_configuration):
