@@ -1,0 +1,80 @@
+"""The single-call / small-batch path of PSFPerturbation::samp_p (psf.rs:48-80: one call = one preimage; benches/psf.rs:38,63-65,90-92 time
+exactly that): the streaming product k_trmm_stream must give the oracle's bits at every batch size around its fragment boundaries, for
+row-tile counts that are odd / not a multiple of the workgroup's eight tasks, and the same bits as the batch kernel for every tile shape."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# (n, q, r, s): m = 496 (31 tiles of 16 rows, 4 row blocks), m = 932 (59 tiles, benches/psf.rs:79), m = 1316 (83 tiles, 11 row blocks)
+SHAPES = [(12, 2**20, np.log2(12), 60.0), (64, 128, np.log2(64), 100.0), (40, 2**16, 4.0, 120.0)]
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tools_amd
+    return tools_amd
+
+
+@pytest.fixture(scope="module", params=SHAPES, ids=lambda p: f"n{p[0]}")
+def pair(request, T, oracle):
+    n, q, r, s = request.param
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+    A, (R, Lp, _) = psf.trap_gen(21)
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s)
+    orc.load_key(A, R, Lp)
+    yield psf, orc, n, q
+    psf.close()
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 31, 32, 33, 63, 64, 65])
+def test_small_batch_stages_bitwise(pair, oracle, B):
+    psf, orc, n, q = pair
+    u = oracle.uniform_targets(90 + B, B, n, q)
+    st = psf.samp_p_stages(u, seed=500 + B, first_index=10 * B)
+    rows = sorted(set([0, B - 1, B // 2, min(B - 1, 16), min(B - 1, 47)]))
+    for b in rows:
+        tr = orc.samp_p_trace(500 + B, 10 * B + b, u[b])
+        assert (st["d"][b].view(np.uint64) == tr["d"].view(np.uint64)).all(), "normals differ"
+        assert (st["x"][b].view(np.uint64) == tr["x"].view(np.uint64)).all(), "centres x = sqrt(Sigma_2) d differ"
+        assert (st["p"][b] == tr["p"]).all() and (st["v"][b] == tr["v"]).all() and (st["z"][b] == tr["z"]).all()
+    e_ref = orc.samp_p(500 + B, u, first_index=10 * B)
+    assert (st["e"] == e_ref).all()
+    assert psf.check_domain(st["e"]).all() and (psf.f_a(st["e"]) == u).all()      # mp_perturbation.rs:433-448
+
+
+@pytest.mark.parametrize("shape,B", [("1,1", 16), ("1,1", 100), ("1,2", 100), ("1,4", 100), ("1,8", 100), ("2,1", 5), ("2,1", 100), ("2,2", 20), ("2,2", 100),
+                                     ("2,4", 100), ("4,2", 100), ("1,4", 300), ("2,4", 257), ("4,2", 513)])
+def test_every_tile_shape_gives_the_batch_kernels_bits(pair, oracle, shape, B):
+    """PSF_TRMM_STREAM_SHAPE forces (row tiles, column fragments) per wave; PSF_TRMM_STREAM_MAX = 0 is the batch kernel (k_trmm_f64_big)."""
+    psf, orc, n, q = pair
+    u = oracle.uniform_targets(4, B, n, q)
+    old = {k: os.environ.get(k) for k in ("PSF_TRMM_STREAM_MAX", "PSF_TRMM_STREAM_SHAPE")}
+    try:
+        os.environ["PSF_TRMM_STREAM_MAX"] = "0"
+        os.environ.pop("PSF_TRMM_STREAM_SHAPE", None)
+        ref = psf.samp_p_stages(u, seed=9, first_index=3)
+        os.environ["PSF_TRMM_STREAM_MAX"] = "4096"
+        os.environ["PSF_TRMM_STREAM_SHAPE"] = shape
+        got = psf.samp_p_stages(u, seed=9, first_index=3)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert (got["x"].view(np.uint64) == ref["x"].view(np.uint64)).all(), "streaming product differs from k_trmm_f64_big"
+    assert (got["e"] == ref["e"]).all()
+
+
+def test_one_call_is_one_preimage_of_the_batch(pair, oracle):
+    """Row b of a batch equals the single call with first_index + b (the reference's call, repeated): the streaming and the batch kernel meet here."""
+    psf, orc, n, q = pair
+    B = 200
+    u = oracle.uniform_targets(8, B, n, q)
+    e = psf.samp_p(u, seed=77, first_index=1000)
+    for b in (0, 63, 64, 199):
+        e1 = psf.samp_p(u[b:b + 1], seed=77, first_index=1000 + b)
+        assert (e1[0] == e[b]).all()

@@ -605,18 +605,25 @@ __global__ __launch_bounds__(256) void k_perturb_round_wave(uint64_t seed, uint6
 // the wave's segment.  Values are those of k_perturb_round_wave bit for bit: a sample's value is the first accepted attempt of its own stream.
 constexpr int PRL_SEG = 8192;
 constexpr int PRL_WIN = 256;
+// `seg` = samples per wave (a multiple of 64, at most PRL_SEG): PRL_SEG for full batches; a single call (one preimage, psf.rs:48-80) has only m
+// samples in all, and the launch lasts as long as its longest wave, so the host cuts them into short segments (prl_segment).
+__host__ inline uint32_t prl_segment(size_t total) {
+  size_t seg = (total / 2048 + 63) / 64 * 64;                  // ~2048 waves = two per SIMD
+  if (seg < 128) seg = 128;
+  return (uint32_t)(seg > (size_t)PRL_SEG ? (size_t)PRL_SEG : seg);
+}
 __global__ __launch_bounds__(256) void k_perturb_round_lean(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
                                                             const double* __restrict__ X, SampleZParams sp, int32_t* __restrict__ P,
-                                                            int* __restrict__ fail) {
+                                                            int* __restrict__ fail, uint32_t seg) {
   __shared__ double s_win[4][PRL_WIN];
   const int lane = threadIdx.x & 63;
   double* win = s_win[threadIdx.x >> 6];
   const size_t total = m * B;
-  const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PRL_SEG;
+  const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * seg;
   if (seg0 >= total) return;                                   // (no workgroup barrier below: a wave may leave alone)
-  const uint32_t nseg = (uint32_t)(total - seg0 < (size_t)PRL_SEG ? total - seg0 : (size_t)PRL_SEG);
+  const uint32_t nseg = (uint32_t)(total - seg0 < (size_t)seg ? total - seg0 : (size_t)seg);
   const uint32_t coord0 = (uint32_t)(seg0 / B), b00 = (uint32_t)(seg0 % B), B32 = (uint32_t)B;
-  const bool few_wraps = B32 >= (uint32_t)PRL_SEG;             // then an offset wraps at most once
+  const bool few_wraps = B32 >= seg;                           // then an offset wraps at most once
   auto locate = [&](uint32_t off, uint32_t* coord, uint32_t* bb) {
     const uint32_t o = b00 + off;
     if (few_wraps) { const bool wrap = o >= B32; *coord = coord0 + (wrap ? 1u : 0u); *bb = wrap ? o - B32 : o; }
@@ -1193,8 +1200,15 @@ constexpr int GQ_WAVES = 4;
 // slots per wave (a power of two).  256 measured slower at k = 30 (LDS limits occupancy); 64 at k = 60 (two workgroups per CU
 // instead of one) measured 0.155 ns per draw against 0.124 with 128
 __host__ __device__ inline int gq_problems_per_wave(uint32_t k) { (void)k; return 128; }
-__host__ inline size_t gadget_queue_lds_bytes(size_t k) {
-  const size_t P = (size_t)gq_problems_per_wave((uint32_t)k);
+// Few problems in all (a single call: n of them, one preimage): a problem is a chain of k dependent draws, so the launch lasts as long as one chain
+// however many problems a wave holds -- the host then gives every wave fewer of them (a power of two), down to one, to use more SIMDs.
+__host__ inline int gq_problems_for(uint32_t k, size_t total) {
+  int P = gq_problems_per_wave(k);
+  while (P > 1 && total / (size_t)P < 2048) P >>= 1;
+  return P;
+}
+__host__ inline size_t gadget_queue_lds_bytes(size_t k, int problems = 0) {
+  const size_t P = (size_t)(problems > 0 ? problems : gq_problems_per_wave((uint32_t)k));
   const size_t tables = k * k * 8 + k * 8 + k * sizeof(SampleZParams) + 4 * k * 4 + k * k * 2;
   const size_t per_wave = k * P * 2 + P * 8 + P * 4 + P * 4 + P * 2 + P * 2;
   return tables + GQ_WAVES * per_wave + 64;
@@ -1203,9 +1217,8 @@ __host__ inline size_t gadget_queue_lds_bytes(size_t k) {
 __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q,
                                                       uint64_t base, size_t B, size_t ld, const uint64_t* __restrict__ V,
                                                       GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
-                                                      int* __restrict__ fail) {
+                                                      int* __restrict__ fail, int P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gq_raw[];
-  const int P = gq_problems_per_wave(k);
   double* s_gso = reinterpret_cast<double*>(gq_raw);                       // k*k
   double* s_norm2 = s_gso + (size_t)k * k;                                 // k
   SampleZParams* s_sz = reinterpret_cast<SampleZParams*>(s_norm2 + k);     // k

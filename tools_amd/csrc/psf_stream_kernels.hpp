@@ -1,0 +1,138 @@
+// psf_stream_kernels.hpp -- the SINGLE-CALL / SMALL-BATCH form of x = sqrt(Sigma_2) d  (mp_perturbation.rs:315; psf.rs:48-80: one `samp_p` call is
+// one preimage, and that is what benches/psf.rs:38,63-65,90-92 time).
+//
+// With a handful of preimages the product is a matrix-VECTOR product: every byte of the factor is used once, 16 B flop per byte at most, so the
+// bound is reading the 3.8 GB chunk stream (C3) from HBM once -- not the FP64 pipe that bounds k_trmm_f64_big at batch 4096.  k_trmm_f64_big
+// cannot get there: its 256 x 128 tiles give 121 workgroups for any batch <= 128 and the bottom one walks 7 712 k-steps x 32 MFMAs alone (7 ms).
+//
+// k_trmm_stream: the unit of work is ONE 16-row tile of the factor (one MFMA accumulator row) x NB column fragments of 16 preimages, owned by ONE
+// wave from k = 0 to the diagonal -- every element of X is still one ascending-k fma chain from +0 (v_mfma_f64_16x16x4_f64 is an ascending chain,
+// profiles/r01_probe_mfma_f64.log), NO split-K, so the bits are those of the oracle and of the three batch kernels.  The chunk stream is already
+// fragment-ordered per 16-row tile: k-step s of tile t is the 512 bytes at (rowblock_base(t / 8) * 2048 + s * 512 + (t % 8) * 64 + lane) doubles, one
+// global_load_dwordx2 per lane.  A tile stops at its diagonal (4 (t + 1) k-steps; the zero fragments behind it inside the diagonal chunk are skipped --
+// they would add exact zeros).
+//
+// Balance without split-K: the 16-row tiles have lengths 4, 8, ..., m / 4 k-steps.  Task i (descending length) and task N - 1 - i add up to the same
+// length for every i, so a workgroup of eight waves takes four (long, short) pairs: waves w and w + 4 of a 512-thread workgroup share a SIMD
+// (MI355X_MICROARCH.md, LDS section: waves are dealt to SIMDs cyclically), every SIMD of every workgroup gets the same number of MFMAs, and all tiles
+// start together: the launch lasts as long as reading the factor takes, plus the tail of the longest chain.
+// PD k-steps of operands are in flight per wave in a register ring (loads and waits are asm volatile: hipcc drains an unrolled ring with vmcnt(0));
+// the 6-bit vmcnt allows 63 loads in flight, so PD <= 63 / (RT + NB) + 1.  Eight waves per CU with eight k-steps each already saturate what a CU
+// takes from HBM (tools/probe_stream.hip: PD 8 / 16 / 32 within 4 %); what a wave must not do is spend issue cycles per k-step beside its loads.
+constexpr size_t TS_SLACK_DOUBLES = 2 * 32 * 512;      // doubles the host allocates behind the factor's and the normals' chunk streams: 2 PD k-steps, PD <= 32
+#pragma once
+#include <type_traits>
+#include "psf_kernels.hpp"
+
+namespace psf {
+
+template <int N> __device__ inline void ts_wait(double& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N)); }
+__device__ inline void ts_touch(double& x) { asm volatile("" : "+v"(x)); }
+template <int OFF> __device__ inline void ts_load(double& dst, uint32_t voff, const double* base) {
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(OFF) : "memory");
+}
+template <int I, int N, class F> __device__ inline void ts_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); ts_for<I + 1, N>(f); }
+}
+
+struct StreamGeom {
+  int ntile;        // groups of RT 16-row tiles (ceil(rows / (16 RT)))
+  int ncg;          // column groups of 16 NB preimages
+  int ntask;        // ntile * ncg
+};
+
+// task (descending length) -> (tile group, column group); column groups of one tile group are neighbours in the order
+template <int RT, int NB, int PD, int HALF = 4, int CD = 0>
+__global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
+                                                        StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
+  static_assert((PD - 1) * (RT + NB) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(8 % RT == 0 && 8 % NB == 0, "a tile group stays inside one row block, a column group inside one column block");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slot = HALF * (int)blockIdx.x + (wave % HALF);           // waves [0, HALF): the long tasks, [HALF, 2 HALF): their mirrors
+  const int mirror = g.ntask - 1 - slot;
+  const int task = wave < HALF ? slot : mirror;
+  if (wave < HALF ? slot > mirror : mirror <= slot) return;          // the middle of an odd count belongs to the long half (no barrier in here)
+  const int tg = g.ntile - 1 - task / g.ncg, cg = task % g.ncg;
+  const int t0 = tg * RT;                                            // first 16-row tile of the group
+  const int nsteps = 4 * (t0 + RT);                                  // k-steps to the diagonal of the group's last tile
+  const int bi = t0 >> 3, tl = t0 & 7;
+  const double* gA = Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK + (size_t)tl * 64;                 // wave-uniform
+  const int cf0 = cg * NB;                                           // first column fragment (16 preimages each)
+  // fragments of one column block (8 per 128 preimages) are 64 doubles apart, blocks nkb chunks apart; NB divides 8: a group stays inside its block
+  // CD: the COMPACT normals stream of small batches, [k-step][column fragment][lane] over the g.ncg * NB fragments in use only -- consecutive k-steps of
+  // a fragment are ncf * 512 B apart instead of 4 KiB (where every wave of the chip reads the same two L2 channels: tools/probe_stream.hip)
+  const size_t strideB = CD ? (size_t)g.ncg * NB * 64 : 512;       // doubles per k-step
+  const double* gB = CD ? Dt + (size_t)cf0 * 64 : Dt + (size_t)(cf0 >> 3) * nkb * TR_CHUNK + (size_t)(cf0 & 7) * 64;
+  // One k-step of a tile is 4 KiB further down the stream (8 tiles x 512 B), beyond the 12-bit immediate: ring slot u carries its own lane offset
+  // (lane * 8 + u * 4096) and the two wave-uniform bases advance once per round of PD steps -- a k-step costs the wave its wait, its MFMAs and its
+  // loads, nothing else.  (Measured with per-step scalar address arithmetic and guards: the LONGEST chain's issue time, not HBM, set the launch time.)
+  // Loads run up to 2 PD k-steps past the diagonal instead of being clamped: those bytes exist (the rest of the diagonal chunk, the next row block, or
+  // the slack the host allocates behind both streams) and are never consumed; every round issues the same number of loads, so the wait count is exact.
+  uint32_t voff[PD], voffB[PD];
+#pragma unroll
+  for (int u = 0; u < PD; ++u) { voff[u] = (uint32_t)lane * 8u + (uint32_t)u * 4096u; voffB[u] = CD ? (uint32_t)lane * 8u + (uint32_t)u * (uint32_t)strideB * 8u : voff[u]; }
+
+  d4 acc[RT][NB];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  double a[PD][RT], b[PD][NB];
+  const double* pa = gA;
+  const double* pb = gB;
+  auto issue = [&](double (&av)[RT], double (&bv)[NB], uint32_t vo, uint32_t vob) {
+    ts_for<0, RT>([&](auto I) { ts_load<decltype(I)::value * 512>(av[decltype(I)::value], vo, pa); });
+    ts_for<0, NB>([&](auto J) { ts_load<decltype(J)::value * 512>(bv[decltype(J)::value], vob, pb); });
+  };
+  auto consume = [&](double (&av)[RT], double (&bv)[NB]) {
+    ts_wait<(PD - 1) * (RT + NB)>(av[0]);                            // all but the PD - 1 newest k-steps have landed
+#pragma unroll
+    for (int i = 1; i < RT; ++i) ts_touch(av[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) ts_touch(bv[j]);
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+  };
+#pragma unroll
+  for (int u = 0; u < PD; ++u) issue(a[u], b[u], voff[u], voffB[u]);
+  const int nfull = nsteps / PD;
+  for (int r = 0; r < nfull; ++r) {
+    pa += (size_t)PD * 512;
+    pb += (size_t)PD * strideB;
+#pragma unroll
+    for (int u = 0; u < PD; ++u) { consume(a[u], b[u]); issue(a[u], b[u], voff[u], voffB[u]); }
+  }
+  {  // the last, partial round (nsteps is a multiple of 4, PD need not divide it); its refills only keep the count
+    const int rest = nsteps - nfull * PD;
+    pa += (size_t)PD * 512;
+    pb += (size_t)PD * strideB;
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      if (u < rest) { consume(a[u], b[u]); issue(a[u], b[u], voff[u], voffB[u]); }      // wave-uniform
+    }
+  }
+  // the unconsumed loads keep their registers until they have landed (see k_trmm_f64_reg)
+  ts_wait<0>(a[0][0]);
+#pragma unroll
+  for (int u = 0; u < PD; ++u) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) ts_touch(a[u][i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) ts_touch(b[u][j]);
+  }
+  // C/D map of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = (size_t)(t0 + i) * 16 + (lane >> 4) + 4 * r;
+        if (row < row_hi) X[row * ldx + (size_t)(cf0 + j) * 16 + (lane & 15)] = acc[i][j][r];
+      }
+}
+
+}  // namespace psf

@@ -11,6 +11,7 @@
 #include "../../include/psf_mi355x.h"
 #include "psf_host.hpp"
 #include "psf_kernels.hpp"
+#include "psf_stream_kernels.hpp"
 #include "psf_gpv_kernels.hpp"
 #include "psf_np_kernels.hpp"
 #include "psf_chol_kernels.hpp"
@@ -130,7 +131,7 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
   for (int i = 0; i < nsets; ++i) {
     auto& t = h->sets[i];
     if (perturb) {
-      HIP_TRY(hipMalloc(&t.dDt, ld / TR_BN * h->nkb * TR_CHUNK * sizeof(double)));
+      HIP_TRY(hipMalloc(&t.dDt, (ld / TR_BN * h->nkb * TR_CHUNK + TS_SLACK_DOUBLES) * sizeof(double)));   // slack: k_trmm_stream reads past the diagonal
       HIP_TRY(hipMalloc(&t.dX, h->M_pad * ld * sizeof(double)));
       HIP_TRY(hipMalloc(&t.dP, h->M_pad * ld * sizeof(int32_t)));
       HIP_TRY(hipMalloc(&t.dP8, 3 * h->K_pad * ld));
@@ -327,7 +328,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipMalloc(&h->dA, h->n * h->m * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dR, h->mb_pad * h->ldr));
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
-  if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dLt, tr_total_chunks(h->nbiL) * TR_CHUNK * sizeof(double)));
+  if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dLt, (tr_total_chunks(h->nbiL) * TR_CHUNK + TS_SLACK_DOUBLES) * sizeof(double)));
   if (h->structured) HIP_TRY(hipMalloc(&h->dR8, round_up(h->mb, 64) * h->ldr));
   for (auto& t : h->sets) {                             // [0] sampler failure, [1] some |z| > 127
     HIP_TRY(hipMalloc(&t.dFail, 2 * sizeof(int)));
@@ -879,7 +880,34 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     const char* venv = std::getenv("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
     const int variant = venv ? std::atoi(venv) : 2;
     const size_t row_hi = h->structured ? h->mb : h->M_pad;
-    if (variant == 2) {
+    // Small batches (one samp_p call of the reference is ONE preimage, psf.rs:48-80): the streaming kernel, bound by reading the factor once.
+    // PSF_TRMM_STREAM_MAX = largest batch it serves (0 switches it off); PSF_TRMM_STREAM_SHAPE = "RT,NB" forces a tile shape (experiments).
+    size_t stream_max = 128;
+    if (const char* e = std::getenv("PSF_TRMM_STREAM_MAX")) stream_max = (size_t)std::atol(e);
+    if (B <= stream_max) {
+      // tile shape per wave (RT 16-row tiles x NB fragments of 16 preimages) and workgroup form, from tools/probe_stream.hip at the C3 shape
+      // (profiles/r04_probe_stream.log): <= 16 preimages the launch is bound by reading the factor, beyond that by the longest MFMA chain
+      int RT = 2, NB = B <= 16 ? 1 : B <= 64 ? 2 : 4;
+      if (const char* e = std::getenv("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
+      const int ntile16 = (int)((h->mL + 15) / 16);
+      auto go = [&](auto kern, int rt, int nb, int half) {
+        StreamGeom g;
+        g.ntile = (ntile16 + rt - 1) / rt;
+        g.ncg = (int)((B + 16 * (size_t)nb - 1) / (16 * (size_t)nb));
+        g.ntask = g.ntile * g.ncg;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((g.ntask + 2 * half - 1) / (2 * half))), dim3(128 * half), 0, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      };
+      if (RT == 2 && NB == 1) go(k_trmm_stream<2, 1, 12, 2>, 2, 1, 2);
+      else if (RT == 2 && NB == 2 && B <= 32) go(k_trmm_stream<2, 2, 8, 2>, 2, 2, 2);
+      else if (RT == 2 && NB == 2) go(k_trmm_stream<2, 2, 16, 4>, 2, 2, 4);
+      else if (RT == 2 && NB == 4) go(k_trmm_stream<2, 4, 8, 4>, 2, 4, 4);
+      else if (RT == 4 && NB == 2) go(k_trmm_stream<4, 2, 10, 4>, 4, 2, 4);
+      else if (RT == 1 && NB == 8) go(k_trmm_stream<1, 8, 8, 4>, 1, 8, 4);
+      else if (RT == 1 && NB == 4) go(k_trmm_stream<1, 4, 8, 4>, 1, 4, 4);
+      else if (RT == 1 && NB == 2) go(k_trmm_stream<1, 2, 8, 4>, 1, 2, 4);
+      else go(k_trmm_stream<1, 1, 8, 4>, 1, 1, 4);
+    }
+    else if (variant == 2) {
       int GR = 8, GC = 4;                                     // super-tile of an XCD's 32 resident workgroups; PSF_TRMM_GR x PSF_TRMM_GC for experiments (product = 32)
       if (const char* e1 = std::getenv("PSF_TRMM_GR")) if (const char* e2 = std::getenv("PSF_TRMM_GC")) { GR = std::atoi(e1); GC = std::atoi(e2); }
       if (GR < 1 || GC < 1 || GR * GC != 32) { GR = 8; GC = 4; }
@@ -907,8 +935,9 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       ScopedTimer t(h, sx, "k_perturb_round");
       const char* renv = std::getenv("PSF_ROUND");                 // "wave": the round-2 kernel (comparison arm; same bits)
       if (h->szR.sh == 16 && !(renv && !std::strcmp(renv, "wave"))) {
-        const size_t waves = (m * Bh + PRL_SEG - 1) / PRL_SEG;
-        hipLaunchKernelGGL(k_perturb_round_lean, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, m, Bh, ld, h->dX + b0, h->szR, h->dP + b0, h->dFail);
+        const uint32_t seg = prl_segment(m * Bh);
+        const size_t waves = (m * Bh + seg - 1) / seg;
+        hipLaunchKernelGGL(k_perturb_round_lean, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, m, Bh, ld, h->dX + b0, h->szR, h->dP + b0, h->dFail, seg);
       } else {
         const size_t waves = (m * Bh + PR_SEG - 1) / PR_SEG;
         hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, m, Bh, ld, h->dX + b0, h->szR, h->dP + b0, h->dFail);
@@ -922,9 +951,10 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       ScopedTimer t(h, sx, "k_gadget");
       if (h->gadget_queue) {
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
-        const size_t per_wg = (size_t)GQ_WAVES * gq_problems_per_wave((uint32_t)h->k);
-        hipLaunchKernelGGL(k_gadget_queue, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k), sx, seed,
-                           first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+        const int P = gq_problems_for((uint32_t)h->k, h->n * Bh);
+        const size_t per_wg = (size_t)GQ_WAVES * P;
+        hipLaunchKernelGGL(k_gadget_queue, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k, P), sx, seed,
+                           first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail, P);
       } else {
         GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
         hipLaunchKernelGGL(k_gadget, dim3((unsigned)((Bh + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(h->k), sx, seed, first_index + b0,
