@@ -971,24 +971,22 @@ __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, 
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        uint64_t t = 0;
+        // S = sum_c T_c 256^c as ONE signed 128-bit integer (|S| < 2^31 2^(8 (NC - 1))), then a single reduction mod q: the per-class form
+        // ((T_c mod q) 256^c mod q, summed) cost two 64-bit divisions per class -- 192 per thread, more than the K loop of a short split
+        Acc128 S{0, 0};
+#pragma unroll
         for (int c = 0; c < NC; ++c) {
-          int32_t T;
-          switch (c) {   // static register indices
-            case 0: T = acc[0][x][y][r]; break;
-            case 1: T = acc[1][x][y][r]; break;
-            case 2: T = acc[2 < NC ? 2 : 0][x][y][r]; break;
-            case 3: T = acc[3 < NC ? 3 : 0][x][y][r]; break;
-            case 4: T = acc[4 < NC ? 4 : 0][x][y][r]; break;
-            case 5: T = acc[5 < NC ? 5 : 0][x][y][r]; break;
-            case 6: T = acc[6 < NC ? 6 : 0][x][y][r]; break;
-            case 7: T = acc[7 < NC ? 7 : 0][x][y][r]; break;
-            case 8: T = acc[8 < NC ? 8 : 0][x][y][r]; break;
-            default: T = acc[9 < NC ? 9 : 0][x][y][r]; break;
-          }
-          t += zq_term(T, zc.pw[c], zc.q, zc.two64, wide != 0);
-          if (t >= zc.q) t -= zc.q;
+          const int64_t T = (int64_t)acc[c][x][y][r];
+          const int sh = 8 * c;
+          uint64_t lo; int64_t hi;
+          if (sh == 0) { lo = (uint64_t)T; hi = T >> 63; }
+          else if (sh < 64) { lo = (uint64_t)T << sh; hi = T >> (64 - sh); }
+          else { lo = 0; hi = (int64_t)((uint64_t)T << (sh - 64)); }
+          const uint64_t nl = S.lo + lo;
+          S.hi += hi + (nl < S.lo ? 1 : 0);
+          S.lo = nl;
         }
+        const uint64_t t = acc128_mod(S, zc.q, zc.two64);
         const size_t i = i0 + wr * 32 + x * 16 + 4 * g + r, cc = b0 + wc * 32 + y * 16 + r16;
         dst[i * ld + cc] = t;
       }
@@ -1394,7 +1392,7 @@ constexpr int RC_LDS = 3 * RC_STAGE;      // 72 KiB: three 24 KiB stages, or fou
 __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int nks,
                                                            const int8_t* __restrict__ Zlo, const int8_t* __restrict__ Zhi, size_t ld,
                                                            const int* __restrict__ flags, const int32_t* __restrict__ P, size_t B,
-                                                           int64_t* __restrict__ E, size_t m, int only_hi) {
+                                                           int64_t* __restrict__ E, size_t m, int only_hi, int ks_per_split) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1402,6 +1400,15 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
   const size_t b0 = (size_t)blockIdx.x * 128, i0 = (size_t)blockIdx.y * 128;
   const bool use_hi = flags[1] != 0;
   if (only_hi && !use_hi) return;                     // k_recombine_mfma_big (launched in front) has done the lo-plane-only case
+  // gridDim.z > 1 (few preimages: a single call has one column tile, and the launch would be 121 workgroups streaming 2 MB of R each): blockIdx.z takes the
+  // K steps [z ks_per_split, (z + 1) ks_per_split) and ADDS its integer partial sum to E (zeroed by the host; z = 0 also adds p) -- exact in any order.
+  const bool split = gridDim.z > 1;
+  if (split) {
+    const int ks0 = (int)blockIdx.z * ks_per_split;
+    if (ks0 >= nks) return;
+    R += (size_t)ks0 * 64; Zlo += (size_t)ks0 * 4 * ld * 16; Zhi += (size_t)ks0 * 4 * ld * 16;
+    nks = nks - ks0 < ks_per_split ? nks - ks0 : ks_per_split;
+  }
 
   v4i alo[4][4], ahi[4][4];
 #pragma unroll
@@ -1519,9 +1526,10 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
   // runs and turned by the padded LDS tile, instead of sixty-four 4-byte gathers per thread across sixteen rows each.
   __syncthreads();                                    // the stage ring is free
   int32_t* sP = reinterpret_cast<int32_t*>(rc_smem);  // [128][129]
+  const bool add_p = !split || blockIdx.z == 0;       // workgroup-uniform
   for (int idx = tid; idx < 128 * 32; idx += 256) {
     const int ii = idx >> 5, c4 = idx & 31;
-    const int4 v = *reinterpret_cast<const int4*>(P + (i0 + (size_t)ii) * ld + b0 + (size_t)c4 * 4);
+    const int4 v = add_p ? *reinterpret_cast<const int4*>(P + (i0 + (size_t)ii) * ld + b0 + (size_t)c4 * 4) : int4{0, 0, 0, 0};
     int32_t* d = sP + ii * 129 + c4 * 4;
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
@@ -1535,8 +1543,11 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
       for (int r = 0; r < 4; ++r) {
         const int bl = wr * 64 + bt * 16 + 4 * g + r, il = wc * 64 + it * 16 + r16;
         const size_t bb = b0 + bl, ii = i0 + il;
-        if (bb < B && ii < mbar)
-          E[bb * m + ii] = (int64_t)sP[il * 129 + bl] + (int64_t)alo[bt][it][r] + 256 * (int64_t)ahi[bt][it][r];
+        if (bb < B && ii < mbar) {
+          const int64_t v = (int64_t)sP[il * 129 + bl] + (int64_t)alo[bt][it][r] + 256 * (int64_t)ahi[bt][it][r];
+          if (split) atomicAdd(reinterpret_cast<unsigned long long*>(E + bb * m + ii), (unsigned long long)v);
+          else E[bb * m + ii] = v;
+        }
       }
 }
 

@@ -135,4 +135,79 @@ __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(cons
       }
 }
 
+// ---- gadget nearest plane for a SINGLE CALL (mp_perturbation.rs:173-191; gadget_classical.rs:169-229 for the digits) ------------------------------
+// k_gadget_queue keeps 64 lanes busy with 128 problems per wave; a problem is a chain of k dependent draws, so with the n problems of one preimage
+// (psf.rs:48-80) the launch lasts one chain of ~3.4 k sampling iterations whatever the wave count (0.2 ms at C3).  Here ONE WAVE OWNS ONE PROBLEM:
+// lane r holds c_r, the 64 lanes evaluate attempts t0 .. t0 + 63 of the current draw at once (exact rule, sz_attempt) and the lowest accepted attempt
+// is taken -- the first accepted attempt of the draw's own Philox stream, i.e. the value every other sampler of the library returns.
+// A draw costs one round (64 attempts miss with probability (11/12)^64 = 0.4 %) and the chain k of them.  Every lane pays an exact attempt, so this
+// form only pays while there are about as many problems as SIMDs; the host switches at n B <= 8192 (psfp.hip).
+// Checks mirror k_gadget_queue (|z_i| <= 16000, c in int16): the failure flag is raised by the same inputs.
+__global__ __launch_bounds__(256) void k_gadget_wave(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q, uint64_t base, size_t B, size_t ld,
+                                                     const uint64_t* __restrict__ V, GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
+                                                     int* __restrict__ fail) {
+  const int lane = threadIdx.x & 63;
+  const size_t pid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pid >= (size_t)n * B) return;                             // wave-uniform; no barrier in this kernel
+  const uint32_t j = (uint32_t)(pid / B);
+  const size_t b = pid % B;
+  int f = 0;
+  int c = 0;
+  {  // digit `lane` of v_j (find_solution_gadget_vec): c = -x
+    uint64_t v = V[(size_t)j * ld + b] % q;
+    uint64_t d = 0;
+    if (base == 2) d = lane < 64 ? (v >> lane) & 1 : 0;
+    else for (int t = 0; t <= lane && t < (int)k; ++t) { d = v % base; v = (v - d) / base; }
+    if (lane < (int)k) c = -(int)d;
+  }
+  const uint64_t index = first_index + b;
+  const uint32_t tw = tag_word(TAG_GADGET, index), idx_lo = (uint32_t)index;
+  for (int i = (int)k - 1; i >= 0; --i) {
+    // centre <c, b~_i> / ||b~_i||^2 over the non-zero rows: ONE ascending fma chain, evaluated by every lane alike
+    double dot = 0.0;
+    const int ghi = tb.rng[k + i];
+    for (int r = tb.rng[i]; r <= ghi; ++r) dot = fma((double)__builtin_amdgcn_readlane(c, r), tb.gso[(size_t)r * k + i], dot);
+    const double cen = dot / tb.norm2[i];
+    const SampleZParams sp = tb.sz[i];
+    const SzRange rg = sz_range(cen, sp);
+    const uint32_t coord = j * k + (uint32_t)i;
+    long long x = 0;
+    bool found = false;
+    for (uint32_t t0 = 0; t0 < kMaxAttempts && !found; t0 += 64) {
+      const uint32_t t = t0 + (uint32_t)lane;
+      uint32_t wa, wb;
+      sz_attempt_words(seed, coord, idx_lo, tw, t, rg.sh, &wa, &wb);
+      long long xl = 0;
+      const bool acc = sz_attempt(seed, coord, idx_lo, tw, t, wa, wb, rg, cen, sp.inv_s, &xl);
+      const uint64_t mask = __ballot(acc);
+      if (mask) {
+        const int first = __builtin_ctzll(mask);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)xl, first), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)xl >> 32), first);
+        x = (long long)(((uint64_t)hi << 32) | lo);
+        found = true;
+      }
+    }
+    if (!found) { f = 1; x = (long long)floor(cen + 0.5); }
+    if (x > 16000 || x < -16000) f = 1;
+    if (lane < (int)k) {
+      const int nv = c - (int)x * tb.Sk[(size_t)lane * k + i];
+      if (nv > 32767 || nv < -32768) f = 1;
+      c = nv;
+    }
+  }
+  int anyhi = 0;
+  if (lane < (int)k) {
+    const int32_t zz = -c;
+    const int32_t zl = (int32_t)(int8_t)(zz & 0xff);
+    const int32_t zh = (zz - zl) >> 8;
+    const size_t cc = (size_t)j * k + (size_t)lane;
+    const size_t addr = ((cc >> 4) * ld + b) * 16 + (cc & 15);
+    Zlo[addr] = (int8_t)zl;
+    Zhi[addr] = (int8_t)zh;
+    if (zh) anyhi = 1;
+  }
+  if (f) atomicOr(fail, 1);
+  if (anyhi) atomicOr(fail + 1, 1);
+}
+
 }  // namespace psf

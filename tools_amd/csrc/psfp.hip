@@ -80,7 +80,7 @@ struct psfp_handle {
                     int8_t* dZlo = nullptr; int8_t* dZhi = nullptr; int* dFail = nullptr; int8_t* dD8 = nullptr; } sets[2];
   int8_t* dD8 = nullptr;                      // five digit planes of d_2 2^32 (structured mode), [ldr/16][ld][16] each
   int32_t* dPf = nullptr; int8_t* dP8f = nullptr;   // scratch of f_a (kept apart from the pipelined sets)
-  uint64_t* dPart = nullptr; int zq_splits = 1, zq_ks = 0;   // per-split residues of the int8-MFMA Z_q product
+  uint64_t* dPart = nullptr; int zq_split_cap = 1;   // per-split residues of the int8-MFMA Z_q product
   bool gadget_queue = true;   // task-queue gadget sampler (PSF_GADGET_QUEUE=0: lock-step kernel)
   bool keep_fail = false;     // sliced host path: the failure flags accumulate over the slices of one call
   bool no_slice = false;      // stage export wants the intermediates of the whole batch
@@ -116,6 +116,18 @@ static void free_batch(psfp_handle* h) {
   h->Bcap = 0;
 }
 
+// K splits of the Z_q product for `ncols` preimages: at most 256 K-steps each (int32 exactness of the digit-class sums), and enough workgroups to
+// fill the chip -- a single call (one preimage) has 8 row tiles x 1 column tile, so its K range is cut as finely as 4 K-steps per split.  The
+// residues are exact integers mod q: the number of splits changes no bit.
+static int zq_plan(const psfp_handle* h, size_t ncols, int cap) {
+  const int nks = (int)(h->K_pad / 64);
+  int splits = (nks + 255) / 256;
+  const size_t tiles = ((ncols + 63) / 64) * (h->n_pad / 64);
+  const int min_ks = tiles * 8 >= 2048 ? 16 : 4;
+  while (splits < cap && tiles * splits < 2048 && nks / (splits + 1) >= min_ks) ++splits;
+  return splits;
+}
+
 static psf_status ensure_batch(psfp_handle* h, size_t B) {
   if (B <= h->Bcap) {
     h->nbj = round_up(B, TR_BN) / TR_BN;
@@ -149,14 +161,15 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
   }
   HIP_TRY(hipMalloc(&h->dPf, h->M_pad * ld * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&h->dP8f, 3 * h->K_pad * ld));
-  {  // K splits of the Z_q product: at most 256 K-steps each (int32 exactness), and enough workgroups to fill the chip
+  {  // K splits of the Z_q product (zq_plan): the partial residues of every split live in dPart, [split][n_pad][ld]
     const int nks = (int)(h->K_pad / 64);
-    int splits = (nks + 255) / 256;
-    const size_t tiles = (ld / 64) * (h->n_pad / 64);
-    while (splits < 8 && tiles * splits < 2048 && nks / (splits + 1) >= 16) ++splits;
-    h->zq_splits = splits;
-    h->zq_ks = (nks + splits - 1) / splits;
-    HIP_TRY(hipMalloc(&h->dPart, (size_t)splits * h->n_pad * ld * sizeof(uint64_t)));
+    const size_t per_split = h->n_pad * ld * sizeof(uint64_t);
+    int cap = (int)(((size_t)256 << 20) / per_split);                 // small batches take up to 64 splits, within 256 MB
+    if (cap > 64) cap = 64;
+    const int legacy = zq_plan(h, ld, 8);
+    h->zq_split_cap = cap > legacy ? cap : legacy;
+    if (h->zq_split_cap > nks) h->zq_split_cap = nks;
+    HIP_TRY(hipMalloc(&h->dPart, (size_t)h->zq_split_cap * per_split));
   }
   HIP_TRY(hipMalloc(&h->dU, B * h->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dE, B * h->m * sizeof(int64_t)));
@@ -646,14 +659,16 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
   size_t cw = round_up(ncols, 64);                                    // the product works on 64-column tiles
   if (col0 + cw > ld) cw = ld - col0;
   hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * cw, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, P8, h->dFail, col0, cw);
-  dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64), (unsigned)h->zq_splits);
+  const int nks = (int)(h->K_pad / 64);
+  const int splits = zq_plan(h, ncols, h->zq_split_cap), zq_ks = (nks + splits - 1) / splits;
+  dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64), (unsigned)splits);
 #define ZQM(NA_)                                                                                                        \
   case NA_:                                                                                                             \
-    hipLaunchKernelGGL((k_zq_mfma<NA_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, h->zq_ks, h->zc,  \
+    hipLaunchKernelGGL((k_zq_mfma<NA_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc,  \
                        (int)h->wide, h->dPart, col0);                                                                   \
     break;
   switch (h->NA) { ZQM(1) ZQM(2) ZQM(3) ZQM(4) ZQM(5) ZQM(6) ZQM(7) ZQM(8) default: break; }
-  hipLaunchKernelGGL(k_zq_combine, dim3(grid_for(h->n * ncols, 256, 256 * 32)), dim3(256), 0, st, mode, h->dPart, h->zq_splits, h->n, h->n_pad, ld, ncols,
+  hipLaunchKernelGGL(k_zq_combine, dim3(grid_for(h->n * ncols, 256, 256 * 32)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols,
                      h->q, U, out, ldo, col0);
 #undef ZQM
 }
@@ -949,7 +964,13 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
     {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
       ScopedTimer t(h, sx, "k_gadget");
-      if (h->gadget_queue) {
+      const char* genv = std::getenv("PSF_GADGET_WAVE");            // max n B served by the one-wave-per-problem kernel (0: never)
+      const size_t wave_max = genv ? (size_t)std::atol(genv) : 8192;
+      if (h->gadget_queue && h->n * Bh <= wave_max) {               // a single call / a handful of preimages: the chain of k draws is the launch time
+        GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
+        hipLaunchKernelGGL(k_gadget_wave, dim3((unsigned)((h->n * Bh + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
+                           h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+      } else if (h->gadget_queue) {
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         const int P = gq_problems_for((uint32_t)h->k, h->n * Bh);
         const size_t per_wg = (size_t)GQ_WAVES * P;
@@ -971,8 +992,20 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         hipLaunchKernelGGL(k_recombine_mfma_big, dim3(((nsup + 7) / 8) * 8 * 32), dim3(512), RCB_LDS, sx, h->dR, h->ldr, h->mb,
                            (int)(h->ldr / 128), h->dZlo + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m, nbx, nby);
       }
-      hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bh + 127) / 128), (unsigned)((h->mb + 127) / 128)), dim3(256), RC_LDS, sx, h->dR,
-                         h->ldr, h->mb, (int)(h->ldr / 64), h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m, big ? 1 : 0);
+      // few preimages: cut K over blockIdx.z (an even number of K steps each, at least 8) until ~2048 workgroups; the partial sums are added into a zeroed E
+      const unsigned tiles = (unsigned)((Bh + 127) / 128) * (unsigned)((h->mb + 127) / 128);
+      const int nks = (int)(h->ldr / 64);
+      int rsplits = 1, kps = nks;
+      if (!big && tiles < 1024 && nks >= 16) {
+        rsplits = (int)(2048 / tiles);
+        kps = (nks + rsplits - 1) / rsplits;
+        if (kps < 8) kps = 8;
+        kps += kps & 1;
+        rsplits = (nks + kps - 1) / kps;
+      }
+      if (rsplits > 1) hipMemset2DAsync(d_e + b0 * m, m * sizeof(int64_t), 0, h->mb * sizeof(int64_t), Bh, sx);
+      hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bh + 127) / 128), (unsigned)((h->mb + 127) / 128), (unsigned)rsplits), dim3(256), RC_LDS, sx, h->dR,
+                         h->ldr, h->mb, nks, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m, big ? 1 : 0, kps);
       hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bh + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, sx, h->mb, h->w,
                          h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
     }
