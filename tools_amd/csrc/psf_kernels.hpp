@@ -79,6 +79,12 @@ __global__ void k_unpack_L(const double* __restrict__ chunks, size_t first, size
 // one ratio-of-uniforms attempt of its current position, accepted lanes store and take the next unassigned position
 // (ballot + mbcnt).  The value of a position is the first accepted attempt of its own (coordinate, preimage) Philox stream.
 constexpr int NR_SEG = 4096;   // two chunks
+// positions per wave: NR_SEG for full batches; with few positions in all (a single call) the launch lasts as long as its longest wave
+__host__ inline uint32_t nr_segment(size_t total) {
+  size_t seg = (total / 4096 + 63) / 64 * 64;
+  if (seg < 128) seg = 128;
+  return (uint32_t)(seg > (size_t)NR_SEG ? (size_t)NR_SEG : seg);
+}
 __device__ inline int lane_rank(uint64_t mask);
 
 // Structured sqrt(Sigma_2) (opt-in, struct NormalsFixed): the coordinates from `split` on (the gadget half, d_2) are taken in FIXED POINT,
@@ -88,19 +94,29 @@ __device__ inline int lane_rank(uint64_t mask);
 struct NormalsFixed { size_t split; int8_t* planes; size_t plane_bytes; size_t ld; double* X; double h; };
 constexpr int kFixPlanes = 5;      // |q| < 2^39: normals beyond +-64 do not occur
 
+// ncf > 0: the COMPACT stream of small batches (k_trmm_stream, psf_stream_kernels.hpp): [k-step][column fragment of 16 preimages, ncf of them][lane],
+// position g -> coordinate 4 (g / (64 ncf)) + (g % 64) / 16, preimage 16 ((g / 64) % ncf) + g % 16 -- only the fragments in use exist, so a single
+// call draws m normals among m_pad x 16 positions instead of m_pad x 128.
 __global__ __launch_bounds__(256) void k_normals_wave(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t nkb, size_t nbj,
-                                                      double* __restrict__ Dt, int* __restrict__ fail, NormalsFixed fx) {
+                                                      double* __restrict__ Dt, int* __restrict__ fail, NormalsFixed fx, uint32_t ncf, uint32_t seg) {
   const int lane = threadIdx.x & 63;
-  const size_t total = nbj * nkb * TR_CHUNK;
-  const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NR_SEG;
+  const size_t total = ncf ? nkb * 4 * (size_t)ncf * 64 : nbj * nkb * TR_CHUNK;
+  const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * seg;     // seg <= NR_SEG positions per wave (nr_segment: short for small batches)
   if (seg0 >= total) return;
-  const size_t seg1 = seg0 + NR_SEG < total ? seg0 + NR_SEG : total;
+  const size_t seg1 = seg0 + seg < total ? seg0 + seg : total;
   const size_t chunk0 = seg0 / TR_CHUNK;
   constexpr int NCH = NR_SEG / TR_CHUNK + 1;
   size_t cbj[NCH], cbk[NCH];                       // (column block, K block) of the chunks this wave touches
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { cbj[i] = (chunk0 + i) / nkb; cbk[i] = (chunk0 + i) % nkb; }
   auto locate = [&](size_t g, size_t* coord, size_t* b) {
+    if (ncf) {
+      const uint32_t ln = (uint32_t)(g & 63);
+      const size_t fr = g >> 6;                                // fragment index = k-step * ncf + column fragment
+      *coord = (fr / ncf) * 4 + (ln >> 4);
+      *b = (fr % ncf) * 16 + (ln & 15);
+      return;
+    }
     const int ci = (int)(g / TR_CHUNK - chunk0);
     const int pos = (int)(g % TR_CHUNK);
     size_t bj = cbj[0], bk = cbk[0];
@@ -182,10 +198,11 @@ __global__ __launch_bounds__(256) void k_narrow_rows(const int64_t* __restrict__
 }
 
 // read one normal back out of the chunk stream (stage export)
-__global__ void k_export_normals(const double* __restrict__ Dt, size_t m, size_t B, size_t nkb, double* __restrict__ out /*B x m*/) {
+__global__ void k_export_normals(const double* __restrict__ Dt, size_t m, size_t B, size_t nkb, double* __restrict__ out /*B x m*/, uint32_t ncf) {
   const size_t total = m * B;
   for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const size_t b = g / m, coord = g % m;
+    if (ncf) { out[g] = Dt[((coord / 4) * ncf + b / 16) * 64 + (coord % 4) * 16 + b % 16]; continue; }      // compact stream of small batches
     const size_t chunk = (b / TR_BN) * nkb + coord / TR_BK;
     out[g] = Dt[chunk * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(coord % TR_BK))];
   }
@@ -609,7 +626,7 @@ constexpr int PRL_WIN = 256;
 // samples in all, and the launch lasts as long as its longest wave, so the host cuts them into short segments (prl_segment).
 __host__ inline uint32_t prl_segment(size_t total) {
   size_t seg = (total / 2048 + 63) / 64 * 64;                  // ~2048 waves = two per SIMD
-  if (seg < 128) seg = 128;
+  if (seg < 64) seg = 64;
   return (uint32_t)(seg > (size_t)PRL_SEG ? (size_t)PRL_SEG : seg);
 }
 __global__ __launch_bounds__(256) void k_perturb_round_lean(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
@@ -1000,7 +1017,15 @@ __global__ void k_zq_combine(int mode, const uint64_t* __restrict__ part, int sp
     const size_t i = g0 / ncols, cc = col0 + g0 % ncols;
     const size_t g = i * ld + cc;
     uint64_t s = 0;
-    for (int z = 0; z < splits; ++z) {
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {                 // eight independent loads in flight (a single call has up to 64 splits and few outputs)
+      uint64_t v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = part[(size_t)(z + t) * n_pad * ld + g];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { s += v[t]; if (s >= q) s -= q; }
+    }
+    for (; z < splits; ++z) {
       s += part[(size_t)z * n_pad * ld + g];
       if (s >= q) s -= q;
     }
@@ -1652,12 +1677,21 @@ __global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __r
 }
 
 // bottom part: e[b][mbar + c] = p[mbar + c][b] + z[c][b]
+// zero_top: also clear e[b][c] for c < mbar (the split-K form of k_recombine_mfma, launched behind, adds its partial sums there); the grid then covers
+// max(w, mbar) columns
 __global__ __launch_bounds__(256) void k_recombine_bottom(size_t mbar, size_t w, const int8_t* __restrict__ Zlo,
                                                           const int8_t* __restrict__ Zhi, size_t ld, const int32_t* __restrict__ P,
-                                                          size_t B, int64_t* __restrict__ E, size_t m) {
+                                                          size_t B, int64_t* __restrict__ E, size_t m, int zero_top) {
   __shared__ int64_t sE[64][65];
   const int tid = threadIdx.x;
   const size_t c0 = (size_t)blockIdx.y * 64, b0 = (size_t)blockIdx.x * 64;
+  if (zero_top) {
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int bb = e >> 6, cc = e & 63;
+      if (b0 + bb < B && c0 + cc < mbar) E[(b0 + bb) * m + c0 + cc] = 0;
+    }
+  }
+  if (c0 >= w) return;                                // workgroup-uniform
   for (int e = tid; e < 64 * 64; e += 256) {
     const int cc = e >> 6, bb = e & 63;
     const size_t c = c0 + cc, b = b0 + bb;

@@ -162,13 +162,35 @@ __global__ __launch_bounds__(256) void k_gadget_wave(uint64_t seed, uint64_t fir
   }
   const uint64_t index = first_index + b;
   const uint32_t tw = tag_word(TAG_GADGET, index), idx_lo = (uint32_t)index;
+  // Nothing the chain waits for comes from memory: lane i holds the per-step scalars of step i (norm, SampleZ parameters, row ranges), read by
+  // v_readlane when step i runs; column i of S_k and of the Gram-Schmidt matrix (lane r: row r) is loaded one step ahead.
+  const int li = lane < (int)k ? lane : 0;
+  const double my_norm2 = tb.norm2[li];
+  const SampleZParams my_sz = tb.sz[li];
+  const int my_glo = tb.rng[li], my_ghi = tb.rng[k + li];
+  auto bcast_d = [&](double v, int src) -> double {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(__double2loint(v), src), hi = (uint32_t)__builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double((int)hi, (int)lo);
+  };
+  auto bcast_ll = [&](long long v, int src) -> long long {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+    return (long long)(((uint64_t)hi << 32) | lo);
+  };
+  double gcol = tb.gso[(size_t)li * k + (k - 1)];
+  int skcol = tb.Sk[(size_t)li * k + (k - 1)];
   for (int i = (int)k - 1; i >= 0; --i) {
+    const double g_now = gcol;
+    const int sk_now = skcol;
+    if (i > 0) { gcol = tb.gso[(size_t)li * k + (i - 1)]; skcol = tb.Sk[(size_t)li * k + (i - 1)]; }      // in flight during this step
     // centre <c, b~_i> / ||b~_i||^2 over the non-zero rows: ONE ascending fma chain, evaluated by every lane alike
     double dot = 0.0;
-    const int ghi = tb.rng[k + i];
-    for (int r = tb.rng[i]; r <= ghi; ++r) dot = fma((double)__builtin_amdgcn_readlane(c, r), tb.gso[(size_t)r * k + i], dot);
-    const double cen = dot / tb.norm2[i];
-    const SampleZParams sp = tb.sz[i];
+    const int ghi = __builtin_amdgcn_readlane(my_ghi, i);
+    for (int r = __builtin_amdgcn_readlane(my_glo, i); r <= ghi; ++r) dot = fma((double)__builtin_amdgcn_readlane(c, r), bcast_d(g_now, r), dot);
+    const double cen = dot / bcast_d(my_norm2, i);
+    SampleZParams sp;
+    sp.inv_s = bcast_d(my_sz.inv_s, i); sp.c6 = bcast_ll(my_sz.c6, i); sp.f6 = bcast_ll(my_sz.f6, i);
+    sp.n_int = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.n_int, i); sp.thr_int = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.thr_int, i);
+    sp.thr_frac = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.thr_frac, i); sp.sh = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.sh, i);
     const SzRange rg = sz_range(cen, sp);
     const uint32_t coord = j * k + (uint32_t)i;
     long long x = 0;
@@ -180,17 +202,12 @@ __global__ __launch_bounds__(256) void k_gadget_wave(uint64_t seed, uint64_t fir
       long long xl = 0;
       const bool acc = sz_attempt(seed, coord, idx_lo, tw, t, wa, wb, rg, cen, sp.inv_s, &xl);
       const uint64_t mask = __ballot(acc);
-      if (mask) {
-        const int first = __builtin_ctzll(mask);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)xl, first), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)xl >> 32), first);
-        x = (long long)(((uint64_t)hi << 32) | lo);
-        found = true;
-      }
+      if (mask) { x = bcast_ll(xl, __builtin_ctzll(mask)); found = true; }
     }
     if (!found) { f = 1; x = (long long)floor(cen + 0.5); }
     if (x > 16000 || x < -16000) f = 1;
     if (lane < (int)k) {
-      const int nv = c - (int)x * tb.Sk[(size_t)lane * k + i];
+      const int nv = c - (int)x * sk_now;
       if (nv > 32767 || nv < -32768) f = 1;
       c = nv;
     }

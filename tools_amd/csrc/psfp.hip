@@ -86,6 +86,7 @@ struct psfp_handle {
   bool no_slice = false;      // stage export wants the intermediates of the whole batch
   bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
   size_t ncall = 0;
+  uint32_t normals_ncf = 0;   // layout of dDt after the last samp_p: 0 = chunk stream, else the compact stream with this many column fragments
   hipStream_t s1 = nullptr;
   hipEvent_t evT[2] = {nullptr, nullptr}, evP[2] = {nullptr, nullptr}, evIn = nullptr;
   hipStream_t last_stream = nullptr;
@@ -882,11 +883,29 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     s2 = h->aux;
   }
   if (!h->keep_fail) hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
+  // Small batches (one samp_p call of the reference is ONE preimage, psf.rs:48-80): the streaming product, bound by reading the factor once, fed by
+  // the compact normals stream.  PSF_TRMM_STREAM_MAX = largest batch it serves (0 switches it off); PSF_TRMM_STREAM_SHAPE = "RT,NB" forces a tile
+  // shape, PSF_COMPACT_D=0 the chunk-stream layout of the normals (experiments; same bits).
+  size_t stream_max = 128;
+  if (const char* e = std::getenv("PSF_TRMM_STREAM_MAX")) stream_max = (size_t)std::atol(e);
+  const bool stream = B <= stream_max;
+  // tile shape per wave (RT 16-row tiles x NB fragments of 16 preimages) and workgroup form, from tools/probe_stream.hip at the C3 shape
+  // (profiles/r04_probe_stream.log): <= 16 preimages the launch is bound by reading the factor, beyond that by the longest MFMA chain
+  int RT = 2, NB = B <= 16 ? 1 : B <= 64 ? 2 : 4;
+  if (const char* e = std::getenv("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
+  if (!(NB == 1 || NB == 2 || NB == 4 || NB == 8)) NB = 1;
+  const int ncg = (int)((B + 16 * (size_t)NB - 1) / (16 * (size_t)NB));
+  bool compact = stream && !h->structured;
+  if (const char* e = std::getenv("PSF_COMPACT_D")) compact = compact && std::atoi(e) != 0;
+  const uint32_t ncf = compact ? (uint32_t)(ncg * NB) : 0u;      // column fragments of the compact normals stream
+  h->normals_ncf = ncf;
   {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
     ScopedTimer t(h, st, "k_normals");
-    const size_t nwaves = (nbj * h->nkb * TR_CHUNK + NR_SEG - 1) / NR_SEG;
+    const size_t npos = ncf ? h->nkb * 4 * (size_t)ncf * 64 : nbj * h->nkb * TR_CHUNK;
+    const uint32_t nseg = nr_segment(npos);
+    const size_t nwaves = (npos + nseg - 1) / nseg;
     const NormalsFixed fx = h->structured ? NormalsFixed{h->mb, h->dD8, h->ldr * ld, ld, h->dX, h->h_const} : NormalsFixed{0, nullptr, 0, 0, nullptr, 0.0};
-    hipLaunchKernelGGL(k_normals_wave, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail, fx);
+    hipLaunchKernelGGL(k_normals_wave, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail, fx, ncf, nseg);
   }
   {  // x = sqrt(Sigma_2) d   (structured: the m_bar x m_bar block L_1 d_1; rows from m_bar on already hold x_bot = h d_2)
     ScopedTimer t(h, st, "k_trmm_f64");
@@ -895,32 +914,26 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     const char* venv = std::getenv("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
     const int variant = venv ? std::atoi(venv) : 2;
     const size_t row_hi = h->structured ? h->mb : h->M_pad;
-    // Small batches (one samp_p call of the reference is ONE preimage, psf.rs:48-80): the streaming kernel, bound by reading the factor once.
-    // PSF_TRMM_STREAM_MAX = largest batch it serves (0 switches it off); PSF_TRMM_STREAM_SHAPE = "RT,NB" forces a tile shape (experiments).
-    size_t stream_max = 128;
-    if (const char* e = std::getenv("PSF_TRMM_STREAM_MAX")) stream_max = (size_t)std::atol(e);
-    if (B <= stream_max) {
-      // tile shape per wave (RT 16-row tiles x NB fragments of 16 preimages) and workgroup form, from tools/probe_stream.hip at the C3 shape
-      // (profiles/r04_probe_stream.log): <= 16 preimages the launch is bound by reading the factor, beyond that by the longest MFMA chain
-      int RT = 2, NB = B <= 16 ? 1 : B <= 64 ? 2 : 4;
-      if (const char* e = std::getenv("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
+    if (stream) {
       const int ntile16 = (int)((h->mL + 15) / 16);
-      auto go = [&](auto kern, int rt, int nb, int half) {
+      auto go = [&](auto kern, int rt, int half) {
         StreamGeom g;
         g.ntile = (ntile16 + rt - 1) / rt;
-        g.ncg = (int)((B + 16 * (size_t)nb - 1) / (16 * (size_t)nb));
+        g.ncg = ncg;
         g.ntask = g.ntile * g.ncg;
         hipLaunchKernelGGL(kern, dim3((unsigned)((g.ntask + 2 * half - 1) / (2 * half))), dim3(128 * half), 0, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
       };
-      if (RT == 2 && NB == 1) go(k_trmm_stream<2, 1, 12, 2>, 2, 1, 2);
-      else if (RT == 2 && NB == 2 && B <= 32) go(k_trmm_stream<2, 2, 8, 2>, 2, 2, 2);
-      else if (RT == 2 && NB == 2) go(k_trmm_stream<2, 2, 16, 4>, 2, 2, 4);
-      else if (RT == 2 && NB == 4) go(k_trmm_stream<2, 4, 8, 4>, 2, 4, 4);
-      else if (RT == 4 && NB == 2) go(k_trmm_stream<4, 2, 10, 4>, 4, 2, 4);
-      else if (RT == 1 && NB == 8) go(k_trmm_stream<1, 8, 8, 4>, 1, 8, 4);
-      else if (RT == 1 && NB == 4) go(k_trmm_stream<1, 4, 8, 4>, 1, 4, 4);
-      else if (RT == 1 && NB == 2) go(k_trmm_stream<1, 2, 8, 4>, 1, 2, 4);
-      else go(k_trmm_stream<1, 1, 8, 4>, 1, 1, 4);
+#define TS_GO(rt, nb, pd, half) { if (compact) go(k_trmm_stream<rt, nb, pd, half, 1>, rt, half); else go(k_trmm_stream<rt, nb, pd, half, 0>, rt, half); }
+      if (RT == 2 && NB == 1) TS_GO(2, 1, 12, 2)
+      else if (RT == 2 && NB == 2 && B <= 32) TS_GO(2, 2, 8, 2)
+      else if (RT == 2 && NB == 2) TS_GO(2, 2, 16, 4)
+      else if (RT == 2 && NB == 4) TS_GO(2, 4, 8, 4)
+      else if (RT == 4 && NB == 2) TS_GO(4, 2, 10, 4)
+      else if (RT == 1 && NB == 8) TS_GO(1, 8, 8, 4)
+      else if (RT == 1 && NB == 4) TS_GO(1, 4, 8, 4)
+      else if (RT == 1 && NB == 2) TS_GO(1, 2, 8, 4)
+      else TS_GO(1, 1, 8, 4)
+#undef TS_GO
     }
     else if (variant == 2) {
       int GR = 8, GC = 4;                                     // super-tile of an XCD's 32 resident workgroups; PSF_TRMM_GR x PSF_TRMM_GC for experiments (product = 32)
@@ -1003,11 +1016,11 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         kps += kps & 1;
         rsplits = (nks + kps - 1) / kps;
       }
-      if (rsplits > 1) hipMemset2DAsync(d_e + b0 * m, m * sizeof(int64_t), 0, h->mb * sizeof(int64_t), Bh, sx);
+      const size_t bot_cols = rsplits > 1 && h->mb > h->w ? h->mb : h->w;
+      hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bh + 63) / 64), (unsigned)((bot_cols + 63) / 64)), dim3(256), 0, sx, h->mb, h->w,
+                         h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m, rsplits > 1 ? 1 : 0);      // also zeroes the top part for the split-K form
       hipLaunchKernelGGL(k_recombine_mfma, dim3((unsigned)((Bh + 127) / 128), (unsigned)((h->mb + 127) / 128), (unsigned)rsplits), dim3(256), RC_LDS, sx, h->dR,
                          h->ldr, h->mb, nks, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m, big ? 1 : 0, kps);
-      hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bh + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, sx, h->mb, h->w,
-                         h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
     }
   };
   // PSF_HALVES=1: the batch's two halves run these stages on two streams, so that the int8 matrix-core kernels of one half (Z_q product, recombination)
@@ -1184,7 +1197,7 @@ psf_status psfp_samp_p_stages(psfp_handle* h, uint64_t seed, uint64_t first_inde
   void* tmp = nullptr;
   HIP_TRY(hipMalloc(&tmp, B * m * sizeof(double)));
   if (d) {
-    hipLaunchKernelGGL(k_export_normals, dim3(grid_for(B * m)), dim3(256), 0, 0, h->dDt, m, B, h->nkb, (double*)tmp);
+    hipLaunchKernelGGL(k_export_normals, dim3(grid_for(B * m)), dim3(256), 0, 0, h->dDt, m, B, h->nkb, (double*)tmp, h->normals_ncf);
     HIP_TRY(hipMemcpy(d, tmp, B * m * sizeof(double), hipMemcpyDeviceToHost));
   }
   if (x) {
