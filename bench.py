@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="preimages timed on the CPU (default: 32 per thread)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the result (N>1)")
     ap.add_argument("--structured", action="store_true", help="PSFPerturbation with the structured square root of Sigma_2 (PSFP_FLAG_STRUCTURED_SQRT): a labelled, different algorithm; the headline stays on the dense path")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency legs (batch 1 / 16 / 64)")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barriers, gather, reductions) on a one-rank RCCL group")
     args = ap.parse_args()
 
@@ -148,6 +149,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # latency of ONE call with few preimages -- the reference's unit of work (psf.rs:48-80: one samp_p call = one preimage; benches/psf.rs:38,63-65,90-92)
+    # and the regime where reading the key from HBM once, not the FP64 pipe, is the roof.  Outside the timed region of the metric.
+    latency = None
+    if rank == 0 and scheme == "PSFPerturbation" and not args.no_latency and not args.structured:
+        latency = single_call_latency(psf, u, e, m, first_index, stream)
+
     # correctness gate on the last step's output: A e == u and check_domain for every row
     u2 = torch.empty_like(u)
     ok = torch.empty((B,), dtype=torch.uint8, device=dev)
@@ -196,12 +203,14 @@ def main():
             "metric": "preimages/sec (whole node) + HBM-BW% for samp_p, n=512 q~2^30 batch=4096",
             "value": round(value, 2), "unit": "preimages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64+int64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64+int64" if scheme == "PSFPerturbation" else "f64+int8+int64", "data": "synthetic",
             "config": {"workload": f"{scheme} samp_p n={n} q={q} k={gp.k} m={m} r={r} s={s} batch={B}/GPU ({args.config})",
                        "global_batch": B * world, "parallelism": f"batch-sharded x{world}" + (" + overlapped RCCL gather of int32 rows to rank 0" if do_gather else "")},
             "valid": valid, "kernels_ms": {k: round(v, 3) for k, v in kern_ms.items()}, "trap_gen_s": round(t_trapgen, 2),
             "roofline": roof,
         }
+        if latency:
+            out["latency"] = latency
         if args.config != "c3" or args.structured:
             out["metric"] = f"preimages/sec for samp_p ({args.config}" + (", structured sqrt(Sigma_2): labelled opt-in, not the parity path" if args.structured else "") + ")"
         if args.structured:
@@ -235,6 +244,44 @@ def main():
         print(json.dumps(out), flush=True)
     if not valid:
         sys.exit(4)
+
+
+def single_call_latency(psf, u, e, m, first_index, stream, reps=30):
+    """One samp_p call at batch 1 / 16 / 64 through the device-pointer entry point: median of `reps` HIP-event times, each call synchronised on both
+    sides (a latency, not a throughput), plus the per-kernel HIP-event times of one call.  The product of these calls is k_trmm_stream, bound by
+    reading the factor (m(m+1)/2 doubles) from HBM once: `frac` = those bytes / its launch time / 8 TB/s."""
+    import torch
+    key_bytes = m * (m + 1) // 2 * 8
+    out = {"bound": "hbm", "bytes": key_bytes, "peak_GBps": PEAK_HBM_GBS, "entry_point": "psfp_samp_p_dev (device pointers)", "reps": reps}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for B in (1, 16, 64):
+        if B > u.shape[0]:
+            continue
+        call = lambda: psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=77, first_index=first_index, stream=stream)
+        call(); call()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            ev0.record(); call(); ev1.record()
+            torch.cuda.synchronize()
+            ts.append(ev0.elapsed_time(ev1))
+        ts.sort()
+        psf.enable_timing(True)
+        call()
+        tm = dict(psf.get_timing())
+        psf.enable_timing(False)
+        out[f"c3_b{B}_ms"] = round(ts[len(ts) // 2], 4)
+        out[f"c3_b{B}_min_ms"] = round(ts[0], 4)
+        out[f"kernels_ms_b{B}"] = {k: round(v, 4) for k, v in tm.items()}
+        if B == 1 and tm.get("k_trmm_f64"):
+            gbps = key_bytes / (tm["k_trmm_f64"] * 1e-3) / 1e9
+            out["product_ms_b1"] = round(tm["k_trmm_f64"], 4)
+            out["achieved_GBps"] = round(gbps, 1)
+            out["frac"] = round(gbps / PEAK_HBM_GBS, 4)                 # of the 8 TB/s spec; ~6.3 TB/s is what a streaming read achieves (MI355X_MICROARCH.md)
+            out["call_frac_b1"] = round(key_bytes / (out["c3_b1_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)   # the whole call against the same roof
+    if psf.last_status() != 0:
+        out["status"] = "sampler failure"
+    return out
 
 
 def load_traffic(config, B, fname="trmm_traffic.json", sources=("psf_kernels.hpp",)):

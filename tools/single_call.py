@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--skip-sets", action="store_true")
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--logq", type=int, default=30)
+    ap.add_argument("--stream-max", default=None, help="PSF_TRMM_STREAM_MAX of the streaming arm (default: the library's)")
     args = ap.parse_args()
 
     import numpy as np
@@ -68,7 +69,9 @@ def main():
             row = {}
             outs = {}
             for label, smax in (("stream", None), ("batch_kernel", "0")):
-                if smax is None:
+                if smax is None and args.stream_max is not None:
+                    os.environ["PSF_TRMM_STREAM_MAX"] = args.stream_max
+                elif smax is None:
                     os.environ.pop("PSF_TRMM_STREAM_MAX", None)
                 else:
                     os.environ["PSF_TRMM_STREAM_MAX"] = smax

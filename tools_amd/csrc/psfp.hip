@@ -886,7 +886,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // Small batches (one samp_p call of the reference is ONE preimage, psf.rs:48-80): the streaming product, bound by reading the factor once, fed by
   // the compact normals stream.  PSF_TRMM_STREAM_MAX = largest batch it serves (0 switches it off); PSF_TRMM_STREAM_SHAPE = "RT,NB" forces a tile
   // shape, PSF_COMPACT_D=0 the chunk-stream layout of the normals (experiments; same bits).
-  size_t stream_max = 128;
+  size_t stream_max = 1024;      // measured at C3 (profiles/r04_notes.md): the streaming form wins up to ~1024 preimages, k_trmm_f64_big beyond
   if (const char* e = std::getenv("PSF_TRMM_STREAM_MAX")) stream_max = (size_t)std::atol(e);
   const bool stream = B <= stream_max;
   // tile shape per wave (RT 16-row tiles x NB fragments of 16 preimages) and workgroup form, from tools/probe_stream.hip at the C3 shape
