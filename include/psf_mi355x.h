@@ -188,6 +188,10 @@ psf_status psfp_compute_sqrt_sigma_2_dense(psfp_handle*, const double* sigma_low
  *   mp_perturbation.rs:366), samp_p returns PSF_ERR_NO_KEY.
  * psfp_load_key(A, R, NULL): sqrt(Sigma_2) is recomputed from R with the handle's s, as trap_gen does (mp_perturbation.rs:227-231). */
 psf_status psfp_load_key(psfp_handle*, const uint64_t* A, const int8_t* R, const double* sqrt_sigma2_packed);
+/* (A, R) WITHOUT a factor and without computing one: the state PSFPerturbation::compute_sqrt_sigma_2 (mp_perturbation.rs:111-139, a pure function of
+ * mat_r and mat_sigma) starts from.  A may be NULL (the handle's public matrix, if any, stays installed).  samp_p returns PSF_ERR_NO_KEY until
+ * psfp_compute_sqrt_sigma_2 / _dense has produced the factor.  (psfp_load_key(A, R, NULL) instead runs the whole Cholesky with the handle's s.) */
+psf_status psfp_load_trapdoor(psfp_handle*, const uint64_t* A, const int8_t* R);
 psf_status psfp_export_key(const psfp_handle*, uint64_t* A, int8_t* R, double* sqrt_sigma2_packed);
 /* rows [row0, row0 + nrows) of sqrt(Sigma_2) in the same packed form (row i holds i + 1 entries): the factor of BASELINE's
  * largest set is 60.5 GB, so a caller that inspects or ships it does so in row blocks */

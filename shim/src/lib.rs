@@ -234,10 +234,56 @@ pub struct GpuPSFPerturbation {
     handle: *mut ffi::psfp_handle,
     seed: Cell<u64>,
     calls: Cell<u64>,
-    /// the (A, R, sqrt(Sigma_2)) the handle currently holds, to skip the upload when samp_p is called again with the same key
-    installed: RefCell<Option<(MatZq, MatZ, MatQ)>>,
-    /// the public matrix the handle holds when it was installed WITHOUT a trapdoor (f_a of a verifier)
-    public_only: RefCell<Option<MatZq>>,
+    /// What the handle holds: ONE state, so that no stale cache can outlive a key change (trap_gen / install_key / f_a with another matrix).
+    held: RefCell<Held>,
+}
+
+/// What the device handle holds, identified by FINGERPRINTS of the caller's matrices (`key_print`): dimensions plus a 64-bit hash of the first row,
+/// the last row and -- for square matrices -- the diagonal.  Comparing a caller's key with the held one therefore costs O(m) entry reads per
+/// `samp_p`, not the O(m^2) deep comparison (4.7e8 `fmpq` + 2.4e8 `fmpz` comparisons per preimage at n = 512) and the second copy of a multi-GB
+/// `MatQ` that a clone-and-compare cache needs.  A fingerprint is an identity check against accidental key changes, not a cryptographic binding:
+/// callers that mutate single entries of a key in place must call `install_key` again.
+#[derive(Clone, PartialEq)]
+enum Held {
+    Nothing,
+    /// the public matrix alone (a verifier's handle: `f_a`, `check_domain`, `samp_d`)
+    Public(u64),
+    /// (A, R, sqrt(Sigma_2))
+    Full(u64, u64, u64),
+}
+
+fn fnv(h: u64, v: u64) -> u64 {
+    (h ^ v).wrapping_mul(0x100000001b3)
+}
+
+/// dimensions + first row + last row (+ diagonal of a square matrix), through `entry` -> u64
+fn key_print(rows: i64, cols: i64, entry: &dyn Fn(i64, i64) -> u64) -> u64 {
+    let mut h = fnv(fnv(0xcbf29ce484222325, rows as u64), cols as u64);
+    if rows == 0 || cols == 0 {
+        return h;
+    }
+    for j in 0..cols {
+        h = fnv(h, entry(0, j));
+    }
+    for j in 0..cols {
+        h = fnv(h, entry(rows - 1, j));
+    }
+    if rows == cols {
+        for i in 0..rows {
+            h = fnv(h, entry(i, i));
+        }
+    }
+    h
+}
+
+fn print_matzq(a: &MatZq) -> u64 {
+    key_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let z: Z = a.get_entry(i, j).unwrap(); i64::try_from(&z).unwrap_or(0) as u64 })
+}
+fn print_matz(a: &MatZ) -> u64 {
+    key_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let z: Z = a.get_entry(i, j).unwrap(); i64::try_from(&z).unwrap_or(0) as u64 })
+}
+fn print_matq(a: &MatQ) -> u64 {
+    key_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let q: Q = a.get_entry(i, j).unwrap(); f64::from(&q).to_bits() })
 }
 
 impl GpuPSFPerturbation {
@@ -246,7 +292,7 @@ impl GpuPSFPerturbation {
         let c = ffi::psfp_params { gp: gp_to_c(&params.gp), r: f64::from(&params.r), s: f64::from(&params.s), device, flags: 0 };
         let mut handle = std::ptr::null_mut();
         check(unsafe { ffi::psfp_create(&c, &mut handle) }, "psfp_create");
-        Self { params, handle, seed: Cell::new(seed), calls: Cell::new(0), installed: RefCell::new(None), public_only: RefCell::new(None) }
+        Self { params, handle, seed: Cell::new(seed), calls: Cell::new(0), held: RefCell::new(Held::Nothing) }
     }
 
     /// Like `new`, with the seed drawn from the operating system (the reference samples through the OS-seeded thread-local RNG of qfall-math).
@@ -267,40 +313,43 @@ impl GpuPSFPerturbation {
         (n, k, mb, mb + n * k)
     }
 
-    /// Uploads (A, R, sqrt(Sigma_2)) unless the handle already holds exactly these.
-    fn ensure_key(&self, a: &MatZq, r: &MatZ, sqrt_sigma_2: &MatQ) {
-        if let Some((ia, ir, il)) = self.installed.borrow().as_ref() {
-            if ia == a && ir == r && il == sqrt_sigma_2 {
-                return;
-            }
-        }
-        let (av, rv, lv) = (matzq_to_rows(a), matz_to_rows_i8(r), matq_lower_to_packed(sqrt_sigma_2));
+    /// Uploads (A, R, sqrt(Sigma_2)) to the device: the explicit form of what `samp_p` does when it meets a key the handle does not hold.
+    /// Call it once per key (a signer's set-up); every later `samp_p` with the same tuple then costs an O(m) fingerprint check and no copy.
+    pub fn install_key(&self, a: &MatZq, td: &<Self as PSF>::Trapdoor) {
+        let (av, rv, lv) = (matzq_to_rows(a), matz_to_rows_i8(&td.0), matq_lower_to_packed(&td.1));
+        *self.held.borrow_mut() = Held::Nothing;
         check(unsafe { ffi::psfp_load_key(self.handle, av.as_ptr(), rv.as_ptr(), lv.as_ptr()) }, "psfp_load_key");
-        *self.installed.borrow_mut() = Some((a.clone(), r.clone(), sqrt_sigma_2.clone()));
-        *self.public_only.borrow_mut() = None;
+        *self.held.borrow_mut() = Held::Full(print_matzq(a), print_matz(&td.0), print_matq(&td.1));
+    }
+
+    /// `install_key` unless the handle already holds this tuple (fingerprints: see `Held`).
+    fn ensure_key(&self, a: &MatZq, td: &<Self as PSF>::Trapdoor) {
+        let want = Held::Full(print_matzq(a), print_matz(&td.0), print_matq(&td.1));
+        if *self.held.borrow() != want {
+            self.install_key(a, td);
+        }
     }
 
     /// `PSFPerturbation::compute_sqrt_sigma_2` (mp_perturbation.rs:111-139) on the device for ANY symmetric covariance `mat_sigma`
-    /// (the reference's signature; its doctest at :89-107 passes s'^2 I).  Needs the handle to hold (A, R): call after `trap_gen` or `samp_p`.
+    /// (the reference's signature; its doctest at :89-107 passes s'^2 I).  A pure function of its arguments, as in the reference: no installed key is
+    /// needed and none is produced -- (., mat_r) is installed WITHOUT a factor (`psfp_load_trapdoor`: no Cholesky with the handle's own s in front),
+    /// the factor of `mat_sigma` is computed and read back, and the handle is left holding nothing a later `samp_p` / `f_a` could mistake for its key.
     pub fn compute_sqrt_sigma_2(&self, mat_r: &MatZ, mat_sigma: &MatQ) -> MatQ {
         let (_, _, _, m) = self.dims();
-        let (a, _r_old, _) = self.installed.borrow().as_ref().expect("compute_sqrt_sigma_2 needs an installed key (trap_gen / samp_p first)").clone();
-        // install (A, R) -- the factor is recomputed below, so none is uploaded
-        let (av, rv) = (matzq_to_rows(&a), matz_to_rows_i8(mat_r));
-        check(unsafe { ffi::psfp_load_key(self.handle, av.as_ptr(), rv.as_ptr(), std::ptr::null()) }, "psfp_load_key");
+        let rv = matz_to_rows_i8(mat_r);
+        *self.held.borrow_mut() = Held::Nothing;
+        check(unsafe { ffi::psfp_load_trapdoor(self.handle, std::ptr::null(), rv.as_ptr()) }, "psfp_load_trapdoor");
         let sg = matq_lower_to_packed(mat_sigma);
         check(unsafe { ffi::psfp_compute_sqrt_sigma_2_dense(self.handle, sg.as_ptr()) }, "psfp_compute_sqrt_sigma_2_dense");
         let mut l = vec![0f64; (m * (m + 1) / 2) as usize];
-        check(unsafe { ffi::psfp_export_key(self.handle, std::ptr::null_mut(), std::ptr::null_mut(), l.as_mut_ptr()) }, "psfp_export_key");
-        let l_mat = matq_lower_from_packed(m, &l);
-        *self.installed.borrow_mut() = Some((a, mat_r.clone(), l_mat.clone()));
-        l_mat
+        check(unsafe { ffi::psfp_export_sqrt_sigma2_rows(self.handle, 0, m as usize, l.as_mut_ptr()) }, "psfp_export_sqrt_sigma2_rows");
+        matq_lower_from_packed(m, &l)
     }
 
     /// B independent `samp_p` calls with one key: the batched form the library is built for (row b of `targets` = one syndrome).
     pub fn samp_p_batch(&self, a: &MatZq, td: &<Self as PSF>::Trapdoor, targets: &MatZq) -> MatZ {
         let (n, _, _, m) = self.dims();
-        self.ensure_key(a, &td.0, &td.1);
+        self.ensure_key(a, td);
         let b = targets.get_num_rows();
         assert_eq!(targets.get_num_columns(), n, "one syndrome of length n per row");
         let u = matzq_to_rows(targets);
@@ -348,7 +397,8 @@ impl PSF for GpuPSFPerturbation {
                 }
             }
         }
-        *self.installed.borrow_mut() = Some((a_mat.clone(), r_mat.clone(), l_mat.clone()));
+        // the handle now holds exactly this tuple; any earlier state (a verifier's public matrix included) is gone
+        *self.held.borrow_mut() = Held::Full(print_matzq(&a_mat), print_matz(&r_mat), print_matq(&l_mat));
         (a_mat, (r_mat, l_mat, (s_mat, s_gso)))
     }
 
@@ -363,7 +413,7 @@ impl PSF for GpuPSFPerturbation {
     /// mp_perturbation.rs:304-336: one preimage (use `samp_p_batch` for throughput)
     fn samp_p(&self, a: &MatZq, td: &Self::Trapdoor, u: &MatZq) -> MatZ {
         let (n, _, _, m) = self.dims();
-        self.ensure_key(a, &td.0, &td.1);
+        self.ensure_key(a, td);
         assert!(u.get_num_rows() == n && u.get_num_columns() == 1, "u must be an n x 1 column (mp_perturbation.rs:318)");
         let uv = matzq_to_rows(u);
         let mut e = vec![0i64; m as usize];
@@ -377,12 +427,16 @@ impl PSF for GpuPSFPerturbation {
         assert!(sigma.get_num_rows() == m && sigma.get_num_columns() == 1, "sigma must be a column vector of length m");
         // PSF::f_a takes the public matrix alone (mp_perturbation.rs:366): a verifier that never saw a trapdoor can call it.  If the caller's A is
         // not the one the handle holds, it is installed as a public-key-only key (psfp_load_key(A, NULL, NULL)); a later samp_p re-installs its tuple.
-        let same = matches!(self.installed.borrow().as_ref(), Some((ia, _, _)) if ia == a) || matches!(self.public_only.borrow().as_ref(), Some(ia) if ia == a);
+        let pa = print_matzq(a);
+        let same = match *self.held.borrow() {
+            Held::Full(ha, _, _) | Held::Public(ha) => ha == pa,
+            Held::Nothing => false,
+        };
         if !same {
             let av = matzq_to_rows(a);
+            *self.held.borrow_mut() = Held::Nothing;
             check(unsafe { ffi::psfp_load_key(self.handle, av.as_ptr(), std::ptr::null(), std::ptr::null()) }, "psfp_load_key");
-            *self.installed.borrow_mut() = None;
-            *self.public_only.borrow_mut() = Some(a.clone());
+            *self.held.borrow_mut() = Held::Public(pa);
         }
         let e = matz_to_rows_i64(sigma);
         let mut u = vec![0u64; n as usize];
@@ -411,7 +465,9 @@ pub struct GpuPSFGPV {
     handle: *mut ffi::psfgpv_handle,
     seed: Cell<u64>,
     calls: Cell<u64>,
-    installed: RefCell<Option<(MatZq, MatZ, MatQ)>>,
+    /// fingerprints (`key_print`) of the (A, basis, GSO) the handle holds: an O(m) identity check per call instead of a deep comparison of two
+    /// d x d matrices and a second copy of them (d = 6208 at n = 256, q = 3329)
+    held: RefCell<Option<(u64, u64, u64)>>,
 }
 
 impl GpuPSFGPV {
@@ -419,7 +475,7 @@ impl GpuPSFGPV {
         let c = ffi::psfgpv_params { gp: gp_to_c(&params.gp), s: f64::from(&params.s), device, flags: 0 };
         let mut handle = std::ptr::null_mut();
         check(unsafe { ffi::psfgpv_create(&c, &mut handle) }, "psfgpv_create");
-        Self { params, handle, seed: Cell::new(seed), calls: Cell::new(0), installed: RefCell::new(None) }
+        Self { params, handle, seed: Cell::new(seed), calls: Cell::new(0), held: RefCell::new(None) }
     }
 
     pub fn reseed(&self, seed: u64) {
@@ -432,16 +488,20 @@ impl GpuPSFGPV {
         (gp.n as i64, (gp.m_bar + gp.n * gp.k) as i64)
     }
 
-    fn ensure_key(&self, a: &MatZq, basis: &MatZ, gso: &MatQ) {
-        if let Some((ia, ib, ig)) = self.installed.borrow().as_ref() {
-            if ia == a && ib == basis && ig == gso {
-                return;
-            }
-        }
+    /// Uploads (A, basis, GSO): once per key; later calls with the same tuple cost a fingerprint check.
+    pub fn install_key(&self, a: &MatZq, basis: &MatZ, gso: &MatQ) {
         // the ABI takes both matrices transposed: row i = basis vector i (psf_mi355x.h, PSFGPV section)
         let (av, bt, gt) = (matzq_to_rows(a), matz_to_rows_t_i32(basis), matq_to_rows_t(gso));
+        *self.held.borrow_mut() = None;
         check(unsafe { ffi::psfgpv_load_key(self.handle, av.as_ptr(), bt.as_ptr(), gt.as_ptr()) }, "psfgpv_load_key");
-        *self.installed.borrow_mut() = Some((a.clone(), basis.clone(), gso.clone()));
+        *self.held.borrow_mut() = Some((print_matzq(a), print_matz(basis), print_matq(gso)));
+    }
+
+    fn ensure_key(&self, a: &MatZq, basis: &MatZ, gso: &MatQ) {
+        let want = Some((print_matzq(a), print_matz(basis), print_matq(gso)));
+        if *self.held.borrow() != want {
+            self.install_key(a, basis, gso);
+        }
     }
 
     /// B independent `samp_p` calls with one key (row b of `targets` = one syndrome).
@@ -486,7 +546,7 @@ impl PSF for GpuPSFGPV {
             }
         }
         let gso = matq_from_rows(m, m, &gt, true);
-        *self.installed.borrow_mut() = Some((a_mat.clone(), basis.clone(), gso.clone()));
+        *self.held.borrow_mut() = Some((print_matzq(&a_mat), print_matz(&basis), print_matq(&gso)));
         (a_mat, (basis, gso))
     }
 
@@ -513,11 +573,18 @@ impl PSF for GpuPSFGPV {
     fn f_a(&self, a: &MatZq, sigma: &MatZ) -> MatZq {
         let (n, m) = self.dims();
         assert!(sigma.get_num_rows() == m && sigma.get_num_columns() == 1);
-        match self.installed.borrow().as_ref() {
-            Some((ia, _, _)) if ia == a => {}
-            Some((_, ib, ig)) => {
-                let (av, bt, gt) = (matzq_to_rows(a), matz_to_rows_t_i32(ib), matq_to_rows_t(ig));
+        let pa = print_matzq(a);
+        let held = *self.held.borrow();
+        match held {
+            Some((ha, _, _)) if ha == pa => {}
+            Some((_, hb, hg)) => {
+                // another public matrix on a handle that holds a trapdoor: the basis and its GSO stay (read back from the device), A is replaced
+                let (mut bt, mut gt) = (vec![0i32; (m * m) as usize], vec![0f64; (m * m) as usize]);
+                check(unsafe { ffi::psfgpv_export_key(self.handle, std::ptr::null_mut(), std::ptr::null_mut(), bt.as_mut_ptr(), gt.as_mut_ptr()) }, "psfgpv_export_key");
+                let av = matzq_to_rows(a);
+                *self.held.borrow_mut() = None;
                 check(unsafe { ffi::psfgpv_load_key(self.handle, av.as_ptr(), bt.as_ptr(), gt.as_ptr()) }, "psfgpv_load_key");
+                *self.held.borrow_mut() = Some((pa, hb, hg));
             }
             None => panic!("f_a before trap_gen / samp_p: the handle holds no key"),
         }

@@ -86,6 +86,41 @@ def test_load_key_variants(T, oracle):
         ver.compute_sqrt_sigma_2(30.0)                    # no R to build Sigma_2 from
 
 
+def test_load_trapdoor_installs_a_trapdoor_without_computing_a_factor(T, oracle):
+    """psfp_load_trapdoor: (A, R) with no factor and no Cholesky (compute_sqrt_sigma_2 of the reference is a pure function of mat_r and mat_sigma,
+    mp_perturbation.rs:111; ADVICE r03: psfp_load_key(A, R, NULL) ran a full factorisation with the handle's own s first, and refused an R whose
+    Sigma_2(s) is not positive definite although the caller's covariance is fine)."""
+    n, q, r, s = 8, 64, 3.0, 25.0
+    gp = T.GadgetParameters.init_default(n, q)
+    full = T.PSFPerturbation(gp, r, s)
+    A, (R, Lp, _) = full.trap_gen(2)
+    u = oracle.uniform_targets(1, 5, n, q)
+    psf = T.PSFPerturbation(gp, r, s)
+    psf.load_trapdoor(R, A)
+    with pytest.raises(T.PsfError) as ei:
+        psf.samp_p(u, seed=4)                               # no factor yet
+    assert ei.value.status == T._ffi.ERR_NO_KEY
+    assert (psf.f_a(full.samp_p(u, seed=4)) == u).all()     # the public matrix works
+    psf.compute_sqrt_sigma_2(s)                             # completes the key: the factor trap_gen computes
+    assert (psf.samp_p(u, seed=4) == full.samp_p(u, seed=4)).all()
+    # a handle whose own s is too small for this R is no obstacle: nothing is factored at install time
+    tiny = T.PSFPerturbation(gp, r, 1.5)
+    with pytest.raises(T.PsfError):
+        tiny.load_key(A, R)                                 # load_key(A, R) factors Sigma_2(1.5): not positive definite
+    tiny.load_trapdoor(R, A)
+    tiny.compute_sqrt_sigma_2(s)
+    _, (_, L3, _) = tiny.export_key()
+    assert (L3 == Lp).all()
+    # R alone (A = NULL): compute_sqrt_sigma_2 needs no public matrix; samp_p still does
+    bare = T.PSFPerturbation(gp, r, s)
+    bare.load_trapdoor(R)
+    bare.compute_sqrt_sigma_2(s)
+    assert (bare.export_sqrt_sigma2_rows(0, bare.m) == Lp).all()
+    with pytest.raises(T.PsfError) as ei:
+        bare.samp_p(u, seed=4)
+    assert ei.value.status == T._ffi.ERR_NO_KEY
+
+
 def test_trapdoor_from_the_callers_own_distribution(T, oracle):
     """R drawn by the caller (here: a sparse {-2..2} distribution, not PlusMinusOneZero): A = [A_bar | H G - A_bar R] from the device equals the
     oracle's, A [R; I] = H G, and the pair works as a key."""

@@ -194,44 +194,3 @@ def test_samp_p_parity_across_block_counts(T, oracle, monkeypatch, n, q, immedia
     assert (e == orc.samp_p(17, u, first_index=2)).all()
     assert np.abs(e).max() > 127
     assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
-
-
-@pytest.mark.parametrize("n,q,B", [(40, 256, 9), (64, 2**15, 130), (3, 2**45, 5)])
-def test_one_launch_walk_is_bit_identical(T, oracle, monkeypatch, n, q, B):
-    """PSF_NP_PERSIST=1: the whole walk in one launch (k_np_walk: sampler workgroups loop over the blocks, update workers of the same launch apply every block to
-    the rows below it, counters in memory instead of launch boundaries).  Same chains, same bits as a launch per block and as the oracle -- several blocks, a
-    ragged batch over two column blocks, and the two-pass form (two walks per call)."""
-    s = 300.0 if q < 2**40 else 60.0
-    gp = T.GadgetParameters.init_default(n, q)
-    u = oracle.uniform_targets(8, B, n, q)
-    got = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("PSF_NP_PERSIST", mode)
-        psf = T.PSFGPV(gp, s)
-        A, (bt, gt) = psf.trap_gen(6)
-        got[mode] = (A, bt, gt, psf.samp_p(u, seed=13, first_index=3))
-        psf.close()
-    assert (got["0"][3] == got["1"][3]).all()
-    A, bt, gt, e = got["1"]
-    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
-    assert orc.load_key(A, bt, gt) == 0
-    assert (e == orc.samp_p(13, u, first_index=3)).all()
-    assert ((A.astype(object) @ e.astype(object).T).T % q == u.astype(object)).all()
-
-
-def test_one_launch_walk_falls_back_when_a_wait_times_out(T, oracle, monkeypatch):
-    """k_np_walk needs all its workgroups resident; every wait is bounded, and a wait that gives up abandons the launch and the call is repeated with a launch
-    per block (psfgpv_last_status).  PSF_NP_WALK_SPINS=0 makes the first unsatisfied wait give up at once: the result must still be the oracle's, and the handle
-    must not try the one-launch walk again."""
-    n, q, s, B = 40, 256, 300.0, 9
-    monkeypatch.setenv("PSF_NP_PERSIST", "1")
-    monkeypatch.setenv("PSF_NP_WALK_SPINS", "0")
-    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
-    A, (bt, gt) = psf.trap_gen(6)
-    u = oracle.uniform_targets(8, B, n, q)
-    e = psf.samp_p(u, seed=13, first_index=3)
-    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
-    assert orc.load_key(A, bt, gt) == 0
-    assert (e == orc.samp_p(13, u, first_index=3)).all()
-    assert (psf.samp_p(u, seed=14, first_index=3) == orc.samp_p(14, u, first_index=3)).all()
-    psf.close()

@@ -47,7 +47,8 @@ def test_impls_only_use_defined_functions_and_cover_the_trait():
     # free-function calls: identifier directly followed by "(" that is neither a method (preceded by "."), a path segment (preceded by "::"),
     # a macro, a keyword, nor a tuple-struct / enum constructor (capitalised)
     calls = set(m.group(1) for m in re.finditer(r"(?<![\w.:!])([a-z_][a-z0-9_]*)\(", re.sub(r"//[^\n]*", "", lib)))
-    calls -= {"if", "while", "for", "match", "fn", "unsafe", "loop", "return", "drop", "assert", "panic", "vec", "format", "check_domain", "allow", "cfg", "test"}
+    calls -= {"if", "while", "for", "match", "fn", "unsafe", "loop", "return", "drop", "assert", "panic", "vec", "format", "check_domain", "allow", "cfg", "test",
+              "derive", "entry"}      # an attribute; the `&dyn Fn` parameter of key_print
     undefined = sorted(c for c in calls if c not in defined)
     assert not undefined, undefined
     for helper in ("matzq_from_rows", "matq_lower_from_packed", "ensure_key", "next_seed", "dims"):      # the helpers round 1 left undefined
@@ -72,3 +73,21 @@ def test_benches_mirror_the_references_names():
     assert "criterion_group!" in b and "criterion_main!" in read(SHIM, "benches", "benchmarks.rs")
     cargo = read(SHIM, "Cargo.toml")
     assert 'name = "benchmarks"' in cargo and "harness = false" in cargo and "qfall-tools" in cargo
+
+
+def test_one_state_for_what_the_handle_holds():
+    """ADVICE r03 (medium): a separate `public_only` cache survived trap_gen, so f_a(A_old) -> trap_gen() -> f_a(A_old) skipped the upload and evaluated
+    A_new * sigma.  The shim now keeps ONE enum (`Held`) that every key-changing path overwrites, and compares fingerprints (O(m)) instead of deep copies
+    (VERDICT r03 weak #5: 4.7e8 fmpq comparisons per samp_p at n = 512)."""
+    lib = read(SHIM, "src", "lib.rs")
+    assert "public_only" not in lib and "enum Held" in lib
+    pert = lib[lib.index("impl PSF for GpuPSFPerturbation"):lib.index("// PSFGPV (gpv.rs")]
+    trap_gen = pert[pert.index("fn trap_gen(&self)"):pert.index("fn samp_d(&self)")]
+    assert "*self.held.borrow_mut() = Held::Full(" in trap_gen                      # trap_gen replaces whatever was held, a verifier's matrix included
+    f_a = pert[pert.index("fn f_a(&self"):pert.index("fn check_domain(&self")]
+    assert "Held::Public(pa)" in f_a and "Held::Full(ha, _, _) | Held::Public(ha) => ha == pa" in f_a
+    inherent = lib[lib.index("impl GpuPSFPerturbation {"):lib.index("impl Drop for GpuPSFPerturbation")]
+    assert "pub fn install_key(&self" in inherent and "psfp_load_trapdoor" in inherent   # explicit install; compute_sqrt_sigma_2 without a wasted Cholesky
+    ensure = inherent[inherent.index("fn ensure_key(&self"):]
+    ensure = ensure[:ensure.index("\n    }\n") + 7]
+    assert ".clone()" not in ensure and "==" not in ensure.replace("!=", "")             # no deep comparison, no second copy of the key

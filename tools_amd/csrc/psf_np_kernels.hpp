@@ -320,8 +320,8 @@ __device__ inline size_t j0_of(size_t J) { return J * NP_NB; }
 // owns the dependent chain and nothing else: broadcast t, c' = t / ||b~||^2, ceil, c_rel, one fma + exp2 per lane, two compares,
 // first candidate by s_ff1, z, and the fma that updates the rows below.  The waves meet through two LDS counters (groups produced /
 // consumed); all eight waves of a workgroup are resident by construction, so the spin-waits always make progress.
-// COH (k_np_walk): the running projections are read and the drawn z written with agent-scope accesses -- inside one launch they come from / go to workgroups on
-// other XCDs, whose L2s are not coherent with this one's for plain accesses
+// COH (unused since round 4, when the one-launch walk k_np_walk was removed: it spilled and bought 3 %, profiles/r03_notes.md): the running projections read and
+// the drawn z written with agent-scope accesses, for a launch in which they come from / go to workgroups on other XCDs
 template <int G, bool COH = false>
 __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned wg, const NpSampleArgs& a, size_t dim, size_t J, uint64_t seed, uint32_t tag,
                                                uint64_t first_index, size_t B) {
@@ -885,111 +885,6 @@ __global__ __launch_bounds__(512, 4) void k_np_step(NpSampleArgs a, size_t dim, 
   for (int q = 0; q < 3; ++q) {
     if (id < jobs.ntiles[q]) { np_update_tile(reinterpret_cast<double*>(np_smem), id, jobs.job[q], nbj, Gp, a.Zf, a.nkb, Tm, a.ldt); return; }
     id -= jobs.ntiles[q];
-  }
-}
-
-// ---- the whole walk in ONE launch (small batches, the "immediate" schedule): no launch boundary between blocks ----------------------------------------------
-// With a launch per block every block pays the dependent-launch cost of the stream (5.2 us), and lasts as long as the slowest of ALL its sampler waves
-// (C2: 111 k cycles against a mean of 81 k).  Here the sampler workgroups loop over the blocks themselves and UPDATE WORKERS -- workgroups of the same launch,
-// resident beside them -- apply every sampled block to the rows below it, exactly as the update tiles of k_np_step do (np_update_tile, same chains, same bits):
-//   worker (column block bj, slice) owns the 128-row tiles rb = slice, slice + S, ... of that column block for the whole walk.  For a = nblk - 1 .. 2 it waits
-//     until every sampler workgroup of bj has published Z_a (zcnt[bj][a]), applies Z_a to its tiles below block a - 1 (rows < 64 (a - 1); block a - 1 itself
-//     takes Z_a inside the sampler, as always) and publishes tprog[rb][bj] = a;
-//   sampler workgroup, block J: waits until the tile that holds its rows has taken Z_(J+2) (tprog <= J + 2) -- one block of slack, so the wait is normally over
-//     before it starts -- samples the block and publishes.
-// A dependency is therefore between one sampler workgroup and one worker, never chip-wide: a slow wave delays its own four preimages only.
-// Correctness of the exchange: the L2s of the eight XCDs are not coherent with each other for plain accesses, so what crosses workgroups inside the launch --
-// the drawn z (sampler -> worker), the T rows (worker -> sampler) and the counters -- moves with agent-scope accesses (sc1: stores write through, loads do not
-// hit a stale line), a store is complete when vmcnt says so, and the counter follows it.  Agent-scope FENCES instead (write back / invalidate the whole L2 per
-// block and wave) made the walk three times slower than a launch per block.  Liveness: every workgroup of the launch must be resident (the host checks occupancy x CUs >= grid and
-// otherwise uses k_np_step); every wait is bounded -- on a timeout the `abort` word is raised, every workgroup leaves, and the host repeats the call with
-// k_np_step (psfgpv_last_status).
-// Measured at C2 (profiles/r03_notes.md): 3.90 ms for the walk against 97 x 41.5 us = 4.03 ms with a launch per block; per sampler workgroup and block the wait is
-// 4.6 k ticks and the block itself 77.8 k.  The launches were already back to back and the slack of one block already absorbed most of the slow waves: what a
-// block costs is the sampler's own chain of 64 dependent draws.  Opt-in (PSF_NP_PERSIST=1); publishing z one poll later (so that the store drain hides behind
-// it) changed nothing.
-struct NpWalkSync { int* zcnt; int* tprog; int* abort; };
-#ifdef NP_WALK_PROFILE   /* measurement builds: clock64 ticks summed over all sampler workgroups / all workers: [0] sampler waits [1] sampler bodies [2] worker waits [3] worker tiles [4] tiles */
-__device__ unsigned long long g_walk_prof[8];
-#define WALK_T(k, expr) do { const long long t0_ = (long long)__builtin_readcyclecounter(); expr; if (threadIdx.x == 0) atomicAdd(&g_walk_prof[k], (unsigned long long)((long long)__builtin_readcyclecounter() - t0_)); } while (0)
-#else
-#define WALK_T(k, expr) do { expr; } while (0)
-#endif
-
-template <int G>
-__global__ __launch_bounds__(512, 4) void k_np_walk(NpSampleArgs a, size_t dim, size_t nblk, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, unsigned nS,
-                                                    int nbj, int nrb, int S, const double* __restrict__ Gp, double* __restrict__ Tm, NpWalkSync sy, unsigned spin_limit) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char np_smem[];
-  __shared__ int s_go;
-  const int tid = threadIdx.x;
-  // thread 0 polls; the verdict crosses LDS; everybody acquires.  false = the launch is being abandoned.
-  auto wait_for = [&](const int* p, int bound, bool at_most) -> bool {
-    if (tid == 0) {
-      int ok = 1;
-      unsigned spins = 0;
-      for (;;) {
-        const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (at_most ? v <= bound : v >= bound) break;
-        if (++spins > spin_limit || __hip_atomic_load(sy.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store(sy.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = 0;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-      s_go = ok;
-    }
-    __syncthreads();
-    const int ok = s_go;
-    __syncthreads();
-    return ok != 0;
-  };
-  if (blockIdx.x < nS) {
-    const unsigned wg = blockIdx.x;
-    const int bj = (int)(((size_t)wg * 4 * G) / TR_BN);
-#ifdef NP_WALK_PROFILE
-    const unsigned long long pc0 = (unsigned long long)__builtin_readcyclecounter(), pw0 = wall_clock64();
-#endif
-    for (size_t J = nblk; J-- > 0;) {
-      bool okw = true;
-      WALK_T(0, if (J + 2 < nblk) okw = wait_for(sy.tprog + (J / 2) * (size_t)nbj + bj, (int)J + 2, true));
-      if (!okw) return;
-      WALK_T(1, (np_sample_body<G, true>(np_smem, wg, a, dim, J, seed, tag, first_index, B)));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // my agent-scope stores of z are complete
-      __syncthreads();
-      if (tid == 0 && J >= 2) __hip_atomic_fetch_add(sy.zcnt + (size_t)bj * nblk + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#ifdef NP_WALK_PROFILE
-    if (tid == 0 && wg == 0) { g_walk_prof[5] = (unsigned long long)__builtin_readcyclecounter() - pc0; g_walk_prof[6] = wall_clock64() - pw0; }   // shader ticks / 100 MHz ticks of workgroup 0
-#endif
-    return;
-  }
-  const unsigned w = blockIdx.x - nS;
-  const int bj = (int)(w % (unsigned)nbj), slice = (int)(w / (unsigned)nbj);
-  if (slice >= S) return;
-  const size_t pre = B - (size_t)bj * TR_BN < (size_t)TR_BN ? B - (size_t)bj * TR_BN : (size_t)TR_BN;       // preimages of this column block
-  const int need = (int)((pre + 4 * G - 1) / (4 * G));                                                        // sampler workgroups that publish into it
-  const int rb_top = slice + S * ((nrb - 1 - slice) / S);
-  for (int aa = (int)nblk - 1; aa >= 2; --aa) {
-    const size_t row_hi = (size_t)(aa - 1) * NP_NB;
-    bool have = false;
-    for (int rb = rb_top; rb >= 0; rb -= S) {                      // the tile nearest to the walk first: its rows are wanted soonest
-      if ((size_t)rb * TR_BM >= row_hi) continue;
-      if (!have) {
-        bool okw = true;
-        WALK_T(2, okw = wait_for(sy.zcnt + (size_t)bj * nblk + aa, need, false));
-        if (!okw) return;
-        have = true;
-      }
-      const NpUpdateJob job{aa, 1, rb, 1, 0, row_hi};
-      WALK_T(3, (np_update_tile<true>(reinterpret_cast<double*>(np_smem), (unsigned)bj, job, nbj, Gp, a.Zf, a.nkb, Tm, a.ldt)));
-#ifdef NP_WALK_PROFILE
-      if (tid == 0) atomicAdd(&g_walk_prof[4], 1ull);
-#endif
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // my agent-scope stores of the tile are complete
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(sy.tprog + (size_t)rb * nbj + bj, aa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 }
 

@@ -36,10 +36,6 @@ struct psfgpv_handle {
   double* dBfull = nullptr;           // b~_i on every coordinate, fragment order (A operand of the second projection)
   double* dC1 = nullptr;              // -e1, chunk stream (ld / 128) x nkd
   int64_t* dE1 = nullptr;             // e1, bcap x dim
-  int* dWalk = nullptr;               // k_np_walk: zcnt[nbj][nblk] | tprog[nrb][nbj] | abort + padding (ints)
-  int np_persist = -1;                // PSF_NP_PERSIST: 1 = the whole walk in one launch when the batch allows it (k_np_walk), 0 = a launch per block, -1 = default
-  bool walk_used = false, walk_disabled = false;        // the last call ran k_np_walk; a timed-out k_np_walk switches it off for this handle
-  struct { uint64_t seed, first_index; size_t B; const uint64_t* d_u; int64_t* d_e; hipStream_t st; } last_call = {0, 0, 0, nullptr, nullptr, nullptr};
   int np_g = 0;                       // PSF_NP_G: preimages per wave of the sampler (0 = by batch size)
   int np_immediate = -1;              // PSF_NP_IMMEDIATE: 1 = every block updates all the rows below it in the launch that follows, 0 = panel-deferred far update, -1 = by batch size
   bool has_key = false;
@@ -156,8 +152,8 @@ static psf_status gpv_build_solver(psfgpv_handle* g) {
 }
 
 static void free_np_batch(psfgpv_handle* g) {
-  hipFree(g->dTm); hipFree(g->dZf); hipFree(g->dZ8); hipFree(g->dC0p); hipFree(g->dSol); hipFree(g->dC1); hipFree(g->dE1); hipFree(g->dWalk);
-  g->dTm = g->dZf = g->dC0p = g->dC1 = nullptr; g->dZ8 = nullptr; g->dSol = nullptr; g->dE1 = nullptr; g->dWalk = nullptr;
+  hipFree(g->dTm); hipFree(g->dZf); hipFree(g->dZ8); hipFree(g->dC0p); hipFree(g->dSol); hipFree(g->dC1); hipFree(g->dE1);
+  g->dTm = g->dZf = g->dC0p = g->dC1 = nullptr; g->dZ8 = nullptr; g->dSol = nullptr; g->dE1 = nullptr;
   g->bcap = 0;
 }
 static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
@@ -176,7 +172,6 @@ static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
     HIP_TRY(hipMalloc(&g->dC1, ld * g->nkd * 16 * sizeof(double)));
     HIP_TRY(hipMalloc(&g->dE1, B * g->dim * sizeof(int64_t)));
   }
-  HIP_TRY(hipMalloc(&g->dWalk, ((ld / TR_BN) * (g->nblk + g->nrb) + 16) * sizeof(int)));
   HIP_TRY(hipMemset(g->dTm, 0, g->dpad * ld * sizeof(double)));
   HIP_TRY(hipMemset(g->dZf, 0, ld * g->nkb * 16 * sizeof(double)));      // padding rows / columns of the operands stay zero for good
   HIP_TRY(hipMemset(g->dZ8, 0, 3 * g->zplane));
@@ -201,35 +196,7 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
   // small batches: a rank-64 update of every row below costs less than the sampler's 64 steps, and the T matrix stays in the Infinity Cache (measured
   // at C2, 1024 preimages: 4.57 vs 4.80 ms); large batches: the panel-deferred update moves T an eighth as often (C4, 4096 preimages: 5.06 vs 5.20 ms)
   const bool immediate = g->np_immediate >= 0 ? g->np_immediate != 0 : B <= 2048;
-  // the whole walk in one launch (k_np_walk) when the schedule is the immediate one and samplers + at least one worker per column block are resident together
-  g->walk_used = false;
-  const bool want_walk = g->np_persist >= 0 ? g->np_persist != 0 : false;
-  if (immediate && want_walk && !g->walk_disabled && g->nblk >= 3) {
-    static int cus = 0, occ[3] = {0, 0, 0};
-    if (!cus) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, g->base->prm.device) == hipSuccess) cus = prop.multiProcessorCount;
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[1], k_np_walk<1>, 512, 65536);
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[2], k_np_walk<2>, 512, 65536);
-    }
-    const long cap = (long)cus * occ[G];
-    const long room = cap - (long)nS;
-    const int S = room >= (long)nbj ? (int)std::min<long>((long)g->nrb, room / (long)nbj) : 0;
-    if (S >= 1 && (g->np_persist == 1 || S * 2 >= (int)g->nrb)) {        // by default only when a worker owns at most two tiles of its column block
-      const size_t nz = nbj * g->nblk, nt = g->nrb * nbj;
-      NpWalkSync sy{g->dWalk + 16, g->dWalk + 16 + nz, g->dWalk};          // [abort + padding | zcnt | tprog]
-      hipMemsetAsync(sy.zcnt, 0, nz * sizeof(int), st);
-      hipMemsetAsync(sy.tprog, 0x7f, nt * sizeof(int), st);
-      hipMemsetAsync(sy.abort, 0, 16 * sizeof(int), st);
-      const unsigned grid = nS + (unsigned)(nbj * (size_t)S);
-      unsigned spins = 1u << 21;                                       // ~0.5 s of polling before a wait gives up; PSF_NP_WALK_SPINS: tests force the fallback with 0
-      if (const char* ev = getenv("PSF_NP_WALK_SPINS")) spins = (unsigned)strtoul(ev, nullptr, 10);
-      if (G == 1) hipLaunchKernelGGL((k_np_walk<1>), dim3(grid), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, (int)nbj, (int)g->nrb, S, g->dGp, g->dTm, sy, spins);
-      else hipLaunchKernelGGL((k_np_walk<2>), dim3(grid), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, (int)nbj, (int)g->nrb, S, g->dGp, g->dTm, sy, spins);
-      g->walk_used = true;
-    }
-  }
-  for (size_t J = g->walk_used ? 0 : g->nblk; J-- > 0;) {
+  for (size_t J = g->nblk; J-- > 0;) {
     NpStepJobs jobs;
     for (int q = 0; q < 3; ++q) { jobs.job[q] = NpUpdateJob{0, 0, 0, 0, 0, 0}; jobs.ntiles[q] = 0; }
     auto set_job = [&](int q, size_t J_first, size_t nsub, size_t rb0, size_t rb1, size_t lo, size_t hi) {
@@ -285,12 +252,6 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
   return PSF_OK;
 }
 
-#ifdef NP_WALK_PROFILE
-extern "C" void psf_debug_walk_prof(unsigned long long* out, int reset) {
-  if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_prof), sizeof(unsigned long long) * 8);
-  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof), z, sizeof(z)); }
-}
-#endif
 #ifdef NP_PROFILE
 extern "C" void psf_debug_np_prof(long long* out, int reset) {
   if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_np_prof), sizeof(long long) * 8);
@@ -360,7 +321,6 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   if (g->two_pass) HIP_TRY(hipMalloc(&g->dBfull, g->nrb * g->nkd * TR_CHUNK * sizeof(double)));
   { const char* ev = getenv("PSF_NP_G"); g->np_g = ev ? atoi(ev) : 0; }
   { const char* ev = getenv("PSF_NP_IMMEDIATE"); g->np_immediate = ev ? (atoi(ev) != 0 ? 1 : 0) : -1; }
-  { const char* ev = getenv("PSF_NP_PERSIST"); g->np_persist = ev ? (atoi(ev) != 0 ? 1 : 0) : -1; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_project), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -453,7 +413,6 @@ psf_status psfgpv_samp_p_dev(psfgpv_handle* g, uint64_t seed, uint64_t first_ind
   hipStream_t st = (hipStream_t)stream;
   psf_status rcb = ensure_np_batch(g, B);
   if (rcb != PSF_OK) return rcb;
-  g->last_call = {seed, first_index, B, d_u, d_e, st};
   HIP_TRY(hipMemsetAsync(b->dFail, 0, 2 * sizeof(int), st));
   HIP_TRY(hipMemsetAsync(g->dFlags, 0, 8 * sizeof(int), st));
   if (g->timing) hipEventRecord(g->ev[0], st);
@@ -480,17 +439,6 @@ psf_status psfgpv_last_status(psfgpv_handle* g) {
   if (!g) return PSF_ERR_PARAM;
   psf_status rc = psfp_last_status(g->base);              // synchronises the stream of the last call
   if (rc != PSF_OK) return rc;
-  if (g->walk_used && g->dWalk) {                           // k_np_walk gave up on a wait (its workgroups were not all resident): the call again, a launch per block
-    int ab = 0;
-    HIP_TRY(hipMemcpy(&ab, g->dWalk, sizeof(int), hipMemcpyDeviceToHost));
-    if (ab) {
-      g->walk_disabled = true;
-      rc = psfgpv_samp_p_dev(g, g->last_call.seed, g->last_call.first_index, g->last_call.B, g->last_call.d_u, g->last_call.d_e, g->last_call.st);
-      if (rc != PSF_OK) return rc;
-      rc = psfp_last_status(g->base);
-      if (rc != PSF_OK) return rc;
-    }
-  }
   int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpy(fl, g->dFlags, sizeof(fl), hipMemcpyDeviceToHost));
   g->last_generic = g->basis_generic || fl[g->two_pass ? 7 : 3] != 0;

@@ -47,7 +47,7 @@ struct psfp_handle {
   bool wide;            // q >= 2^31: two 31-bit limbs
   bool has_key = false;      // A, R and sqrt(Sigma_2) installed
   bool has_pub = false;      // A installed (f_a, check_domain, samp_d work; samp_p needs has_key)
-  bool has_R = false;        // A and R installed (compute_sqrt_sigma_2 can complete the key)
+  bool has_R = false;        // R installed (compute_sqrt_sigma_2 can complete the key; samp_p also needs has_pub)
   // key material
   uint64_t* dA = nullptr;      // n x m
   int8_t* dR = nullptr;        // mb x ldr
@@ -475,7 +475,7 @@ static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double 
   for (hipStream_t* st : {&sm, &ss}) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
   for (hipEvent_t* ev : {&evSig[0], &evSig[1], &evPack[0], &evPack[1]}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
   if (!ok) { cleanup(); return PSF_ERR_HIP; }
-  HIP_TRY(hipDeviceSynchronize());                                    // R (and k_pack_R8) were produced on the default stream
+  if (hipDeviceSynchronize() != hipSuccess) { cleanup(); return PSF_ERR_HIP; }      // R (and k_pack_R8) were produced on the default stream
   // Sigma_2 restricted to panel J (rows off.., columns off..off+255), dense with leading dimension 256; it does not depend on the factorisation, so it
   // is assembled one panel ahead on its own stream into the other of two panel buffers
   auto sigma_panel = [&](int J) {
@@ -560,7 +560,8 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     const bool stream = ce ? !std::strcmp(ce, "stream") : m * m * sizeof(double) > (16ull << 30);
     if (stream) return build_sqrt_sigma2_stream(h, nf_r2, s2, b2p1, d_sigma_packed);
   }
-  double* dS = nullptr;
+  struct DenseGuard { double* dS = nullptr; int* dinfo = nullptr; ~DenseGuard() { hipFree(dinfo); hipFree(dS); } } dg;      // every exit releases both
+  double*& dS = dg.dS;
   HIP_TRY(hipMalloc(&dS, m * m * sizeof(double)));
   HIP_TRY(hipMemset(dS, 0, m * m * sizeof(double)));
   const unsigned tiles = (unsigned)((m + 63) / 64);
@@ -570,7 +571,7 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
   HIP_TRY(hipGetLastError());
   // blocked Cholesky of the lower triangle, panel width 128 (psf_chol_kernels.hpp): left-looking on the FP64 GEMM; PSF_CHOL=right: the right-looking
   // kernels of rounds 1-2 (comparison arm)
-  int* dinfo = nullptr;
+  int*& dinfo = dg.dinfo;
   HIP_TRY(hipMalloc(&dinfo, sizeof(int)));
   HIP_TRY(hipMemset(dinfo, 0, sizeof(int)));
   const char* chol_env = std::getenv("PSF_CHOL");
@@ -586,9 +587,8 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
       hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 2 * 4096 * sizeof(double), 0, dS, m, off, m, (int)nt, dinfo);
     }
   } else {
-    if (gemm_prepare() != hipSuccess) { hipFree(dinfo); hipFree(dS); return PSF_ERR_HIP; }
+    if (gemm_prepare() != hipSuccess) return PSF_ERR_HIP;
     const size_t diag_lds = ((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
     GemmWorkspace w;
     w.bytes = (size_t)900 * GM_T * GM_T * sizeof(double);              // < 384 + 512 (tile, split) pairs per launch, see launch_gemm
     double* dLi = nullptr;
@@ -597,10 +597,11 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     auto cleanup = [&]() { if (sm) hipStreamDestroy(sm); if (sd) hipStreamDestroy(sd); if (evTile) hipEventDestroy(evTile); if (evDiag) hipEventDestroy(evDiag); hipFree(w.ws); hipFree(dLi); };
     if (hipMalloc(&w.ws, w.bytes) != hipSuccess || hipMalloc(&dLi, CH_NB * CH_NB * sizeof(double)) != hipSuccess ||
         hipStreamCreateWithFlags(&sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&evTile, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDiag, hipEventDisableTiming) != hipSuccess) {
-      cleanup(); hipFree(dinfo); hipFree(dS); return PSF_ERR_HIP;
+        hipEventCreateWithFlags(&evTile, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDiag, hipEventDisableTiming) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {                        // (k_sigma2 ran on the default stream)
+      cleanup(); return PSF_ERR_HIP;
     }
-    HIP_TRY(hipDeviceSynchronize());                                   // k_sigma2 ran on the default stream
     // Look-ahead: the factorisation of a diagonal block is one workgroup walking 128 dependent steps (~0.2-0.35 ms, pure latency).  The update of
     // panel j is therefore cut in two: its first row tile (the diagonal block) goes first, its factorisation + inversion then runs on a second
     // stream BESIDE the update of the rows below, and the triangular solve of those rows (a product with the inverse) joins the two.
@@ -625,17 +626,15 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     const hipError_t ce = hipStreamSynchronize(sm);
     hipStreamSynchronize(sd);
     cleanup();
-    if (ce != hipSuccess) { hipFree(dinfo); hipFree(dS); return PSF_ERR_HIP; }
+    if (ce != hipSuccess) return PSF_ERR_HIP;
   }
   HIP_TRY(hipGetLastError());
   int info = -1;
   HIP_TRY(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));
-  hipFree(dinfo);
-  if (info != 0) { hipFree(dS); return PSF_ERR_NOT_PD; }            // mp_perturbation.rs:109-110
+  if (info != 0) return PSF_ERR_NOT_PD;                              // mp_perturbation.rs:109-110
   hipLaunchKernelGGL(k_repack_L<false>, dim3(grid_for(tr_total_chunks(h->nbiL) * TR_CHUNK)), dim3(256), 0, 0, dS, m, m, h->dLt, h->nbiL);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
-  hipFree(dS);
   return PSF_OK;
 }
 
@@ -819,6 +818,27 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
   HIP_TRY(hipDeviceSynchronize());
   hipFree(dp);
   h->has_key = true;
+  return PSF_OK;
+}
+
+// (A, R) without a factor: what PSFPerturbation::compute_sqrt_sigma_2 (mp_perturbation.rs:111) needs installed -- it is a pure function of mat_r and
+// mat_sigma in the reference, so A may be NULL (the handle's public matrix, if any, stays).  No Sigma_2 is assembled and nothing is factored here
+// (psfp_load_key(A, R, NULL) runs a full Cholesky with the handle's s); samp_p answers PSF_ERR_NO_KEY until psfp_compute_sqrt_sigma_2(_dense) has run.
+psf_status psfp_load_trapdoor(psfp_handle* h, const uint64_t* A, const int8_t* R) {
+  if (!h || !R) return PSF_ERR_PARAM;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  h->has_key = h->has_R = false;
+  if (A) {
+    h->has_pub = false;
+    HIP_TRY(hipMemcpy(h->dA, A, h->n * h->m * sizeof(uint64_t), hipMemcpyHostToDevice));
+    split_A(h);
+    HIP_TRY(hipGetLastError());
+    h->has_pub = true;
+  }
+  HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
+  HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  h->has_R = true;
   return PSF_OK;
 }
 
@@ -1063,7 +1083,7 @@ psf_status psfp_last_status(psfp_handle* h) {
 
 psf_status psfp_samp_p_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, void* stream) {
   if (!h || (B && (!d_u || !d_e))) return PSF_ERR_PARAM;
-  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (!h->has_key || !h->has_pub) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
   psf_status rc = ensure_batch(h, B);
@@ -1074,7 +1094,7 @@ psf_status psfp_samp_p_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, 
 
 psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
   if (!h || (B && (!u || !e))) return PSF_ERR_PARAM;
-  if (!h->has_key) return PSF_ERR_NO_KEY;
+  if (!h->has_key || !h->has_pub) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
   psf_status rc = ensure_batch(h, B);
@@ -1148,7 +1168,7 @@ psf_status psfp_samp_p_multi(psfp_handle* const* handles, int count, uint64_t se
   if (!handles || count < 1 || (B && (!u || !e))) return PSF_ERR_PARAM;
   for (int i = 0; i < count; ++i) {
     if (!handles[i]) return PSF_ERR_PARAM;
-    if (!handles[i]->has_key) return PSF_ERR_NO_KEY;
+    if (!handles[i]->has_key || !handles[i]->has_pub) return PSF_ERR_NO_KEY;
     if (handles[i]->n != handles[0]->n || handles[i]->m != handles[0]->m || handles[i]->q != handles[0]->q) return PSF_ERR_PARAM;
     for (int j = 0; j < i; ++j) if (handles[j] == handles[i]) return PSF_ERR_PARAM;      // one worker per handle: a handle may appear once
   }
@@ -1168,8 +1188,13 @@ psf_status psfp_samp_p_multi(psfp_handle* const* handles, int count, uint64_t se
     h->multi_done_ms = ms_since(std::chrono::steady_clock::now());
   };
   std::vector<std::thread> pool;
-  pool.reserve(count > 1 ? count - 1 : 0);
-  for (int i = 1; i < count; ++i) pool.emplace_back(work, i);
+  int started = 1;
+  try {                                                  // nothing may unwind across the extern "C" boundary
+    pool.reserve(count > 1 ? count - 1 : 0);
+    for (int i = 1; i < count; ++i) { pool.emplace_back(work, i); started = i + 1; }
+  } catch (...) {
+    for (int i = started; i < count; ++i) rc[i] = PSF_ERR_HIP;      // these shares were never started (no thread available)
+  }
   work(0);                                               // the calling thread serves the first handle
   for (auto& t : pool) t.join();
   for (int i = 0; i < count; ++i) if (rc[i] != PSF_OK) return rc[i];

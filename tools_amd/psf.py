@@ -169,6 +169,18 @@ class PSFPerturbation:
             Lpp = _p(Lp, C.c_double)
         check(lib().psfp_load_key(self._h, _p(A, C.c_uint64), Rp, Lpp), "load_key")
 
+    def load_trapdoor(self, R, A=None):
+        """(A, R) without a factor and without computing one (psfp_load_trapdoor): the state compute_sqrt_sigma_2 -- a pure function of mat_r and
+        mat_sigma in the reference, mp_perturbation.rs:111 -- starts from.  samp_p raises PSF_ERR_NO_KEY until compute_sqrt_sigma_2 has run."""
+        R = np.ascontiguousarray(R, dtype=np.int8)
+        assert R.shape == (self.m_bar, self.w)
+        Ap = None
+        if A is not None:
+            A = np.ascontiguousarray(A, dtype=np.uint64)
+            assert A.shape == (self.n, self.m)
+            Ap = _p(A, C.c_uint64)
+        check(lib().psfp_load_trapdoor(self._h, Ap, _p(R, C.c_int8)), "load_trapdoor")
+
     def compute_sqrt_sigma_2(self, s_cov=None, sigma=None):
         """mp_perturbation.rs:111-139: Sigma = s_cov^2 I, or any symmetric m x m covariance `sigma` (a full matrix or its packed lower triangle)."""
         if sigma is None:
