@@ -254,6 +254,7 @@ def single_call_latency(psf, u, e, m, first_index, stream, reps=30):
     key_bytes = m * (m + 1) // 2 * 8
     out = {"bound": "hbm", "bytes": key_bytes, "peak_GBps": PEAK_HBM_GBS, "entry_point": "psfp_samp_p_dev (device pointers)", "reps": reps}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e = torch.empty((min(64, u.shape[0]), m), dtype=torch.int64, device=u.device)      # its own rows: the step's output is still to be checked against the oracle
     for B in (1, 16, 64):
         if B > u.shape[0]:
             continue

@@ -203,6 +203,12 @@ psf_status psfp_export_gadget_basis(const psfp_handle*, int64_t* Sk, double* Sk_
 psf_status psfp_samp_d(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, int64_t* e);
 /* PSF::samp_p (mp_perturbation.rs:304-336), B independent calls */
 psf_status psfp_samp_p(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
+/* The same, asynchronous: returns once the work is enqueued (u has been staged and may be reused); e[] is complete when psfp_wait returns.  At most
+ * two calls are in flight per handle (a third waits for the first).  The rows of call i cross PCIe (narrowed to int32 on the device, widened into e by
+ * worker threads) while call i + 1 computes, so a loop of asynchronous calls runs at the device-resident rate; psfp_samp_p = psfp_samp_p_async +
+ * psfp_wait.  psfp_wait returns the first non-OK status of the outstanding calls, oldest first (PSF_ERR_SAMPLER as psfp_samp_p would). */
+psf_status psfp_samp_p_async(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
+psf_status psfp_wait(psfp_handle*);
 /* PSF::f_a (mp_perturbation.rs:366-369): u[b] = A e[b] mod q; PSF_ERR_DOMAIN (u still written) if any
  * row fails check_domain */
 psf_status psfp_f_a(psfp_handle*, size_t B, const int64_t* e, uint64_t* u);

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <vector>
 #include "../../include/psf_mi355x.h"
 #include "psf_host.hpp"
@@ -83,6 +84,26 @@ struct psfp_handle {
   uint64_t* dPart = nullptr; int zq_split_cap = 1;   // per-split residues of the int8-MFMA Z_q product
   bool gadget_queue = true;   // task-queue gadget sampler (PSF_GADGET_QUEUE=0: lock-step kernel)
   bool keep_fail = false;     // sliced host path: the failure flags accumulate over the slices of one call
+  // Host-pointer calls (psfp_samp_p / psfp_samp_p_async): rows are narrowed to int32 on the device, cross PCIe in chunks into pinned buffers and are
+  // widened into the caller's int64 rows by worker threads, while the compute stream already runs the next slice / the next call.
+  struct HostPipe {
+    static constexpr int NW = 4;                // worker threads per call (each: its own pinned chunk buffers, copies + widening of chunks c = w mod NW)
+    int32_t* dE32[2] = {nullptr, nullptr};      // device: narrowed rows of the call in flight, two calls deep
+    size_t cap_entries = 0;                     // entries each dE32 holds
+    int32_t* hbuf[NW][2] = {};                  // pinned chunk buffers
+    hipEvent_t evC[NW][2] = {};                 // chunk landed in its pinned buffer
+    size_t chunk_entries = 0;
+    hipEvent_t evSlice[2][4] = {};              // slice j of call slot s has been narrowed (compute stream)
+    int* hFlags[2] = {nullptr, nullptr};        // pinned: [0] sampler failure, [1] unused, [2] int32 overflow of a row entry
+    int* dOvf = nullptr;                        // device: overflow flag of the narrowing kernel
+    uint64_t* hU[2] = {nullptr, nullptr};       // pinned staging of the targets (a copy from pageable memory would block the caller behind the stream)
+    size_t u_cap = 0;
+    std::vector<std::thread> workers[2];
+    bool busy[2] = {false, false};
+    std::atomic<int> status[2] = {{0}, {0}};     // psf_status of the call in each slot (written by its workers)
+    size_t next = 0;                            // slot of the next asynchronous call
+    hipStream_t copy = nullptr;                 // D2H stream
+  } hp;
   bool no_slice = false;      // stage export wants the intermediates of the whole batch
   bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
   size_t ncall = 0;
@@ -404,9 +425,11 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   return PSF_OK;
 }
 
+static void hp_release(psfp_handle* h);
 void psfp_destroy(psfp_handle* h) {
   if (!h) return;
   hipSetDevice(h->prm.device);
+  hp_release(h);
   free_batch(h);
   clear_slots(h);
   if (h->aux) hipStreamDestroy(h->aux);
@@ -1092,64 +1115,207 @@ psf_status psfp_samp_p_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, 
   return run_samp_p(h, seed, first_index, B, d_u, d_e, (hipStream_t)stream);
 }
 
+// ---- host-pointer entry points ---------------------------------------------------------------------------------------------------------------
+// wait for the asynchronous call in `slot` (its workers have copied and widened every row), release it, return its status
+static psf_status hp_join(psfp_handle* h, int slot) {
+  auto& hp = h->hp;
+  if (!hp.busy[slot]) return PSF_OK;
+  for (auto& t : hp.workers[slot]) if (t.joinable()) t.join();
+  hp.workers[slot].clear();
+  hp.busy[slot] = false;
+  psf_status rc = (psf_status)hp.status[slot].load();
+  if (rc == PSF_OK && (hp.hFlags[slot][0] || hp.hFlags[slot][2])) rc = PSF_ERR_SAMPLER;
+  return rc;
+}
+
+static void hp_release(psfp_handle* h) {
+  auto& hp = h->hp;
+  for (int s = 0; s < 2; ++s) hp_join(h, s);
+  for (int s = 0; s < 2; ++s) {
+    hipFree(hp.dE32[s]); hp.dE32[s] = nullptr;
+    if (hp.hFlags[s]) { hipHostFree(hp.hFlags[s]); hp.hFlags[s] = nullptr; }
+    for (auto& ev : hp.evSlice[s]) if (ev) { hipEventDestroy(ev); ev = nullptr; }
+  }
+  for (int w = 0; w < psfp_handle::HostPipe::NW; ++w)
+    for (int k = 0; k < 2; ++k) {
+      if (hp.hbuf[w][k]) { hipHostFree(hp.hbuf[w][k]); hp.hbuf[w][k] = nullptr; }
+      if (hp.evC[w][k]) { hipEventDestroy(hp.evC[w][k]); hp.evC[w][k] = nullptr; }
+    }
+  hipFree(hp.dOvf); hp.dOvf = nullptr;
+  for (int s = 0; s < 2; ++s) if (hp.hU[s]) { hipHostFree(hp.hU[s]); hp.hU[s] = nullptr; }
+  hp.u_cap = 0;
+  if (hp.copy) { hipStreamDestroy(hp.copy); hp.copy = nullptr; }
+  hp.cap_entries = 0; hp.chunk_entries = 0;
+}
+
+static psf_status hp_ensure(psfp_handle* h, size_t entries, size_t u_words) {
+  auto& hp = h->hp;
+  constexpr int NW = psfp_handle::HostPipe::NW;
+  if (!hp.copy) {
+    HIP_TRY(hipStreamCreateWithFlags(&hp.copy, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&hp.dOvf, 2 * sizeof(int)));
+    for (int s = 0; s < 2; ++s) {
+      HIP_TRY(hipHostMalloc(&hp.hFlags[s], 4 * sizeof(int), hipHostMallocDefault));
+      for (auto& ev : hp.evSlice[s]) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    hp.chunk_entries = (size_t)8 << 20;                                  // 32 MiB of int32 per chunk: ~1.5 ms on PCIe Gen5, ~3 ms to widen on one core
+    for (int w = 0; w < NW; ++w)
+      for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipHostMalloc(&hp.hbuf[w][k], hp.chunk_entries * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&hp.evC[w][k], hipEventDisableTiming));
+      }
+  }
+  if (entries > hp.cap_entries) {
+    for (int s = 0; s < 2; ++s) { const psf_status rc = hp_join(h, s); (void)rc; }
+    for (int s = 0; s < 2; ++s) { hipFree(hp.dE32[s]); hp.dE32[s] = nullptr; }
+    hp.cap_entries = 0;
+    for (int s = 0; s < 2; ++s) HIP_TRY(hipMalloc(&hp.dE32[s], entries * sizeof(int32_t)));
+    hp.cap_entries = entries;
+  }
+  if (u_words > hp.u_cap) {
+    for (int s = 0; s < 2; ++s) { const psf_status rc = hp_join(h, s); (void)rc; }
+    for (int s = 0; s < 2; ++s) { if (hp.hU[s]) hipHostFree(hp.hU[s]); hp.hU[s] = nullptr; }
+    hp.u_cap = 0;
+    for (int s = 0; s < 2; ++s) HIP_TRY(hipHostMalloc(&hp.hU[s], u_words * sizeof(uint64_t), hipHostMallocDefault));
+    hp.u_cap = u_words;
+  }
+  return PSF_OK;
+}
+
+// Asynchronous samp_p on host buffers: returns once the work is enqueued (the targets have been staged); `e` is complete when psfp_wait returns.
+// At most two calls are in flight: a third waits for the first.  The compute stream runs the slices of the call back to back (row b draws from global
+// index first_index + b, so slicing changes no bit); behind each slice its rows are narrowed to int32 (every entry of a preimage is below 2^31: |p| < 2^23
+// and |R z| <= w 2^15, both checked on the device), copied in chunks to pinned memory on a second stream and widened into `e` by NW worker threads --
+// while the compute stream is already in the next slice or the next call.  A single call therefore ends one short slice after its product
+// (slices: all but the last ~1024 rows, then the rest), and back-to-back calls run at the device-resident rate.
+psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
+  if (!h || (B && (!u || !e))) return PSF_ERR_PARAM;
+  if (!h->has_key || !h->has_pub) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  auto& hp = h->hp;
+  constexpr int NW = psfp_handle::HostPipe::NW;
+  const size_t m = h->m, total = B * m;
+  const int slot = (int)(hp.next & 1);
+  psf_status rc = hp_join(h, slot);                         // the call before last used this slot
+  if (rc != PSF_OK) return rc;
+  if (B > h->Bcap) { rc = hp_join(h, slot ^ 1); if (rc != PSF_OK) return rc; }      // ensure_batch reallocates: nothing may be in flight
+  rc = ensure_batch(h, B);
+  if (rc != PSF_OK) return rc;
+  rc = hp_ensure(h, total, B * h->n);
+  if (rc != PSF_OK) return rc;
+  ++hp.next;
+  // targets: pageable -> pinned (this thread) -> device on the compute stream (ordered behind the previous call's kernels, which read dU)
+  std::memcpy(hp.hU[slot], u, B * h->n * sizeof(uint64_t));
+  HIP_TRY(hipMemcpyAsync(h->dU, hp.hU[slot], B * h->n * sizeof(uint64_t), hipMemcpyHostToDevice, h->s1));
+  if (h->timing) clear_slots(h);
+  // slices: everything but a short tail, then the tail (its transfer is all that remains exposed behind the last kernel)
+  size_t cuts[5] = {0, B, B, B, B};
+  int nsl = 1;
+  if (!h->no_slice && !h->pipeline && B >= 2048) { cuts[1] = B - 1024; cuts[2] = B; nsl = 2; }
+  if (const char* env = std::getenv("PSF_HOST_SLICE")) {    // experiments: equal slices of this many rows (at most four)
+    const long v = std::atol(env);
+    if (v >= 128 && !h->no_slice && !h->pipeline && (size_t)v < B) {
+      nsl = 0;
+      for (size_t off = 0; off < B && nsl < 4; off += (size_t)v) cuts[nsl++] = off;
+      cuts[nsl] = B;
+    }
+  }
+  struct FailGuard { psfp_handle* h; size_t B; ~FailGuard() { h->keep_fail = false; h->nbj = round_up(B, TR_BN) / TR_BN; } } guard{h, B};
+  HIP_TRY(hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), h->s1));
+  HIP_TRY(hipMemsetAsync(hp.dOvf, 0, 2 * sizeof(int), h->s1));
+  h->keep_fail = true;
+  for (int j = 0; j < nsl; ++j) {
+    const size_t off = cuts[j], cnt = cuts[j + 1] - cuts[j];
+    h->nbj = round_up(cnt, TR_BN) / TR_BN;
+    rc = run_samp_p(h, seed, first_index + off, cnt, h->dU + off * h->n, h->dE + off * m, h->s1);
+    if (rc != PSF_OK) return rc;
+    hipLaunchKernelGGL(k_narrow_rows, dim3(grid_for(cnt * m / 2 + 1, 256, 256 * 16)), dim3(256), 0, h->s1, h->dE + off * m, hp.dE32[slot] + off * m, cnt * m, hp.dOvf);
+    if (j == nsl - 1) {                                     // the call's flags travel with its last slice
+      HIP_TRY(hipMemcpyAsync(hp.hFlags[slot], h->dFail, 2 * sizeof(int), hipMemcpyDeviceToHost, h->s1));
+      HIP_TRY(hipMemcpyAsync(hp.hFlags[slot] + 2, hp.dOvf, sizeof(int), hipMemcpyDeviceToHost, h->s1));
+    }
+    HIP_TRY(hipEventRecord(hp.evSlice[slot][j], h->s1));
+  }
+  HIP_TRY(hipGetLastError());
+  h->last_stream = h->s1;
+  // workers: chunk c of the call's entries belongs to worker c % NW; a worker copies its chunk into one of its two pinned buffers and widens the
+  // previous one meanwhile
+  const size_t CE = hp.chunk_entries, nchunks = (total + CE - 1) / CE;
+  hp.status[slot] = (int)PSF_OK;
+  hp.busy[slot] = true;
+  const int32_t* src = hp.dE32[slot];
+  const int device = h->prm.device;
+  size_t slice_end[4]; hipEvent_t slice_ev[4];
+  for (int j = 0; j < nsl; ++j) { slice_end[j] = cuts[j + 1] * m; slice_ev[j] = hp.evSlice[slot][j]; }
+  auto worker = [&hp, slot, src, e, total, CE, nchunks, nsl, device, slice_end, slice_ev](int w) {
+    if (hipSetDevice(device) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
+    auto widen = [&](size_t c, int k) {
+      if (hipEventSynchronize(hp.evC[w][k]) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
+      const size_t b0 = c * CE, cnt = total - b0 < CE ? total - b0 : CE;
+      const int32_t* hs = hp.hbuf[w][k];
+      int64_t* dst = e + b0;
+      for (size_t i = 0; i < cnt; ++i) dst[i] = (int64_t)hs[i];
+    };
+    long prev = -1; int pk = 0, k = 0;
+    for (size_t c = (size_t)w; c < nchunks; c += psfp_handle::HostPipe::NW) {
+      const size_t b0 = c * CE, cnt = total - b0 < CE ? total - b0 : CE;
+      int j = 0;
+      while (j < nsl - 1 && b0 + cnt > slice_end[j]) ++j;                // the last slice this chunk touches
+      if (hipStreamWaitEvent(hp.copy, slice_ev[j], 0) != hipSuccess ||
+          hipMemcpyAsync(hp.hbuf[w][k], src + b0, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, hp.copy) != hipSuccess ||
+          hipEventRecord(hp.evC[w][k], hp.copy) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; break; }
+      if (prev >= 0) widen((size_t)prev, pk);
+      prev = (long)c; pk = k; k ^= 1;
+    }
+    if (prev >= 0) widen((size_t)prev, pk);
+  };
+  try {
+    for (int w = 0; w < NW && (size_t)w < nchunks; ++w) hp.workers[slot].emplace_back(worker, w);
+  } catch (...) {                                                        // no thread available: the started ones finish, the rest of the rows are missing
+    hp.status[slot] = (int)PSF_ERR_HIP;
+  }
+  // (the call's flags were copied on the compute stream in front of the last slice's event, which the worker of the last chunk waits for: once the
+  // workers have been joined the flags have landed)
+  return PSF_OK;
+}
+
+// all asynchronous calls of this handle have completed: their rows are in the callers' buffers; the first non-OK status (oldest call first)
+psf_status psfp_wait(psfp_handle* h) {
+  if (!h) return PSF_ERR_PARAM;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  auto& hp = h->hp;
+  psf_status first = PSF_OK;
+  for (int i = 0; i < 2; ++i) {
+    const int slot = (int)((hp.next + (size_t)i) & 1);                   // oldest first
+    const psf_status rc = hp_join(h, slot);
+    if (first == PSF_OK) first = rc;
+  }
+  return first;
+}
+
 psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
   if (!h || (B && (!u || !e))) return PSF_ERR_PARAM;
   if (!h->has_key || !h->has_pub) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
-  psf_status rc = ensure_batch(h, B);
-  if (rc != PSF_OK) return rc;
-  HIP_TRY(hipMemcpy(h->dU, u, B * h->n * sizeof(uint64_t), hipMemcpyHostToDevice));
-  if (h->timing) clear_slots(h);
-  // Large batches are cut into slices of preimages: the rows of slice i cross PCIe (copy stream) while slice i+1 is computed
-  // (compute stream).  Row b draws from global index first_index + b, so slicing does not change a single bit.
-  size_t slice = B;
-  if (B >= 3072 && !h->pipeline && !h->no_slice) slice = round_up((B + 1) / 2, TR_BN);   // two halves: 84 -> 80 ms for a C3 batch; more, smaller slices cost the FP64 product more than the overlap returns
-  if (const char* env = std::getenv("PSF_HOST_SLICE")) {      // not under PSF_PIPELINE: the set switching has its own failure flags
-    const long v = std::atol(env);
-    if (v >= 128 && !h->no_slice && !h->pipeline) slice = (size_t)v < B ? (size_t)v : B;
-  }
-  if (slice >= B) {
+  if (B * h->m < ((size_t)1 << 20) || h->no_slice || h->pipeline) {
+    // a single call / a handful of preimages (or a stage export): nothing to overlap -- straight through on the default stream
+    psf_status rc = psfp_wait(h);
+    if (rc != PSF_OK) return rc;
+    rc = ensure_batch(h, B);
+    if (rc != PSF_OK) return rc;
+    HIP_TRY(hipMemcpy(h->dU, u, B * h->n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (h->timing) clear_slots(h);
     rc = run_samp_p(h, seed, first_index, B, h->dU, h->dE, nullptr);
     if (rc != PSF_OK) return rc;
     rc = psfp_last_status(h);
     HIP_TRY(hipMemcpy(e, h->dE, B * h->m * sizeof(int64_t), hipMemcpyDeviceToHost));
     return rc;
   }
-  HIP_TRY(hipDeviceSynchronize());
-  // every exit -- including a HIP error in the middle of the loop -- restores the handle's per-call state and releases the events
-  struct SliceGuard {
-    psfp_handle* h; size_t B; hipEvent_t done[2] = {nullptr, nullptr};
-    ~SliceGuard() {
-      h->keep_fail = false;
-      h->nbj = round_up(B, TR_BN) / TR_BN;
-      for (auto& ev : done) if (ev) hipEventDestroy(ev);
-    }
-  } guard{h, B};
-  hipEvent_t* done = guard.done;
-  for (int j = 0; j < 2; ++j) HIP_TRY(hipEventCreateWithFlags(&done[j], hipEventDisableTiming));
-  HIP_TRY(hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), h->s1));
-  h->keep_fail = true;
-  size_t prev_off = 0, prev_n = 0;
-  int i = 0;
-  auto fetch = [&](size_t off, size_t cnt, hipEvent_t ev) -> psf_status {
-    HIP_TRY(hipEventSynchronize(ev));
-    HIP_TRY(hipMemcpyAsync(e + off * h->m, h->dE + off * h->m, cnt * h->m * sizeof(int64_t), hipMemcpyDeviceToHost, h->aux));
-    HIP_TRY(hipStreamSynchronize(h->aux));
-    return PSF_OK;
-  };
-  for (size_t off = 0; off < B; off += slice, ++i) {
-    const size_t cnt = B - off < slice ? B - off : slice;
-    h->nbj = round_up(cnt, TR_BN) / TR_BN;
-    rc = run_samp_p(h, seed, first_index + off, cnt, h->dU + off * h->n, h->dE + off * h->m, h->s1);
-    if (rc != PSF_OK) return rc;
-    HIP_TRY(hipEventRecord(done[i & 1], h->s1));
-    if (prev_n) { rc = fetch(prev_off, prev_n, done[(i - 1) & 1]); if (rc != PSF_OK) return rc; }
-    prev_off = off; prev_n = cnt;
-  }
-  if (prev_n) { rc = fetch(prev_off, prev_n, done[(i - 1) & 1]); if (rc != PSF_OK) return rc; }
-  h->last_stream = h->s1;
-  return psfp_last_status(h);
+  const psf_status rc = psfp_samp_p_async(h, seed, first_index, B, u, e);
+  const psf_status rw = psfp_wait(h);
+  return rc != PSF_OK ? rc : rw;
 }
 
 // One job over several handles (one per GPU of the node, each with the same key): rows are cut into contiguous shares
@@ -1314,6 +1480,7 @@ psf_status psfp_f_a(psfp_handle* h, size_t B, const int64_t* e, uint64_t* u) {
   if (!h->has_pub) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
+  { const psf_status rw = psfp_wait(h); if (rw != PSF_OK) return rw; }      // the handle's dU / dE may belong to an asynchronous samp_p in flight
   psf_status rc = ensure_batch(h, B);
   if (rc != PSF_OK) return rc;
   HIP_TRY(hipMemcpy(h->dE, e, B * h->m * sizeof(int64_t), hipMemcpyHostToDevice));
