@@ -173,3 +173,34 @@ def test_bench_multi_rank_path_on_a_one_rank_group():
     line = r.stdout.strip().splitlines()[-1]
     d = json.loads(line)
     assert d["valid"] is True and d["n_gpus"] == 1 and d["steps"] == 2 and "RCCL gather" in d["config"]["parallelism"]
+
+
+def test_overlapped_async_calls_return_the_rows_of_synchronous_ones(oracle):
+    """psfp_samp_p_async / psfp_wait (host buffers): two calls in flight at once -- rows narrowed to int32 on the device, copied in chunks to pinned memory and
+    widened by worker threads while the next call computes -- return exactly the rows of two synchronous calls; a third call waits for the first; sliced
+    large calls (>= 2048 rows: all but the last 1024, then the tail) equal the device-pointer path bit for bit."""
+    import numpy as np
+    import tools_amd as T
+    n, q, r, s = 24, 2**10, 4.0, 80.0                      # m = 505: 2600 rows are 1.3 M entries (above the straight-through threshold), 2 slices
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+    A, (R, Lp, _) = psf.trap_gen(5)
+    Bs = [2600, 2100, 2304]
+    us = [oracle.uniform_targets(30 + i, B, n, q) for i, B in enumerate(Bs)]
+    sync = [psf.samp_p(u, seed=70 + i, first_index=1000 * i) for i, u in enumerate(us)]
+    outs = [np.full((B, psf.m), -7, dtype=np.int64) for B in Bs]
+    for i, u in enumerate(us):                              # three calls: the third waits for the first inside the library
+        psf.samp_p_async(u, outs[i], seed=70 + i, first_index=1000 * i)
+    psf.wait()
+    for i in range(3):
+        assert (outs[i] == sync[i]).all(), i
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s)
+    orc.load_key(A, R, Lp)
+    assert (outs[1][:64] == orc.samp_p(71, us[1][:64], first_index=1000)).all()
+    assert (psf.f_a(outs[2]) == us[2]).all() and psf.check_domain(outs[2]).all()
+    # a small call between asynchronous ones takes the straight path and waits for what is in flight
+    psf.samp_p_async(us[0], outs[0], seed=90)
+    small = psf.samp_p(us[1][:3], seed=91)
+    assert (small == orc.samp_p(91, us[1][:3])).all()
+    psf.wait()
+    assert (outs[0] == psf.samp_p(us[0], seed=90)).all()
+    psf.close()

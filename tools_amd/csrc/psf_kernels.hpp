@@ -197,6 +197,17 @@ __global__ __launch_bounds__(256) void k_narrow_rows(const int64_t* __restrict__
   if (bad) atomicOr(overflow, 1);
 }
 
+// targets: pinned host memory -> device by a kernel on the compute stream.  An SDMA / second-stream upload of the next call's targets is queued by
+// the runtime behind the previous call's download (measured with rocprofv3: the upload ran 25 ms late and the compute stream idled), a kernel in
+// stream order is not.  16-byte loads over PCIe, 16 MB at C3.
+__global__ __launch_bounds__(256) void k_copy_words(const uint64_t* __restrict__ host_src, uint64_t* __restrict__ dst, size_t count) {
+  const size_t stride = (size_t)gridDim.x * 256, pairs = count / 2;
+  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride)
+    reinterpret_cast<u2*>(dst)[i] = __builtin_nontemporal_load(reinterpret_cast<const u2*>(host_src) + i);
+  if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[count - 1] = host_src[count - 1];
+}
+
 // read one normal back out of the chunk stream (stage export)
 __global__ void k_export_normals(const double* __restrict__ Dt, size_t m, size_t B, size_t nkb, double* __restrict__ out /*B x m*/, uint32_t ncf) {
   const size_t total = m * B;

@@ -87,22 +87,26 @@ struct psfp_handle {
   // Host-pointer calls (psfp_samp_p / psfp_samp_p_async): rows are narrowed to int32 on the device, cross PCIe in chunks into pinned buffers and are
   // widened into the caller's int64 rows by worker threads, while the compute stream already runs the next slice / the next call.
   struct HostPipe {
-    static constexpr int NW = 4;                // worker threads per call (each: its own pinned chunk buffers, copies + widening of chunks c = w mod NW)
+    static constexpr int NW = 8;                // at most this many worker threads per call (each: its own pinned chunk buffers, copies + widening of chunks c = w mod nw)
+    int nw = 4;                                 // workers in use (PSF_HOST_WORKERS)
     int32_t* dE32[2] = {nullptr, nullptr};      // device: narrowed rows of the call in flight, two calls deep
     size_t cap_entries = 0;                     // entries each dE32 holds
-    int32_t* hbuf[NW][2] = {};                  // pinned chunk buffers
-    hipEvent_t evC[NW][2] = {};                 // chunk landed in its pinned buffer
+    int32_t* hbuf[2][NW][2] = {};               // pinned chunk buffers [call slot][worker][double buffer]: two calls in flight never share one
+    hipEvent_t evC[2][NW][2] = {};              // chunk landed in its pinned buffer
     size_t chunk_entries = 0;
     hipEvent_t evSlice[2][4] = {};              // slice j of call slot s has been narrowed (compute stream)
     int* hFlags[2] = {nullptr, nullptr};        // pinned: [0] sampler failure, [1] unused, [2] int32 overflow of a row entry
     int* dOvf = nullptr;                        // device: overflow flag of the narrowing kernel
     uint64_t* hU[2] = {nullptr, nullptr};       // pinned staging of the targets (a copy from pageable memory would block the caller behind the stream)
+    uint64_t* dU2[2] = {nullptr, nullptr};      // device copy of the targets per call in flight (filled by k_copy_words at the head of the call)
     size_t u_cap = 0;
     std::vector<std::thread> workers[2];
     bool busy[2] = {false, false};
     std::atomic<int> status[2] = {{0}, {0}};     // psf_status of the call in each slot (written by its workers)
     size_t next = 0;                            // slot of the next asynchronous call
-    hipStream_t copy = nullptr;                 // D2H stream
+    bool slice_tail = false;                    // set by psfp_samp_p around its own asynchronous call: cut a short last slice (single-call latency)
+    hipStream_t copy = nullptr;                 // D2H stream (high priority)
+    hipStream_t compute = nullptr;              // stream of the asynchronous calls' kernels (normal priority)
   } hp;
   bool no_slice = false;      // stage export wants the intermediates of the whole batch
   bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
@@ -1136,15 +1140,20 @@ static void hp_release(psfp_handle* h) {
     if (hp.hFlags[s]) { hipHostFree(hp.hFlags[s]); hp.hFlags[s] = nullptr; }
     for (auto& ev : hp.evSlice[s]) if (ev) { hipEventDestroy(ev); ev = nullptr; }
   }
-  for (int w = 0; w < psfp_handle::HostPipe::NW; ++w)
-    for (int k = 0; k < 2; ++k) {
-      if (hp.hbuf[w][k]) { hipHostFree(hp.hbuf[w][k]); hp.hbuf[w][k] = nullptr; }
-      if (hp.evC[w][k]) { hipEventDestroy(hp.evC[w][k]); hp.evC[w][k] = nullptr; }
-    }
+  for (int s = 0; s < 2; ++s)
+    for (int w = 0; w < psfp_handle::HostPipe::NW; ++w)
+      for (int k = 0; k < 2; ++k) {
+        if (hp.hbuf[s][w][k]) { hipHostFree(hp.hbuf[s][w][k]); hp.hbuf[s][w][k] = nullptr; }
+        if (hp.evC[s][w][k]) { hipEventDestroy(hp.evC[s][w][k]); hp.evC[s][w][k] = nullptr; }
+      }
   hipFree(hp.dOvf); hp.dOvf = nullptr;
-  for (int s = 0; s < 2; ++s) if (hp.hU[s]) { hipHostFree(hp.hU[s]); hp.hU[s] = nullptr; }
+  for (int s = 0; s < 2; ++s) {
+    if (hp.hU[s]) { hipHostFree(hp.hU[s]); hp.hU[s] = nullptr; }
+    hipFree(hp.dU2[s]); hp.dU2[s] = nullptr;
+  }
   hp.u_cap = 0;
   if (hp.copy) { hipStreamDestroy(hp.copy); hp.copy = nullptr; }
+  if (hp.compute) { hipStreamDestroy(hp.compute); hp.compute = nullptr; }
   hp.cap_entries = 0; hp.chunk_entries = 0;
 }
 
@@ -1152,18 +1161,28 @@ static psf_status hp_ensure(psfp_handle* h, size_t entries, size_t u_words) {
   auto& hp = h->hp;
   constexpr int NW = psfp_handle::HostPipe::NW;
   if (!hp.copy) {
-    HIP_TRY(hipStreamCreateWithFlags(&hp.copy, hipStreamNonBlocking));
+    {  // The runtime moves these copies with shader kernels (__amd_rocclr_copyBuffer in the rocprofv3 trace): on a queue of lower priority than the compute
+       // stream they only ran when that stream was idle, and a loop of asynchronous calls degenerated into compute, then copy (90 ms per call at C3).
+       // So: copies on the HIGH-priority queue (PCIe-bound, a few waves), the asynchronous calls' kernels on a normal one (hp.compute).
+      int lo_prio = 0, hi_prio = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+      HIP_TRY(hipStreamCreateWithPriority(&hp.copy, hipStreamNonBlocking, hi_prio));
+      HIP_TRY(hipStreamCreateWithPriority(&hp.compute, hipStreamNonBlocking, (lo_prio + hi_prio) / 2));
+    }
     HIP_TRY(hipMalloc(&hp.dOvf, 2 * sizeof(int)));
     for (int s = 0; s < 2; ++s) {
       HIP_TRY(hipHostMalloc(&hp.hFlags[s], 4 * sizeof(int), hipHostMallocDefault));
       for (auto& ev : hp.evSlice[s]) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    hp.chunk_entries = (size_t)8 << 20;                                  // 32 MiB of int32 per chunk: ~1.5 ms on PCIe Gen5, ~3 ms to widen on one core
-    for (int w = 0; w < NW; ++w)
-      for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipHostMalloc(&hp.hbuf[w][k], hp.chunk_entries * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&hp.evC[w][k], hipEventDisableTiming));
-      }
+    hp.chunk_entries = (size_t)4 << 20;                                  // 16 MiB of int32 per chunk
+    if (const char* env = std::getenv("PSF_HOST_WORKERS")) { const int v = std::atoi(env); if (v >= 1 && v <= NW) hp.nw = v; }
+    if (const char* env = std::getenv("PSF_HOST_CHUNK_MB")) { const long v = std::atol(env); if (v >= 1 && v <= 256) hp.chunk_entries = (size_t)v << 18; }
+    for (int s = 0; s < 2; ++s)
+      for (int w = 0; w < hp.nw; ++w)
+        for (int k = 0; k < 2; ++k) {
+          HIP_TRY(hipHostMalloc(&hp.hbuf[s][w][k], hp.chunk_entries * sizeof(int32_t), hipHostMallocDefault));
+          HIP_TRY(hipEventCreateWithFlags(&hp.evC[s][w][k], hipEventDisableTiming));
+        }
   }
   if (entries > hp.cap_entries) {
     for (int s = 0; s < 2; ++s) { const psf_status rc = hp_join(h, s); (void)rc; }
@@ -1174,9 +1193,12 @@ static psf_status hp_ensure(psfp_handle* h, size_t entries, size_t u_words) {
   }
   if (u_words > hp.u_cap) {
     for (int s = 0; s < 2; ++s) { const psf_status rc = hp_join(h, s); (void)rc; }
-    for (int s = 0; s < 2; ++s) { if (hp.hU[s]) hipHostFree(hp.hU[s]); hp.hU[s] = nullptr; }
+    for (int s = 0; s < 2; ++s) { if (hp.hU[s]) hipHostFree(hp.hU[s]); hp.hU[s] = nullptr; hipFree(hp.dU2[s]); hp.dU2[s] = nullptr; }
     hp.u_cap = 0;
-    for (int s = 0; s < 2; ++s) HIP_TRY(hipHostMalloc(&hp.hU[s], u_words * sizeof(uint64_t), hipHostMallocDefault));
+    for (int s = 0; s < 2; ++s) {
+      HIP_TRY(hipHostMalloc(&hp.hU[s], u_words * sizeof(uint64_t), hipHostMallocDefault));
+      HIP_TRY(hipMalloc(&hp.dU2[s], u_words * sizeof(uint64_t)));
+    }
     hp.u_cap = u_words;
   }
   return PSF_OK;
@@ -1194,7 +1216,6 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
   auto& hp = h->hp;
-  constexpr int NW = psfp_handle::HostPipe::NW;
   const size_t m = h->m, total = B * m;
   const int slot = (int)(hp.next & 1);
   psf_status rc = hp_join(h, slot);                         // the call before last used this slot
@@ -1205,14 +1226,17 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   rc = hp_ensure(h, total, B * h->n);
   if (rc != PSF_OK) return rc;
   ++hp.next;
-  // targets: pageable -> pinned (this thread) -> device on the compute stream (ordered behind the previous call's kernels, which read dU)
+  hipStream_t cs = hp.compute;
+  // targets: pageable -> pinned (this thread) -> this call's device copy, by a kernel at the head of the call on the compute stream
   std::memcpy(hp.hU[slot], u, B * h->n * sizeof(uint64_t));
-  HIP_TRY(hipMemcpyAsync(h->dU, hp.hU[slot], B * h->n * sizeof(uint64_t), hipMemcpyHostToDevice, h->s1));
+  hipLaunchKernelGGL(k_copy_words, dim3(64), dim3(256), 0, cs, hp.hU[slot], hp.dU2[slot], B * h->n);      // (see k_copy_words: not an SDMA copy)
+  const uint64_t* dUcall = hp.dU2[slot];
   if (h->timing) clear_slots(h);
   // slices: everything but a short tail, then the tail (its transfer is all that remains exposed behind the last kernel)
   size_t cuts[5] = {0, B, B, B, B};
   int nsl = 1;
-  if (!h->no_slice && !h->pipeline && B >= 2048) { cuts[1] = B - 1024; cuts[2] = B; nsl = 2; }
+  // (only the synchronous form cuts: in a loop of asynchronous calls the next call's compute covers the transfer, and two slices cost the product ~4 ms)
+  if (h->hp.slice_tail && !h->no_slice && !h->pipeline && B >= 2048) { cuts[1] = B - 1024; cuts[2] = B; nsl = 2; }
   if (const char* env = std::getenv("PSF_HOST_SLICE")) {    // experiments: equal slices of this many rows (at most four)
     const long v = std::atol(env);
     if (v >= 128 && !h->no_slice && !h->pipeline && (size_t)v < B) {
@@ -1222,23 +1246,23 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
   }
   struct FailGuard { psfp_handle* h; size_t B; ~FailGuard() { h->keep_fail = false; h->nbj = round_up(B, TR_BN) / TR_BN; } } guard{h, B};
-  HIP_TRY(hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), h->s1));
-  HIP_TRY(hipMemsetAsync(hp.dOvf, 0, 2 * sizeof(int), h->s1));
+  HIP_TRY(hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), cs));
+  HIP_TRY(hipMemsetAsync(hp.dOvf, 0, 2 * sizeof(int), cs));
   h->keep_fail = true;
   for (int j = 0; j < nsl; ++j) {
     const size_t off = cuts[j], cnt = cuts[j + 1] - cuts[j];
     h->nbj = round_up(cnt, TR_BN) / TR_BN;
-    rc = run_samp_p(h, seed, first_index + off, cnt, h->dU + off * h->n, h->dE + off * m, h->s1);
+    rc = run_samp_p(h, seed, first_index + off, cnt, dUcall + off * h->n, h->dE + off * m, cs);
     if (rc != PSF_OK) return rc;
-    hipLaunchKernelGGL(k_narrow_rows, dim3(grid_for(cnt * m / 2 + 1, 256, 256 * 16)), dim3(256), 0, h->s1, h->dE + off * m, hp.dE32[slot] + off * m, cnt * m, hp.dOvf);
+    hipLaunchKernelGGL(k_narrow_rows, dim3(grid_for(cnt * m / 2 + 1, 256, 256 * 16)), dim3(256), 0, cs, h->dE + off * m, hp.dE32[slot] + off * m, cnt * m, hp.dOvf);
     if (j == nsl - 1) {                                     // the call's flags travel with its last slice
-      HIP_TRY(hipMemcpyAsync(hp.hFlags[slot], h->dFail, 2 * sizeof(int), hipMemcpyDeviceToHost, h->s1));
-      HIP_TRY(hipMemcpyAsync(hp.hFlags[slot] + 2, hp.dOvf, sizeof(int), hipMemcpyDeviceToHost, h->s1));
+      HIP_TRY(hipMemcpyAsync(hp.hFlags[slot], h->dFail, 2 * sizeof(int), hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(hp.hFlags[slot] + 2, hp.dOvf, sizeof(int), hipMemcpyDeviceToHost, cs));
     }
-    HIP_TRY(hipEventRecord(hp.evSlice[slot][j], h->s1));
+    HIP_TRY(hipEventRecord(hp.evSlice[slot][j], cs));
   }
   HIP_TRY(hipGetLastError());
-  h->last_stream = h->s1;
+  h->last_stream = cs;
   // workers: chunk c of the call's entries belongs to worker c % NW; a worker copies its chunk into one of its two pinned buffers and widens the
   // previous one meanwhile
   const size_t CE = hp.chunk_entries, nchunks = (total + CE - 1) / CE;
@@ -1248,30 +1272,34 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   const int device = h->prm.device;
   size_t slice_end[4]; hipEvent_t slice_ev[4];
   for (int j = 0; j < nsl; ++j) { slice_end[j] = cuts[j + 1] * m; slice_ev[j] = hp.evSlice[slot][j]; }
-  auto worker = [&hp, slot, src, e, total, CE, nchunks, nsl, device, slice_end, slice_ev](int w) {
+  const int nw = hp.nw;
+  int dbg = 0;
+  if (const char* env = std::getenv("PSF_HOST_DEBUG")) dbg = std::atoi(env);      // measurement only: 1 = no widening, 2 = no copies either (e is NOT filled)
+  auto worker = [&hp, slot, src, e, total, CE, nchunks, nsl, device, slice_end, slice_ev, nw, dbg](int w) {
     if (hipSetDevice(device) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
     auto widen = [&](size_t c, int k) {
-      if (hipEventSynchronize(hp.evC[w][k]) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
+      if (hipEventSynchronize(hp.evC[slot][w][k]) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
       const size_t b0 = c * CE, cnt = total - b0 < CE ? total - b0 : CE;
-      const int32_t* hs = hp.hbuf[w][k];
+      const int32_t* hs = hp.hbuf[slot][w][k];
       int64_t* dst = e + b0;
+      if (dbg) return;
       for (size_t i = 0; i < cnt; ++i) dst[i] = (int64_t)hs[i];
     };
     long prev = -1; int pk = 0, k = 0;
-    for (size_t c = (size_t)w; c < nchunks; c += psfp_handle::HostPipe::NW) {
+    for (size_t c = (size_t)w; c < nchunks; c += (size_t)nw) {
       const size_t b0 = c * CE, cnt = total - b0 < CE ? total - b0 : CE;
       int j = 0;
       while (j < nsl - 1 && b0 + cnt > slice_end[j]) ++j;                // the last slice this chunk touches
       if (hipStreamWaitEvent(hp.copy, slice_ev[j], 0) != hipSuccess ||
-          hipMemcpyAsync(hp.hbuf[w][k], src + b0, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, hp.copy) != hipSuccess ||
-          hipEventRecord(hp.evC[w][k], hp.copy) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; break; }
+          (dbg < 2 ? hipMemcpyAsync(hp.hbuf[slot][w][k], src + b0, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, hp.copy) : hipSuccess) != hipSuccess ||
+          hipEventRecord(hp.evC[slot][w][k], hp.copy) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; break; }
       if (prev >= 0) widen((size_t)prev, pk);
       prev = (long)c; pk = k; k ^= 1;
     }
     if (prev >= 0) widen((size_t)prev, pk);
   };
   try {
-    for (int w = 0; w < NW && (size_t)w < nchunks; ++w) hp.workers[slot].emplace_back(worker, w);
+    for (int w = 0; w < nw && (size_t)w < nchunks; ++w) hp.workers[slot].emplace_back(worker, w);
   } catch (...) {                                                        // no thread available: the started ones finish, the rest of the rows are missing
     hp.status[slot] = (int)PSF_ERR_HIP;
   }
@@ -1313,7 +1341,9 @@ psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size
     HIP_TRY(hipMemcpy(e, h->dE, B * h->m * sizeof(int64_t), hipMemcpyDeviceToHost));
     return rc;
   }
+  h->hp.slice_tail = true;
   const psf_status rc = psfp_samp_p_async(h, seed, first_index, B, u, e);
+  h->hp.slice_tail = false;
   const psf_status rw = psfp_wait(h);
   return rc != PSF_OK ? rc : rw;
 }

@@ -104,6 +104,24 @@ class PSFPerturbation:
                                 _p(e, C.c_int64)), "samp_p")
         return e[0] if single else e
 
+    def samp_p_async(self, u, out, seed=0, first_index=0):
+        """psfp_samp_p_async: enqueue B samp_p calls on host buffers and return; `out` ((B, m) int64, C-contiguous) is complete after wait().
+        At most two calls are in flight per handle; `out` must stay alive (and untouched) until wait() -- the wrapper keeps a reference."""
+        u2 = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, self.n)
+        B = u2.shape[0]
+        assert out.dtype == np.int64 and out.shape == (B, self.m) and out.flags.c_contiguous
+        check(lib().psfp_samp_p_async(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64), _p(out, C.c_int64)),
+              "samp_p_async")
+        self._inflight = getattr(self, "_inflight", []) + [out]
+        return out
+
+    def wait(self):
+        """psfp_wait: every asynchronous call of this handle has completed; raises PsfError with the first failure (oldest call first)."""
+        try:
+            check(lib().psfp_wait(self._h), "wait")
+        finally:
+            self._inflight = []
+
     def f_a(self, sigma):
         """mp_perturbation.rs:366-369; raises PsfError(ERR_DOMAIN) where the reference's assert! panics."""
         sigma = np.ascontiguousarray(sigma, dtype=np.int64)
