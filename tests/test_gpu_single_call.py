@@ -78,3 +78,72 @@ def test_one_call_is_one_preimage_of_the_batch(pair, oracle):
     for b in (0, 63, 64, 199):
         e1 = psf.samp_p(u[b:b + 1], seed=77, first_index=1000 + b)
         assert (e1[0] == e[b]).all()
+
+
+def test_fused_call_with_a_general_base(T, oracle):
+    """base 3 / 5 gadgets (gadget_classical.rs:169-229 digits in base b) through the fused kernel"""
+    for n, k, base, q in [(4, 5, 3, 243), (3, 4, 5, 600)]:
+        m_bar = n * int(np.ceil(np.log2(q))) + 7
+        gp = T.GadgetParameters(n, k, m_bar, base, q)
+        r = 3.0
+        s = r * np.sqrt(base * base + 1) * (np.sqrt(m_bar) + np.sqrt(n * k) + 4.0) * 1.5
+        psf = T.PSFPerturbation(gp, r, s)
+        assert psf.m <= 256
+        A, (R, Lp, _) = psf.trap_gen(8)
+        orc = oracle.PSFPerturbation(oracle.GadgetParams(n, k, m_bar, base, q), r, s)
+        orc.load_key(A, R, Lp)
+        u = oracle.uniform_targets(2, 9, n, q)
+        e = psf.samp_p(u, seed=19)
+        assert (e == orc.samp_p(19, u)).all() and (psf.f_a(e) == u).all()
+        psf.close()
+
+
+FUSED = [  # (n, q, r, s): m <= 256, every kind of modulus / sampler word the stage kernels know
+    (8, 128, 3.0, 30.0),             # benches/psf.rs:51-66 (m = 121)
+    (8, 64, 3.0, 25.0),              # README.md:62-66
+    (15, 157, np.log2(15), 40.0),    # m = 256 exactly; prime modulus: digit column in S_k
+    (2, 2**60, 2.0, 70.0),           # k = 60, 128-bit products in v = u - A p
+    (2, 2**61 - 1, 2.0, 70.0),
+    (8, 64, 100.0, 25.0),            # |z| > 127
+    (8, 64, 400.0, 25.0),            # 32-bit attempt words
+]
+
+
+@pytest.mark.parametrize("n,q,r,s", FUSED)
+@pytest.mark.parametrize("B", [1, 5, 64])
+def test_fused_one_launch_call_gives_the_oracles_rows(T, oracle, monkeypatch, n, q, r, s, B):
+    """k_samp_p_small: the whole samp_p of a preimage in one workgroup (small m, few preimages -- the reference's own benchmarks, benches/psf.rs:51-66).
+    Same rows as the oracle and as the stage kernels (PSF_FUSED_MAX=0)."""
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+    assert psf.m <= 256
+    A, (R, Lp, _) = psf.trap_gen(31)
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s)
+    orc.load_key(A, R, Lp)
+    u = oracle.uniform_targets(12, B, n, q)
+    psf.enable_timing(True)
+    e = psf.samp_p(u, seed=600 + B, first_index=77)
+    assert "k_samp_p_small" in dict(psf.get_timing()), "the fused kernel did not run"
+    psf.enable_timing(False)
+    assert (e == orc.samp_p(600 + B, u, first_index=77)).all()
+    assert psf.check_domain(e).all() and (psf.f_a(e) == u).all()
+    monkeypatch.setenv("PSF_FUSED_MAX", "0")
+    assert (psf.samp_p(u, seed=600 + B, first_index=77) == e).all()
+    psf.close()
+
+
+def test_fused_call_with_a_general_base(T, oracle):
+    """base 3 / 5 gadgets (gadget_classical.rs:169-229 digits in base b) through the fused kernel"""
+    for n, k, base, q in [(4, 5, 3, 243), (3, 4, 5, 600)]:
+        m_bar = n * int(np.ceil(np.log2(q))) + 7
+        gp = T.GadgetParameters(n, k, m_bar, base, q)
+        r = 3.0
+        s = r * np.sqrt(base * base + 1) * (np.sqrt(m_bar) + np.sqrt(n * k) + 4.0) * 1.5
+        psf = T.PSFPerturbation(gp, r, s)
+        assert psf.m <= 256
+        A, (R, Lp, _) = psf.trap_gen(8)
+        orc = oracle.PSFPerturbation(oracle.GadgetParams(n, k, m_bar, base, q), r, s)
+        orc.load_key(A, R, Lp)
+        u = oracle.uniform_targets(2, 9, n, q)
+        e = psf.samp_p(u, seed=19)
+        assert (e == orc.samp_p(19, u)).all() and (psf.f_a(e) == u).all()
+        psf.close()

@@ -143,24 +143,18 @@ __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(cons
 // A draw costs one round (64 attempts miss with probability (11/12)^64 = 0.4 %) and the chain k of them.  Every lane pays an exact attempt, so this
 // form only pays while there are about as many problems as SIMDs; the host switches at n B <= 8192 (psfp.hip).
 // Checks mirror k_gadget_queue (|z_i| <= 16000, c in int16): the failure flag is raised by the same inputs.
-__global__ __launch_bounds__(256) void k_gadget_wave(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q, uint64_t base, size_t B, size_t ld,
-                                                     const uint64_t* __restrict__ V, GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
-                                                     int* __restrict__ fail) {
+// one problem (row j of v, preimage index `index`, value v = v_j mod q) on ONE WAVE; out(row r, z_r) is called by lane r < k.  Returns the failure flag.
+template <class Out>
+__device__ __forceinline__ int gadget_wave_problem(uint64_t seed, uint64_t index, uint32_t j, uint32_t k, uint64_t base, uint64_t v, const GadgetTablesQ& tb, Out&& out) {
   const int lane = threadIdx.x & 63;
-  const size_t pid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pid >= (size_t)n * B) return;                             // wave-uniform; no barrier in this kernel
-  const uint32_t j = (uint32_t)(pid / B);
-  const size_t b = pid % B;
   int f = 0;
   int c = 0;
   {  // digit `lane` of v_j (find_solution_gadget_vec): c = -x
-    uint64_t v = V[(size_t)j * ld + b] % q;
     uint64_t d = 0;
     if (base == 2) d = lane < 64 ? (v >> lane) & 1 : 0;
     else for (int t = 0; t <= lane && t < (int)k; ++t) { d = v % base; v = (v - d) / base; }
     if (lane < (int)k) c = -(int)d;
   }
-  const uint64_t index = first_index + b;
   const uint32_t tw = tag_word(TAG_GADGET, index), idx_lo = (uint32_t)index;
   // Nothing the chain waits for comes from memory: lane i holds the per-step scalars of step i (norm, SampleZ parameters, row ranges), read by
   // v_readlane when step i runs; column i of S_k and of the Gram-Schmidt matrix (lane r: row r) is loaded one step ahead.
@@ -168,12 +162,12 @@ __global__ __launch_bounds__(256) void k_gadget_wave(uint64_t seed, uint64_t fir
   const double my_norm2 = tb.norm2[li];
   const SampleZParams my_sz = tb.sz[li];
   const int my_glo = tb.rng[li], my_ghi = tb.rng[k + li];
-  auto bcast_d = [&](double v, int src) -> double {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(__double2loint(v), src), hi = (uint32_t)__builtin_amdgcn_readlane(__double2hiint(v), src);
+  auto bcast_d = [&](double x, int src) -> double {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(__double2loint(x), src), hi = (uint32_t)__builtin_amdgcn_readlane(__double2hiint(x), src);
     return __hiloint2double((int)hi, (int)lo);
   };
-  auto bcast_ll = [&](long long v, int src) -> long long {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+  auto bcast_ll = [&](long long x, int src) -> long long {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), src);
     return (long long)(((uint64_t)hi << 32) | lo);
   };
   double gcol = tb.gso[(size_t)li * k + (k - 1)];
@@ -212,19 +206,118 @@ __global__ __launch_bounds__(256) void k_gadget_wave(uint64_t seed, uint64_t fir
       c = nv;
     }
   }
+  if (lane < (int)k) out(lane, -c);
+  return f;
+}
+
+__global__ __launch_bounds__(256) void k_gadget_wave(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q, uint64_t base, size_t B, size_t ld,
+                                                     const uint64_t* __restrict__ V, GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
+                                                     int* __restrict__ fail) {
+  const size_t pid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pid >= (size_t)n * B) return;                             // wave-uniform; no barrier in this kernel
+  const uint32_t j = (uint32_t)(pid / B);
+  const size_t b = pid % B;
   int anyhi = 0;
-  if (lane < (int)k) {
-    const int32_t zz = -c;
+  const int f = gadget_wave_problem(seed, first_index + b, j, k, base, V[(size_t)j * ld + b] % q, tb, [&](int r, int zz) {
     const int32_t zl = (int32_t)(int8_t)(zz & 0xff);
     const int32_t zh = (zz - zl) >> 8;
-    const size_t cc = (size_t)j * k + (size_t)lane;
+    const size_t cc = (size_t)j * k + (size_t)r;
     const size_t addr = ((cc >> 4) * ld + b) * 16 + (cc & 15);
     Zlo[addr] = (int8_t)zl;
     Zhi[addr] = (int8_t)zh;
     if (zh) anyhi = 1;
-  }
+  });
   if (f) atomicOr(fail, 1);
   if (anyhi) atomicOr(fail + 1, 1);
+}
+
+// ---- the whole samp_p of ONE preimage in ONE workgroup, for small parameter sets (mp_perturbation.rs:304-336) ------------------------------------
+// The reference's own benchmarks call samp_p once at n = 8 (m = 121; benches/psf.rs:51-66): nine dependent launches cost more than the arithmetic.
+// Here workgroup b does everything for preimage b with LDS between the stages: normals (thread = coordinate), x = sqrt(Sigma_2) d (thread = row, one
+// ascending fma chain over the key's chunk stream), p <- D_{Z,r,x} (thread = coordinate), v = u - A p (all threads, partial sums mod q, then a tree),
+// the gadget walk (one wave per row of v: gadget_wave_problem), e = p + [R; I] z (thread = row).  Every value is the one the multi-kernel path
+// computes (same Philox streams, same chains, exact integers), so the bits are the oracle's.  Limits (host: fused_small_ok): m <= FS_MAX_M, no
+// structured factor.  Failure flag as in the stage kernels.
+constexpr int FS_MAX_M = 256;
+constexpr int FS_THREADS = 512;
+__global__ __launch_bounds__(FS_THREADS) void k_samp_p_small(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint32_t mb, uint64_t q, uint64_t two64,
+                                                             uint64_t base, const double* __restrict__ Lt, const uint64_t* __restrict__ A,
+                                                             const int8_t* __restrict__ R, size_t ldr, SampleZParams szR, GadgetTablesQ tb,
+                                                             const uint64_t* __restrict__ U, int64_t* __restrict__ E, int* __restrict__ fail) {
+  __shared__ double s_d[FS_MAX_M];
+  __shared__ double s_x[FS_MAX_M];
+  __shared__ int32_t s_p[FS_MAX_M];
+  __shared__ int32_t s_z[FS_MAX_M];
+  __shared__ uint64_t s_part[FS_THREADS];
+  const int tid = threadIdx.x;
+  const uint32_t w = n * k, m = mb + w;
+  const size_t b = blockIdx.x;
+  const uint64_t index = first_index + b;
+  int f = 0;
+  // 1a: d <- N(0,1)^m
+  for (uint32_t i = tid; i < m; i += FS_THREADS) s_d[i] = sample_normal(seed, index, i, &f);
+  __syncthreads();
+  // 1b: x_i = sum_{j <= i} L_ij d_j, ascending from +0 (element (i, j) of the chunk stream: psf_kernels.hpp, tr_chunk_pos)
+  for (uint32_t i = tid; i < m; i += FS_THREADS) {
+    const double* row = Lt + tr_rowblock_base(i / TR_BM) * TR_CHUNK;
+    const int r = (int)(i % TR_BM);
+    double acc = 0.0;
+    for (uint32_t j = 0; j <= i; ++j) acc = fma(row[(size_t)(j / TR_BK) * TR_CHUNK + tr_chunk_pos(r, (int)(j % TR_BK))], s_d[j], acc);
+    s_x[i] = acc;
+  }
+  __syncthreads();
+  // 1c: p_i <- D_{Z, r, x_i}
+  for (uint32_t i = tid; i < m; i += FS_THREADS) {
+    const double c = s_x[i];
+    const SzRange rg = sz_range(c, szR);
+    const uint32_t tw = tag_word(TAG_PERTURB, index);
+    long long x = 0;
+    bool acc = false;
+    for (uint32_t g = 0; g < kMaxAttempts / 4 && !acc; ++g) acc = sz_group4(seed, i, (uint32_t)index, tw, g, rg, c, szR.inv_s, &x);
+    if (!acc) { f = 1; x = (long long)floor(c + 0.5); }
+    if (x > kDigitRangeP || x < -kDigitRangeP) f = 1;
+    s_p[i] = (int32_t)x;
+  }
+  __syncthreads();
+  // 2: v_i = u_i - sum_j A_ij p_j mod q: thread t takes row t % n and the columns j = t / n, t / n + FS_THREADS / n, ...; partial sums mod q; tree over the row
+  const uint32_t per_row = FS_THREADS / n;                     // n <= FS_MAX_M / k: at least two threads per row
+  {
+    const uint32_t i = tid % n, slot = tid / n;
+    uint64_t s = 0;
+    if (slot < per_row)
+      for (uint32_t j = slot; j < m; j += per_row) {
+        const int32_t pj = s_p[j];
+        const uint64_t a = A[(size_t)i * m + j], ap = (uint64_t)(pj < 0 ? -(int64_t)pj : (int64_t)pj);
+        uint64_t t = acc128_mod(Acc128{a * ap, (int64_t)__umul64hi(a, ap)}, q, two64);
+        if (pj < 0 && t) t = q - t;
+        s += t; if (s >= q) s -= q;
+      }
+    s_part[tid] = s;
+  }
+  __syncthreads();
+  if (tid < (int)n) {                                           // thread i finishes row i
+    uint64_t s = 0;
+    for (uint32_t slot = 0; slot < per_row; ++slot) { s += s_part[slot * n + tid]; if (s >= q) s -= q; }
+    const uint64_t u = U[b * n + tid] % q;
+    s_part[tid] = u >= s ? u - s : u + q - s;                   // v_i (the partial sums of threads < n were read by their owners only: row i, slot 0 = thread i)
+  }
+  __syncthreads();
+  // 3: z <- the gadget walk, one wave per row of v
+  for (uint32_t j = tid >> 6; j < n; j += FS_THREADS / 64)
+    f |= gadget_wave_problem(seed, index, j, k, base, s_part[j], tb, [&](int r, int zz) { s_z[j * k + r] = zz; });
+  __syncthreads();
+  // 4: e = p + [R; I] z
+  for (uint32_t i = tid; i < m; i += FS_THREADS) {
+    int64_t e = (int64_t)s_p[i];
+    if (i < mb) {
+      const int8_t* rr = R + (size_t)i * ldr;
+      for (uint32_t c = 0; c < w; ++c) e += (int64_t)rr[c] * (int64_t)s_z[c];
+    } else {
+      e += (int64_t)s_z[i - mb];
+    }
+    E[b * m + i] = e;
+  }
+  if (f) atomicOr(fail, 1);
 }
 
 }  // namespace psf

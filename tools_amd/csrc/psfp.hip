@@ -930,6 +930,22 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     s2 = h->aux;
   }
   if (!h->keep_fail) hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
+  {  // small parameter sets, few preimages (the reference's own benchmarks: n = 8, one call; benches/psf.rs:51-66): the whole call in ONE launch, one
+     // workgroup per preimage (k_samp_p_small).  PSF_FUSED_MAX = largest batch it serves (0: never).  Stage exports need the intermediates: not here.
+    size_t fused_max = 64;
+    if (const char* e = std::getenv("PSF_FUSED_MAX")) fused_max = (size_t)std::atol(e);
+    if (!pipe && !h->structured && !h->no_slice && h->gadget_queue && m <= (size_t)FS_MAX_M && h->n <= 64 && B <= fused_max) {
+      ScopedTimer t(h, st, "k_samp_p_small");
+      GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
+      hipLaunchKernelGGL(k_samp_p_small, dim3((unsigned)B), dim3(FS_THREADS), 0, st, seed, first_index, (uint32_t)h->n, (uint32_t)h->k, (uint32_t)h->mb, h->q, h->two64,
+                         h->prm.gp.base, h->dLt, h->dA, h->dR, h->ldr, h->szR, tq, d_u, d_e, h->dFail);
+      HIP_TRY(hipGetLastError());
+      h->last_stream = user_st;
+      if (h->multi_t0 && h->multi_launched_ms < 0.0)
+        h->multi_launched_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - *h->multi_t0).count();
+      return PSF_OK;
+    }
+  }
   // Small batches (one samp_p call of the reference is ONE preimage, psf.rs:48-80): the streaming product, bound by reading the factor once, fed by
   // the compact normals stream.  PSF_TRMM_STREAM_MAX = largest batch it serves (0 switches it off); PSF_TRMM_STREAM_SHAPE = "RT,NB" forces a tile
   // shape, PSF_COMPACT_D=0 the chunk-stream layout of the normals (experiments; same bits).
