@@ -926,7 +926,7 @@ __device__ inline uint64_t zq_term(int32_t T, uint64_t pw, uint64_t q, uint64_t 
 // grid = (column tiles, row tiles, K splits).  A split covers at most 256 K-steps (16384 coordinates), so its int32 class
 // accumulators never overflow and are folded into a residue exactly once, after the loop; the per-split residues go to
 // `part[split][i][c]` and k_zq_combine adds them.  (Folding inside the K loop made hipcc spill accumulators to scratch.)
-template <int NA>
+template <int NA, bool FOLD128>
 __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, size_t n_pad, size_t K_pad, const int8_t* __restrict__ P8, size_t ld,
                                                  int ks_per_split, ZqConsts zc, int wide, uint64_t* __restrict__ part, size_t col0) {
   constexpr int STAGE = (NA + 3) * 4096;
@@ -999,22 +999,43 @@ __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, 
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        // S = sum_c T_c 256^c as ONE signed 128-bit integer (|S| < 2^31 2^(8 (NC - 1))), then a single reduction mod q: the per-class form
-        // ((T_c mod q) 256^c mod q, summed) cost two 64-bit divisions per class -- 192 per thread, more than the K loop of a short split
-        Acc128 S{0, 0};
+        uint64_t t = 0;
+        if constexpr (FOLD128) {
+          // S = sum_c T_c 256^c as ONE signed 128-bit integer (|S| < 2^31 2^(8 (NC - 1))), then a single reduction mod q: a short split of a single call
+          // spends more time in the per-class form below (two 64-bit divisions per class) than in its K loop
+          Acc128 S{0, 0};
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const int64_t T = (int64_t)acc[c][x][y][r];
-          const int sh = 8 * c;
-          uint64_t lo; int64_t hi;
-          if (sh == 0) { lo = (uint64_t)T; hi = T >> 63; }
-          else if (sh < 64) { lo = (uint64_t)T << sh; hi = T >> (64 - sh); }
-          else { lo = 0; hi = (int64_t)((uint64_t)T << (sh - 64)); }
-          const uint64_t nl = S.lo + lo;
-          S.hi += hi + (nl < S.lo ? 1 : 0);
-          S.lo = nl;
+          for (int c = 0; c < NC; ++c) {
+            const int64_t T = (int64_t)acc[c][x][y][r];
+            const int sh = 8 * c;
+            uint64_t lo; int64_t hi;
+            if (sh == 0) { lo = (uint64_t)T; hi = T >> 63; }
+            else if (sh < 64) { lo = (uint64_t)T << sh; hi = T >> (64 - sh); }
+            else { lo = 0; hi = (int64_t)((uint64_t)T << (sh - 64)); }
+            const uint64_t nl = S.lo + lo;
+            S.hi += hi + (nl < S.lo ? 1 : 0);
+            S.lo = nl;
+          }
+          t = acc128_mod(S, zc.q, zc.two64);
+        } else {
+          for (int c = 0; c < NC; ++c) {
+            int32_t T;
+            switch (c) {   // static register indices
+              case 0: T = acc[0][x][y][r]; break;
+              case 1: T = acc[1][x][y][r]; break;
+              case 2: T = acc[2 < NC ? 2 : 0][x][y][r]; break;
+              case 3: T = acc[3 < NC ? 3 : 0][x][y][r]; break;
+              case 4: T = acc[4 < NC ? 4 : 0][x][y][r]; break;
+              case 5: T = acc[5 < NC ? 5 : 0][x][y][r]; break;
+              case 6: T = acc[6 < NC ? 6 : 0][x][y][r]; break;
+              case 7: T = acc[7 < NC ? 7 : 0][x][y][r]; break;
+              case 8: T = acc[8 < NC ? 8 : 0][x][y][r]; break;
+              default: T = acc[9 < NC ? 9 : 0][x][y][r]; break;
+            }
+            t += zq_term(T, zc.pw[c], zc.q, zc.two64, wide != 0);
+            if (t >= zc.q) t -= zc.q;
+          }
         }
-        const uint64_t t = acc128_mod(S, zc.q, zc.two64);
         const size_t i = i0 + wr * 32 + x * 16 + 4 * g + r, cc = b0 + wc * 32 + y * 16 + r16;
         dst[i * ld + cc] = t;
       }
@@ -1248,11 +1269,15 @@ __host__ inline size_t gadget_queue_lds_bytes(size_t k, int problems = 0) {
   return tables + GQ_WAVES * per_wave + 64;
 }
 
+// FIXED: 128 problems per wave as a compile-time constant (full batches: the ring masks and strides fold; a run-time P cost 4 % there);
+// otherwise Prt (a power of two below 128) for mid-size batches, see gq_problems_for
+template <bool FIXED>
 __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q,
                                                       uint64_t base, size_t B, size_t ld, const uint64_t* __restrict__ V,
                                                       GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
-                                                      int* __restrict__ fail, int P) {
+                                                      int* __restrict__ fail, int Prt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gq_raw[];
+  const int P = FIXED ? 128 : Prt;
   double* s_gso = reinterpret_cast<double*>(gq_raw);                       // k*k
   double* s_norm2 = s_gso + (size_t)k * k;                                 // k
   SampleZParams* s_sz = reinterpret_cast<SampleZParams*>(s_norm2 + k);     // k

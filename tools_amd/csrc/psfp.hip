@@ -423,7 +423,8 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_mfma_big), hipFuncAttributeMaxDynamicSharedMemorySize, RCB_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rd2_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (1 + kFixPlanes) * 4096));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   if (const char* env = std::getenv("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
   for (int64_t v : h->hSk) if (v > 32767 || v < -32768) h->gadget_queue = false;      // the queue kernel keeps S_k in int16
   return PSF_OK;
@@ -689,9 +690,13 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
   const int nks = (int)(h->K_pad / 64);
   const int splits = zq_plan(h, ncols, h->zq_split_cap), zq_ks = (nks + splits - 1) / splits;
   dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64), (unsigned)splits);
+  int fold128 = zq_ks <= 32 ? 1 : 0;                                  // short splits (few preimages): one 128-bit fold per output; long ones: the per-class fold
+  if (const char* e = std::getenv("PSF_ZQ_FOLD128")) fold128 = std::atoi(e);
 #define ZQM(NA_)                                                                                                        \
   case NA_:                                                                                                             \
-    hipLaunchKernelGGL((k_zq_mfma<NA_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc,  \
+    if (fold128) hipLaunchKernelGGL((k_zq_mfma<NA_, true>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc,  \
+                       (int)h->wide, h->dPart, col0);                                                                   \
+    else hipLaunchKernelGGL((k_zq_mfma<NA_, false>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc,  \
                        (int)h->wide, h->dPart, col0);                                                                   \
     break;
   switch (h->NA) { ZQM(1) ZQM(2) ZQM(3) ZQM(4) ZQM(5) ZQM(6) ZQM(7) ZQM(8) default: break; }
@@ -1050,8 +1055,12 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         const int P = gq_problems_for((uint32_t)h->k, h->n * Bh);
         const size_t per_wg = (size_t)GQ_WAVES * P;
-        hipLaunchKernelGGL(k_gadget_queue, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k, P), sx, seed,
-                           first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail, P);
+        if (P == 128)
+          hipLaunchKernelGGL(k_gadget_queue<true>, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k, P), sx, seed,
+                             first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail, P);
+        else
+          hipLaunchKernelGGL(k_gadget_queue<false>, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k, P), sx, seed,
+                             first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail, P);
       } else {
         GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
         hipLaunchKernelGGL(k_gadget, dim3((unsigned)((Bh + 255) / 256), (unsigned)h->n), dim3(256), gadget_lds_bytes(h->k), sx, seed, first_index + b0,
