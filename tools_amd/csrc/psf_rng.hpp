@@ -198,16 +198,20 @@ __device__ inline bool sz_maybe(uint32_t wa, uint32_t wb, const SzRange rg, doub
 // only for the attempt that survives.  Outcome classes: 0 = certainly rejected; 1 = certainly accepted (wb + 1 <= 0.999 rho_f 2^16
 // < rho 2^16, so wb is below floor(rho 2^16) and no tie can occur); 2 = inside the +-0.1 % band around the threshold -- only
 // these are settled in f64.
+// Straight-line since round 4 (no early return: four screens behind four exec-mask branches were the largest single item of the rounding kernel's
+// iteration, profiles/r03_notes.md): every lane evaluates the whole screen and the class is selected at the end.  rho = 2^(-pi log2(e) a^2) with the two
+// constants merged into one multiply (the argument moves by < 1e-6 relative, rho by < 1.2e-4 relative at |arg| <= 113: inside the 0.1 % margins).
 __device__ inline int sz_screen16(uint32_t word, const SzRange rg, float c_rel, float inv_s_f, uint32_t* idx_out) {
   const uint32_t prod = __umul24(word >> 16, rg.N);
-  if ((prod & 0xffffu) < rg.thr) return 0;
+  const bool valid = (prod & 0xffffu) >= rg.thr;                       // Lemire: the attempt is void below the threshold
   const uint32_t idx = prod >> 16;
   const float a = ((float)idx + c_rel) * inv_s_f;
-  const float rho = __expf(-3.14159274f * (a * a));
+  const float rho = __builtin_amdgcn_exp2f(-4.53236014f * (a * a));    // exp(-pi a^2); v_exp_f32 flushes denormals to zero: covered by the absolute slack
   const float wbf = (float)(word & 0xffffu);
+  const bool maybe = wbf <= (rho * 1.001f + 1e-9f) * 65536.0f;         // not certainly rejected
+  const bool sure = wbf + 1.0f <= rho * 0.999f * 65536.0f;             // certainly accepted
   *idx_out = idx;
-  if (wbf > (rho * 1.001f + 1e-9f) * 65536.0f) return 0;
-  return (wbf + 1.0f <= rho * 0.999f * 65536.0f) ? 1 : 2;
+  return (valid && maybe) ? (sure ? 1 : 2) : 0;
 }
 // attempts 4g .. 4g+3 of one sample: screened in fp32, the first "maybe" settled exactly; the rare screened-in-but-rejected
 // case finishes the group with exact attempts, so the outcome is that of four sequential sz_attempt calls
@@ -227,7 +231,7 @@ __device__ inline bool sz_group4(uint64_t seed, uint32_t coord, uint32_t idx_lo,
     for (int j = 0; j < 4; ++j) {
       wa[j] = word[j] >> 16; wb[j] = word[j] & 0xffffu;
       uint32_t idx = 0;
-      const int cj = tm < 0 ? sz_screen16(word[j], rg, c_rel, inv_s_f, &idx) : 0;
+      const int cj = sz_screen16(word[j], rg, c_rel, inv_s_f, &idx);
       if (tm < 0 && cj) { tm = j; idxm = idx; cls = cj; }
     }
     if (tm >= 0) { wbm = wb[tm]; x = rg.lo + (long long)idxm; }
