@@ -231,6 +231,128 @@ __global__ __launch_bounds__(256) void k_gadget_wave(uint64_t seed, uint64_t fir
   if (anyhi) atomicOr(fail + 1, 1);
 }
 
+// ---- the same walk with SIXTEEN lanes per problem (four problems per wave): a handful to a few hundred preimages ------------------------------------
+// k_gadget_wave spends a whole wave's instruction stream on one problem; from ~1 k problems on that stream is what bounds the launch.  Here a DPP row
+// (16 lanes) owns a problem: lane n of the row holds c_r for r = n, n + 16, n + 32, n + 48; the 16 lanes evaluate attempts t0 .. t0 + 15 of the row's
+// current draw (exact rule), a draw takes 1.33 rounds on average (attempts miss with probability (11/12)^16), and the four rows of a wave share every
+// instruction, the ascending centre chain included -- its terms come from v_mov_dpp row_share (lane r % 16 of each row to the whole row), the
+// coefficients <-, b~_i> from v_readlane.  The DPP control is an immediate, so the chain is unrolled over the 64 possible rows behind wave-uniform
+// guards on the support of b~_i.  Same checks, same values as k_gadget_wave / k_gadget_queue.
+template <int N> __device__ __forceinline__ int ts_row_share(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false); }
+
+__global__ __launch_bounds__(256) void k_gadget_wave16(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q, uint64_t base, size_t B, size_t ld,
+                                                       const uint64_t* __restrict__ V, GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
+                                                       int* __restrict__ fail) {
+  const int lane = threadIdx.x & 63, row16 = lane >> 4, ln = lane & 15;
+  const size_t total = (size_t)n * B;
+  const size_t pid0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  if (pid0 >= total) return;                                    // wave-uniform; no barrier in this kernel
+  const size_t pid = pid0 + (size_t)row16;
+  const bool active = pid < total;
+  const uint32_t j = active ? (uint32_t)(pid / B) : 0;
+  const size_t b = active ? pid % B : 0;
+  int f = 0;
+  int c[4] = {0, 0, 0, 0};
+  {  // digits of v_j: row r = slot * 16 + ln
+    const uint64_t v0 = V[(size_t)j * ld + b] % q;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int r = sl * 16 + ln;
+      uint64_t v = v0, d = 0;
+      if (base == 2) d = (v >> r) & 1;
+      else for (int t = 0; t <= r && t < (int)k; ++t) { d = v % base; v = (v - d) / base; }
+      if (r < (int)k) c[sl] = -(int)d;
+    }
+  }
+  const uint64_t index = first_index + b;
+  const uint32_t tw = tag_word(TAG_GADGET, index), idx_lo = (uint32_t)index;
+  // per-step scalars and the coefficient column: held wave-wide, lane L <-> step / row L (k <= 64), read by v_readlane
+  const int li = lane < (int)k ? lane : 0;
+  const double my_norm2 = tb.norm2[li];
+  const SampleZParams my_sz = tb.sz[li];
+  const int my_glo = tb.rng[li], my_ghi = tb.rng[k + li];
+  auto bcast_d = [&](double x, int src) -> double {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(__double2loint(x), src), hi = (uint32_t)__builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double((int)hi, (int)lo);
+  };
+  auto bcast_ll = [&](long long x, int src) -> long long {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), src);
+    return (long long)(((uint64_t)hi << 32) | lo);
+  };
+  double gcol = tb.gso[(size_t)li * k + (k - 1)];
+  int skc[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) { const int r = sl * 16 + ln; skc[sl] = r < (int)k ? tb.Sk[(size_t)r * k + (k - 1)] : 0; }
+  for (int i = (int)k - 1; i >= 0; --i) {
+    const double g_now = gcol;
+    int sk_now[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) sk_now[sl] = skc[sl];
+    if (i > 0) {                                                 // in flight during this step
+      gcol = tb.gso[(size_t)li * k + (i - 1)];
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) { const int r = sl * 16 + ln; skc[sl] = r < (int)k ? tb.Sk[(size_t)r * k + (i - 1)] : 0; }
+    }
+    // centre <c, b~_i> / ||b~_i||^2: ONE ascending fma chain over the rows 0 .. k - 1 (zeros outside the support of b~_i), per DPP row its own c
+    double dot = 0.0;
+    const int glo = __builtin_amdgcn_readlane(my_glo, i), ghi = __builtin_amdgcn_readlane(my_ghi, i);      // support of b~_i (zeros outside: skipped, exact)
+    ts_for<0, 64>([&](auto R) {
+      constexpr int r = decltype(R)::value;
+      if (r >= glo && r <= ghi) dot = fma((double)ts_row_share<r % 16>(c[r / 16]), bcast_d(g_now, r), dot);      // (wave-uniform guard)
+    });
+    const double cen = dot / bcast_d(my_norm2, i);
+    SampleZParams sp;
+    sp.inv_s = bcast_d(my_sz.inv_s, i); sp.c6 = bcast_ll(my_sz.c6, i); sp.f6 = bcast_ll(my_sz.f6, i);
+    sp.n_int = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.n_int, i); sp.thr_int = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.thr_int, i);
+    sp.thr_frac = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.thr_frac, i); sp.sh = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.sh, i);
+    const SzRange rg = sz_range(cen, sp);
+    const uint32_t coord = j * k + (uint32_t)i;
+    long long x = 0;
+    bool found = !active;
+    for (uint32_t t0 = 0; t0 < kMaxAttempts; t0 += 16) {           // t0 advances for every row alike; a row that has found its draw idles
+      if (!__ballot(!found)) break;
+      const uint32_t t = t0 + (uint32_t)ln;
+      long long xl = 0;
+      bool acc = false;
+      if (!found) {
+        uint32_t wa, wb;
+        sz_attempt_words(seed, coord, idx_lo, tw, t, rg.sh, &wa, &wb);
+        acc = sz_attempt(seed, coord, idx_lo, tw, t, wa, wb, rg, cen, sp.inv_s, &xl);
+      }
+      const uint32_t gm = (uint32_t)(__ballot(acc) >> (16 * row16)) & 0xffffu;
+      const int fl = gm ? (16 * row16 + __builtin_ctz(gm)) : lane;
+      const long long xs = __shfl(xl, fl);
+      if (!found && gm) { x = xs; found = true; }
+    }
+    if (!found) { f = 1; x = (long long)floor(cen + 0.5); }
+    if (active && (x > 16000 || x < -16000)) f = 1;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int nv = c[sl] - (int)x * sk_now[sl];
+      if (active && sl * 16 + ln < (int)k && (nv > 32767 || nv < -32768)) f = 1;
+      c[sl] = nv;
+    }
+  }
+  int anyhi = 0;
+  if (active) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int r = sl * 16 + ln;
+      if (r >= (int)k) continue;
+      const int32_t zz = -c[sl];
+      const int32_t zl = (int32_t)(int8_t)(zz & 0xff);
+      const int32_t zh = (zz - zl) >> 8;
+      const size_t cc = (size_t)j * k + (size_t)r;
+      const size_t addr = ((cc >> 4) * ld + b) * 16 + (cc & 15);
+      Zlo[addr] = (int8_t)zl;
+      Zhi[addr] = (int8_t)zh;
+      if (zh) anyhi = 1;
+    }
+  }
+  if (f) atomicOr(fail, 1);
+  if (anyhi) atomicOr(fail + 1, 1);
+}
+
 // ---- the whole samp_p of ONE preimage in ONE workgroup, for small parameter sets (mp_perturbation.rs:304-336) ------------------------------------
 // The reference's own benchmarks call samp_p once at n = 8 (m = 121; benches/psf.rs:51-66): nine dependent launches cost more than the arithmetic.
 // Here workgroup b does everything for preimage b with LDS between the stages: normals (thread = coordinate), x = sqrt(Sigma_2) d (thread = row, one

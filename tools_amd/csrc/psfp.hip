@@ -1046,10 +1046,16 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
       ScopedTimer t(h, sx, "k_gadget");
       const char* genv = std::getenv("PSF_GADGET_WAVE");            // max n B served by the one-wave-per-problem kernel (0: never)
-      const size_t wave_max = genv ? (size_t)std::atol(genv) : 8192;
+      const size_t wave_max = genv ? (size_t)std::atol(genv) : 1024;
+      const char* genv16 = std::getenv("PSF_GADGET_WAVE16");        // max n B served by the sixteen-lanes-per-problem kernel (0: never)
+      const size_t wave16_max = genv16 ? (size_t)std::atol(genv16) : 65536;
       if (h->gadget_queue && h->n * Bh <= wave_max) {               // a single call / a handful of preimages: the chain of k draws is the launch time
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         hipLaunchKernelGGL(k_gadget_wave, dim3((unsigned)((h->n * Bh + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
+                           h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+      } else if (h->gadget_queue && h->n * Bh <= wave16_max) {      // up to a few hundred preimages: four problems per wave
+        GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
+        hipLaunchKernelGGL(k_gadget_wave16, dim3((unsigned)((h->n * Bh + 15) / 16)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
                            h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
       } else if (h->gadget_queue) {
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
