@@ -1048,7 +1048,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       const char* genv = std::getenv("PSF_GADGET_WAVE");            // max n B served by the one-wave-per-problem kernel (0: never)
       const size_t wave_max = genv ? (size_t)std::atol(genv) : 1024;
       const char* genv16 = std::getenv("PSF_GADGET_WAVE16");        // max n B served by the sixteen-lanes-per-problem kernel (0: never)
-      const size_t wave16_max = genv16 ? (size_t)std::atol(genv16) : 65536;
+      const size_t wave16_max = genv16 ? (size_t)std::atol(genv16) : 49152;     // measured at C3: 0.33 vs 0.48 ms at 64 preimages, 0.65 vs 0.60 at 128
       if (h->gadget_queue && h->n * Bh <= wave_max) {               // a single call / a handful of preimages: the chain of k draws is the launch time
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         hipLaunchKernelGGL(k_gadget_wave, dim3((unsigned)((h->n * Bh + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
