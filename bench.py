@@ -153,7 +153,7 @@ def main():
     # and the regime where reading the key from HBM once, not the FP64 pipe, is the roof.  Outside the timed region of the metric.
     latency = None
     if rank == 0 and scheme == "PSFPerturbation" and not args.no_latency and not args.structured:
-        latency = single_call_latency(psf, u, e, m, first_index, stream)
+        latency = single_call_latency(psf, u, e, m, first_index, stream, args.config)
 
     # correctness gate on the last step's output: A e == u and check_domain for every row
     u2 = torch.empty_like(u)
@@ -246,7 +246,7 @@ def main():
         sys.exit(4)
 
 
-def single_call_latency(psf, u, e, m, first_index, stream, reps=30):
+def single_call_latency(psf, u, e, m, first_index, stream, cfg="c3", reps=30):
     """One samp_p call at batch 1 / 16 / 64 through the device-pointer entry point: median of `reps` HIP-event times, each call synchronised on both
     sides (a latency, not a throughput), plus the per-kernel HIP-event times of one call.  The product of these calls is k_trmm_stream, bound by
     reading the factor (m(m+1)/2 doubles) from HBM once: `frac` = those bytes / its launch time / 8 TB/s."""
@@ -271,15 +271,15 @@ def single_call_latency(psf, u, e, m, first_index, stream, reps=30):
         call()
         tm = dict(psf.get_timing())
         psf.enable_timing(False)
-        out[f"c3_b{B}_ms"] = round(ts[len(ts) // 2], 4)
-        out[f"c3_b{B}_min_ms"] = round(ts[0], 4)
+        out[f"{cfg}_b{B}_ms"] = round(ts[len(ts) // 2], 4)
+        out[f"{cfg}_b{B}_min_ms"] = round(ts[0], 4)
         out[f"kernels_ms_b{B}"] = {k: round(v, 4) for k, v in tm.items()}
         if B == 1 and tm.get("k_trmm_f64"):
             gbps = key_bytes / (tm["k_trmm_f64"] * 1e-3) / 1e9
             out["product_ms_b1"] = round(tm["k_trmm_f64"], 4)
             out["achieved_GBps"] = round(gbps, 1)
             out["frac"] = round(gbps / PEAK_HBM_GBS, 4)                 # of the 8 TB/s spec; ~6.3 TB/s is what a streaming read achieves (MI355X_MICROARCH.md)
-            out["call_frac_b1"] = round(key_bytes / (out["c3_b1_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)   # the whole call against the same roof
+            out["call_frac_b1"] = round(key_bytes / (out[f"{cfg}_b1_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)   # the whole call against the same roof
     if psf.last_status() != 0:
         out["status"] = "sampler failure"
     return out

@@ -71,6 +71,8 @@ class PSFPerturbation {
   }
   void load_key(const MatZq& A, const Trapdoor& td) { check(psfp_load_key(h_, A.data(), td.R.data(), td.sqrt_sigma_2.data()), "load_key"); }
   void load_public_key(const MatZq& A) { check(psfp_load_key(h_, A.data(), nullptr, nullptr), "load_key"); }      // a verifier's handle: f_a / check_domain only
+  // (A, R) without a factor and without computing one: what compute_sqrt_sigma_2 (a pure function of mat_r and mat_sigma, :111) starts from; A may be null
+  void load_trapdoor(const std::vector<int8_t>& R, const MatZq* A = nullptr) { check(psfp_load_trapdoor(h_, A ? A->data() : nullptr, R.data()), "load_trapdoor"); }
   // compute_sqrt_sigma_2 (:111-139): Sigma = s_cov^2 I, or any symmetric covariance as its packed lower triangle (row i: i + 1 entries)
   void compute_sqrt_sigma_2(double s_cov) { check(psfp_compute_sqrt_sigma_2(h_, s_cov), "compute_sqrt_sigma_2"); }
   void compute_sqrt_sigma_2(const std::vector<double>& sigma_lower_packed) { check(psfp_compute_sqrt_sigma_2_dense(h_, sigma_lower_packed.data()), "compute_sqrt_sigma_2"); }
@@ -85,6 +87,13 @@ class PSFPerturbation {
     check(psfp_samp_p(h_, seed, first_index, B, u.data(), e.data()), "samp_p");
     return e;
   }
+  // the same, asynchronous: e (B * m entries, caller-owned) is complete after wait(); at most two calls in flight per handle
+  void samp_p_async(const MatZq& u, MatZ& e, uint64_t seed, uint64_t first_index = 0) {
+    const size_t B = u.size() / n();
+    e.resize(B * m());
+    check(psfp_samp_p_async(h_, seed, first_index, B, u.data(), e.data()), "samp_p_async");
+  }
+  void wait() { check(psfp_wait(h_), "wait"); }
   MatZq f_a(const MatZ& sigma) {                                                                  // :366-369
     if (sigma.empty() || sigma.size() % m() != 0) throw PsfError(PSF_ERR_DOMAIN, "f_a");
     const size_t B = sigma.size() / m();

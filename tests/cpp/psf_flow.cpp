@@ -30,6 +30,23 @@ int main() {
     bool threw = false;
     try { p.f_a(big); } catch (const PsfError& e) { threw = e.status == PSF_ERR_DOMAIN; }
     if (!threw) { std::printf("f_a accepted a vector outside D_n\n"); ok = false; }
+    {  // psfp_samp_p_async / psfp_wait: two calls in flight return the rows of two synchronous calls
+      auto key = p.trap_gen(7);
+      auto u1 = p.f_a(p.samp_d(8, 3)), u2 = p.f_a(p.samp_d(9, 3));
+      const MatZ s1 = p.samp_p(u1, 10), s2 = p.samp_p(u2, 11);
+      MatZ a1, a2;
+      p.samp_p_async(u1, a1, 10);
+      p.samp_p_async(u2, a2, 11);
+      p.wait();
+      if (a1 != s1 || a2 != s2) { std::printf("asynchronous calls differ from synchronous ones\n"); ok = false; }
+      // a trapdoor installed without a factor cannot sample until compute_sqrt_sigma_2 has run
+      PSFPerturbation p2(gadget_parameters_default(8, 64), 3.0, 25.0);
+      p2.load_trapdoor(key.second.R, &key.first);
+      bool nokey = false;
+      try { p2.samp_p(u1, 10); } catch (const PsfError& e) { nokey = e.status == PSF_ERR_NO_KEY; }
+      p2.compute_sqrt_sigma_2(25.0);
+      if (!nokey || p2.samp_p(u1, 10) != s1) { std::printf("load_trapdoor / compute_sqrt_sigma_2 flow failed\n"); ok = false; }
+    }
     return ok ? 0 : 1;
   } catch (const PsfError& e) {
     std::printf("PsfError: %s\n", e.what());

@@ -20,10 +20,11 @@ def sha(files):
     return h.hexdigest()[:16]
 
 
-def last_json(path):
+def last_json(path, key=None):
+    """the last JSON line of a log (the last one carrying `key`, if given)"""
     try:
         with open(path) as fh:
-            lines = [ln for ln in fh.read().splitlines() if ln.strip().startswith("{")]
+            lines = [ln for ln in fh.read().splitlines() if ln.strip().startswith("{") and (key is None or f'"{key}"' in ln)]
         return json.loads(lines[-1]) if lines else None
     except (OSError, ValueError):
         return None
@@ -42,6 +43,11 @@ COPY = {
     "probe_stream.log": "r04_probe_stream.log", "host_path.log": "r04_host_path.log", "host_async_timeline.txt": "r04_host_async_timeline.txt",
     "polymul.log": "r04_polymul.log", "kernel_stats_polymul.csv": "r04_kernel_stats_polymul.csv", "keygen.log": "r04_keygen.log",
 }
+for cfg in ("c3", "c2", "c4"):          # the bench line a profiled process printed sits in the middle of rocprofv3's own output
+    r = last_json(os.path.join(SRC, f"rocprof_{cfg}.log"), "metric")
+    if r:
+        with open(os.path.join(SRC, f"bench_under_rocprof_{cfg}.json"), "w") as fh:
+            json.dump(r, fh)
 for s, d in COPY.items():
     p = os.path.join(SRC, s)
     if os.path.exists(p) and os.path.getsize(p) > 0:
@@ -51,13 +57,13 @@ for s, d in COPY.items():
 
 # hash-tied traffic records
 t = {}
-c3 = last_json(os.path.join(SRC, "traffic_c3.json"))
+c3 = last_json(os.path.join(SRC, "traffic_c3.json"), "hbm_bytes_per_launch")
 if c3 and "hbm_bytes_per_launch" in c3:
     t["c3:B4096"] = {"hbm_bytes_per_launch": c3["hbm_bytes_per_launch"], "kernel": "k_trmm_f64_big", "kernel_source_sha256": sha(["psf_kernels.hpp"]),
                      "how": f"tools/pmc_traffic.sh c3 k_trmm_f64 (round 4): FETCH_SIZE {c3['FETCH_SIZE_KiB_avg']:.0f} KiB doubled + WRITE_SIZE {c3['WRITE_SIZE_KiB_avg']:.0f} KiB, "
                             "separate --pmc passes, averages over the launches of `bench.py --config c3 --steps 2 --warmup 1`",
                      "algorithmic_bytes_per_launch": 5840000000.0}
-c3s = last_json(os.path.join(SRC, "traffic_c3_structured.json"))
+c3s = last_json(os.path.join(SRC, "traffic_c3_structured.json"), "hbm_bytes_per_launch")
 if c3s and "hbm_bytes_per_launch" in c3s:
     t["c3:structured:B4096"] = {"hbm_bytes_per_launch": c3s["hbm_bytes_per_launch"], "kernel": "k_trmm_f64_big", "kernel_source_sha256": sha(["psf_kernels.hpp"]),
                                 "how": "same passes with --structured", "algorithmic_bytes_per_launch": 1960000000.0}
@@ -66,7 +72,7 @@ if t:
         json.dump(t, fh, indent=1)
 npt = {}
 for cfg, B, alg in (("c2", 1024, 515424256), ("c4", 4096, None)):
-    r = last_json(os.path.join(SRC, f"traffic_{cfg}.json"))
+    r = last_json(os.path.join(SRC, f"traffic_{cfg}.json"), "hbm_bytes_per_call")
     if r and "hbm_bytes_per_call" in r:
         old = {}
         try:

@@ -14,7 +14,7 @@ cd /tmp
 for cfg in c3 c2 c4; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$cfg -o t --output-format csv -- python3 $R/bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline > $O/rocprof_$cfg.log 2>&1
   f=$(ls $O/prof_$cfg/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_$cfg.csv
-  tail -1 $O/rocprof_$cfg.log > $O/bench_under_rocprof_$cfg.json
+  grep '^{"metric' $O/rocprof_$cfg.log | tail -1 > $O/bench_under_rocprof_$cfg.json
   rm -rf $O/prof_$cfg
 done
 cd $R
