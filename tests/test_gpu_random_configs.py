@@ -131,3 +131,16 @@ def test_ring_random_configuration(oracle, case):
     if psf.check_domain(sg).all():
         assert (psf.f_a(sg) == u).all()
     psf.close()
+
+
+LEGACY = {"PSF_TRMM_STREAM_MAX": "0", "PSF_FUSED_MAX": "0", "PSF_GADGET_WAVE": "0", "PSF_GADGET_WAVE16": "0", "PSF_COMPACT_D": "0", "PSF_ZQ_FOLD128": "0"}
+
+
+@pytest.mark.parametrize("case", range(0, 64, 3))
+def test_perturbation_random_configuration_on_the_batch_kernels(oracle, monkeypatch, case):
+    """Since round 4 every batch of this file's menus (<= 300 preimages) takes the single-call kernels (k_samp_p_small, k_trmm_stream, k_gadget_wave*, the
+    128-bit Z_q fold).  The same seeded draws with those switched off keep the batch kernels (k_trmm_f64_big, k_gadget_queue, the per-class fold, the
+    chunk-stream normals) under the random shapes they were found correct on."""
+    for k, v in LEGACY.items():
+        monkeypatch.setenv(k, v)
+    test_perturbation_random_configuration(oracle, case)

@@ -195,12 +195,12 @@ int main(int argc, char** argv) {
   const size_t nL = tr_total_chunks(nbi) * TR_CHUNK;
   const int ntile = (int)((m + 15) / 16);
   const size_t nLs = (size_t)128 * ntile * (ntile + 1);                  // tile streams
-  const size_t ld = 128, dstride = (size_t)ntile * 2 * 128 + 128;
+  const size_t ld = 256, dstride = (size_t)ntile * 2 * 128 + 128;
   double *L, *Ls, *D, *Ds, *X;
   unsigned long long* tlog;
-  CK(hipMalloc(&L, (nL + TS_SLACK_DOUBLES) * 8)); CK(hipMalloc(&Ls, nLs * 8)); CK(hipMalloc(&D, (nkb * TR_CHUNK + TS_SLACK_DOUBLES) * 8)); CK(hipMalloc(&Ds, 8 * dstride * 8)); CK(hipMalloc(&X, M_pad * ld * 8));
+  CK(hipMalloc(&L, (nL + TS_SLACK_DOUBLES) * 8)); CK(hipMalloc(&Ls, nLs * 8)); CK(hipMalloc(&D, (2 * nkb * TR_CHUNK + TS_SLACK_DOUBLES) * 8)); CK(hipMalloc(&Ds, 8 * dstride * 8)); CK(hipMalloc(&X, M_pad * ld * 8));
   CK(hipMalloc(&tlog, (size_t)ntile * 8 * 2 * 8));
-  k_fill<<<4096, 256>>>(L, nL, 1); k_fill<<<4096, 256>>>(Ls, nLs, 2); k_fill<<<1024, 256>>>(D, nkb * TR_CHUNK, 3); k_fill<<<256, 256>>>(Ds, 8 * dstride, 4);
+  k_fill<<<4096, 256>>>(L, nL, 1); k_fill<<<4096, 256>>>(Ls, nLs, 2); k_fill<<<1024, 256>>>(D, 2 * nkb * TR_CHUNK, 3); k_fill<<<256, 256>>>(Ds, 8 * dstride, 4);
   CK(hipDeviceSynchronize());
   const double bytes_tri = (double)ntile * (ntile + 1) / 2 * 4 * 512;     // bytes of the factor a launch must read (tiles to their diagonals)
   std::printf("m=%zu tiles=%d chunk stream %.2f GB, bytes to the diagonals %.3f GB\n", m, ntile, nL * 8 / 1e9, bytes_tri / 1e9);
@@ -248,5 +248,7 @@ int main(int argc, char** argv) {
   P1(1, 16, 0) P1(1, 24, 0) P1(1, 32, 1) P1(1, 24, 2)
   P0(2, 22, 0, 1) P0(4, 13, 0, 1) P0(4, 13, 1, 1) P0(4, 13, 2, 1)
   P1(2, 16, 0) P1(4, 8, 0) P1(4, 12, 0)
+  std::printf("-- 256 preimages\n");
+  PSC(2, 4, 8, 4, 4) PSC(4, 2, 10, 4, 8) PSC(4, 4, 6, 4, 4) PSC(4, 4, 5, 4, 4)
   return 0;
 }
