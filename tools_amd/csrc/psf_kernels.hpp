@@ -96,11 +96,12 @@ constexpr int kFixPlanes = 5;      // |q| < 2^39: normals beyond +-64 do not occ
 
 // ncf > 0: the COMPACT stream of small batches (k_trmm_stream, psf_stream_kernels.hpp): [k-step][column fragment of 16 preimages, ncf of them][lane],
 // position g -> coordinate 4 (g / (64 ncf)) + (g % 64) / 16, preimage 16 ((g / 64) % ncf) + g % 16 -- only the fragments in use exist, so a single
-// call draws m normals among m_pad x 16 positions instead of m_pad x 128.
+// call draws m normals among m_pad x 16 positions instead of m_pad x 128.  ncf = 0x100 + bc: the DENSE stream of a call with at most bc <= 16 preimages,
+// [k-step][preimage < bc][k % 4] (k_trmm_stream CD == 2): m_pad x bc positions, no padding columns at all.
 __global__ __launch_bounds__(256) void k_normals_wave(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t nkb, size_t nbj,
                                                       double* __restrict__ Dt, int* __restrict__ fail, NormalsFixed fx, uint32_t ncf, uint32_t seg) {
   const int lane = threadIdx.x & 63;
-  const size_t total = ncf ? nkb * 4 * (size_t)ncf * 64 : nbj * nkb * TR_CHUNK;
+  const size_t total = ncf >= 0x100u ? nkb * 4 * 4 * (size_t)(ncf - 0x100u) : ncf ? nkb * 4 * (size_t)ncf * 64 : nbj * nkb * TR_CHUNK;
   const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * seg;     // seg <= NR_SEG positions per wave (nr_segment: short for small batches)
   if (seg0 >= total) return;
   const size_t seg1 = seg0 + seg < total ? seg0 + seg : total;
@@ -110,6 +111,12 @@ __global__ __launch_bounds__(256) void k_normals_wave(uint64_t seed, uint64_t fi
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { cbj[i] = (chunk0 + i) / nkb; cbk[i] = (chunk0 + i) % nkb; }
   auto locate = [&](size_t g, size_t* coord, size_t* b) {
+    if (ncf >= 0x100u) {                                       // dense stream of <= 16 preimages: [k-step][preimage < bc][k % 4], bc = ncf - 0x100
+      const uint32_t bc = ncf - 0x100u;
+      *coord = (g / (4 * bc)) * 4 + (g & 3);
+      *b = (g >> 2) % bc;
+      return;
+    }
     if (ncf) {
       const uint32_t ln = (uint32_t)(g & 63);
       const size_t fr = g >> 6;                                // fragment index = k-step * ncf + column fragment
@@ -213,6 +220,7 @@ __global__ void k_export_normals(const double* __restrict__ Dt, size_t m, size_t
   const size_t total = m * B;
   for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const size_t b = g / m, coord = g % m;
+    if (ncf >= 0x100u) { out[g] = Dt[((coord / 4) * (ncf - 0x100u) + b) * 4 + coord % 4]; continue; }      // dense stream of <= 16 preimages
     if (ncf) { out[g] = Dt[((coord / 4) * ncf + b / 16) * 64 + (coord % 4) * 16 + b % 16]; continue; }      // compact stream of small batches
     const size_t chunk = (b / TR_BN) * nkb + coord / TR_BK;
     out[g] = Dt[chunk * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(coord % TR_BK))];

@@ -39,6 +39,7 @@ struct StreamGeom {
   int ntile;        // groups of RT 16-row tiles (ceil(rows / (16 RT)))
   int ncg;          // column groups of 16 NB preimages
   int ntask;        // ntile * ncg
+  int bc;           // CD == 2: preimages the dense normals stream stores per k-step (1, 2, 4, 8 or 16)
 };
 
 // task (descending length) -> (tile group, column group); column groups of one tile group are neighbours in the order
@@ -46,6 +47,7 @@ template <int RT, int NB, int PD, int HALF = 4, int CD = 0>
 __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
                                                         StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
   static_assert((PD - 1) * (RT + NB) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(CD != 2 || NB == 1, "the dense normals stream holds one fragment");
   static_assert(8 % RT == 0 && 8 % NB == 0, "a tile group stays inside one row block, a column group inside one column block");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -62,8 +64,16 @@ __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(cons
   // fragments of one column block (8 per 128 preimages) are 64 doubles apart, blocks nkb chunks apart; NB divides 8: a group stays inside its block
   // CD: the COMPACT normals stream of small batches, [k-step][column fragment][lane] over the g.ncg * NB fragments in use only -- consecutive k-steps of
   // a fragment are ncf * 512 B apart instead of 4 KiB (where every wave of the chip reads the same two L2 channels: tools/probe_stream.hip)
-  const size_t strideB = CD ? (size_t)g.ncg * NB * 64 : 512;       // doubles per k-step
-  const double* gB = CD ? Dt + (size_t)cf0 * 64 : Dt + (size_t)(cf0 >> 3) * nkb * TR_CHUNK + (size_t)(cf0 & 7) * 64;
+  // CD == 2 (one fragment, NB = 1, ncg = 1): the DENSE stream of a call with bc = 1, 2, 4, 8 or 16 preimages, [k-step][preimage < bc][k % 4] -- 32 bc
+  // bytes per k-step instead of 512: with one preimage the whole stream is 0.25 MB, resident in L1 / L2, and the normals kernel draws m_pad x bc
+  // positions instead of m_pad x 16.  (The product itself did not get faster: it sits at the ~10 B / clock / CU an HBM stream delivers, profiles/r04_notes.md.)
+  // Lanes whose column holds no preimage load a neighbour's value and replace it by zero before the MFMA.
+  const int bc = CD == 2 ? g.bc : 16;
+  const size_t strideB = CD == 2 ? (size_t)4 * bc : CD ? (size_t)g.ncg * NB * 64 : 512;       // doubles per k-step
+  const double* gB = CD == 2 ? Dt : CD ? Dt + (size_t)cf0 * 64 : Dt + (size_t)(cf0 >> 3) * nkb * TR_CHUNK + (size_t)(cf0 & 7) * 64;
+  const bool bact = CD != 2 || (lane & 15) < bc;
+  const int colB = (lane & 15) < bc ? (lane & 15) : bc - 1;           // lanes without a preimage read a neighbour's value and discard it (no exec-masked asm)
+  const uint32_t laneB = CD == 2 ? (uint32_t)((colB * 4 + (lane >> 4)) * 8) : (uint32_t)lane * 8u;
   // One k-step of a tile is 4 KiB further down the stream (8 tiles x 512 B), beyond the 12-bit immediate: ring slot u carries its own lane offset
   // (lane * 8 + u * 4096) and the two wave-uniform bases advance once per round of PD steps -- a k-step costs the wave its wait, its MFMAs and its
   // loads, nothing else.  (Measured with per-step scalar address arithmetic and guards: the LONGEST chain's issue time, not HBM, set the launch time.)
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(cons
   // the slack the host allocates behind both streams) and are never consumed; every round issues the same number of loads, so the wait count is exact.
   uint32_t voff[PD], voffB[PD];
 #pragma unroll
-  for (int u = 0; u < PD; ++u) { voff[u] = (uint32_t)lane * 8u + (uint32_t)u * 4096u; voffB[u] = CD ? (uint32_t)lane * 8u + (uint32_t)u * (uint32_t)strideB * 8u : voff[u]; }
+  for (int u = 0; u < PD; ++u) { voff[u] = (uint32_t)lane * 8u + (uint32_t)u * 4096u; voffB[u] = CD ? laneB + (uint32_t)u * (uint32_t)strideB * 8u : voff[u]; }
 
   d4 acc[RT][NB];
 #pragma unroll
@@ -94,7 +104,7 @@ __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(cons
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], (CD == 2 && !bact) ? 0.0 : bv[j], acc[i][j], 0, 0, 0);
   };
 #pragma unroll
   for (int u = 0; u < PD; ++u) issue(a[u], b[u], voff[u], voffB[u]);

@@ -965,11 +965,14 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   const int ncg = (int)((B + 16 * (size_t)NB - 1) / (16 * (size_t)NB));
   bool compact = stream && !h->structured;
   if (const char* e = std::getenv("PSF_COMPACT_D")) compact = compact && std::atoi(e) != 0;
-  const uint32_t ncf = compact ? (uint32_t)(ncg * NB) : 0u;      // column fragments of the compact normals stream
+  // <= 16 preimages in one fragment: the dense stream of bc = 1, 2, 4, 8, 16 preimages (PSF_COMPACT_D=1 keeps the fragment stream)
+  int bc = 0;
+  if (compact && NB == 1 && ncg == 1 && !(std::getenv("PSF_COMPACT_D") && std::atoi(std::getenv("PSF_COMPACT_D")) == 1)) { bc = 1; while ((size_t)bc < B) bc <<= 1; }
+  const uint32_t ncf = bc ? 0x100u + (uint32_t)bc : compact ? (uint32_t)(ncg * NB) : 0u;      // layout code of the normals stream (k_normals_wave)
   h->normals_ncf = ncf;
   {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
     ScopedTimer t(h, st, "k_normals");
-    const size_t npos = ncf ? h->nkb * 4 * (size_t)ncf * 64 : nbj * h->nkb * TR_CHUNK;
+    const size_t npos = bc ? h->nkb * 4 * 4 * (size_t)bc : ncf ? h->nkb * 4 * (size_t)ncf * 64 : nbj * h->nkb * TR_CHUNK;
     const uint32_t nseg = nr_segment(npos);
     const size_t nwaves = (npos + nseg - 1) / nseg;
     const NormalsFixed fx = h->structured ? NormalsFixed{h->mb, h->dD8, h->ldr * ld, ld, h->dX, h->h_const} : NormalsFixed{0, nullptr, 0, 0, nullptr, 0.0};
@@ -989,10 +992,13 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         g.ntile = (ntile16 + rt - 1) / rt;
         g.ncg = ncg;
         g.ntask = g.ntile * g.ncg;
+        g.bc = bc;
         hipLaunchKernelGGL(kern, dim3((unsigned)((g.ntask + 2 * half - 1) / (2 * half))), dim3(128 * half), 0, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
       };
 #define TS_GO(rt, nb, pd, half) { if (compact) go(k_trmm_stream<rt, nb, pd, half, 1>, rt, half); else go(k_trmm_stream<rt, nb, pd, half, 0>, rt, half); }
-      if (RT == 2 && NB == 1) TS_GO(2, 1, 12, 2)
+      if (bc && RT == 2 && NB == 1) go(k_trmm_stream<2, 1, 12, 2, 2>, 2, 2);
+      else if (bc && NB == 1) go(k_trmm_stream<1, 1, 8, 4, 2>, 1, 4);
+      else if (RT == 2 && NB == 1) TS_GO(2, 1, 12, 2)
       else if (RT == 2 && NB == 2 && B <= 32) TS_GO(2, 2, 8, 2)
       else if (RT == 2 && NB == 2) TS_GO(2, 2, 16, 4)
       else if (RT == 2 && NB == 4) TS_GO(2, 4, 8, 4)
