@@ -338,8 +338,16 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
   const SampleZParams* g_sz = a.sz + j0_of(J);                                              // full SampleZ tables, in L2: only 1 / s' is not in the LDS record
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef NP_ROLE_SPLIT_SIMD       /* every SIMD hosts one sampler and the helper of ANOTHER pair (waves w and w + 4 of a workgroup share a SIMD) */
   const bool helper = wave >= 4;
-  const int pw = helper ? ((wave + 1) & 3) : wave;                  // waves w and w + 4 share a SIMD: a sampler and ITS helper sit on different ones
+  const int pw = helper ? ((wave + 1) & 3) : wave;
+#else
+  // Measured in round 4 and NOT kept ("helper and sampler on different SIMDs"): samplers on the waves 0, 1, 4, 5 (two SIMDs, two dependent
+  // chains each) and helpers on 2, 3, 6, 7 (the other two SIMDs, two Philox streams each).  tools/probe_np_chain.hip: the chain alone on a SIMD takes ~420 ticks
+  // per step against ~1.1 k beside a helper -- but two helpers on one SIMD do not keep two samplers fed: C2 4.73 -> 5.03 ms, C4 4.84 -> 5.60 ms.  Same bits.
+  const bool helper = (wave & 2) != 0;
+  const int pw = (wave & 1) | ((wave >> 1) & 2);
+#endif
   const size_t j0 = J * NP_NB;
   const int nrows = (int)(dim - j0 < (size_t)NP_NB ? dim - j0 : (size_t)NP_NB);
 #ifdef NP_PROFILE
@@ -519,6 +527,9 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   NP_T(0);
+#ifndef NP_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(3);      // the sampler's dependent chain before the helper's Philox stream on the shared SIMD (round 4, tools/probe_np_chain.hip)
+#endif
   auto bcast_d = [&](double v, int src_in_sg) -> double {
     if (G == 1) return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_in_sg), __builtin_amdgcn_readlane(__double2loint(v), src_in_sg));
     return __shfl(v, sgbase + src_in_sg);
