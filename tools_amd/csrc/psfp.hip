@@ -700,8 +700,12 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
                        (int)h->wide, h->dPart, col0);                                                                   \
     break;
   switch (h->NA) { ZQM(1) ZQM(2) ZQM(3) ZQM(4) ZQM(5) ZQM(6) ZQM(7) ZQM(8) default: break; }
-  hipLaunchKernelGGL(k_zq_combine, dim3(grid_for(h->n * ncols, 256, 256 * 32)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols,
-                     h->q, U, out, ldo, col0);
+  if (splits >= 16 && h->n * ncols <= 16384)      // a single call: few outputs, many splits -- one wave per output
+    hipLaunchKernelGGL(k_zq_combine_wave, dim3((unsigned)((h->n * ncols + 3) / 4)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols,
+                       h->q, U, out, ldo, col0);
+  else
+    hipLaunchKernelGGL(k_zq_combine, dim3(grid_for(h->n * ncols, 256, 256 * 32)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols,
+                       h->q, U, out, ldo, col0);
 #undef ZQM
 }
 
