@@ -1424,7 +1424,10 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
     GQ_FENCE();
     // ---- advance a full wave of PENDING problems (or whatever is left once nothing else can run)
     const bool starving = !__ballot(has) && rcount == 0;
-    while (pcount >= 64 || (starving && pcount > 0)) {
+    // full batches advance 64 pending problems at a time; with P < 128 problems per wave (mid-size batches) the pass runs as soon as half of them are
+    // pending -- otherwise it only ran when every problem had drawn, and a round lasted as long as its slowest draw
+    const int adv = FIXED ? 64 : (P >= 128 ? 64 : (P >= 2 ? P / 2 : 1));
+    while (pcount >= adv || (starving && pcount > 0)) {
       const int cnt = pcount < 64 ? pcount : 64;
       bool to_ready = false;
       int p = 0;
