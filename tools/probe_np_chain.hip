@@ -55,9 +55,18 @@ __global__ __launch_bounds__(256) void k_chain(int iters, const float4* __restri
         if (V >= 3) {
           const bool bad = cc == cen || !(fabs(cen) < 0x1.0p30);
           const unsigned long long mc = __ballot(cand), m1 = __ballot(sure), bw = __ballot(bad);
+          if (V == 5) {
+            // selection without s_ff1 / v_readlane(SGPR lane): lowest candidate = mc & -mc; its index read by v_readfirstlane under exec = candidates
+            const unsigned long long first = mc & (0ull - mc);
+            int idx = 0;
+            if (cand) idx = __builtin_amdgcn_readfirstlane((int)__float_as_uint(rec.z) & 0xfff);
+            idx = __builtin_amdgcn_readfirstlane(idx);          // (uniform again for the lanes that were masked off)
+            z = (bw == 0 && (first & m1)) ? (long long)(lo + idx) : (long long)(lo + 1);
+          } else {
           const int fl = mc ? __builtin_ctzll(mc) : 0;
           const int idx = __builtin_amdgcn_readlane((int)__float_as_uint(rec.z) & 0xfff, fl);
           z = (bw == 0 && ((m1 >> fl) & 1)) ? (long long)(lo + idx) : (long long)(lo + 1);
+          }
         } else {
           z = lo + ((cand ? 1 : 0) + (sure ? 2 : 0));   // keeps the screen alive without the scalar part
         }
@@ -95,5 +104,6 @@ int main(int argc, char** argv) {
   run("2: + fp32 screen (fma, mul, v_exp_f32, two compares)", k_chain<2>);
   run("3: + three ballots, s_ff1, mask test, v_readlane(idx), z = lo + idx", k_chain<3>);
   run("4: + next step's record / g from LDS (ds_read_b128, ds_read_b64) in flight", k_chain<4>);
+  run("5: as 4, selection by v_readfirstlane under exec = candidates (no s_ff1, no v_readlane with an SGPR lane)", k_chain<5>);
   return 0;
 }

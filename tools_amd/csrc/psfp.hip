@@ -1277,7 +1277,9 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   size_t cuts[5] = {0, B, B, B, B};
   int nsl = 1;
   // (only the synchronous form cuts: in a loop of asynchronous calls the next call's compute covers the transfer, and two slices cost the product ~4 ms)
-  if (!h->no_slice && !h->pipeline && B >= 2048) { cuts[1] = B - 1024; cuts[2] = B; nsl = 2; }
+  size_t tail = 1024;
+  if (const char* env = std::getenv("PSF_HOST_TAIL")) { const long v = std::atol(env); if (v >= 128) tail = (size_t)v; }
+  if (!h->no_slice && !h->pipeline && B >= 2 * tail) { cuts[1] = B - tail; cuts[2] = B; nsl = 2; }
   if (const char* env = std::getenv("PSF_HOST_SLICE")) {    // experiments: equal slices of this many rows (at most four)
     const long v = std::atol(env);
     if (v >= 128 && !h->no_slice && !h->pipeline && (size_t)v < B) {
