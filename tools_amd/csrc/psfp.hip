@@ -1207,8 +1207,10 @@ static psf_status hp_ensure(psfp_handle* h, size_t entries, size_t u_words) {
        // So: copies on the HIGH-priority queue (PCIe-bound, a few waves), the asynchronous calls' kernels on a normal one (hp.compute).
       int lo_prio = 0, hi_prio = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-      HIP_TRY(hipStreamCreateWithPriority(&hp.copy, hipStreamNonBlocking, hi_prio));
-      HIP_TRY(hipStreamCreateWithPriority(&hp.compute, hipStreamNonBlocking, (lo_prio + hi_prio) / 2));
+      int pc = hi_prio, pk = (lo_prio + hi_prio) / 2;
+      if (const char* env = std::getenv("PSF_HOST_PRIO")) { if (std::atoi(env) == 0) pc = pk; else if (std::atoi(env) == 2) { pc = pk; pk = hi_prio; } }      // experiments: 0 = equal, 2 = compute high
+      HIP_TRY(hipStreamCreateWithPriority(&hp.copy, hipStreamNonBlocking, pc));
+      HIP_TRY(hipStreamCreateWithPriority(&hp.compute, hipStreamNonBlocking, pk));
     }
     HIP_TRY(hipMalloc(&hp.dOvf, 2 * sizeof(int)));
     for (int s = 0; s < 2; ++s) {
