@@ -360,6 +360,42 @@ impl GpuPSFPerturbation {
     }
 }
 
+/// The rows of an asynchronous batch: owns the buffers the library reads from / writes into until `GpuPSFPerturbation::wait_batches` has returned.
+pub struct PendingBatch {
+    rows: i64,
+    cols: i64,
+    _u: Vec<u64>,
+    e: Vec<i64>,
+}
+
+impl PendingBatch {
+    /// the preimages, one per row; only meaningful after `wait_batches`
+    pub fn into_matz(self) -> MatZ {
+        matz_from_rows(self.rows, self.cols, &self.e)
+    }
+}
+
+impl GpuPSFPerturbation {
+    /// `samp_p_batch` without waiting (`psfp_samp_p_async`): at most two batches in flight per handle; the rows of batch i cross PCIe and are widened
+    /// by worker threads while batch i + 1 computes.  Call `wait_batches` before `into_matz`.
+    pub fn samp_p_batch_async(&self, a: &MatZq, td: &<Self as PSF>::Trapdoor, targets: &MatZq) -> PendingBatch {
+        let (n, _, _, m) = self.dims();
+        self.ensure_key(a, td);
+        let b = targets.get_num_rows();
+        assert_eq!(targets.get_num_columns(), n, "one syndrome of length n per row");
+        let u = matzq_to_rows(targets);
+        let mut e = vec![0i64; (b * m) as usize];
+        let seed = next_seed(&self.seed, &self.calls);
+        check(unsafe { ffi::psfp_samp_p_async(self.handle, seed, 0, b as usize, u.as_ptr(), e.as_mut_ptr()) }, "psfp_samp_p_async");
+        PendingBatch { rows: b, cols: m, _u: u, e }
+    }
+
+    /// every asynchronous batch of this handle has completed (`psfp_wait`); panics with the first failure, oldest batch first
+    pub fn wait_batches(&self) {
+        check(unsafe { ffi::psfp_wait(self.handle) }, "psfp_wait");
+    }
+}
+
 impl Drop for GpuPSFPerturbation {
     fn drop(&mut self) {
         unsafe { ffi::psfp_destroy(self.handle) }

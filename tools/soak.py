@@ -54,7 +54,7 @@ for it in range(iters):
     psf.f_a_dev(e.data_ptr(), u2.data_ptr(), ok.data_ptr(), B, stream=st)
     torch.cuda.synchronize()
     inv = bool((u2 == u).all().item()) and bool(ok.all().item()) and status == 0
-    lo = (it * 37) % (B - rows)
+    lo = (it * 37) % (B - rows) if B > rows else 0
     uh = u[lo:lo + rows].cpu().numpy().astype(np.uint64)
     e_cpu = orc.samp_p(9000 + it, uh, first_index=it * B + lo, nthreads=threads)
     same = bool((e_cpu.reshape(rows, -1) == e[lo:lo + rows].cpu().numpy()).all())
