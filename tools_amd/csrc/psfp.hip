@@ -1231,7 +1231,7 @@ static psf_status hp_ensure(psfp_handle* h, size_t entries, size_t u_words) {
     for (int s = 0; s < 2; ++s) { const psf_status rc = hp_join(h, s); (void)rc; }
     for (int s = 0; s < 2; ++s) { hipFree(hp.dE32[s]); hp.dE32[s] = nullptr; }
     hp.cap_entries = 0;
-    for (int s = 0; s < 2; ++s) HIP_TRY(hipMalloc(&hp.dE32[s], entries * sizeof(int32_t)));
+    for (int s = 0; s < 2; ++s) HIP_TRY(hipMalloc(&hp.dE32[s], entries * sizeof(int32_t) + 8));      // (+8: the copy kernel moves 8-byte words)
     hp.cap_entries = entries;
   }
   if (u_words > hp.u_cap) {
@@ -1320,7 +1320,9 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   const int nw = hp.nw;
   int dbg = 0;
   if (const char* env = std::getenv("PSF_HOST_DEBUG")) dbg = std::atoi(env);      // measurement only: 1 = no widening, 2 = no copies either (e is NOT filled)
-  auto worker = [&hp, slot, src, e, total, CE, nchunks, nsl, device, slice_end, slice_ev, nw, dbg](int w) {
+  int copy_grid = 0;                                                     // > 0: chunks cross PCIe by a kernel of this many workgroups storing into the pinned buffer
+  if (const char* env = std::getenv("PSF_HOST_COPY_KERNEL")) copy_grid = std::atoi(env);
+  auto worker = [&hp, slot, src, e, total, CE, nchunks, nsl, device, slice_end, slice_ev, nw, dbg, copy_grid](int w) {
     if (hipSetDevice(device) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
     auto widen = [&](size_t c, int k) {
       if (hipEventSynchronize(hp.evC[slot][w][k]) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
@@ -1330,13 +1332,18 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
       if (dbg) return;
       for (size_t i = 0; i < cnt; ++i) dst[i] = (int64_t)hs[i];
     };
+    auto move_chunk = [&](int32_t* dst, const int32_t* from, size_t cnt) -> hipError_t {
+      if (copy_grid <= 0) return hipMemcpyAsync(dst, from, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, hp.copy);
+      hipLaunchKernelGGL(k_copy_words, dim3(copy_grid), dim3(256), 0, hp.copy, reinterpret_cast<const uint64_t*>(from), reinterpret_cast<uint64_t*>(dst), (cnt + 1) / 2);
+      return hipGetLastError();
+    };
     long prev = -1; int pk = 0, k = 0;
     for (size_t c = (size_t)w; c < nchunks; c += (size_t)nw) {
       const size_t b0 = c * CE, cnt = total - b0 < CE ? total - b0 : CE;
       int j = 0;
       while (j < nsl - 1 && b0 + cnt > slice_end[j]) ++j;                // the last slice this chunk touches
       if (hipStreamWaitEvent(hp.copy, slice_ev[j], 0) != hipSuccess ||
-          (dbg < 2 ? hipMemcpyAsync(hp.hbuf[slot][w][k], src + b0, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, hp.copy) : hipSuccess) != hipSuccess ||
+          (dbg < 2 ? move_chunk(hp.hbuf[slot][w][k], src + b0, cnt) : hipSuccess) != hipSuccess ||
           hipEventRecord(hp.evC[slot][w][k], hp.copy) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; break; }
       if (prev >= 0) widen((size_t)prev, pk);
       prev = (long)c; pk = k; k ^= 1;
