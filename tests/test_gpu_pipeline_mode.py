@@ -204,3 +204,38 @@ def test_overlapped_async_calls_return_the_rows_of_synchronous_ones(oracle):
     psf.wait()
     assert (outs[0] == psf.samp_p(us[0], seed=90)).all()
     psf.close()
+
+
+@pytest.mark.parametrize("mode", ["sdma", "runtime", "kernel:8"])
+def test_every_chunk_transport_of_the_host_path_returns_the_same_rows(oracle, monkeypatch, mode):
+    """PSF_HOST_COPY picks how a chunk of narrowed rows crosses PCIe: the DMA engine through the HSA runtime (default, psf_sdma.hpp), the HIP runtime's copies,
+    or a copy kernel storing into pinned memory.  Each must hand back the rows of the device-pointer path, with chunks smaller than a call (PSF_HOST_CHUNK_MB=1:
+    several chunks per worker, both pinned buffers of a worker in use) and asynchronous calls cut into slices or not."""
+    import numpy as np
+    import torch
+    import tools_amd as T
+    monkeypatch.setenv("PSF_HOST_COPY", mode)
+    monkeypatch.setenv("PSF_HOST_CHUNK_MB", "1")
+    n, q, r, s = 24, 2**10, 4.0, 80.0
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+    A, (R, Lp, _) = psf.trap_gen(6)
+    B = 2500                                                # 2500 x 505 int32 = 5 MB: five chunks, the last one ragged
+    u = oracle.uniform_targets(44, B, n, q)
+    dev = torch.device("cuda", 0)
+    ud = torch.from_numpy(u.astype(np.int64)).to(dev)
+    ed = torch.empty((B, psf.m), dtype=torch.int64, device=dev)
+    want = []
+    for i in range(3):
+        psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=300 + i, first_index=17 * i, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want.append(ed.cpu().numpy().copy())
+    for sliced in ("0", "1"):
+        monkeypatch.setenv("PSF_HOST_ASYNC_SLICE", sliced)
+        outs = [np.full((B, psf.m), -3, dtype=np.int64) for _ in range(3)]
+        for i in range(3):
+            psf.samp_p_async(u, outs[i], seed=300 + i, first_index=17 * i)
+        psf.wait()
+        for i in range(3):
+            assert (outs[i] == want[i]).all(), (mode, sliced, i)
+    assert (psf.samp_p(u, seed=300) == want[0]).all()       # the synchronous form (async + wait, tail slice)
+    psf.close()

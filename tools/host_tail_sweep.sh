@@ -1,0 +1,10 @@
+cd /root/repo
+run() { echo "=== $*"; env "$@" timeout 300 python3 tools/host_path_timing.py 8 2>&1 | grep -E "synchronous|async|device-pointer|same rows|fresh" | tail -9; }
+run PSF_HOST_TAIL=256
+run PSF_HOST_TAIL=512
+run PSF_HOST_TAIL=768
+run PSF_HOST_TAIL=1024
+run PSF_HOST_TAIL=2048
+run PSF_HOST_TAIL=4096
+run PSF_HOST_TAIL=512 PSF_HOST_WORKERS=8
+run PSF_HOST_TAIL=512 PSF_HOST_CHUNK_MB=8

@@ -17,6 +17,7 @@
 #include "psf_np_kernels.hpp"
 #include "psf_chol_kernels.hpp"
 #include "psf_gemm_kernels.hpp"
+#include "psf_sdma.hpp"
 
 #define PSFP_FLAG_NO_PERTURB 1u   // internal: handle used as the Z_q / f_a engine of PSFGPV(Ring); no sqrt(Sigma_2) buffers
 // PSFP_FLAG_STRUCTURED_SQRT (2u) is public: include/psf_mi355x.h
@@ -105,6 +106,11 @@ struct psfp_handle {
     std::atomic<int> status[2] = {{0}, {0}};     // psf_status of the call in each slot (written by its workers)
     size_t next = 0;                            // slot of the next asynchronous call
     bool slice_tail = false;                    // set by psfp_samp_p around its own asynchronous call: cut a short last slice (single-call latency)
+    int copy_mode = 1;                          // how a chunk crosses PCIe: 1 = SDMA engine through the HSA runtime (psf_sdma.hpp), 0 = hipMemcpyAsync, 2 = a copy kernel (PSF_HOST_COPY)
+    int copy_grid = 32;                         // workgroups of the copy kernel (mode 2)
+    psf::SdmaCopy sdma;
+    hsa_signal_t sigC[2][NW][2] = {};           // mode 1: chunk landed in its pinned buffer
+    hsa_signal_t sigU = {};                     // mode 1: the call's targets have reached the device
     hipStream_t copy = nullptr;                 // D2H stream (high priority)
     hipStream_t compute = nullptr;              // stream of the asynchronous calls' kernels (normal priority)
   } hp;
@@ -1161,6 +1167,33 @@ psf_status psfp_samp_p_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, 
 }
 
 // ---- host-pointer entry points ---------------------------------------------------------------------------------------------------------------
+// int32 -> int64 into the caller's rows with streaming stores: the destination is written once and not read here, so there is no point in pulling its
+// lines into the cache first (a plain loop moves 20 bytes per entry through the memory system, this one 12) -- the widening of a C3 batch is 1.5 GB of
+// host memory traffic per call and has to fit under the next call's 60 ms on a handful of threads.
+static void widen_rows(int64_t* __restrict__ dst, const int32_t* __restrict__ src, size_t cnt) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  typedef long long v2l __attribute__((ext_vector_type(2)));
+  size_t i = 0;
+  while (i < cnt && (reinterpret_cast<uintptr_t>(dst + i) & 15)) { dst[i] = (int64_t)src[i]; ++i; }
+  for (; i + 4 <= cnt; i += 4) {
+    v4i x;
+    std::memcpy(&x, src + i, sizeof(x));
+    const v2i a = __builtin_shufflevector(x, x, 0, 1), b = __builtin_shufflevector(x, x, 2, 3);
+    __builtin_nontemporal_store(__builtin_convertvector(a, v2l), reinterpret_cast<v2l*>(dst + i));
+    __builtin_nontemporal_store(__builtin_convertvector(b, v2l), reinterpret_cast<v2l*>(dst + i + 2));
+  }
+  for (; i < cnt; ++i) dst[i] = (int64_t)src[i];
+  std::atomic_thread_fence(std::memory_order_seq_cst);      // (streaming stores are weakly ordered: fence before the thread reports its chunk done)
+}
+
+// The flags of an asynchronous call: cleared and sent to pinned host memory by one-wave kernels in stream order.  (hipMemsetAsync / hipMemcpyAsync on the
+// compute stream go through the runtime's copy path, where they queue behind the chunk copies of the call before: the next call's kernels then waited for them.)
+__global__ void k_host_flags_clear(int* __restrict__ fail, int* __restrict__ ovf) { if (threadIdx.x < 2) { fail[threadIdx.x] = 0; ovf[threadIdx.x] = 0; } }
+__global__ void k_host_flags_send(const int* __restrict__ fail, const int* __restrict__ ovf, int* __restrict__ host_flags) {
+  if (threadIdx.x == 0) { host_flags[0] = fail[0]; host_flags[1] = fail[1]; host_flags[2] = ovf[0]; host_flags[3] = 0; __threadfence_system(); }
+}
+
 // wait for the asynchronous call in `slot` (its workers have copied and widened every row), release it, return its status
 static psf_status hp_join(psfp_handle* h, int slot) {
   auto& hp = h->hp;
@@ -1186,7 +1219,10 @@ static void hp_release(psfp_handle* h) {
       for (int k = 0; k < 2; ++k) {
         if (hp.hbuf[s][w][k]) { hipHostFree(hp.hbuf[s][w][k]); hp.hbuf[s][w][k] = nullptr; }
         if (hp.evC[s][w][k]) { hipEventDestroy(hp.evC[s][w][k]); hp.evC[s][w][k] = nullptr; }
+        if (hp.sigC[s][w][k].handle) { hp.sdma.drop_signal(hp.sigC[s][w][k]); hp.sigC[s][w][k].handle = 0; }
       }
+  if (hp.sigU.handle) { hp.sdma.drop_signal(hp.sigU); hp.sigU.handle = 0; }
+  hp.sdma.close();
   hipFree(hp.dOvf); hp.dOvf = nullptr;
   for (int s = 0; s < 2; ++s) {
     if (hp.hU[s]) { hipHostFree(hp.hU[s]); hp.hU[s] = nullptr; }
@@ -1220,11 +1256,24 @@ static psf_status hp_ensure(psfp_handle* h, size_t entries, size_t u_words) {
     hp.chunk_entries = (size_t)4 << 20;                                  // 16 MiB of int32 per chunk
     if (const char* env = std::getenv("PSF_HOST_WORKERS")) { const int v = std::atoi(env); if (v >= 1 && v <= NW) hp.nw = v; }
     if (const char* env = std::getenv("PSF_HOST_CHUNK_MB")) { const long v = std::atol(env); if (v >= 1 && v <= 256) hp.chunk_entries = (size_t)v << 18; }
+    if (const char* env = std::getenv("PSF_HOST_COPY")) {                 // sdma (default) | runtime | kernel[:workgroups]
+      if (std::strncmp(env, "runtime", 7) == 0) hp.copy_mode = 0;
+      else if (std::strncmp(env, "kernel", 6) == 0) { hp.copy_mode = 2; if (env[6] == ':') { const int g = std::atoi(env + 7); if (g >= 1 && g <= 4096) hp.copy_grid = g; } }
+    }
+    if (hp.copy_mode == 1) {
+      int dom = 0, bus = 0, dv = 0;
+      HIP_TRY(hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, h->prm.device));
+      HIP_TRY(hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, h->prm.device));
+      HIP_TRY(hipDeviceGetAttribute(&dv, hipDeviceAttributePciDeviceId, h->prm.device));
+      if (!hp.sdma.open(dom, bus, dv)) hp.copy_mode = 0;                  // no HSA agent for this device: the HIP copies (slower under overlap, same rows)
+      else if (!hp.sdma.make_signal(&hp.sigU)) return PSF_ERR_HIP;
+    }
     for (int s = 0; s < 2; ++s)
       for (int w = 0; w < hp.nw; ++w)
         for (int k = 0; k < 2; ++k) {
           HIP_TRY(hipHostMalloc(&hp.hbuf[s][w][k], hp.chunk_entries * sizeof(int32_t), hipHostMallocDefault));
           HIP_TRY(hipEventCreateWithFlags(&hp.evC[s][w][k], hipEventDisableTiming));
+          if (hp.copy_mode == 1 && !hp.sdma.make_signal(&hp.sigC[s][w][k])) return PSF_ERR_HIP;
         }
   }
   if (entries > hp.cap_entries) {
@@ -1272,16 +1321,22 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   hipStream_t cs = hp.compute;
   // targets: pageable -> pinned (this thread) -> this call's device copy, by a kernel at the head of the call on the compute stream
   std::memcpy(hp.hU[slot], u, B * h->n * sizeof(uint64_t));
-  hipLaunchKernelGGL(k_copy_words, dim3(64), dim3(256), 0, cs, hp.hU[slot], hp.dU2[slot], B * h->n);      // (see k_copy_words: not an SDMA copy)
+  if (hp.copy_mode == 1) {                                  // by the DMA engine, now, while the call before computes (dU2[slot]'s last reader has been joined above)
+    if (!hp.sdma.start_upload(hp.dU2[slot], hp.hU[slot], B * h->n * sizeof(uint64_t), hp.sigU) || !hp.sdma.wait(hp.sigU)) return PSF_ERR_HIP;
+  } else {
+    hipLaunchKernelGGL(k_copy_words, dim3(64), dim3(256), 0, cs, hp.hU[slot], hp.dU2[slot], B * h->n);    // (see k_copy_words: a HIP copy would queue behind the download before)
+  }
   const uint64_t* dUcall = hp.dU2[slot];
   if (h->timing) clear_slots(h);
   // slices: everything but a short tail, then the tail (its transfer is all that remains exposed behind the last kernel)
   size_t cuts[5] = {0, B, B, B, B};
   int nsl = 1;
-  // (only the synchronous form cuts: in a loop of asynchronous calls the next call's compute covers the transfer, and two slices cost the product ~4 ms)
+  // (two slices cost the product ~4 ms)
   size_t tail = 1024;
   if (const char* env = std::getenv("PSF_HOST_TAIL")) { const long v = std::atol(env); if (v >= 128) tail = (size_t)v; }
-  if (!h->no_slice && !h->pipeline && B >= 2 * tail) { cuts[1] = B - tail; cuts[2] = B; nsl = 2; }
+  bool cut = hp.slice_tail;                                 // the synchronous form only: behind an asynchronous call the next call's compute covers the transfer
+  if (const char* env = std::getenv("PSF_HOST_ASYNC_SLICE")) cut = cut || std::atoi(env) != 0;      // experiments: 1 = asynchronous calls cut the tail slice too
+  if (cut && !h->no_slice && !h->pipeline && B >= 2 * tail) { cuts[1] = B - tail; cuts[2] = B; nsl = 2; }
   if (const char* env = std::getenv("PSF_HOST_SLICE")) {    // experiments: equal slices of this many rows (at most four)
     const long v = std::atol(env);
     if (v >= 128 && !h->no_slice && !h->pipeline && (size_t)v < B) {
@@ -1291,8 +1346,7 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
   }
   struct FailGuard { psfp_handle* h; size_t B; ~FailGuard() { h->keep_fail = false; h->nbj = round_up(B, TR_BN) / TR_BN; } } guard{h, B};
-  HIP_TRY(hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), cs));
-  HIP_TRY(hipMemsetAsync(hp.dOvf, 0, 2 * sizeof(int), cs));
+  hipLaunchKernelGGL(k_host_flags_clear, dim3(1), dim3(64), 0, cs, h->dFail, hp.dOvf);
   h->keep_fail = true;
   for (int j = 0; j < nsl; ++j) {
     const size_t off = cuts[j], cnt = cuts[j + 1] - cuts[j];
@@ -1301,8 +1355,7 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
     if (rc != PSF_OK) return rc;
     hipLaunchKernelGGL(k_narrow_rows, dim3(grid_for(cnt * m / 2 + 1, 256, 256 * 16)), dim3(256), 0, cs, h->dE + off * m, hp.dE32[slot] + off * m, cnt * m, hp.dOvf);
     if (j == nsl - 1) {                                     // the call's flags travel with its last slice
-      HIP_TRY(hipMemcpyAsync(hp.hFlags[slot], h->dFail, 2 * sizeof(int), hipMemcpyDeviceToHost, cs));
-      HIP_TRY(hipMemcpyAsync(hp.hFlags[slot] + 2, hp.dOvf, sizeof(int), hipMemcpyDeviceToHost, cs));
+      hipLaunchKernelGGL(k_host_flags_send, dim3(1), dim3(64), 0, cs, h->dFail, hp.dOvf, hp.hFlags[slot]);
     }
     HIP_TRY(hipEventRecord(hp.evSlice[slot][j], cs));
   }
@@ -1320,20 +1373,21 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   const int nw = hp.nw;
   int dbg = 0;
   if (const char* env = std::getenv("PSF_HOST_DEBUG")) dbg = std::atoi(env);      // measurement only: 1 = no widening, 2 = no copies either (e is NOT filled)
-  int copy_grid = 0;                                                     // > 0: chunks cross PCIe by a kernel of this many workgroups storing into the pinned buffer
-  if (const char* env = std::getenv("PSF_HOST_COPY_KERNEL")) copy_grid = std::atoi(env);
-  auto worker = [&hp, slot, src, e, total, CE, nchunks, nsl, device, slice_end, slice_ev, nw, dbg, copy_grid](int w) {
+  const int copy_mode = hp.copy_mode, copy_grid = hp.copy_grid;
+  const bool plain_widen = std::getenv("PSF_HOST_PLAIN_WIDEN") != nullptr;      // measurement only: the scalar loop with ordinary stores
+  auto worker = [&hp, slot, src, e, total, CE, nchunks, nsl, device, slice_end, slice_ev, nw, dbg, copy_mode, copy_grid, plain_widen](int w) {
     if (hipSetDevice(device) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
     auto widen = [&](size_t c, int k) {
-      if (hipEventSynchronize(hp.evC[slot][w][k]) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
+      if (copy_mode == 1 ? (dbg < 2 && !hp.sdma.wait(hp.sigC[slot][w][k])) : hipEventSynchronize(hp.evC[slot][w][k]) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
       const size_t b0 = c * CE, cnt = total - b0 < CE ? total - b0 : CE;
       const int32_t* hs = hp.hbuf[slot][w][k];
       int64_t* dst = e + b0;
       if (dbg) return;
-      for (size_t i = 0; i < cnt; ++i) dst[i] = (int64_t)hs[i];
+      if (plain_widen) { for (size_t i = 0; i < cnt; ++i) dst[i] = (int64_t)hs[i]; }
+      else widen_rows(dst, hs, cnt);
     };
     auto move_chunk = [&](int32_t* dst, const int32_t* from, size_t cnt) -> hipError_t {
-      if (copy_grid <= 0) return hipMemcpyAsync(dst, from, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, hp.copy);
+      if (copy_mode == 0) return hipMemcpyAsync(dst, from, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, hp.copy);
       hipLaunchKernelGGL(k_copy_words, dim3(copy_grid), dim3(256), 0, hp.copy, reinterpret_cast<const uint64_t*>(from), reinterpret_cast<uint64_t*>(dst), (cnt + 1) / 2);
       return hipGetLastError();
     };
@@ -1342,9 +1396,12 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
       const size_t b0 = c * CE, cnt = total - b0 < CE ? total - b0 : CE;
       int j = 0;
       while (j < nsl - 1 && b0 + cnt > slice_end[j]) ++j;                // the last slice this chunk touches
-      if (hipStreamWaitEvent(hp.copy, slice_ev[j], 0) != hipSuccess ||
-          (dbg < 2 ? move_chunk(hp.hbuf[slot][w][k], src + b0, cnt) : hipSuccess) != hipSuccess ||
-          hipEventRecord(hp.evC[slot][w][k], hp.copy) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; break; }
+      if (copy_mode == 1) {                                              // the slice's rows are complete (host wait), then the DMA engine moves the chunk
+        if (hipEventSynchronize(slice_ev[j]) != hipSuccess ||
+            (dbg < 2 && !hp.sdma.start(hp.hbuf[slot][w][k], src + b0, cnt * sizeof(int32_t), hp.sigC[slot][w][k]))) { hp.status[slot] = (int)PSF_ERR_HIP; break; }
+      } else if (hipStreamWaitEvent(hp.copy, slice_ev[j], 0) != hipSuccess ||
+                 (dbg < 2 ? move_chunk(hp.hbuf[slot][w][k], src + b0, cnt) : hipSuccess) != hipSuccess ||
+                 hipEventRecord(hp.evC[slot][w][k], hp.copy) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; break; }
       if (prev >= 0) widen((size_t)prev, pk);
       prev = (long)c; pk = k; k ^= 1;
     }
