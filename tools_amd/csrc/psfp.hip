@@ -8,6 +8,7 @@
 #include <string>
 #include <thread>
 #include <atomic>
+#include <functional>
 #include <vector>
 #include "../../include/psf_mi355x.h"
 #include "psf_host.hpp"
@@ -85,6 +86,9 @@ struct psfp_handle {
   uint64_t* dPart = nullptr; int zq_split_cap = 1;   // per-split residues of the int8-MFMA Z_q product
   bool gadget_queue = true;   // task-queue gadget sampler (PSF_GADGET_QUEUE=0: lock-step kernel)
   bool keep_fail = false;     // sliced host path: the failure flags accumulate over the slices of one call
+  // host path: the targets are first read by the syndrome stage, ~50 ms into a C3 batch -- this runs (once) on the calling thread right before that stage is
+  // enqueued, i.e. while the product already executes: staging and upload of u cost the call nothing
+  std::function<psf_status()> before_u;
   // Host-pointer calls (psfp_samp_p / psfp_samp_p_async): rows are narrowed to int32 on the device, cross PCIe in chunks into pinned buffers and are
   // widened into the caller's int64 rows by worker threads, while the compute stream already runs the next slice / the next call.
   struct HostPipe {
@@ -945,11 +949,15 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     s2 = h->aux;
   }
   if (!h->keep_fail) hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
+  psf_status gate_rc = PSF_OK;
+  auto u_gate = [&]() { if (h->before_u) { auto f = std::move(h->before_u); h->before_u = nullptr; gate_rc = f(); } };
   {  // small parameter sets, few preimages (the reference's own benchmarks: n = 8, one call; benches/psf.rs:51-66): the whole call in ONE launch, one
      // workgroup per preimage (k_samp_p_small).  PSF_FUSED_MAX = largest batch it serves (0: never).  Stage exports need the intermediates: not here.
     size_t fused_max = 64;
     if (const char* e = std::getenv("PSF_FUSED_MAX")) fused_max = (size_t)std::atol(e);
     if (!pipe && !h->structured && !h->no_slice && h->gadget_queue && m <= (size_t)FS_MAX_M && h->n <= 64 && B <= fused_max) {
+      u_gate();
+      if (gate_rc != PSF_OK) return gate_rc;
       ScopedTimer t(h, st, "k_samp_p_small");
       GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
       hipLaunchKernelGGL(k_samp_p_small, dim3((unsigned)B), dim3(FS_THREADS), 0, st, seed, first_index, (uint32_t)h->n, (uint32_t)h->k, (uint32_t)h->mb, h->q, h->two64,
@@ -1055,6 +1063,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         hipLaunchKernelGGL(k_perturb_round_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, m, Bh, ld, h->dX + b0, h->szR, h->dP + b0, h->dFail);
       }
     }
+    u_gate();                                                      // (host path: u reaches the device now)
     {  // mp_perturbation.rs:318 -- v = u - A p
       ScopedTimer t(h, sx, "k_zq_matmul(syndrome)");
       launch_zq_mfma(h, sx, ZQ_SYNDROME, h->dP, h->dP8, Bh, d_u, h->dV, ld, b0);
@@ -1140,6 +1149,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     HIP_TRY(hipStreamWaitEvent(user_st, h->evP[cur], 0));   // results of this call are ordered before later work on the caller's stream
   }
   HIP_TRY(hipGetLastError());
+  if (gate_rc != PSF_OK) return gate_rc;
   h->last_stream = user_st;
   if (h->multi_t0 && h->multi_launched_ms < 0.0)
     h->multi_launched_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - *h->multi_t0).count();
@@ -1319,12 +1329,23 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   if (rc != PSF_OK) return rc;
   ++hp.next;
   hipStream_t cs = hp.compute;
-  // targets: pageable -> pinned (this thread) -> this call's device copy, by a kernel at the head of the call on the compute stream
-  std::memcpy(hp.hU[slot], u, B * h->n * sizeof(uint64_t));
-  if (hp.copy_mode == 1) {                                  // by the DMA engine, now, while the call before computes (dU2[slot]'s last reader has been joined above)
-    if (!hp.sdma.start_upload(hp.dU2[slot], hp.hU[slot], B * h->n * sizeof(uint64_t), hp.sigU) || !hp.sdma.wait(hp.sigU)) return PSF_ERR_HIP;
-  } else {
-    hipLaunchKernelGGL(k_copy_words, dim3(64), dim3(256), 0, cs, hp.hU[slot], hp.dU2[slot], B * h->n);    // (see k_copy_words: a HIP copy would queue behind the download before)
+  // targets: pageable -> pinned (this thread) -> this call's device copy -- deferred until the syndrome stage of the first slice is about to be enqueued
+  // (h->before_u, run_samp_p): by then the product is executing, and neither the staging copy nor the upload delays the call
+  h->before_u = [h, slot, u, B, cs]() -> psf_status {
+    auto& hp = h->hp;
+    std::memcpy(hp.hU[slot], u, B * h->n * sizeof(uint64_t));
+    if (hp.copy_mode == 1) {                                // by the DMA engine (dU2[slot]'s last reader was joined before this call began)
+      if (!hp.sdma.start_upload(hp.dU2[slot], hp.hU[slot], B * h->n * sizeof(uint64_t), hp.sigU) || !hp.sdma.wait(hp.sigU)) return PSF_ERR_HIP;
+    } else {
+      hipLaunchKernelGGL(k_copy_words, dim3(64), dim3(256), 0, cs, hp.hU[slot], hp.dU2[slot], B * h->n);  // (see k_copy_words: a HIP copy would queue behind the download before)
+    }
+    return PSF_OK;
+  };
+  struct GateGuard { psfp_handle* h; ~GateGuard() { h->before_u = nullptr; } } gate_guard{h};      // (an error return must not leave a callback with dead captures behind)
+  if (hp.copy_mode != 1) {                                  // the copy kernel is ordered by the compute stream only: at the head of the call, as before
+    auto f = std::move(h->before_u); h->before_u = nullptr;
+    rc = f();
+    if (rc != PSF_OK) return rc;
   }
   const uint64_t* dUcall = hp.dU2[slot];
   if (h->timing) clear_slots(h);
