@@ -452,4 +452,129 @@ __global__ __launch_bounds__(FS_THREADS) void k_samp_p_small(uint64_t seed, uint
   if (f) atomicOr(fail, 1);
 }
 
+// e = p + [R; I] z (mp_perturbation.rs:328-335) for a handful of preimages (B <= NB <= 4): R is read ONCE, as a stream of 16-byte row pieces, by one wave per
+// row (all of a row's pieces in flight at once, 15 KB at C3); z of every preimage sits in LDS as its two balanced int8 digit planes in the planes' own 16-byte
+// groups, so a lane's piece of R meets the matching 16 digits with four v_dot4_i32_i8 per plane.  Integer sums: any order is exact.  The matrix-core kernel
+// pads such a call to 128 columns and splits K over atomics (68 us + 15 us for the bottom part at C3, one preimage); this one is bound by reading R's 237 MB.
+// LDS: 32 B x ldr / 16 x B.  Rows are dealt to the workgroups' waves round robin; the identity block (e_bot = p_bot + z) rides along.
+template <int NB>
+__global__ __launch_bounds__(512) void k_recombine_small(const int8_t* __restrict__ R, size_t ldr, size_t mbar, size_t w, const int8_t* __restrict__ Zlo,
+                                                         const int8_t* __restrict__ Zhi, size_t ld, const int32_t* __restrict__ P, size_t B, int64_t* __restrict__ E, size_t m) {
+  extern __shared__ int4 s_zd[];                                // [b][plane][group]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ng = (int)(ldr / 16);
+  for (int e = tid; e < (int)B * 2 * ng; e += 512) {
+    const int g = e % ng, pl = (e / ng) & 1, b = e / (2 * ng);
+    s_zd[e] = *reinterpret_cast<const int4*>((pl ? Zhi : Zlo) + ((size_t)g * ld + (size_t)b) * 16);
+  }
+  __syncthreads();
+  // identity block
+  const int8_t* zb = reinterpret_cast<const int8_t*>(s_zd);
+  for (size_t g = (size_t)blockIdx.x * 512 + tid; g < w * B; g += (size_t)gridDim.x * 512) {
+    const size_t b = g / w, c = g % w;
+    const size_t at = ((b * 2) * (size_t)ng + (c >> 4)) * 16 + (c & 15);
+    E[b * m + mbar + c] = (int64_t)P[(mbar + c) * ld + b] + (int64_t)zb[at] + 256 * (int64_t)zb[at + (size_t)ng * 16];
+  }
+  // trapdoor block: one wave per row
+  for (size_t i = (size_t)blockIdx.x * 8 + wave; i < mbar; i += (size_t)gridDim.x * 8) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i* row = reinterpret_cast<const v4i*>(R + i * ldr);
+    int accl[NB], acch[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { accl[b] = 0; acch[b] = 0; }
+    for (int g0 = 0; g0 < ng; g0 += 16 * 64) {
+      v4i r[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int g = g0 + u * 64 + lane;
+        r[u] = g < ng ? __builtin_nontemporal_load(row + g) : v4i{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int g = g0 + u * 64 + lane;
+        if (g0 + u * 64 >= ng) break;                          // (wave-uniform)
+        const int gc = g < ng ? g : 0;                         // (a lane beyond the row holds r = 0)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (b >= (int)B) break;
+          const int4 zl = s_zd[(b * 2) * ng + gc], zh = s_zd[(b * 2 + 1) * ng + gc];
+          accl[b] = __builtin_amdgcn_sdot4(r[u].x, zl.x, accl[b], false); accl[b] = __builtin_amdgcn_sdot4(r[u].y, zl.y, accl[b], false);
+          accl[b] = __builtin_amdgcn_sdot4(r[u].z, zl.z, accl[b], false); accl[b] = __builtin_amdgcn_sdot4(r[u].w, zl.w, accl[b], false);
+          acch[b] = __builtin_amdgcn_sdot4(r[u].x, zh.x, acch[b], false); acch[b] = __builtin_amdgcn_sdot4(r[u].y, zh.y, acch[b], false);
+          acch[b] = __builtin_amdgcn_sdot4(r[u].z, zh.z, acch[b], false); acch[b] = __builtin_amdgcn_sdot4(r[u].w, zh.w, acch[b], false);
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b >= (int)B) break;
+      long long v = (long long)accl[b] + 256 * (long long)acch[b];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) E[(size_t)b * m + i] = (int64_t)P[i * ld + (size_t)b] + (int64_t)v;
+    }
+  }
+}
+
+// A p mod q (the sum of v = u - A p, mp_perturbation.rs:318) for a handful of preimages (B <= NB <= 4): A is read ONCE as 64-bit words, row by row, by one
+// wave per (row, K range); the range's entries of p (int32, |p| < 2^23) sit in LDS.  A word a < 2^62 meets p as two signed 64-bit sums (low and high 32 bits of a:
+// at most SYN_KLEN / 64 = 32 terms of < 2^55 per lane), joined in 128 bits, reduced over the wave and taken mod q once -- integer arithmetic, exact in any order.
+// The residues go where the matrix-core product puts its per-split residues ([split][n_pad][ld]); k_zq_combine_wave finishes v as before.  The int8 matrix-core
+// path (digit planes of p, LDS-staged tiles, 46 + 6 us at C3 for one preimage) is bound by its staging; this one by reading A's 126 MB.
+constexpr int SYN_KLEN = 2048;
+template <int NB>
+__global__ __launch_bounds__(512) void k_syndrome_small(const uint64_t* __restrict__ A, size_t n, size_t m, const int32_t* __restrict__ P, size_t ld, size_t B, uint64_t q,
+                                                        int rows_per_wg, uint64_t* __restrict__ part, size_t n_pad, size_t col0) {
+  __shared__ int s_p[NB * SYN_KLEN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t j0 = (size_t)blockIdx.x * SYN_KLEN;
+  const int klen = (int)(m - j0 < (size_t)SYN_KLEN ? m - j0 : (size_t)SYN_KLEN);
+  for (int e = tid; e < NB * SYN_KLEN; e += 512) {
+    const int b = e / SYN_KLEN, jj = e % SYN_KLEN;
+    s_p[e] = (b < (int)B && jj < klen) ? P[(j0 + (size_t)jj) * ld + col0 + (size_t)b] : 0;
+  }
+  __syncthreads();
+  const size_t i_end = ((size_t)blockIdx.y + 1) * (size_t)rows_per_wg < n ? ((size_t)blockIdx.y + 1) * (size_t)rows_per_wg : n;
+  for (size_t i = (size_t)blockIdx.y * (size_t)rows_per_wg + wave; i < i_end; i += 8) {
+    const uint64_t* a = A + i * m + j0;
+    long long lo[NB], hi[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { lo[b] = 0; hi[b] = 0; }
+#pragma unroll 1
+    for (int h0 = 0; h0 < SYN_KLEN / 64; h0 += 8) {
+      if (h0 * 64 >= klen) break;
+      uint64_t av[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int jj = (h0 + u) * 64 + lane; av[u] = jj < klen ? __builtin_nontemporal_load(a + jj) : 0ull; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int jj = (h0 + u) * 64 + lane;
+        const long long al = (long long)(uint32_t)av[u], ah = (long long)(av[u] >> 32);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const long long pv = (long long)s_p[b * SYN_KLEN + jj];
+          lo[b] += al * pv;
+          hi[b] += ah * pv;
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b >= (int)B) break;
+      __int128 v = (__int128)lo[b] + (((__int128)hi[b]) << 32);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long ol = __shfl_xor((unsigned long long)v, off);
+        const long long oh = __shfl_xor((long long)(v >> 64), off);
+        v += (((__int128)oh) << 64) | (__int128)ol;
+      }
+      if (lane == 0) {
+        __int128 r = v % (__int128)q;
+        if (r < 0) r += (__int128)q;
+        part[((size_t)blockIdx.x * n_pad + i) * ld + col0 + (size_t)b] = (uint64_t)r;
+      }
+    }
+  }
+}
+
 }  // namespace psf

@@ -95,7 +95,7 @@ struct psfp_handle {
     static constexpr int NW = 8;                // at most this many worker threads per call (each: its own pinned chunk buffers, copies + widening of chunks c = w mod nw)
     int nw = 4;                                 // workers in use (PSF_HOST_WORKERS)
     int32_t* dE32[2] = {nullptr, nullptr};      // device: narrowed rows of the call in flight, two calls deep
-    size_t cap_entries = 0;                     // entries each dE32 holds
+    size_t cap_entries[2] = {0, 0};             // entries dE32[slot] holds
     int32_t* hbuf[2][NW][2] = {};               // pinned chunk buffers [call slot][worker][double buffer]: two calls in flight never share one
     hipEvent_t evC[2][NW][2] = {};              // chunk landed in its pinned buffer
     size_t chunk_entries = 0;
@@ -104,7 +104,7 @@ struct psfp_handle {
     int* dOvf = nullptr;                        // device: overflow flag of the narrowing kernel
     uint64_t* hU[2] = {nullptr, nullptr};       // pinned staging of the targets (a copy from pageable memory would block the caller behind the stream)
     uint64_t* dU2[2] = {nullptr, nullptr};      // device copy of the targets per call in flight (filled by k_copy_words at the head of the call)
-    size_t u_cap = 0;
+    size_t u_cap[2] = {0, 0};
     std::vector<std::thread> workers[2];
     bool busy[2] = {false, false};
     std::atomic<int> status[2] = {{0}, {0}};     // psf_status of the call in each slot (written by its workers)
@@ -431,6 +431,9 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_mfma_big), hipFuncAttributeMaxDynamicSharedMemorySize, RCB_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rd2_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (1 + kFixPlanes) * 4096));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
@@ -694,6 +697,21 @@ static void split_A(psfp_handle* h) {
 // out = (mode syndrome) U - A P  or  (mode f_a) A P for the columns [col0, col0 + ncols), with P (K x ld int32) first cut into digit planes
 static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32_t* P, int8_t* P8, size_t ncols, const uint64_t* U, uint64_t* out, size_t ldo, size_t col0 = 0) {
   const size_t ld = h->ld;
+  {  // a handful of preimages: A streamed once as 64-bit words (k_syndrome_small; PSF_SYNDROME_SMALL = largest batch it serves, 0: never)
+    size_t small_max = 1;                                             // measured at C3: 39 vs 48 us at one preimage, 52 vs 50 at two, 81 vs 50 at four (64-bit multiply-adds)
+    if (const char* e = std::getenv("PSF_SYNDROME_SMALL")) small_max = (size_t)std::atol(e);
+    if (small_max > 4) small_max = 4;
+    const int splits = (int)((h->m + SYN_KLEN - 1) / SYN_KLEN);
+    if (mode == ZQ_SYNDROME && P == h->dP && ncols <= small_max && splits <= h->zq_split_cap && splits <= 64) {
+      const int rows_per_wg = 16;
+      dim3 grid((unsigned)splits, (unsigned)((h->n + rows_per_wg - 1) / rows_per_wg));
+      if (ncols == 1) hipLaunchKernelGGL(k_syndrome_small<1>, grid, dim3(512), 0, st, h->dA, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
+      else if (ncols == 2) hipLaunchKernelGGL(k_syndrome_small<2>, grid, dim3(512), 0, st, h->dA, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
+      else hipLaunchKernelGGL(k_syndrome_small<4>, grid, dim3(512), 0, st, h->dA, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
+      hipLaunchKernelGGL(k_zq_combine_wave, dim3((unsigned)((h->n * ncols + 3) / 4)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols, h->q, U, out, ldo, col0);
+      return;
+    }
+  }
   size_t cw = round_up(ncols, 64);                                    // the product works on 64-column tiles
   if (col0 + cw > ld) cw = ld - col0;
   hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * cw, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, P8, h->dFail, col0, cw);
@@ -1071,7 +1089,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
       ScopedTimer t(h, sx, "k_gadget");
       const char* genv = std::getenv("PSF_GADGET_WAVE");            // max n B served by the one-wave-per-problem kernel (0: never)
-      const size_t wave_max = genv ? (size_t)std::atol(genv) : 1024;
+      const size_t wave_max = genv ? (size_t)std::atol(genv) : 4096;    // measured at C3 (n = 512): 55 vs 98 us at 3-4 preimages, 90 vs 100 at 8, 162 vs 119 at 16
       const char* genv16 = std::getenv("PSF_GADGET_WAVE16");        // max n B served by the sixteen-lanes-per-problem kernel (0: never)
       const size_t wave16_max = genv16 ? (size_t)std::atol(genv16) : 49152;     // measured at C3: 0.33 vs 0.48 ms at 64 preimages, 0.65 vs 0.60 at 128
       if (h->gadget_queue && h->n * Bh <= wave_max) {               // a single call / a handful of preimages: the chain of k draws is the launch time
@@ -1100,6 +1118,18 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
     {  // mp_perturbation.rs:328-335 -- e = p + [R; I] z
       ScopedTimer t(h, sx, "k_recombine");
+      // a handful of preimages: R streamed once by one wave per row (PSF_RECOMBINE_SMALL = largest batch it serves, 0: never)
+      size_t small_max = 4;
+      if (const char* e = std::getenv("PSF_RECOMBINE_SMALL")) small_max = (size_t)std::atol(e);
+      if (small_max > 4) small_max = 4;
+      const size_t small_lds = 32 * (h->ldr / 16) * Bh;
+      if (Bh <= small_max && small_lds <= 150 * 1024) {
+        const unsigned wgs = (unsigned)std::min<size_t>((h->mb + 7) / 8, small_lds > 64 * 1024 ? 256 : 512);
+        if (Bh == 1) hipLaunchKernelGGL(k_recombine_small<1>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
+        else if (Bh == 2) hipLaunchKernelGGL(k_recombine_small<2>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
+        else hipLaunchKernelGGL(k_recombine_small<4>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
+        return;
+      }
       // one digit plane (decided on the device by the gadget kernel): 256 x 256 tiles; otherwise, or for shapes the big tile does not fit, the 128 x 128 kernel
       const bool big = Bh % 256 == 0 && b0 % 256 == 0 && h->mb >= 512 && (h->ldr / 64) % 2 == 0;
       if (big) {
@@ -1238,19 +1268,20 @@ static void hp_release(psfp_handle* h) {
     if (hp.hU[s]) { hipHostFree(hp.hU[s]); hp.hU[s] = nullptr; }
     hipFree(hp.dU2[s]); hp.dU2[s] = nullptr;
   }
-  hp.u_cap = 0;
+  hp.u_cap[0] = hp.u_cap[1] = 0;
   if (hp.copy) { hipStreamDestroy(hp.copy); hp.copy = nullptr; }
   if (hp.compute) { hipStreamDestroy(hp.compute); hp.compute = nullptr; }
-  hp.cap_entries = 0; hp.chunk_entries = 0;
+  hp.cap_entries[0] = hp.cap_entries[1] = 0; hp.chunk_entries = 0;
 }
 
-static psf_status hp_ensure(psfp_handle* h, size_t entries, size_t u_words) {
+// streams, transport and the rings of call slot `slot` (which the caller has joined).  Everything is allocated on first use and per slot: a caller that only ever
+// makes synchronous calls pays for one slot (pinning memory is the expensive part of a handle's first host-pointer call).
+static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_words) {
   auto& hp = h->hp;
   constexpr int NW = psfp_handle::HostPipe::NW;
   if (!hp.copy) {
-    {  // The runtime moves these copies with shader kernels (__amd_rocclr_copyBuffer in the rocprofv3 trace): on a queue of lower priority than the compute
-       // stream they only ran when that stream was idle, and a loop of asynchronous calls degenerated into compute, then copy (90 ms per call at C3).
-       // So: copies on the HIGH-priority queue (PCIe-bound, a few waves), the asynchronous calls' kernels on a normal one (hp.compute).
+    {  // (matters for the HIP-copy transports only: their copies are shader kernels, which on a queue of lower priority than the compute stream ran only when
+       // that stream was idle -- copies on the HIGH-priority queue, the asynchronous calls' kernels on a normal one)
       int lo_prio = 0, hi_prio = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
       int pc = hi_prio, pk = (lo_prio + hi_prio) / 2;
@@ -1259,11 +1290,7 @@ static psf_status hp_ensure(psfp_handle* h, size_t entries, size_t u_words) {
       HIP_TRY(hipStreamCreateWithPriority(&hp.compute, hipStreamNonBlocking, pk));
     }
     HIP_TRY(hipMalloc(&hp.dOvf, 2 * sizeof(int)));
-    for (int s = 0; s < 2; ++s) {
-      HIP_TRY(hipHostMalloc(&hp.hFlags[s], 4 * sizeof(int), hipHostMallocDefault));
-      for (auto& ev : hp.evSlice[s]) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
-    hp.chunk_entries = (size_t)4 << 20;                                  // 16 MiB of int32 per chunk
+    hp.chunk_entries = (size_t)2 << 20;                                  // 8 MiB of int32 per chunk
     if (const char* env = std::getenv("PSF_HOST_WORKERS")) { const int v = std::atoi(env); if (v >= 1 && v <= NW) hp.nw = v; }
     if (const char* env = std::getenv("PSF_HOST_CHUNK_MB")) { const long v = std::atol(env); if (v >= 1 && v <= 256) hp.chunk_entries = (size_t)v << 18; }
     if (const char* env = std::getenv("PSF_HOST_COPY")) {                 // sdma (default) | runtime | kernel[:workgroups]
@@ -1278,30 +1305,30 @@ static psf_status hp_ensure(psfp_handle* h, size_t entries, size_t u_words) {
       if (!hp.sdma.open(dom, bus, dv)) hp.copy_mode = 0;                  // no HSA agent for this device: the HIP copies (slower under overlap, same rows)
       else if (!hp.sdma.make_signal(&hp.sigU)) return PSF_ERR_HIP;
     }
-    for (int s = 0; s < 2; ++s)
-      for (int w = 0; w < hp.nw; ++w)
-        for (int k = 0; k < 2; ++k) {
-          HIP_TRY(hipHostMalloc(&hp.hbuf[s][w][k], hp.chunk_entries * sizeof(int32_t), hipHostMallocDefault));
-          HIP_TRY(hipEventCreateWithFlags(&hp.evC[s][w][k], hipEventDisableTiming));
-          if (hp.copy_mode == 1 && !hp.sdma.make_signal(&hp.sigC[s][w][k])) return PSF_ERR_HIP;
-        }
   }
-  if (entries > hp.cap_entries) {
-    for (int s = 0; s < 2; ++s) { const psf_status rc = hp_join(h, s); (void)rc; }
-    for (int s = 0; s < 2; ++s) { hipFree(hp.dE32[s]); hp.dE32[s] = nullptr; }
-    hp.cap_entries = 0;
-    for (int s = 0; s < 2; ++s) HIP_TRY(hipMalloc(&hp.dE32[s], entries * sizeof(int32_t) + 8));      // (+8: the copy kernel moves 8-byte words)
-    hp.cap_entries = entries;
+  if (!hp.hFlags[slot]) {
+    HIP_TRY(hipHostMalloc(&hp.hFlags[slot], 4 * sizeof(int), hipHostMallocDefault));
+    for (auto& ev : hp.evSlice[slot]) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (int w = 0; w < hp.nw; ++w)
+      for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipHostMalloc(&hp.hbuf[slot][w][k], hp.chunk_entries * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&hp.evC[slot][w][k], hipEventDisableTiming));
+        if (hp.copy_mode == 1 && !hp.sdma.make_signal(&hp.sigC[slot][w][k])) return PSF_ERR_HIP;
+      }
   }
-  if (u_words > hp.u_cap) {
-    for (int s = 0; s < 2; ++s) { const psf_status rc = hp_join(h, s); (void)rc; }
-    for (int s = 0; s < 2; ++s) { if (hp.hU[s]) hipHostFree(hp.hU[s]); hp.hU[s] = nullptr; hipFree(hp.dU2[s]); hp.dU2[s] = nullptr; }
-    hp.u_cap = 0;
-    for (int s = 0; s < 2; ++s) {
-      HIP_TRY(hipHostMalloc(&hp.hU[s], u_words * sizeof(uint64_t), hipHostMallocDefault));
-      HIP_TRY(hipMalloc(&hp.dU2[s], u_words * sizeof(uint64_t)));
-    }
-    hp.u_cap = u_words;
+  if (entries > hp.cap_entries[slot]) {
+    hipFree(hp.dE32[slot]); hp.dE32[slot] = nullptr;
+    hp.cap_entries[slot] = 0;
+    HIP_TRY(hipMalloc(&hp.dE32[slot], entries * sizeof(int32_t) + 8));      // (+8: the copy kernel moves 8-byte words)
+    hp.cap_entries[slot] = entries;
+  }
+  if (u_words > hp.u_cap[slot]) {
+    if (hp.hU[slot]) hipHostFree(hp.hU[slot]);
+    hp.hU[slot] = nullptr; hipFree(hp.dU2[slot]); hp.dU2[slot] = nullptr;
+    hp.u_cap[slot] = 0;
+    HIP_TRY(hipHostMalloc(&hp.hU[slot], u_words * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&hp.dU2[slot], u_words * sizeof(uint64_t)));
+    hp.u_cap[slot] = u_words;
   }
   return PSF_OK;
 }
@@ -1325,7 +1352,7 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   if (B > h->Bcap) { rc = hp_join(h, slot ^ 1); if (rc != PSF_OK) return rc; }      // ensure_batch reallocates: nothing may be in flight
   rc = ensure_batch(h, B);
   if (rc != PSF_OK) return rc;
-  rc = hp_ensure(h, total, B * h->n);
+  rc = hp_ensure(h, slot, total, B * h->n);
   if (rc != PSF_OK) return rc;
   ++hp.next;
   hipStream_t cs = hp.compute;
