@@ -29,7 +29,7 @@ def pair(request, T, oracle):
     psf.close()
 
 
-@pytest.mark.parametrize("B", [1, 15, 16, 17, 31, 32, 33, 63, 64, 65])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65])
 def test_small_batch_stages_bitwise(pair, oracle, B):
     psf, orc, n, q = pair
     u = oracle.uniform_targets(90 + B, B, n, q)
@@ -147,3 +147,50 @@ def test_fused_call_with_a_general_base(T, oracle):
         e = psf.samp_p(u, seed=19)
         assert (e == orc.samp_p(19, u)).all() and (psf.f_a(e) == u).all()
         psf.close()
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4])
+def test_streaming_stage_kernels_of_a_handful_of_preimages_equal_the_matrix_core_ones(pair, oracle, B):
+    """Up to four preimages e = p + [R; I] z streams R once (k_recombine_small), one preimage also streams A for v = u - A p (k_syndrome_small), up to
+    n B = 4096 the gadget walk runs one wave per problem: PSF_RECOMBINE_SMALL=0 / PSF_SYNDROME_SMALL=0 / PSF_GADGET_WAVE=0 are the matrix-core and queue forms.
+    PSF_SYNDROME_SMALL=4 takes the streaming syndrome where it is not the default."""
+    psf, orc, n, q = pair
+    u = oracle.uniform_targets(61 + B, B, n, q)
+    names = ("PSF_RECOMBINE_SMALL", "PSF_SYNDROME_SMALL", "PSF_GADGET_WAVE")
+    old = {k: os.environ.get(k) for k in names}
+    try:
+        for k in names:
+            os.environ[k] = "0"
+        ref = psf.samp_p_stages(u, seed=33, first_index=7)
+        for k in names:
+            os.environ.pop(k, None)
+        got = psf.samp_p_stages(u, seed=33, first_index=7)
+        os.environ["PSF_SYNDROME_SMALL"] = "4"
+        got4 = psf.samp_p_stages(u, seed=33, first_index=7)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for g in (got, got4):
+        assert (g["v"] == ref["v"]).all() and (g["z"] == ref["z"]).all() and (g["e"] == ref["e"]).all()
+    assert (ref["e"] == orc.samp_p(33, u, first_index=7)).all()
+
+
+@pytest.mark.parametrize("q", [2**61 - 1, 2**60, 1073741789])
+def test_streaming_syndrome_with_wide_moduli(T, oracle, q):
+    """k_syndrome_small joins two signed 64-bit sums in 128 bits and reduces once: words of A up to 2^62, negative p."""
+    n, r, s = 6, 4.0, 90.0
+    gp = T.GadgetParameters.init_default(n, q)
+    psf = T.PSFPerturbation(gp, r, s)
+    A, (R, Lp, _) = psf.trap_gen(3)
+    assert psf.m > 256                                      # not the one-launch kernel
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s)
+    orc.load_key(A, R, Lp)
+    for B in (1, 2):
+        u = oracle.uniform_targets(5 + B, B, n, q)
+        e = psf.samp_p(u, seed=12, first_index=4)
+        assert (e == orc.samp_p(12, u, first_index=4)).all()
+        assert (psf.f_a(e) == u).all()
+    psf.close()

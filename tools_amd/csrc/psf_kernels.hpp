@@ -1755,7 +1755,9 @@ __global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __r
 __global__ __launch_bounds__(256) void k_recombine_bottom(size_t mbar, size_t w, const int8_t* __restrict__ Zlo,
                                                           const int8_t* __restrict__ Zhi, size_t ld, const int32_t* __restrict__ P,
                                                           size_t B, int64_t* __restrict__ E, size_t m, int zero_top) {
-  __shared__ int64_t sE[64][65];
+  // a 64 x 64 tile (preimages x coordinates) through LDS as int32 (|p| < 2^23, |z| < 2^15): z arrives as the planes' own 16-byte groups (one load per plane,
+  // preimage and group, not sixteen byte loads), p coalesced along the preimages, e leaves as whole rows
+  __shared__ int sE[64][65];
   const int tid = threadIdx.x;
   const size_t c0 = (size_t)blockIdx.y * 64, b0 = (size_t)blockIdx.x * 64;
   if (zero_top) {
@@ -1765,20 +1767,28 @@ __global__ __launch_bounds__(256) void k_recombine_bottom(size_t mbar, size_t w,
     }
   }
   if (c0 >= w) return;                                // workgroup-uniform
+  {
+    const int g = tid >> 6, bb = tid & 63;            // group g of the tile's four, preimage bb
+    const size_t at = ((c0 / 16 + (size_t)g) * ld + b0 + (size_t)bb) * 16;
+    int4 zl = make_int4(0, 0, 0, 0), zh = make_int4(0, 0, 0, 0);
+    if (c0 + 16 * (size_t)g < w) { zl = *reinterpret_cast<const int4*>(Zlo + at); zh = *reinterpret_cast<const int4*>(Zhi + at); }      // (b0 + bb < ld always: the planes are ld wide)
+    const int lo[4] = {zl.x, zl.y, zl.z, zl.w}, hi[4] = {zh.x, zh.y, zh.z, zh.w};
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sE[bb][g * 16 + q4 * 4 + r] = (int)(int8_t)(lo[q4] >> (8 * r)) + 256 * (int)(int8_t)(hi[q4] >> (8 * r));
+  }
+  __syncthreads();
   for (int e = tid; e < 64 * 64; e += 256) {
     const int cc = e >> 6, bb = e & 63;
-    const size_t c = c0 + cc, b = b0 + bb;
-    int64_t v = 0;
-    if (c < w) {
-      const size_t addr = ((c >> 4) * ld + b) * 16 + (c & 15);
-      v = (int64_t)P[(mbar + c) * ld + b] + (int64_t)Zlo[addr] + 256 * (int64_t)Zhi[addr];
-    }
-    sE[bb][cc] = v;
+    const size_t c = c0 + cc;
+    if (c < w) sE[bb][cc] += P[(mbar + c) * ld + b0 + bb];
   }
   __syncthreads();
   for (int e = tid; e < 64 * 64; e += 256) {
     const int bb = e >> 6, cc = e & 63;
-    if (b0 + bb < B && c0 + cc < w) E[(b0 + bb) * m + mbar + c0 + cc] = sE[bb][cc];
+    if (b0 + bb < B && c0 + cc < w) E[(b0 + bb) * m + mbar + c0 + cc] = (int64_t)sE[bb][cc];
   }
 }
 
