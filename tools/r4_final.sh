@@ -27,7 +27,7 @@ timeout 600 bash tools/pmc_single_call.sh 16 > $O/traffic_single_b16.json 2>&1
 timeout 600 bash tools/pmc_single_call.sh 1 > $O/traffic_single_b1.json 2>&1
 for cfg in c2 c4; do timeout 1200 bash tools/pmc_np.sh $cfg > $O/traffic_$cfg.json 2>$O/traffic_$cfg.err; done
 timeout 300 tools/bin/probe_stream 30801 5 > $O/probe_stream.log 2>&1
-timeout 300 python3 tools/host_path_timing.py 8 > $O/host_path.log 2>&1
+timeout 300 python3 tools/host_path_timing.py 32 > $O/host_path.log 2>&1
 timeout 300 bash tools/prof_host_async.sh > $O/host_async_timeline.txt 2>&1
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_poly -o t --output-format csv -- python3 $R/tools/time_polymul.py > $O/polymul.log 2>&1
