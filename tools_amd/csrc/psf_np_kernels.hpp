@@ -535,6 +535,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
     return __shfl(v, sgbase + src_in_sg);
   };
   auto tri_at = [&](int l, int col) -> double { return col < l ? s_tri[l * (l - 1) / 2 + col] : 0.0; };
+  const uint64_t live_w = __ballot(live);
   int k = 0;
 #pragma unroll
   for (int slot = G - 1; slot >= 0; --slot) {
@@ -575,6 +576,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           const double cen = tl * rw.inv_n2;
           const uint32_t coord = (uint32_t)(j0 + l);
           long long z = 0;
+          double zd = 0.0;                                          // z as a double, converted where z is decided: from 32 bits on the common paths
           bool got = !live;
           uint32_t t0 = 0;
           NP_T(2);
@@ -582,27 +584,33 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           const uint32_t idx = rec.z & 0x7fffffffu;
           const bool okidx = (rec.z >> 31) != 0;
           const float u = G == 1 ? __uint_as_float(rec.x) : (float)idx * rw.inv_sk;                                   // the helper's expressions, evaluated here for
-          const float wbf = G == 1 ? __uint_as_float(rec.y) : (float)rec.w * (narrow ? 0x1.0p-16f : 0x1.0p-32f);      // the packed records of G == 2
+          const float wbf0 = G == 1 ? __uint_as_float(rec.y) : (float)rec.w * (narrow ? 0x1.0p-16f : 0x1.0p-32f);    // the packed records of G == 2
+          const float wbf = okidx ? wbf0 : __builtin_inff();        // a Lemire-rejected attempt is never a candidate: folded into the word, so that each ballot below is ONE compare
           const float wbe = wbf + (narrow ? 0x1.0p-16f : 1e-7f);
           // --- the dependent chain ----------------------------------------------------------------------------------
           const double cc = ceil(cen);
-          const float c_rel = (float)(cc - cen) - (float)rw.c6;     // lo - c with lo = ceil(c) - ceil(6 s')
+          const float frf = (float)(cc - cen);                      // ceil(c) - c in [0, 1): 0 for an integral centre (and for one within 1e-38 below zero: those
+                                                                    // take the generic rounds too, which are exact for every centre)
+          const float c_rel = frf - (float)rw.c6;                   // lo - c with lo = ceil(c) - ceil(6 s')
           const int lo = (int)cc - rw.c6;
           const float ak = fmaf(c_rel, rw.inv_sk, u);
           const float rho = __builtin_amdgcn_exp2f(-(ak * ak));     // exp(-pi a^2)
-          const bool cand_b = okidx && wbf <= fmaf(rho, 1.001f, 1e-9f);
-          const bool sure_b = okidx && wbe <= rho * 0.999f;
+          // Each mask is the ballot of a single compare (a v_cmp writing the SGPR pair); conditions are combined on the masks with scalar instructions.  hipcc turns
+          // the ballot of a combined condition into v_cndmask 0 / 1 + v_cmp_ne: two more dependent vector instructions per ballot on the chain.
           // not covered by the lines above: integral centres (one more candidate), huge centres, candidate ranges beyond fp32
-          const bool bad = live && (cc == cen || !(fabs(cen) < 0x1.0p30) || rw.sh == 0);
-          const uint64_t mc_w = __ballot(cand_b), m1_w = __ballot(sure_b), bad_w = __ballot(bad);
+          const uint64_t mc_w = __builtin_amdgcn_ballot_w64(wbf <= fmaf(rho, 1.001f, 1e-9f)), m1_w = __builtin_amdgcn_ballot_w64(wbe <= rho * 0.999f);
+          const uint64_t plain_w = __builtin_amdgcn_ballot_w64(frf > 0.0f) & __builtin_amdgcn_ballot_w64(fabs(cen) < 0x1.0p30);      // non-integral, below 2^30
+          const uint64_t bad_w = (rw.sh == 0 ? ~0ull : ~plain_w) & live_w;
           NP_T(3);
           NP_EVENT(0);
           if (bad_w) NP_EVENT(3);
           // common case: the first candidate of the draw (in attempt = lane order) is a certain accept
           bool settle = false;
+          bool fast1 = false;                                       // G == 1: the draw was decided by the fast path (wave-uniform: everything rare hangs off ONE scalar branch)
           if (G == 1) {
             const int fl = mc_w ? __builtin_ctzll(mc_w) : 0;
-            if (bad_w == 0 && ((m1_w >> fl) & 1)) { z = (long long)(lo + __builtin_amdgcn_readlane((int)idx, fl)); got = true; }
+            fast1 = bad_w == 0 && ((m1_w >> fl) & 1);
+            if (fast1) { const int zi = lo + __builtin_amdgcn_readlane((int)idx, fl); z = (long long)zi; zd = (double)zi; got = true; }
             else settle = live;
           } else {
             // G == 2: two sets of LPD attempts with the fast screen.  Set A as always; set B (attempts LPD .. 2 LPD - 1) is read and screened only when a
@@ -624,7 +632,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
                 const uint64_t accm = __ballot(acc);
                 const int xi = __shfl((int)idxv, fl);
                 if (pending) {
-                  if (sure || ((accm >> fl) & 1)) { z = (long long)(lo + xi); got = true; }
+                  if (sure || ((accm >> fl) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
                   else m2 &= ~(1ull << fl);
                 }
               }
@@ -633,12 +641,12 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
               const uint64_t cand = mc_w & sgmask;
               const int fl = cand ? (__ffsll((long long)cand) - 1) : lane;
               const int xi = __shfl((int)idx, fl);
-              if (live && usable && cand && ((m1_w >> fl) & 1)) { z = (long long)(lo + xi); got = true; }
+              if (live && usable && cand && ((m1_w >> fl) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
               const bool pend = live && !got && usable && cand != 0;                 // the first candidate of set A is a "to be settled" one
-              if (__ballot(pend)) { NP_EVENT(1); settle_set(pend ? (m1_w & sgmask) : 0, pend ? ((mc_w & ~m1_w) & sgmask) : 0, idx, rec.w, 0u); }
+              if (__builtin_expect(__ballot(pend) != 0, 0)) { NP_EVENT(1); settle_set(pend ? (m1_w & sgmask) : 0, pend ? ((mc_w & ~m1_w) & sgmask) : 0, idx, rec.w, 0u); }
             }
             const bool need_b = live && !got && usable;
-            if (__ballot(need_b)) {
+            if (__builtin_expect(__ballot(need_b) != 0, 0)) {
               const uint2 rb = rslot2[(sp * 2 + 1) * 64];
               const uint32_t idx_b = rb.x & 0x7fffffffu;
               const bool ok_b = (rb.x >> 31) != 0;
@@ -653,13 +661,13 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
               const uint64_t cand = mcb_w & sgmask;
               const int fl = cand ? (__ffsll((long long)cand) - 1) : lane;
               const int xi = __shfl((int)idx_b, fl);
-              if (need_b && cand && ((m1b_w >> fl) & 1)) { z = (long long)(lo + xi); got = true; }
+              if (need_b && cand && ((m1b_w >> fl) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
               const bool pend = need_b && !got && cand != 0;
               if (__ballot(pend)) settle_set(pend ? (m1b_w & sgmask) : 0, pend ? ((mcb_w & ~m1b_w) & sgmask) : 0, idx_b, rb.y, (uint32_t)LPD);
             }
             t0 = usable ? 2u * (uint32_t)LPD : 0u;                  // special centres start over with the generic rounds
           }
-          if (G == 1 && __ballot(settle)) {
+          if (G == 1 && __builtin_expect(!fast1, 0) && __ballot(settle) != 0) {
             NP_EVENT(1);
             // rare: a "to be settled" attempt comes first, or there is no candidate among the first LPD attempts, or the centre is special
             const bool usable = !(bad_w & sgmask);
@@ -679,7 +687,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
               const uint64_t accm = __ballot(acc);
               const int xi = __shfl((int)idx, fl);
               if (pending) {
-                if (sure || ((accm >> fl) & 1)) { z = (long long)(lo + xi); got = true; }
+                if (sure || ((accm >> fl) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
                 else m2 &= ~(1ull << fl);
               }
             }
@@ -690,8 +698,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           // walk's 64-bit integers.  The draw ends with 0 and the call reports PSF_ERR_SAMPLER; the oracle does the same in orc_sample_z, where the conversion
           // would otherwise be undefined behaviour (found by tools/fuzz_configs.py: x86 and gfx950 saturate differently, silently).  Every such centre comes
           // through here: `bad` sends |c| >= 2^30 to the generic rounds.
-          if (__ballot(!got)) {                                      // generic rounds: attempts t0 + lam, t0 + LPD + lam, ...
-            if (!got && !(fabs(cen) < 0x1.0p62)) { f = 1; z = 0; got = true; }      // (inside the rare branch: as a test of its own in front of it the step cost 2 % more)
+          if ((G != 1 || __builtin_expect(!fast1, 0)) && __builtin_expect(__ballot(!got) != 0, 0)) {      // generic rounds: attempts t0 + lam, t0 + LPD + lam, ...
+            if (!got && !(fabs(cen) < 0x1.0p62)) { f = 1; z = 0; zd = 0.0; got = true; }      // (inside the rare branch: as a test of its own in front of it the step cost 2 % more)
             NP_EVENT(2);
             // (an "accepted for certain" class here as in the first round was measured: C2 3.5 % slower, C4 unchanged -- the rounds are rare and the
             // extra live values cost the hot path registers)
@@ -729,16 +737,17 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
                 const uint64_t accm = __ballot(acc);
                 const long long xs = __shfl(x, fl);
                 if (pending) {
-                  if ((accm >> fl) & 1) { z = xs; got = true; }
+                  if ((accm >> fl) & 1) { z = xs; zd = (double)xs; got = true; }
                   else m2 &= ~(1ull << fl);
                 }
               }
             }
-            if (!got) { f = 1; z = (long long)floor(cen + 0.5); }
+            if (!got) { f = 1; z = (long long)floor(cen + 0.5); zd = (double)z; }
           }
           NP_T(7);
           if (lam == ls) zr[slot] = z;
-          const double nz = -(double)z;
+          // (the common draw fits 32 bits: |c'| < 2^30 on the fast path; the 64-bit conversion is a sequence of its own on the chain)
+          const double nz = -zd;
 #pragma unroll
           for (int s2 = 0; s2 <= slot; ++s2) t[s2] = fma(nz, gl[s2], t[s2]);
           NP_T(5);
