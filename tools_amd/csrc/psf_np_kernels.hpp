@@ -587,6 +587,11 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           const float wbf0 = G == 1 ? __uint_as_float(rec.y) : (float)rec.w * (narrow ? 0x1.0p-16f : 0x1.0p-32f);    // the packed records of G == 2
           const float wbf = okidx ? wbf0 : __builtin_inff();        // a Lemire-rejected attempt is never a candidate: folded into the word, so that each ballot below is ONE compare
           const float wbe = wbf + (narrow ? 0x1.0p-16f : 1e-7f);
+          // the two thresholds moved to the words' side (off the chain: they depend on the record only), so that both compares read v_exp_f32's result directly:
+          //   candidate  <=>  wbf <= 1.001 rho + 1e-9  <=>  (wbf - 1e-9) / 1.001 <= rho      (factor rounded DOWN: a superset of the old candidates)
+          //   certain    <=>  wbe <= 0.999 rho         <=>  wbe / 0.999 <= rho               (factor rounded UP: a subset of the old certain accepts)
+          const float wcand = (wbf - 1e-9f) * 0.998999f;
+          const float wsure = wbe * 1.001002f;
           // --- the dependent chain ----------------------------------------------------------------------------------
           const double cc = ceil(cen);
           const float frf = (float)(cc - cen);                      // ceil(c) - c in [0, 1): 0 for an integral centre (and for one within 1e-38 below zero: those
@@ -598,7 +603,9 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           // Each mask is the ballot of a single compare (a v_cmp writing the SGPR pair); conditions are combined on the masks with scalar instructions.  hipcc turns
           // the ballot of a combined condition into v_cndmask 0 / 1 + v_cmp_ne: two more dependent vector instructions per ballot on the chain.
           // not covered by the lines above: integral centres (one more candidate), huge centres, candidate ranges beyond fp32
-          const uint64_t mc_w = __builtin_amdgcn_ballot_w64(wbf <= fmaf(rho, 1.001f, 1e-9f)), m1_w = __builtin_amdgcn_ballot_w64(wbe <= rho * 0.999f);
+          const uint64_t mc_w = __builtin_amdgcn_ballot_w64(wcand <= rho), m1_w = __builtin_amdgcn_ballot_w64(wsure <= rho);
+          const int zc = lo + (int)idx;                              // every lane's own candidate, as a double too: ready before the ballots are
+          const double zcd = (double)zc;
           const uint64_t plain_w = __builtin_amdgcn_ballot_w64(frf > 0.0f) & __builtin_amdgcn_ballot_w64(fabs(cen) < 0x1.0p30);      // non-integral, below 2^30
           const uint64_t bad_w = (rw.sh == 0 ? ~0ull : ~plain_w) & live_w;
           NP_T(3);
@@ -610,7 +617,11 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           if (G == 1) {
             const int fl = mc_w ? __builtin_ctzll(mc_w) : 0;
             fast1 = bad_w == 0 && ((m1_w >> fl) & 1);
-            if (fast1) { const int zi = lo + __builtin_amdgcn_readlane((int)idx, fl); z = (long long)zi; zd = (double)zi; got = true; }
+            if (fast1) {
+              zd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zcd), fl), __builtin_amdgcn_readlane(__double2loint(zcd), fl));
+              z = (long long)__builtin_amdgcn_readlane(zc, fl);
+              got = true;
+            }
             else settle = live;
           } else {
             // G == 2: two sets of LPD attempts with the fast screen.  Set A as always; set B (attempts LPD .. 2 LPD - 1) is read and screened only when a
