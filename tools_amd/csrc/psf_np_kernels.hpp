@@ -534,7 +534,12 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
     if (G == 1) return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_in_sg), __builtin_amdgcn_readlane(__double2loint(v), src_in_sg));
     return __shfl(v, sgbase + src_in_sg);
   };
-  auto tri_at = [&](int l, int col) -> double { return col < l ? s_tri[l * (l - 1) / 2 + col] : 0.0; };
+  // (an unconditional load from a clamped index + a select: the conditional form became an exec-masked block with a branch and a full LDS wait in every step)
+  auto tri_at = [&](int l, int col) -> double {
+    if (G != 1) return col < l ? s_tri[l * (l - 1) / 2 + col] : 0.0;      // (two draws per step: the conditional form measured faster there, C4 4.38 vs 4.44 ms)
+    const double v = s_tri[col < l ? l * (l - 1) / 2 + col : 0];
+    return col < l ? v : 0.0;
+  };
   const uint64_t live_w = __ballot(live);
   int k = 0;
 #pragma unroll
@@ -547,8 +552,13 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
       NP_T(1);
       const uint4* rslot = ring + (k & 1) * 4 * 64 + lane;
       const uint2* rslot2 = reinterpret_cast<const uint2*>(ring) + (k & 1) * 4 * 2 * 64 + lane;     // G == 2: [step][set][lane], 8-byte records
-      // operands of the first step of the group; those of the following steps are fetched one step ahead
-      NpRow rw = s_row[lbase + 3];
+      // the row records of the group's four steps up front: they are wave-uniform, hipcc moves them to SGPRs (v_readfirstlane) right behind their LDS load, and
+      // fetched one step ahead that was an exposed LDS round trip in front of every step's chain; once per group it is one
+      // (G == 2 keeps the fetch one step ahead: with two draws per step its registers are full)
+      NpRow rws[4];
+#pragma unroll
+      for (int sp = 0; sp < (G == 1 ? 4 : 1); ++sp) rws[sp] = s_row[lbase + 3 - sp];
+      // per-lane operands of the first step of the group; those of the following steps are fetched one step ahead
       double gl[G];
 #pragma unroll
       for (int s2 = 0; s2 <= slot; ++s2) gl[s2] = tri_at(lbase + 3, s2 * LPD + lam);
@@ -558,17 +568,20 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp) {
         const int l = lbase + 3 - sp;
+        const NpRow rw = rws[G == 1 ? sp : 0];
         NpRow rwn = rw;
         double gln[G];
         uint4 recn = rec;
 #pragma unroll
         for (int s2 = 0; s2 <= slot; ++s2) gln[s2] = gl[s2];
         if (sp < 3) {
-          rwn = s_row[l - 1];
+          if (G != 1) rwn = s_row[l - 1];
+          // (the record first: its registers are the ones the previous step's fetch wrote, and hipcc puts a full LDS wait in front of that overwrite -- behind the
+          // g load it waited for that load, a round trip in front of every step's chain; in front of it nothing is in flight)
+          if (G == 1) { recn = rslot[(sp + 1) * 64]; asm volatile("" ::: "memory"); }
 #pragma unroll
           for (int s2 = 0; s2 <= slot; ++s2) gln[s2] = tri_at(l - 1, s2 * LPD + lam);
-          if (G == 1) recn = rslot[(sp + 1) * 64];
-          else { const uint2 r2 = rslot2[(sp + 1) * 2 * 64]; recn.z = r2.x; recn.w = r2.y; }
+          if (G != 1) { const uint2 r2 = rslot2[(sp + 1) * 2 * 64]; recn.z = r2.x; recn.w = r2.y; }
         }
         if (l < nrows) {
           const int ls = l - slot * LPD;
@@ -605,7 +618,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           // not covered by the lines above: integral centres (one more candidate), huge centres, candidate ranges beyond fp32
           const uint64_t mc_w = __builtin_amdgcn_ballot_w64(wcand <= rho), m1_w = __builtin_amdgcn_ballot_w64(wsure <= rho);
           const int zc = lo + (int)idx;                              // every lane's own candidate, as a double too: ready before the ballots are
-          const double zcd = (double)zc;
+          double zcd = 0.0;
+          if (G == 1) { zcd = (double)zc; asm volatile("" : "+v"(zcd)); }      // (kept per lane: otherwise hipcc reads the integer across and converts behind the readlane, on the chain)
           const uint64_t plain_w = __builtin_amdgcn_ballot_w64(frf > 0.0f) & __builtin_amdgcn_ballot_w64(fabs(cen) < 0x1.0p30);      // non-integral, below 2^30
           const uint64_t bad_w = (rw.sh == 0 ? ~0ull : ~plain_w) & live_w;
           NP_T(3);
@@ -763,7 +777,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           for (int s2 = 0; s2 <= slot; ++s2) t[s2] = fma(nz, gl[s2], t[s2]);
           NP_T(5);
         }
-        rw = rwn; rec = recn;
+        if (G != 1) rws[0] = rwn;
+        rec = recn;
 #pragma unroll
         for (int s2 = 0; s2 <= slot; ++s2) gl[s2] = gln[s2];
       }
