@@ -420,7 +420,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           } else {
             *reinterpret_cast<uint4*>(dst + 2 * g) = make_uint4(w.x, w.y, w.z, w.w);
           }
-          if (__ballot(shs == 32)) {
+          if (__builtin_amdgcn_ballot_w64(shs == 32)) {
             const U4 w2 = philox(seed, coord_s, (uint32_t)index, (uint32_t)(g + BPS), tw);
             if (shs == 32) *reinterpret_cast<uint4*>(dst + 2 * (g + BPS)) = make_uint4(w2.x, w2.y, w2.z, w2.w);
           }
@@ -460,7 +460,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
             d4p[0] = make_uint4(w.x >> 16, w.x & 0xffffu, w.y >> 16, w.y & 0xffffu);
             d4p[1] = make_uint4(w.z >> 16, w.z & 0xffffu, w.w >> 16, w.w & 0xffffu);
           }
-          if (__ballot(shs == 32)) {
+          if (__builtin_amdgcn_ballot_w64(shs == 32)) {
             const U4 w1 = philox(seed, coord_s, (uint32_t)index, (uint32_t)(2 * BPS + g), tw), w2 = philox(seed, coord_s, (uint32_t)index, (uint32_t)(3 * BPS + g), tw);
             if (shs == 32) {
               *reinterpret_cast<uint4*>(dst + 2 * g) = make_uint4(w1.x, w1.y, w1.z, w1.w);
@@ -540,7 +540,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
     const double v = s_tri[col < l ? l * (l - 1) / 2 + col : 0];
     return col < l ? v : 0.0;
   };
-  const uint64_t live_w = __ballot(live);
+  const uint64_t live_w = __builtin_amdgcn_ballot_w64(live);
   int k = 0;
 #pragma unroll
   for (int slot = G - 1; slot >= 0; --slot) {
@@ -645,7 +645,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
               while (true) {
                 const uint64_t cnd = m1 | m2;
                 const bool pending = !got && cnd != 0;
-                if (!__ballot(pending)) break;
+                if (!__builtin_amdgcn_ballot_w64(pending)) break;
                 const int fl = pending ? (__ffsll((long long)cnd) - 1) : lane;
                 const bool sure = (m1 >> fl) & 1;
                 bool acc = false;
@@ -654,7 +654,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
                   asm volatile("" : "+v"(ta));
                   acc = sz_decide(seed, coord, (uint32_t)index, tw, ta, (long long)lo + (long long)idxv, wbraw, cen, s_invs[l], rw.sh);
                 }
-                const uint64_t accm = __ballot(acc);
+                const uint64_t accm = __builtin_amdgcn_ballot_w64(acc);
                 const int xi = __shfl((int)idxv, fl);
                 if (pending) {
                   if (sure || ((accm >> fl) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
@@ -668,10 +668,10 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
               const int xi = __shfl((int)idx, fl);
               if (live && usable && cand && ((m1_w >> fl) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
               const bool pend = live && !got && usable && cand != 0;                 // the first candidate of set A is a "to be settled" one
-              if (__builtin_expect(__ballot(pend) != 0, 0)) { NP_EVENT(1); settle_set(pend ? (m1_w & sgmask) : 0, pend ? ((mc_w & ~m1_w) & sgmask) : 0, idx, rec.w, 0u); }
+              if (__builtin_expect(__builtin_amdgcn_ballot_w64(pend) != 0, 0)) { NP_EVENT(1); settle_set(pend ? (m1_w & sgmask) : 0, pend ? ((mc_w & ~m1_w) & sgmask) : 0, idx, rec.w, 0u); }
             }
             const bool need_b = live && !got && usable;
-            if (__builtin_expect(__ballot(need_b) != 0, 0)) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(need_b) != 0, 0)) {
               const uint2 rb = rslot2[(sp * 2 + 1) * 64];
               const uint32_t idx_b = rb.x & 0x7fffffffu;
               const bool ok_b = (rb.x >> 31) != 0;
@@ -682,17 +682,17 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
               const float rho_b = __builtin_amdgcn_exp2f(-(ak_b * ak_b));
               const bool cand_bb = ok_b && wbf_b <= fmaf(rho_b, 1.001f, 1e-9f);
               const bool sure_bb = ok_b && wbe_b <= rho_b * 0.999f;
-              const uint64_t mcb_w = __ballot(cand_bb), m1b_w = __ballot(sure_bb);
+              const uint64_t mcb_w = __builtin_amdgcn_ballot_w64(cand_bb), m1b_w = __builtin_amdgcn_ballot_w64(sure_bb);
               const uint64_t cand = mcb_w & sgmask;
               const int fl = cand ? (__ffsll((long long)cand) - 1) : lane;
               const int xi = __shfl((int)idx_b, fl);
               if (need_b && cand && ((m1b_w >> fl) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
               const bool pend = need_b && !got && cand != 0;
-              if (__ballot(pend)) settle_set(pend ? (m1b_w & sgmask) : 0, pend ? ((mcb_w & ~m1b_w) & sgmask) : 0, idx_b, rb.y, (uint32_t)LPD);
+              if (__builtin_amdgcn_ballot_w64(pend)) settle_set(pend ? (m1b_w & sgmask) : 0, pend ? ((mcb_w & ~m1b_w) & sgmask) : 0, idx_b, rb.y, (uint32_t)LPD);
             }
             t0 = usable ? 2u * (uint32_t)LPD : 0u;                  // special centres start over with the generic rounds
           }
-          if (G == 1 && __builtin_expect(!fast1, 0) && __ballot(settle) != 0) {
+          if (G == 1 && __builtin_expect(!fast1, 0) && __builtin_amdgcn_ballot_w64(settle) != 0) {
             NP_EVENT(1);
             // rare: a "to be settled" attempt comes first, or there is no candidate among the first LPD attempts, or the centre is special
             const bool usable = !(bad_w & sgmask);
@@ -700,7 +700,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
             while (true) {
               const uint64_t cand = m1 | m2;
               const bool pending = !got && cand != 0;
-              if (!__ballot(pending)) break;
+              if (!__builtin_amdgcn_ballot_w64(pending)) break;
               const int fl = pending ? (__ffsll((long long)cand) - 1) : lane;
               const bool sure = (m1 >> fl) & 1;
               bool acc = false;
@@ -709,7 +709,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
                 asm volatile("" : "+v"(ta));
                 acc = sz_decide(seed, coord, (uint32_t)index, tw, ta, (long long)lo + (long long)idx, rec.w, cen, s_invs[l], rw.sh);
               }
-              const uint64_t accm = __ballot(acc);
+              const uint64_t accm = __builtin_amdgcn_ballot_w64(acc);
               const int xi = __shfl((int)idx, fl);
               if (pending) {
                 if (sure || ((accm >> fl) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
@@ -723,7 +723,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
           // walk's 64-bit integers.  The draw ends with 0 and the call reports PSF_ERR_SAMPLER; the oracle does the same in orc_sample_z, where the conversion
           // would otherwise be undefined behaviour (found by tools/fuzz_configs.py: x86 and gfx950 saturate differently, silently).  Every such centre comes
           // through here: `bad` sends |c| >= 2^30 to the generic rounds.
-          if ((G != 1 || __builtin_expect(!fast1, 0)) && __builtin_expect(__ballot(!got) != 0, 0)) {      // generic rounds: attempts t0 + lam, t0 + LPD + lam, ...
+          if ((G != 1 || __builtin_expect(!fast1, 0)) && __builtin_expect(__builtin_amdgcn_ballot_w64(!got) != 0, 0)) {      // generic rounds: attempts t0 + lam, t0 + LPD + lam, ...
             if (!got && !(fabs(cen) < 0x1.0p62)) { f = 1; z = 0; zd = 0.0; got = true; }      // (inside the rare branch: as a test of its own in front of it the step cost 2 % more)
             NP_EVENT(2);
             // (an "accepted for certain" class here as in the first round was measured: C2 3.5 % slower, C4 unchanged -- the rounds are rare and the
@@ -739,7 +739,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
             }
             const SzRange rg = sz_range(cen, sp2);
             for (; t0 < kMaxAttempts; t0 += LPD) {
-              if (!__ballot(!got)) break;
+              if (!__builtin_amdgcn_ballot_w64(!got)) break;
               bool maybe = false;
               long long x = 0;
               uint32_t wa = 0, wb = 0;
@@ -748,10 +748,10 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
                 sz_attempt_words(seed, coord, (uint32_t)index, tw, ta, rg.sh, &wa, &wb);
                 maybe = sz_maybe(wa, wb, rg, cen, sp2.inv_s, &x);
               }
-              uint64_t m2 = __ballot(maybe) & sgmask;
+              uint64_t m2 = __builtin_amdgcn_ballot_w64(maybe) & sgmask;
               while (true) {
                 const bool pending = !got && m2 != 0;
-                if (!__ballot(pending)) break;
+                if (!__builtin_amdgcn_ballot_w64(pending)) break;
                 const int fl = pending ? (__ffsll((long long)m2) - 1) : lane;
                 bool acc = false;
                 if (pending && lane == fl) {
@@ -759,7 +759,7 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
                   asm volatile("" : "+v"(tb));
                   acc = sz_decide(seed, coord, (uint32_t)index, tw, tb, x, wb, cen, sp2.inv_s, rg.sh);
                 }
-                const uint64_t accm = __ballot(acc);
+                const uint64_t accm = __builtin_amdgcn_ballot_w64(acc);
                 const long long xs = __shfl(x, fl);
                 if (pending) {
                   if ((accm >> fl) & 1) { z = xs; zd = (double)xs; got = true; }
@@ -814,10 +814,10 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
     }
   }
   // one atomic per wave at most, and none once the flag is up (at C2 / C4 "second digit in use" is raised by almost every wave of every launch)
-  if (__ballot(f) && lane == 0) atomicOr(a.flags, 1);
-  if (__ballot(use1) && lane == 0 && __hip_atomic_load(a.flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(a.flags + 1, 1);
-  if (__ballot(use2) && lane == 0 && __hip_atomic_load(a.flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(a.flags + 2, 1);
-  if (__ballot(big) && lane == 0) atomicOr(a.flags + 3, 1);
+  if (__builtin_amdgcn_ballot_w64(f) && lane == 0) atomicOr(a.flags, 1);
+  if (__builtin_amdgcn_ballot_w64(use1) && lane == 0 && __hip_atomic_load(a.flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(a.flags + 1, 1);
+  if (__builtin_amdgcn_ballot_w64(use2) && lane == 0 && __hip_atomic_load(a.flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(a.flags + 2, 1);
+  if (__builtin_amdgcn_ballot_w64(big) && lane == 0) atomicOr(a.flags + 3, 1);
 #ifdef NP_PROFILE
   NP_T(6);
   if (wg == 0 && tid == 0) for (int kk = 0; kk < 7; ++kk) atomicAdd((unsigned long long*)&g_np_prof[kk], (unsigned long long)tacc_[kk]);
