@@ -1346,6 +1346,7 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   HIP_TRY(hipSetDevice(h->prm.device));
   auto& hp = h->hp;
   const size_t m = h->m, total = B * m;
+  if (!hp.busy[0] && !hp.busy[1]) hp.next = 0;              // nothing in flight: slot 0 (a caller that only makes synchronous calls never needs -- or allocates -- the second)
   const int slot = (int)(hp.next & 1);
   psf_status rc = hp_join(h, slot);                         // the call before last used this slot
   if (rc != PSF_OK) return rc;
