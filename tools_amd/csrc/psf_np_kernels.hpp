@@ -663,13 +663,10 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
               }
             };
             {
-              // a lane looks at its own half of the masks: 32-bit find-first-set and shift instead of the 64-bit forms (LPD = 32)
-              const bool hi = sgbase != 0;
-              const uint32_t cand = hi ? (uint32_t)(mc_w >> 32) : (uint32_t)mc_w;
-              const uint32_t sure32 = hi ? (uint32_t)(m1_w >> 32) : (uint32_t)m1_w;
-              const int fl32 = cand ? __builtin_ctz(cand) : lam;
-              const int xi = __shfl((int)idx, sgbase + fl32);
-              if (live && usable && cand && ((sure32 >> fl32) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
+              const uint64_t cand = mc_w & sgmask;
+              const int fl = cand ? (__ffsll((long long)cand) - 1) : lane;
+              const int xi = __shfl((int)idx, fl);
+              if (live && usable && cand && ((m1_w >> fl) & 1)) { z = (long long)(lo + xi); zd = (double)(lo + xi); got = true; }
               const bool pend = live && !got && usable && cand != 0;                 // the first candidate of set A is a "to be settled" one
               if (__builtin_expect(__builtin_amdgcn_ballot_w64(pend) != 0, 0)) { NP_EVENT(1); settle_set(pend ? (m1_w & sgmask) : 0, pend ? ((mc_w & ~m1_w) & sgmask) : 0, idx, rec.w, 0u); }
             }
