@@ -239,3 +239,26 @@ def test_every_chunk_transport_of_the_host_path_returns_the_same_rows(oracle, mo
             assert (outs[i] == want[i]).all(), (mode, sliced, i)
     assert (psf.samp_p(u, seed=300) == want[0]).all()       # the synchronous form (async + wait, tail slice)
     psf.close()
+
+
+def test_small_host_calls_through_one_pinned_buffer_equal_the_straight_form(oracle, monkeypatch):
+    """A small host-pointer call (u + e <= 1 MiB) stages u, e and the flags through one pinned buffer with kernels in stream order and synchronises once;
+    PSF_HOST_STRAIGHT=1 keeps the hipMemcpy form.  Same rows, same status, for the three PSF types, growing and shrinking batches."""
+    import numpy as np
+    import tools_amd as T
+    gp = T.GadgetParameters.init_default(8, 128)
+    gp2 = T.GadgetParameters.init_default(24, 2**10)
+    mk = [(lambda: T.PSFPerturbation(gp, 3.0, 30.0), 8, 128), (lambda: T.PSFGPV(gp, 30.0 * 3.0), 8, 128), (lambda: T.PSFPerturbation(gp2, 4.0, 80.0), 24, 2**10)]
+    for make, nn, qq in mk:
+        psf = make()
+        psf.trap_gen(9)
+        for B in (1, 7, 300, 2):
+            u = oracle.uniform_targets(100 + B, B, nn, qq)
+            monkeypatch.delenv("PSF_HOST_STRAIGHT", raising=False)
+            fast = psf.samp_p(u, seed=40 + B, first_index=3)
+            monkeypatch.setenv("PSF_HOST_STRAIGHT", "1")
+            straight = psf.samp_p(u, seed=40 + B, first_index=3)
+            assert (fast == straight).all(), (type(psf).__name__, B)
+            assert (psf.f_a(fast) == u).all()
+        monkeypatch.delenv("PSF_HOST_STRAIGHT", raising=False)
+        psf.close()

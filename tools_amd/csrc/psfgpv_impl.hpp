@@ -450,6 +450,19 @@ psf_status psfgpv_samp_p(psfgpv_handle* g, uint64_t seed, uint64_t first_index, 
   if (!g->has_key) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(g->base->prm.device));
+  if (B * (g->n + g->m) * 8 <= SIO_MAX_BYTES && !std::getenv("PSF_HOST_STRAIGHT")) {
+    // a small call (the reference's call is one preimage): cached device buffers, u / e / flags through one pinned buffer, one synchronisation
+    psfp_handle* h = g->base;
+    if (B * g->n > h->sio_du_cap) { hipFree(h->sio_du); h->sio_du = nullptr; h->sio_du_cap = 0; HIP_TRY(hipMalloc(&h->sio_du, B * g->n * sizeof(uint64_t))); h->sio_du_cap = B * g->n; }
+    if (B * g->m > h->sio_de_cap) { hipFree(h->sio_de); h->sio_de = nullptr; h->sio_de_cap = 0; HIP_TRY(hipMalloc(&h->sio_de, B * g->m * sizeof(int64_t))); h->sio_de_cap = B * g->m; }
+    int fl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    psf_status rc = sio_call(h, B * g->n, B * g->m, u, e, h->sio_du, h->sio_de, h->sets[0].dFail, h->sets[1].dFail, g->dFlags, 8, fl,
+                             [&]() { return psfgpv_samp_p_dev(g, seed, first_index, B, h->sio_du, h->sio_de, nullptr); });
+    if (rc != PSF_OK) return rc;
+    if (fl[0]) return PSF_ERR_SAMPLER;
+    g->last_generic = g->basis_generic || fl[1 + (g->two_pass ? 7 : 3)] != 0;
+    return (fl[1 + 0] || fl[1 + 4]) ? PSF_ERR_SAMPLER : PSF_OK;
+  }
   uint64_t* du = nullptr; int64_t* de = nullptr;
   HIP_TRY(hipMalloc(&du, B * g->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&de, B * g->m * sizeof(int64_t)));

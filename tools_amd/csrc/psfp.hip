@@ -118,6 +118,10 @@ struct psfp_handle {
     hipStream_t copy = nullptr;                 // D2H stream (high priority)
     hipStream_t compute = nullptr;              // stream of the asynchronous calls' kernels (normal priority)
   } hp;
+  // small host-pointer calls (one preimage is the reference's call): u, e and the flags travel through ONE pinned buffer by kernels in stream order, one
+  // synchronisation per call -- the straight form (hipMemcpy in, flags out twice, hipMemcpy out: five blocking runtime calls) cost ~70 us around 47 us of kernels
+  uint8_t* sio_pin = nullptr; size_t sio_cap = 0;
+  uint64_t* sio_du = nullptr; int64_t* sio_de = nullptr; size_t sio_du_cap = 0, sio_de_cap = 0;      // device side for handles without their own (PSFGPV / ring)
   bool no_slice = false;      // stage export wants the intermediates of the whole batch
   bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
   size_t ncall = 0;
@@ -448,6 +452,8 @@ void psfp_destroy(psfp_handle* h) {
   if (!h) return;
   hipSetDevice(h->prm.device);
   hp_release(h);
+  if (h->sio_pin) hipHostFree(h->sio_pin);
+  hipFree(h->sio_du); hipFree(h->sio_de);
   free_batch(h);
   clear_slots(h);
   if (h->aux) hipStreamDestroy(h->aux);
@@ -1207,6 +1213,45 @@ psf_status psfp_samp_p_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, 
 }
 
 // ---- host-pointer entry points ---------------------------------------------------------------------------------------------------------------
+constexpr size_t SIO_MAX_BYTES = (size_t)1 << 20;           // calls whose u + e fit this take the one-buffer form (at 4 MB the runtime's copies are faster again: 1.27 vs 1.17 ms at C3, 16 preimages)
+// flags of a small call into the pinned buffer: [0] = a[0] | b[0] (the two failure words psfp_last_status reads), [1 ..] = c[0 .. nc)
+__global__ void k_sio_flags(const int* __restrict__ a, const int* __restrict__ b, const int* __restrict__ c, int nc, int* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t == 0) out[0] = (a ? a[0] : 0) | (b ? b[0] : 0);
+  if (t >= 1 && t <= nc) out[t] = c[t - 1];
+}
+static psf_status sio_ensure(psfp_handle* h, size_t bytes) {
+  if (bytes <= h->sio_cap) return PSF_OK;
+  if (h->sio_pin) { hipHostFree(h->sio_pin); h->sio_pin = nullptr; h->sio_cap = 0; }
+  const size_t cap = round_up(bytes, (size_t)64 << 10);
+  HIP_TRY(hipHostMalloc(&h->sio_pin, cap, hipHostMallocDefault));
+  h->sio_cap = cap;
+  return PSF_OK;
+}
+static inline unsigned sio_grid(size_t words) { const size_t g = (words / 2 + 255) / 256; return (unsigned)(g < 1 ? 1 : g > 64 ? 64 : g); }
+// u -> pinned -> d_u (kernel); [the caller's launches]; d_e -> pinned, flags -> pinned (kernels); one synchronisation; pinned -> e.  `flags_out` receives
+// 1 + nc ints.  `run` enqueues the call on the null stream and returns its status.
+static psf_status sio_call(psfp_handle* h, size_t nu, size_t ne, const uint64_t* u, int64_t* e, uint64_t* d_u, int64_t* d_e, const int* fa, const int* fb, const int* fc, int nc,
+                           int* flags_out, const std::function<psf_status()>& run) {
+  const size_t ub = round_up(nu * 8, 64), eb = round_up(ne * 8, 64);
+  psf_status rc = sio_ensure(h, ub + eb + 64);
+  if (rc != PSF_OK) return rc;
+  uint64_t* hu = reinterpret_cast<uint64_t*>(h->sio_pin);
+  int64_t* he = reinterpret_cast<int64_t*>(h->sio_pin + ub);
+  int* hf = reinterpret_cast<int*>(h->sio_pin + ub + eb);
+  std::memcpy(hu, u, nu * 8);
+  hipLaunchKernelGGL(k_copy_words, dim3(sio_grid(nu)), dim3(256), 0, nullptr, hu, d_u, nu);
+  rc = run();
+  if (rc != PSF_OK) { hipStreamSynchronize(nullptr); return rc; }
+  hipLaunchKernelGGL(k_copy_words, dim3(sio_grid(ne)), dim3(256), 0, nullptr, reinterpret_cast<const uint64_t*>(d_e), reinterpret_cast<uint64_t*>(he), ne);
+  hipLaunchKernelGGL(k_sio_flags, dim3(1), dim3(64), 0, nullptr, fa, fb, fc, nc, hf);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  for (int i = 0; i <= nc; ++i) flags_out[i] = hf[i];
+  std::memcpy(e, he, ne * 8);
+  return PSF_OK;
+}
+
 // int32 -> int64 into the caller's rows with streaming stores: the destination is written once and not read here, so there is no point in pulling its
 // lines into the cache first (a plain loop moves 20 bytes per entry through the memory system, this one 12) -- the widening of a C3 batch is 1.5 GB of
 // host memory traffic per call and has to fit under the next call's 60 ms on a handful of threads.
@@ -1491,6 +1536,14 @@ psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size
     if (rc != PSF_OK) return rc;
     rc = ensure_batch(h, B);
     if (rc != PSF_OK) return rc;
+    if (!h->no_slice && !h->pipeline && B * (h->n + h->m) * 8 <= SIO_MAX_BYTES && !std::getenv("PSF_HOST_STRAIGHT")) {
+      if (h->timing) clear_slots(h);
+      int fl[1] = {0};
+      rc = sio_call(h, B * h->n, B * h->m, u, e, h->dU, h->dE, h->sets[0].dFail, h->sets[1].dFail, nullptr, 0, fl,
+                    [&]() { return run_samp_p(h, seed, first_index, B, h->dU, h->dE, nullptr); });
+      if (rc != PSF_OK) return rc;
+      return fl[0] ? PSF_ERR_SAMPLER : PSF_OK;
+    }
     HIP_TRY(hipMemcpy(h->dU, u, B * h->n * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (h->timing) clear_slots(h);
     rc = run_samp_p(h, seed, first_index, B, h->dU, h->dE, nullptr);
