@@ -120,6 +120,7 @@ struct psfp_handle {
   } hp;
   // small host-pointer calls (one preimage is the reference's call): u, e and the flags travel through ONE pinned buffer by kernels in stream order, one
   // synchronisation per call -- the straight form (hipMemcpy in, flags out twice, hipMemcpy out: five blocking runtime calls) cost ~70 us around 47 us of kernels
+  std::thread hp_warm;        // hp_prewarm's worker; joined by whoever touches the host-pointer machinery next
   uint8_t* sio_pin = nullptr; size_t sio_cap = 0;
   uint64_t* sio_du = nullptr; int64_t* sio_de = nullptr; size_t sio_du_cap = 0, sio_de_cap = 0;      // device side for handles without their own (PSFGPV / ring)
   bool no_slice = false;      // stage export wants the intermediates of the whole batch
@@ -448,6 +449,18 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
 }
 
 static void hp_release(psfp_handle* h);
+static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_words);
+// A key whose batches will cross PCIe (m >= 8192: a preimage is >= 64 KiB) gets the batch-independent part of the host-pointer machinery -- streams, the DMA path,
+// one slot's pinned rings -- when the key is installed, next to a factorisation that takes a quarter of a second, instead of inside the first samp_p call
+// (PSF_HOST_PREWARM=0: on first use, as for small keys).
+static void hp_prewarm(psfp_handle* h) {
+  if (h->m < 8192) return;
+  if (const char* env = std::getenv("PSF_HOST_PREWARM")) if (std::atoi(env) == 0) return;
+  if (h->hp_warm.joinable()) h->hp_warm.join();
+  try {
+    h->hp_warm = std::thread([h]() { if (hipSetDevice(h->prm.device) == hipSuccess) (void)hp_ensure(h, 0, 0, 0); });      // beside the factorisation, not behind it
+  } catch (...) { }                                         // no thread: on first use then
+}
 void psfp_destroy(psfp_handle* h) {
   if (!h) return;
   hipSetDevice(h->prm.device);
@@ -821,6 +834,7 @@ psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
   const psf_status rc = build_sqrt_sigma2(h, h->prm.s);            // mp_perturbation.rs:227-231
   if (rc != PSF_OK) { h->has_key = false; return rc; }
   h->has_key = true;
+  hp_prewarm(h);
   return PSF_OK;
 }
 
@@ -888,6 +902,7 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
   HIP_TRY(hipDeviceSynchronize());
   hipFree(dp);
   h->has_key = true;
+  hp_prewarm(h);
   return PSF_OK;
 }
 
@@ -1292,6 +1307,7 @@ static psf_status hp_join(psfp_handle* h, int slot) {
 }
 
 static void hp_release(psfp_handle* h) {
+  if (h->hp_warm.joinable()) h->hp_warm.join();
   auto& hp = h->hp;
   for (int s = 0; s < 2; ++s) hp_join(h, s);
   for (int s = 0; s < 2; ++s) {
@@ -1322,6 +1338,7 @@ static void hp_release(psfp_handle* h) {
 // streams, transport and the rings of call slot `slot` (which the caller has joined).  Everything is allocated on first use and per slot: a caller that only ever
 // makes synchronous calls pays for one slot (pinning memory is the expensive part of a handle's first host-pointer call).
 static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_words) {
+  if (h->hp_warm.joinable() && std::this_thread::get_id() != h->hp_warm.get_id()) h->hp_warm.join();
   auto& hp = h->hp;
   constexpr int NW = psfp_handle::HostPipe::NW;
   if (!hp.copy) {
