@@ -96,6 +96,8 @@ struct psfp_handle {
     int nw = 4;                                 // workers in use (PSF_HOST_WORKERS)
     int32_t* dE32[2] = {nullptr, nullptr};      // device: narrowed rows of the call in flight, two calls deep
     size_t cap_entries[2] = {0, 0};             // entries dE32[slot] holds
+    bool slot_ready[2] = {false, false};        // the slot's flags, events, pinned chunk buffers and signals exist
+    bool common_ready = false;                  // streams, overflow word, transport
     int32_t* hbuf[2][NW][2] = {};               // pinned chunk buffers [call slot][worker][double buffer]: two calls in flight never share one
     hipEvent_t evC[2][NW][2] = {};              // chunk landed in its pinned buffer
     size_t chunk_entries = 0;
@@ -1333,6 +1335,7 @@ static void hp_release(psfp_handle* h) {
   if (hp.copy) { hipStreamDestroy(hp.copy); hp.copy = nullptr; }
   if (hp.compute) { hipStreamDestroy(hp.compute); hp.compute = nullptr; }
   hp.cap_entries[0] = hp.cap_entries[1] = 0; hp.chunk_entries = 0;
+  hp.slot_ready[0] = hp.slot_ready[1] = false; hp.common_ready = false;
 }
 
 // streams, transport and the rings of call slot `slot` (which the caller has joined).  Everything is allocated on first use and per slot: a caller that only ever
@@ -1341,17 +1344,17 @@ static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_w
   if (h->hp_warm.joinable() && std::this_thread::get_id() != h->hp_warm.get_id()) h->hp_warm.join();
   auto& hp = h->hp;
   constexpr int NW = psfp_handle::HostPipe::NW;
-  if (!hp.copy) {
+  if (!hp.common_ready) {
     {  // (matters for the HIP-copy transports only: their copies are shader kernels, which on a queue of lower priority than the compute stream ran only when
        // that stream was idle -- copies on the HIGH-priority queue, the asynchronous calls' kernels on a normal one)
       int lo_prio = 0, hi_prio = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
       int pc = hi_prio, pk = (lo_prio + hi_prio) / 2;
       if (const char* env = std::getenv("PSF_HOST_PRIO")) { if (std::atoi(env) == 0) pc = pk; else if (std::atoi(env) == 2) { pc = pk; pk = hi_prio; } }      // experiments: 0 = equal, 2 = compute high
-      HIP_TRY(hipStreamCreateWithPriority(&hp.copy, hipStreamNonBlocking, pc));
-      HIP_TRY(hipStreamCreateWithPriority(&hp.compute, hipStreamNonBlocking, pk));
+      if (!hp.copy) HIP_TRY(hipStreamCreateWithPriority(&hp.copy, hipStreamNonBlocking, pc));
+      if (!hp.compute) HIP_TRY(hipStreamCreateWithPriority(&hp.compute, hipStreamNonBlocking, pk));
     }
-    HIP_TRY(hipMalloc(&hp.dOvf, 2 * sizeof(int)));
+    if (!hp.dOvf) HIP_TRY(hipMalloc(&hp.dOvf, 2 * sizeof(int)));
     hp.chunk_entries = (size_t)2 << 20;                                  // 8 MiB of int32 per chunk
     if (const char* env = std::getenv("PSF_HOST_WORKERS")) { const int v = std::atoi(env); if (v >= 1 && v <= NW) hp.nw = v; }
     if (const char* env = std::getenv("PSF_HOST_CHUNK_MB")) { const long v = std::atol(env); if (v >= 1 && v <= 256) hp.chunk_entries = (size_t)v << 18; }
@@ -1365,18 +1368,20 @@ static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_w
       HIP_TRY(hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, h->prm.device));
       HIP_TRY(hipDeviceGetAttribute(&dv, hipDeviceAttributePciDeviceId, h->prm.device));
       if (!hp.sdma.open(dom, bus, dv)) hp.copy_mode = 0;                  // no HSA agent for this device: the HIP copies (slower under overlap, same rows)
-      else if (!hp.sdma.make_signal(&hp.sigU)) return PSF_ERR_HIP;
+      else if (!hp.sigU.handle && !hp.sdma.make_signal(&hp.sigU)) return PSF_ERR_HIP;
     }
+    hp.common_ready = true;
   }
-  if (!hp.hFlags[slot]) {
-    HIP_TRY(hipHostMalloc(&hp.hFlags[slot], 4 * sizeof(int), hipHostMallocDefault));
-    for (auto& ev : hp.evSlice[slot]) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (!hp.slot_ready[slot]) {                                 // (every piece behind its own test: a call that failed half-way is completed, not repeated, by the next)
+    if (!hp.hFlags[slot]) HIP_TRY(hipHostMalloc(&hp.hFlags[slot], 4 * sizeof(int), hipHostMallocDefault));
+    for (auto& ev : hp.evSlice[slot]) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (int w = 0; w < hp.nw; ++w)
       for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipHostMalloc(&hp.hbuf[slot][w][k], hp.chunk_entries * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&hp.evC[slot][w][k], hipEventDisableTiming));
-        if (hp.copy_mode == 1 && !hp.sdma.make_signal(&hp.sigC[slot][w][k])) return PSF_ERR_HIP;
+        if (!hp.hbuf[slot][w][k]) HIP_TRY(hipHostMalloc(&hp.hbuf[slot][w][k], hp.chunk_entries * sizeof(int32_t), hipHostMallocDefault));
+        if (!hp.evC[slot][w][k]) HIP_TRY(hipEventCreateWithFlags(&hp.evC[slot][w][k], hipEventDisableTiming));
+        if (hp.copy_mode == 1 && !hp.sigC[slot][w][k].handle && !hp.sdma.make_signal(&hp.sigC[slot][w][k])) return PSF_ERR_HIP;
       }
+    hp.slot_ready[slot] = true;
   }
   if (entries > hp.cap_entries[slot]) {
     hipFree(hp.dE32[slot]); hp.dE32[slot] = nullptr;
