@@ -1,0 +1,35 @@
+"""Host-pointer against device-pointer samp_p for PSFGPV (C2: n=256, q=3329, s=1024, batch 1024) and PSFGPVRing (C4: batch 4096)."""
+import os, sys, time, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import tools_amd as T
+
+def run(name, psf, B, m, n, q):
+    rng = np.random.default_rng(1)
+    u = rng.integers(0, q, size=(B, n), dtype=np.uint64)
+    dev = torch.device("cuda:0")
+    ud = torch.from_numpy(u.astype(np.int64)).to(dev)
+    ed = torch.empty((B, m), dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=1, stream=st); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(10):
+        psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=2 + i, stream=st)
+    torch.cuda.synchronize(); dd = (time.perf_counter() - t0) / 10
+    e = psf.samp_p(u, seed=1)
+    ts = []
+    for i in range(6):
+        t0 = time.perf_counter(); e = psf.samp_p(u, seed=2 + i); ts.append(time.perf_counter() - t0)
+    psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=7, stream=st); torch.cuda.synchronize()
+    same = bool((ed.cpu().numpy() == e).all())
+    print(f"{name}: device pointers {dd*1e3:.2f} ms per call, host pointers {min(ts)*1e3:.2f} ms (median {sorted(ts)[3]*1e3:.2f}), same rows {same}", flush=True)
+
+gpv = T.PSFGPV(T.GadgetParameters.init_default(256, 3329), 1024.0); gpv.trap_gen(3, export=False)
+run("C2 PSFGPV batch 1024", gpv, 1024, gpv.m, 256, 3329)
+gpv.close()
+n = 256; s = ((2 * 2 * 1.005 * math.sqrt(n) + 1) * 2) * 4
+ring = T.PSFGPVRing(T.GadgetParametersRing.init_default(n, 3329), s, 1.005); ring.trap_gen(4)
+try:
+    run("C4 PSFGPVRing batch 4096", ring, 4096, ring.d, ring.n if hasattr(ring, "n") else n, 3329)
+except Exception as ex:
+    print("ring:", type(ex).__name__, ex)
