@@ -262,3 +262,25 @@ def test_small_host_calls_through_one_pinned_buffer_equal_the_straight_form(orac
             assert (psf.f_a(fast) == u).all()
         monkeypatch.delenv("PSF_HOST_STRAIGHT", raising=False)
         psf.close()
+
+
+def test_batch_host_calls_of_the_nearest_plane_types_equal_the_straight_form(oracle, monkeypatch):
+    """psfgpv_samp_p / psfring_samp_p above 1 MiB: cached device buffers, rows narrowed to int32, one pinned copy, threaded widening -- against the straight form
+    (PSF_HOST_STRAIGHT=1: two allocations and two pageable copies per call) and the device-pointer call."""
+    import numpy as np
+    import torch
+    import tools_amd as T
+    n, q = 16, 257
+    gp = T.GadgetParameters.init_default(n, q)
+    psf = T.PSFGPV(gp, 60.0)
+    psf.trap_gen(4)
+    for B in (1200, 700, 1500):                              # m = 304: 2.9 / 1.7 / 3.6 MB of rows, growing and shrinking
+        u = oracle.uniform_targets(9 + B, B, n, q)
+        monkeypatch.delenv("PSF_HOST_STRAIGHT", raising=False)
+        fast = psf.samp_p(u, seed=5 + B, first_index=11)
+        monkeypatch.setenv("PSF_HOST_STRAIGHT", "1")
+        straight = psf.samp_p(u, seed=5 + B, first_index=11)
+        monkeypatch.delenv("PSF_HOST_STRAIGHT", raising=False)
+        assert (fast == straight).all(), B
+        assert (psf.f_a(fast) == u).all()
+    psf.close()

@@ -19,9 +19,16 @@ def run(name, psf, B, m, n, q):
     e = psf.samp_p(u, seed=1)
     ts = []
     for i in range(6):
-        t0 = time.perf_counter(); e = psf.samp_p(u, seed=2 + i); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); e = psf.samp_p(u, seed=2 + i, out=e); ts.append(time.perf_counter() - t0)
+    os.environ["PSF_HOST_STRAIGHT"] = "1"
+    ts2 = []
+    for i in range(4):
+        t0 = time.perf_counter(); psf.samp_p(u, seed=2 + i, out=e); ts2.append(time.perf_counter() - t0)
+    os.environ.pop("PSF_HOST_STRAIGHT")
+    print(f"{name}: straight form (two allocations, pageable copies) {min(ts2)*1e3:.2f} ms into the same reused buffer")
+    e = psf.samp_p(u, seed=7, out=e)
     psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=7, stream=st); torch.cuda.synchronize()
-    same = bool((ed.cpu().numpy() == e).all())
+    same = bool((ed.cpu().numpy().reshape(-1) == np.asarray(e).reshape(-1)).all())
     print(f"{name}: device pointers {dd*1e3:.2f} ms per call, host pointers {min(ts)*1e3:.2f} ms (median {sorted(ts)[3]*1e3:.2f}), same rows {same}", flush=True)
 
 gpv = T.PSFGPV(T.GadgetParameters.init_default(256, 3329), 1024.0); gpv.trap_gen(3, export=False)

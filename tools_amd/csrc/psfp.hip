@@ -125,6 +125,7 @@ struct psfp_handle {
   std::thread hp_warm;        // hp_prewarm's worker; joined by whoever touches the host-pointer machinery next
   uint8_t* sio_pin = nullptr; size_t sio_cap = 0;
   uint64_t* sio_du = nullptr; int64_t* sio_de = nullptr; size_t sio_du_cap = 0, sio_de_cap = 0;      // device side for handles without their own (PSFGPV / ring)
+  int32_t* sio_d32 = nullptr; size_t sio_d32_cap = 0;         // narrowed rows of a PSFGPV / ring batch on their way to the host
   bool no_slice = false;      // stage export wants the intermediates of the whole batch
   bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
   size_t ncall = 0;
@@ -468,7 +469,7 @@ void psfp_destroy(psfp_handle* h) {
   hipSetDevice(h->prm.device);
   hp_release(h);
   if (h->sio_pin) hipHostFree(h->sio_pin);
-  hipFree(h->sio_du); hipFree(h->sio_de);
+  hipFree(h->sio_du); hipFree(h->sio_de); hipFree(h->sio_d32);
   free_batch(h);
   clear_slots(h);
   if (h->aux) hipStreamDestroy(h->aux);

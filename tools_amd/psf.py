@@ -322,13 +322,17 @@ class PSFGPV:
         check(lib().psfgpv_samp_d(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(nb), _p(e, C.c_int64)), "samp_d")
         return e[0] if B is None else e
 
-    def samp_p(self, u, seed=0, first_index=0):
-        """gpv.rs:152-161"""
+    def samp_p(self, u, seed=0, first_index=0, out=None):
+        """gpv.rs:152-161; out: optional (B, m) int64 C-contiguous array to fill (a reused buffer avoids the first-touch page faults of a fresh one)"""
         u = np.ascontiguousarray(u, dtype=np.uint64)
         single = u.ndim == 1
         u2 = u.reshape(-1, self.n)
         B = u2.shape[0]
-        e = np.zeros((B, self.m), dtype=np.int64)
+        if out is None:
+            e = np.empty((B, self.m), dtype=np.int64)
+        else:
+            e = out
+            assert e.dtype == np.int64 and e.shape == (B, self.m) and e.flags.c_contiguous
         check(lib().psfgpv_samp_p(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64),
                                   _p(e, C.c_int64)), "samp_p")
         return e[0] if single else e
@@ -442,13 +446,17 @@ class PSFGPVRing:
         check(lib().psfring_samp_d(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(nb), _p(sg, C.c_int64)), "samp_d")
         return sg[0] if B is None else sg
 
-    def samp_p(self, u, seed=0, first_index=0):
-        """gpv_ring.rs:160-212; u: n coefficients (or B x n)."""
+    def samp_p(self, u, seed=0, first_index=0, out=None):
+        """gpv_ring.rs:160-212; u: n coefficients (or B x n); out: optional (B, K, n) int64 C-contiguous array to fill."""
         u = np.ascontiguousarray(u, dtype=np.uint64)
         single = u.ndim == 1
         u2 = u.reshape(-1, self.n)
         B = u2.shape[0]
-        sg = np.zeros((B, self.K, self.n), dtype=np.int64)
+        if out is None:
+            sg = np.empty((B, self.K, self.n), dtype=np.int64)
+        else:
+            sg = out
+            assert sg.dtype == np.int64 and sg.shape == (B, self.K, self.n) and sg.flags.c_contiguous
         check(lib().psfring_samp_p(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64),
                                    _p(sg, C.c_int64)), "samp_p")
         return sg[0] if single else sg
