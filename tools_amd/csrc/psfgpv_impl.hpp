@@ -495,31 +495,41 @@ psf_status psfgpv_samp_p(psfgpv_handle* g, uint64_t seed, uint64_t first_index, 
   rc = psfgpv_samp_p_dev(g, seed, first_index, B, h->sio_du, h->sio_de, nullptr);
   if (rc != PSF_OK) { hipStreamSynchronize(nullptr); return rc; }
   hipLaunchKernelGGL(k_narrow_rows, dim3(grid_for(ne / 2 + 1, 256, 256 * 16)), dim3(256), 0, nullptr, h->sio_de, h->sio_d32, ne, d_ovf);
-  HIP_TRY(hipMemcpyAsync(he, h->sio_d32, ne * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
+  // flags first (with the overflow word of the narrowing), then the rows in NT pieces, an event behind each: thread i widens piece i as soon as it has landed,
+  // while the later pieces are still crossing PCIe
   hipLaunchKernelGGL(k_sio_flags, dim3(1), dim3(64), 0, nullptr, h->sets[0].dFail, h->sets[1].dFail, g->dFlags, 8, hf);
-  int ovf = 0;
   HIP_TRY(hipMemcpyAsync(hf + 12, d_ovf, sizeof(int), hipMemcpyDeviceToHost, nullptr));
+  constexpr int NT = 4;
+  if (!h->sio_ev[0]) for (auto& ev : h->sio_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(h->sio_ev[NT], nullptr));                       // flags and overflow word are in pinned memory
+  const size_t per = round_up((ne + NT - 1) / NT, 16);
+  for (int i = 0; i < NT; ++i) {
+    const size_t b0 = (size_t)i * per, cnt = b0 >= ne ? 0 : (ne - b0 < per ? ne - b0 : per);
+    if (cnt) HIP_TRY(hipMemcpyAsync(he + b0, h->sio_d32 + b0, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipEventRecord(h->sio_ev[i], nullptr));
+  }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(nullptr));
-  ovf = hf[12];
-  if (ovf) {
+  HIP_TRY(hipEventSynchronize(h->sio_ev[NT]));
+  if (hf[12]) {                                                            // an entry beyond 32 bits: the int64 rows, as before
+    HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(hipMemcpy(e, h->sio_de, ne * sizeof(int64_t), hipMemcpyDeviceToHost));
   } else {
-    constexpr int NT = 4;
     std::thread th[NT];
-    const size_t per = (ne + NT - 1) / NT;
+    std::atomic<int> bad{0};
+    const int device = h->prm.device;
+    auto piece = [&, device](int i, bool set_dev) {
+      const size_t b0 = (size_t)i * per, cnt = b0 >= ne ? 0 : (ne - b0 < per ? ne - b0 : per);
+      if (set_dev && hipSetDevice(device) != hipSuccess) { bad = 1; return; }
+      if (hipEventSynchronize(h->sio_ev[i]) != hipSuccess) { bad = 1; return; }
+      if (cnt) widen_rows(e + b0, he + b0, cnt);
+    };
     int started = 0;
     try {
-      for (; started < NT; ++started) {
-        const size_t b0 = (size_t)started * per, cnt = b0 >= ne ? 0 : (ne - b0 < per ? ne - b0 : per);
-        th[started] = std::thread([=]() { if (cnt) widen_rows(e + b0, he + b0, cnt); });
-      }
+      for (; started < NT; ++started) th[started] = std::thread(piece, started, true);
     } catch (...) { }
+    for (int i = started; i < NT; ++i) piece(i, false);                   // (no thread to be had: this one does the rest)
     for (int i = 0; i < started; ++i) th[i].join();
-    for (int i = started; i < NT; ++i) {                                  // (no thread to be had: this one does the rest)
-      const size_t b0 = (size_t)i * per, cnt = b0 >= ne ? 0 : (ne - b0 < per ? ne - b0 : per);
-      if (cnt) widen_rows(e + b0, he + b0, cnt);
-    }
+    if (bad) return PSF_ERR_HIP;
   }
   if (hf[0]) return PSF_ERR_SAMPLER;
   g->last_generic = g->basis_generic || hf[1 + (g->two_pass ? 7 : 3)] != 0;

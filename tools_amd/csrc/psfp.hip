@@ -126,6 +126,7 @@ struct psfp_handle {
   uint8_t* sio_pin = nullptr; size_t sio_cap = 0;
   uint64_t* sio_du = nullptr; int64_t* sio_de = nullptr; size_t sio_du_cap = 0, sio_de_cap = 0;      // device side for handles without their own (PSFGPV / ring)
   int32_t* sio_d32 = nullptr; size_t sio_d32_cap = 0;         // narrowed rows of a PSFGPV / ring batch on their way to the host
+  hipEvent_t sio_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // pieces 0..3 of such a batch have landed; [4]: its flags have
   bool no_slice = false;      // stage export wants the intermediates of the whole batch
   bool pipeline = false;   // PSF_PIPELINE=1 enables it; measured zero-sum on MI355X (profiles/r01_notes.md)
   size_t ncall = 0;
@@ -470,6 +471,7 @@ void psfp_destroy(psfp_handle* h) {
   hp_release(h);
   if (h->sio_pin) hipHostFree(h->sio_pin);
   hipFree(h->sio_du); hipFree(h->sio_de); hipFree(h->sio_d32);
+  for (auto& ev : h->sio_ev) if (ev) hipEventDestroy(ev);
   free_batch(h);
   clear_slots(h);
   if (h->aux) hipStreamDestroy(h->aux);
