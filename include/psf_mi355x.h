@@ -128,6 +128,22 @@ psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t coun
  * available when q < 2^31 is a prime with 4 | q-1 and n is a power of two (q = 3329, n = 256: seven levels and degree-1
  * leaves, as in ML-KEM); PSF_ERR_UNSUPPORTED otherwise.  psf_poly_mul_negacyclic uses the NTT whenever it is available. */
 psf_status psf_poly_mul_negacyclic_method(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out, int method);
+/* The same product on DEVICE buffers in the caller's stream, nothing allocated per call (the tables of a (device, q, n) are built at first use and
+ * kept): `count` products d_out[c] = d_a[c] * d_b[c] (PolynomialRingZq multiplication, gadget_ring.rs:78, gpv_ring.rs:245-246).
+ *   io_bits = 64: the layout above (a uint64 of any value, b int64 of any value, out uint64 in [0, q)); every modulus below 2^62 (NTT when q is an
+ *                 NTT-friendly prime below 2^31, the schoolbook kernel otherwise).
+ *   io_bits = 16: a uint16 in [0, q), b int16 in (-q, q), out uint16 in [0, q) -- a quarter of the bytes; NTT-friendly primes q < 2^14
+ *                 (3329, 7681, 12289: common_moduli.rs:41-48) with n = 128 ... 1024; PSF_ERR_UNSUPPORTED otherwise.
+ * One 128 ... 1024-point transform per WAVEFRONT: every butterfly in registers, lane bits exchanged by DPP / permlane swaps, Montgomery
+ * arithmetic (R = 2^16 on 24-bit multiplies for q < 2^14, R = 2^32 above), no division and no barrier (tools_amd/csrc/psf_ntt_core.hpp). */
+psf_status psf_poly_mul_negacyclic_dev(int device, uint64_t q, size_t n, size_t count, const void* d_a, const void* d_b, void* d_out, int io_bits, void* stream);
+/* A polynomial that takes part in many products (a key: a_bar of gadget_ring.rs:78, a of gpv_ring.rs:245) is transformed ONCE:
+ * psf_ntt_forward_dev writes its image (count * n 32-bit words, opaque), psf_poly_mul_hat_dev multiplies images by polynomials: d_out[c] =
+ * image[c * hat_stride ...] * d_b[c]; hat_stride in words, 0 = one image for every product.  Shapes with a wave kernel only (q an NTT-friendly
+ * prime < 2^31, n = 128 ... 1024, leaf degree <= 4); PSF_ERR_UNSUPPORTED otherwise. */
+psf_status psf_ntt_forward_dev(int device, uint64_t q, size_t n, size_t count, const void* d_a, int io_bits, uint32_t* d_hat, void* stream);
+psf_status psf_poly_mul_hat_dev(int device, uint64_t q, size_t n, size_t count, const uint32_t* d_hat, size_t hat_stride, const void* d_b, void* d_out, int io_bits,
+                                void* stream);
 /* rot_minus_matrix (rotation_matrix.rs:85-96): mat[rows x cols] -> out[rows x rows*cols] */
 psf_status psf_rot_minus_matrix(const int64_t* mat, size_t rows, size_t cols, int64_t* out);
 

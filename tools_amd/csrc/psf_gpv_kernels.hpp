@@ -148,71 +148,6 @@ __global__ __launch_bounds__(256) void k_polymul_negacyclic(uint64_t q, uint64_t
   }
 }
 
-// ---- the same product through an (incomplete) negacyclic NTT, for NTT-friendly prime q < 2^31 -------------------------------------
-// X^n + 1 splits over Z_q into 2^L factors X^d - gamma_i (L = min(v2(q-1) - 1, log2 n), d = n >> L; q = 3329, n = 256 gives Kyber's
-// L = 7, d = 2).  Forward transform: L Cooley-Tukey levels in LDS with zetas in bit-reversed order; leaf products in
-// Z_q[X]/(X^d - gamma_i) with gamma_i = zetas[2^(L-1) + i/2]^2 ... computed as +-zeta_leaf; inverse: Gentleman-Sande + 2^-L.
-// Exact arithmetic mod q, so the result equals k_polymul_negacyclic bit for bit (tested).
-__global__ __launch_bounds__(256) void k_polymul_ntt(uint32_t q32, uint32_t n, uint32_t L, uint32_t d, const uint64_t* __restrict__ zetas,
-                                                     const uint64_t* __restrict__ zetas_inv, uint64_t inv_scale, const uint64_t* __restrict__ A,
-                                                     const int64_t* __restrict__ Bp, uint64_t* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t nt_smem[];   // a[n] | b[n] | c[n]
-  uint32_t* sa = reinterpret_cast<uint32_t*>(nt_smem);
-  uint32_t* sb = sa + n;
-  uint32_t* sc = sb + n;
-  const uint64_t q = q32;
-  const size_t pair = blockIdx.x;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    sa[i] = (uint32_t)(A[pair * n + i] % q);
-    const int64_t v = Bp[pair * n + i] % (int64_t)q;
-    sb[i] = (uint32_t)(v < 0 ? v + (int64_t)q : v);
-  }
-  __syncthreads();
-  // forward: level l has 2^l blocks of length 2*len, block b uses zetas[2^l + b]
-  uint32_t len = n >> 1;
-  for (uint32_t l = 0; l < L; ++l, len >>= 1) {
-    for (uint32_t e = threadIdx.x; e < n / 2; e += 256) {
-      const uint32_t blk = e / len, j = e % len;
-      const uint32_t lo = blk * 2 * len + j, hi = lo + len;
-      const uint64_t z = zetas[(1u << l) + blk];
-      const uint32_t ta = (uint32_t)((z * sa[hi]) % q), tb = (uint32_t)((z * sb[hi]) % q);
-      const uint32_t ua = sa[lo], ub = sb[lo];
-      sa[hi] = ua >= ta ? ua - ta : ua + q32 - ta;  sa[lo] = (uint32_t)(((uint64_t)ua + ta) % q);
-      sb[hi] = ub >= tb ? ub - tb : ub + q32 - tb;  sb[lo] = (uint32_t)(((uint64_t)ub + tb) % q);
-    }
-    __syncthreads();
-  }
-  // leaves: 2^L rings Z_q[X]/(X^d - gamma), leaf i occupies coefficients [i d, (i+1) d); consecutive leaves are the +- pair of the last level
-  for (uint32_t e = threadIdx.x; e < n; e += 256) {
-    const uint32_t leaf = e / d, c = e % d;
-    uint64_t gamma;
-    if (L == 0) gamma = q - 1;                                     // X^n + 1 itself: X^d = -1
-    else { const uint64_t z = zetas[(1u << (L - 1)) + (leaf >> 1)]; gamma = (leaf & 1) ? q - z : z; }
-    const uint32_t* pa = sa + leaf * d;
-    const uint32_t* pb = sb + leaf * d;
-    uint64_t lo = 0, hi = 0;                                       // c-th coefficient: sum_{i+j=c} + gamma * sum_{i+j=c+d}
-    for (uint32_t i = 0; i < d; ++i) {
-      if (i <= c) lo = (lo + (uint64_t)pa[i] * pb[c - i]) % q;
-      else hi = (hi + (uint64_t)pa[i] * pb[d + c - i]) % q;
-    }
-    sc[e] = (uint32_t)((lo + (gamma * hi) % q) % q);
-  }
-  __syncthreads();
-  // inverse: Gentleman-Sande, levels in reverse order
-  len = d;
-  for (int l = (int)L - 1; l >= 0; --l, len <<= 1) {
-    for (uint32_t e = threadIdx.x; e < n / 2; e += 256) {
-      const uint32_t blk = e / len, j = e % len;
-      const uint32_t lo = blk * 2 * len + j, hi = lo + len;
-      const uint64_t zi = zetas_inv[(1u << l) + blk];
-      const uint32_t u = sc[lo], v = sc[hi];
-      sc[lo] = (uint32_t)(((uint64_t)u + v) % q);
-      const uint32_t dif = u >= v ? u - v : u + q32 - v;
-      sc[hi] = (uint32_t)((zi * dif) % q);
-    }
-    __syncthreads();
-  }
-  for (uint32_t i = threadIdx.x; i < n; i += 256) out[pair * n + i] = (inv_scale * sc[i]) % q;
-}
+// The NTT forms of this product (one transform per wavefront, Montgomery arithmetic) are in psf_ntt_kernels.hpp / psf_ntt.hip.
 
 }  // namespace psf

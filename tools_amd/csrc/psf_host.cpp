@@ -409,6 +409,42 @@ NttPlan make_ntt_plan(uint64_t q, uint32_t n) {
   return pl;
 }
 
+static uint32_t ntt_form(uint64_t v, uint64_t q, int qb) {          // centred int32 bits for the 16-bit form, canonical otherwise
+  if (qb == 0) return (uint32_t)v;
+  const int64_t c = v > q / 2 ? (int64_t)v - (int64_t)q : (int64_t)v;
+  return (uint32_t)(int32_t)c;
+}
+NttTables make_ntt_tables(const NttPlan& pl) {
+  NttTables t;
+  if (!pl.ok) return t;
+  const uint64_t q = pl.q;
+  t.q = (uint32_t)q;
+  while ((1u << t.logn) < pl.n) ++t.logn;
+  while ((1u << t.ld) < pl.d) ++t.ld;
+  // the 12-bit bound analysis (fewer uniform reductions) is instantiated for the seven-level shapes of q = 3329 (n = 128, 256, 512) only
+  t.wave = t.logn >= 7 && t.logn <= 10 && t.ld <= 2 && t.ld <= t.logn - 6 && pl.L >= 1;
+  t.qb = !t.wave ? 0 : q < (1ull << 12) && pl.L == 7 && t.ld == t.logn - 7 ? 12 : q < (1ull << 14) ? 14 : 0;   // the generic LDS kernel computes in the 32-bit form
+  uint32_t inv = 1;                                                   // Newton: q^-1 mod 2^32 (q odd)
+  for (int i = 0; i < 5; ++i) inv *= 2u - (uint32_t)q * inv;
+  t.nqinv32 = 0u - inv;
+  t.qinv16 = (int32_t)(int16_t)(uint16_t)inv;
+  const uint64_t R = (t.qb ? (1ull << 16) : (1ull << 32)) % q;
+  t.r2 = ntt_form(mulmod_u64(R, R, q), q, t.qb);
+  const size_t cnt = pl.zetas.size();
+  t.zetas.resize(2 * cnt);
+  for (size_t i = 0; i < cnt; ++i) {
+    t.zetas[i] = ntt_form(mulmod_u64(pl.zetas[i], R, q), q, t.qb);
+    t.zetas[cnt + i] = ntt_form(mulmod_u64(pl.zetas_inv[i], R, q), q, t.qb);
+  }
+  return t;
+}
+uint32_t ntt_final_scale(const NttTables& t, const NttPlan& pl, int e) {
+  const uint64_t q = pl.q, R = (t.qb ? (1ull << 16) : (1ull << 32)) % q;
+  uint64_t f = pl.inv_scale % q;
+  for (int i = 0; i <= e; ++i) f = mulmod_u64(f, R, q);
+  return ntt_form(f, q, t.qb);
+}
+
 // gpv_ring.rs:172-178
 void ring_embed_a(const uint64_t* a, size_t n, size_t K, uint64_t q, std::vector<uint64_t>& A_emb) {
   const size_t d = n * K;

@@ -75,6 +75,13 @@ psf_status ring_short_basis_t(const psf_gadget_params& gp, const uint64_t* a, co
 // ok = false when q is not a prime with v2(q-1) >= 2, n is not a power of two, or q >= 2^31.
 struct NttPlan { bool ok = false; uint32_t n = 0, L = 0, d = 0; uint64_t q = 0, inv_scale = 0; std::vector<uint64_t> zetas, zetas_inv; };
 NttPlan make_ntt_plan(uint64_t q, uint32_t n);
+// The same plan in the form the wave-level kernels of psf_ntt_core.hpp read: which arithmetic (qb = 12 / 14: signed 16-bit Montgomery form for
+// q < 2^12 / 2^14; qb = 0: 32-bit Montgomery form), the constants of the reduction, and the zetas (forward [2^L] | inverse [2^L]) multiplied by
+// R = 2^16 (centred, as int32 bits) or 2^32.  wave = false when the shape has no wave kernel (n outside 128 ... 1024, leaf degree above 4 or wider than a lane).
+struct NttTables { bool wave = false; int logn = 0, ld = 0, qb = 0; uint32_t q = 0; int32_t qinv16 = 0; uint32_t nqinv32 = 0, r2 = 0; std::vector<uint32_t> zetas; };
+NttTables make_ntt_tables(const NttPlan& pl);
+// 2^-L R^(e+1) mod q in the tables' form: the last multiplication of a product that carries e factors R^-1
+uint32_t ntt_final_scale(const NttTables& t, const NttPlan& pl, int e);
 // rot^-(iota(a)) (gpv_ring.rs:172-178, rotation_matrix.rs:85-96): n x n(k+2) over Z_q
 void ring_embed_a(const uint64_t* a, size_t n, size_t K, uint64_t q, std::vector<uint64_t>& A_emb);
 

@@ -602,6 +602,8 @@ struct psfring_handle {
   double s_td = 0;
   std::vector<uint64_t> a;             // (k+2) x n
   std::vector<int64_t> r, e;           // k x n
+  uint32_t* dHat = nullptr;            // NTT images of the k+2 polynomials of a (psf_ntt_api.hpp), when (q, n) has a wave kernel
+  bool fa_ntt = false;                 // f_a as k+2 R_q products (gpv_ring.rs:243-247) instead of the embedded matrix product
 };
 
 static psf_status ring_install(psfring_handle* h) {
@@ -624,6 +626,35 @@ static psf_status ring_install(psfring_handle* h) {
   if (rc2 != PSF_OK) return rc2;
   b->has_key = true; b->has_pub = true;
   g->has_key = true;
+  // the key side of f_a is transformed once: a -> the images of its k+2 polynomials
+  h->fa_ntt = false;
+  if (ntt_route(h->gp.q, n) == 2 && ((size_t)K * n + 4 * n) * sizeof(uint32_t) <= 64 * 1024) {
+    if (!h->dHat) HIP_TRY(hipMalloc(&h->dHat, K * n * sizeof(uint32_t)));
+    uint64_t* da = nullptr;
+    HIP_TRY(hipMalloc(&da, K * n * sizeof(uint64_t)));
+    psf_status rf = hipMemcpy(da, h->a.data(), K * n * sizeof(uint64_t), hipMemcpyHostToDevice) == hipSuccess ? PSF_OK : PSF_ERR_HIP;
+    if (rf == PSF_OK) rf = ntt_forward_dev(b->prm.device, h->gp.q, n, K, da, 64, h->dHat, nullptr);
+    if (rf == PSF_OK && hipDeviceSynchronize() != hipSuccess) rf = PSF_ERR_HIP;
+    hipFree(da);
+    if (rf != PSF_OK) return rf;
+    h->fa_ntt = true;
+  }
+  return PSF_OK;
+}
+
+// one R_q product kernel launch on device buffers: the NTT when (q, n) has one, the exact schoolbook kernel otherwise (64-bit layout only)
+static psf_status polymul_dev_any(int device, uint64_t q, size_t n, size_t count, const void* da, const void* db, void* dout, int io_bits, int method, hipStream_t st) {
+  if (method != 0) {
+    const psf_status rc = ntt_polymul_dev(device, q, n, count, da, db, dout, io_bits, st);
+    if (rc != PSF_ERR_UNSUPPORTED || method == 1) return rc;
+  }
+  if (io_bits != 64) return PSF_ERR_UNSUPPORTED;
+  if (count == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(device));
+  const uint64_t two64 = (uint64_t)((((u128)1) << 64) % q);
+  hipLaunchKernelGGL(k_polymul_negacyclic, dim3((unsigned)count), dim3(256), 2 * n * sizeof(uint64_t), st, q, two64, (uint32_t)n, (const uint64_t*)da, n, (const int64_t*)db, n,
+                     (uint64_t*)dout, n);
+  HIP_TRY(hipGetLastError());
   return PSF_OK;
 }
 
@@ -647,51 +678,45 @@ psf_status psfring_create(const psfring_params* prm, psfring_handle** out) {
 
 void psfring_destroy(psfring_handle* h) {
   if (!h) return;
+  if (h->dHat) hipFree(h->dHat);
   psfgpv_destroy(h->g);
   delete h;
 }
 
+// method: 0 = schoolbook kernel, 1 = NTT (PSF_ERR_UNSUPPORTED without a plan), -1 = NTT when there is one
 psf_status psf_poly_mul_negacyclic_method(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out, int method) {
   if (q <= 1 || q >= (1ull << 62) || n < 1 || n > 8192 || (count && (!a || !b || !out))) return PSF_ERR_PARAM;
-  NttPlan plan;
-  if (method == 1) {
-    plan = make_ntt_plan(q, (uint32_t)n);
-    if (!plan.ok) return PSF_ERR_UNSUPPORTED;
-  }
+  if (method == 1 && ntt_route(q, n) == 0) return PSF_ERR_UNSUPPORTED;
   if (count == 0) return PSF_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return PSF_ERR_HIP;
   HIP_TRY(hipSetDevice(device));
   uint64_t *da = nullptr, *dout = nullptr; int64_t* db = nullptr;
-  HIP_TRY(hipMalloc(&da, count * n * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc(&db, count * n * sizeof(int64_t)));
-  HIP_TRY(hipMalloc(&dout, count * n * sizeof(uint64_t)));
-  HIP_TRY(hipMemcpy(da, a, count * n * sizeof(uint64_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(db, b, count * n * sizeof(int64_t), hipMemcpyHostToDevice));
-  if (method == 1) {
-    uint64_t *dz = nullptr, *dzi = nullptr;
-    HIP_TRY(hipMalloc(&dz, plan.zetas.size() * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&dzi, plan.zetas.size() * sizeof(uint64_t)));
-    HIP_TRY(hipMemcpy(dz, plan.zetas.data(), plan.zetas.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dzi, plan.zetas_inv.data(), plan.zetas.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_polymul_ntt, dim3((unsigned)count), dim3(256), 3 * n * sizeof(uint32_t) + 16, 0, (uint32_t)q, (uint32_t)n, plan.L, plan.d, dz, dzi,
-                       plan.inv_scale, da, db, dout);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    hipFree(dz); hipFree(dzi);
-  } else {
-    const uint64_t two64 = (uint64_t)((((u128)1) << 64) % q);
-    hipLaunchKernelGGL(k_polymul_negacyclic, dim3((unsigned)count), dim3(256), 2 * n * sizeof(uint64_t), 0, q, two64, (uint32_t)n, da, n, db, n, dout, n);
-    HIP_TRY(hipGetLastError());
-  }
-  HIP_TRY(hipMemcpy(out, dout, count * n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  hipFree(da); hipFree(db); hipFree(dout);
-  return PSF_OK;
+  auto done = [&](psf_status st) { hipFree(da); hipFree(db); hipFree(dout); return st; };
+  if (hipMalloc(&da, count * n * sizeof(uint64_t)) != hipSuccess || hipMalloc(&db, count * n * sizeof(int64_t)) != hipSuccess ||
+      hipMalloc(&dout, count * n * sizeof(uint64_t)) != hipSuccess) return done(PSF_ERR_HIP);
+  if (hipMemcpy(da, a, count * n * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(db, b, count * n * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return done(PSF_ERR_HIP);
+  const psf_status rc = polymul_dev_any(device, q, n, count, da, db, dout, 64, method, nullptr);
+  if (rc != PSF_OK) return done(rc);
+  if (hipMemcpy(out, dout, count * n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return done(PSF_ERR_HIP);
+  return done(PSF_OK);
 }
 
 psf_status psf_poly_mul_negacyclic(int device, uint64_t q, size_t n, size_t count, const uint64_t* a, const int64_t* b, uint64_t* out) {
-  const bool ntt = q < (1ull << 31) && n >= 2 && n <= 8192 && make_ntt_plan(q, (uint32_t)n).ok;
-  return psf_poly_mul_negacyclic_method(device, q, n, count, a, b, out, ntt ? 1 : 0);
+  return psf_poly_mul_negacyclic_method(device, q, n, count, a, b, out, -1);
+}
+
+psf_status psf_poly_mul_negacyclic_dev(int device, uint64_t q, size_t n, size_t count, const void* d_a, const void* d_b, void* d_out, int io_bits, void* stream) {
+  if (q <= 1 || q >= (1ull << 62) || n < 1 || n > 8192 || (io_bits != 16 && io_bits != 64) || (count && (!d_a || !d_b || !d_out))) return PSF_ERR_PARAM;
+  return polymul_dev_any(device, q, n, count, d_a, d_b, d_out, io_bits, -1, (hipStream_t)stream);
+}
+psf_status psf_ntt_forward_dev(int device, uint64_t q, size_t n, size_t count, const void* d_a, int io_bits, uint32_t* d_hat, void* stream) {
+  return ntt_forward_dev(device, q, n, count, d_a, io_bits, d_hat, (hipStream_t)stream);
+}
+psf_status psf_poly_mul_hat_dev(int device, uint64_t q, size_t n, size_t count, const uint32_t* d_hat, size_t hat_stride, const void* d_b, void* d_out, int io_bits,
+                                void* stream) {
+  return ntt_mul_hat_dev(device, q, n, count, d_hat, hat_stride, d_b, d_out, io_bits, (hipStream_t)stream);
 }
 
 // MatQ::gso (gpv.rs:88-91) as a free function: rows of an integer matrix -> their Gram-Schmidt vectors
@@ -720,11 +745,29 @@ psf_status psf_gso_rows(int device, const int32_t* basis_t, size_t rows, size_t 
 static psf_status ring_lwe_assemble(int device, const psf_gadget_params* gp, const uint64_t* a_bar, const int64_t* r, const int64_t* e, uint64_t* a) {
   const size_t n = gp->n, k = gp->k;
   const uint64_t q = gp->q;
-  std::vector<uint64_t> abar_rep(k * n), prod(k * n);
-  for (size_t j = 0; j < k; ++j)
-    for (size_t c = 0; c < n; ++c) abar_rep[j * n + c] = a_bar[c] % q;
-  const psf_status rc = psf_poly_mul_negacyclic(device, q, n, k, abar_rep.data(), r, prod.data());   // a_bar * r (:78)
-  if (rc != PSF_OK) return rc;
+  std::vector<uint64_t> prod(k * n);
+  psf_status rc;
+  if (ntt_route(q, n) == 2) {                                            // a_bar is transformed ONCE, then k products image x r_j
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return PSF_ERR_HIP;
+    HIP_TRY(hipSetDevice(device));
+    uint64_t *da = nullptr, *dout = nullptr; int64_t* dr = nullptr; uint32_t* dhat = nullptr;
+    auto done = [&](psf_status st) { hipFree(da); hipFree(dr); hipFree(dout); hipFree(dhat); return st; };
+    if (hipMalloc(&da, n * sizeof(uint64_t)) != hipSuccess || hipMalloc(&dr, k * n * sizeof(int64_t)) != hipSuccess ||
+        hipMalloc(&dout, k * n * sizeof(uint64_t)) != hipSuccess || hipMalloc(&dhat, n * sizeof(uint32_t)) != hipSuccess) return done(PSF_ERR_HIP);
+    if (hipMemcpy(da, a_bar, n * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dr, r, k * n * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return done(PSF_ERR_HIP);
+    rc = ntt_forward_dev(device, q, n, 1, da, 64, dhat, nullptr);
+    if (rc == PSF_OK) rc = ntt_mul_hat_dev(device, q, n, k, dhat, 0, dr, dout, 64, nullptr);                 // a_bar * r (:78)
+    if (rc == PSF_OK && hipMemcpy(prod.data(), dout, k * n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = PSF_ERR_HIP;
+    if (done(rc) != PSF_OK) return rc;
+  } else {
+    std::vector<uint64_t> abar_rep(k * n);
+    for (size_t j = 0; j < k; ++j)
+      for (size_t c = 0; c < n; ++c) abar_rep[j * n + c] = a_bar[c] % q;
+    rc = psf_poly_mul_negacyclic(device, q, n, k, abar_rep.data(), r, prod.data());                 // a_bar * r (:78)
+    if (rc != PSF_OK) return rc;
+  }
   for (size_t c = 0; c < (k + 2) * n; ++c) a[c] = 0;
   a[0] = 1 % q;                                                                                 // :74-76
   for (size_t c = 0; c < n; ++c) a[n + c] = a_bar[c] % q;
@@ -830,11 +873,47 @@ psf_status psfring_samp_p(psfring_handle* h, uint64_t seed, uint64_t first_index
 psf_status psfring_samp_p_dev(psfring_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_sigma, void* stream) {
   return h ? psfgpv_samp_p_dev(h->g, seed, first_index, B, d_u, d_sigma, stream) : PSF_ERR_PARAM;
 }
-psf_status psfring_f_a(psfring_handle* h, size_t B, const int64_t* sigma, uint64_t* u) {
-  return h ? psfgpv_f_a(h->g, B, sigma, u) : PSF_ERR_PARAM;
+// gpv_ring.rs:243-247: the domain check, then u = sum_j a_j * sigma_j in R_q.  With the images of a (ring_install) that is k+2 forward
+// transforms, k+2 leaf products and one inverse transform per preimage (k_ring_fa); PSF_RING_FA=matmul keeps the product with rot^-(iota(a)) on
+// the int8 matrix cores (same residues; also the route of every (q, n) without a wave kernel).
+static bool ring_fa_by_ntt(const psfring_handle* h) {
+  static const int forced = [] { const char* e = std::getenv("PSF_RING_FA"); return !e ? 0 : (std::strcmp(e, "matmul") == 0 ? 1 : 2); }();
+  return h->fa_ntt && forced != 1;
 }
 psf_status psfring_f_a_dev(psfring_handle* h, size_t B, const int64_t* d_sigma, uint64_t* d_u, uint8_t* d_ok, void* stream) {
-  return h ? psfgpv_f_a_dev(h->g, B, d_sigma, d_u, d_ok, stream) : PSF_ERR_PARAM;
+  if (!h) return PSF_ERR_PARAM;
+  if (!ring_fa_by_ntt(h)) return psfgpv_f_a_dev(h->g, B, d_sigma, d_u, d_ok, stream);
+  if (B && (!d_sigma || !d_u || !d_ok)) return PSF_ERR_PARAM;
+  if (!h->g->has_key) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  psfp_handle* b = h->g->base;
+  HIP_TRY(hipSetDevice(b->prm.device));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_check_domain, dim3((unsigned)B), dim3(256), 0, st, d_sigma, b->m, b->m, domain_bound(b), d_ok);      // :244
+  HIP_TRY(hipGetLastError());
+  const psf_status rc = ntt_ring_fa_dev(b->prm.device, h->gp.q, h->gp.n, (uint32_t)(h->gp.k + 2), h->dHat, d_sigma, d_u, B, st);   // :245-246
+  b->last_stream = st;
+  return rc;
+}
+psf_status psfring_f_a(psfring_handle* h, size_t B, const int64_t* sigma, uint64_t* u) {
+  if (!h) return PSF_ERR_PARAM;
+  if (!ring_fa_by_ntt(h)) return psfgpv_f_a(h->g, B, sigma, u);
+  if (B && (!sigma || !u)) return PSF_ERR_PARAM;
+  if (!h->g->has_key) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  psfp_handle* b = h->g->base;
+  HIP_TRY(hipSetDevice(b->prm.device));
+  { const psf_status rw = psfp_wait(b); if (rw != PSF_OK) return rw; }
+  psf_status rc = ensure_batch(b, B);
+  if (rc != PSF_OK) return rc;
+  HIP_TRY(hipMemcpy(b->dE, sigma, B * b->m * sizeof(int64_t), hipMemcpyHostToDevice));
+  rc = psfring_f_a_dev(h, B, b->dE, b->dU, b->dOk, nullptr);
+  if (rc != PSF_OK) return rc;
+  std::vector<uint8_t> ok(B);
+  HIP_TRY(hipMemcpy(u, b->dU, B * b->n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ok.data(), b->dOk, B, hipMemcpyDeviceToHost));
+  for (uint8_t o : ok) if (!o) return PSF_ERR_DOMAIN;
+  return PSF_OK;
 }
 psf_status psfring_check_domain(psfring_handle* h, size_t B, const int64_t* sigma, size_t len, uint8_t* ok) {
   return h ? psfgpv_check_domain(h->g, B, sigma, len, ok) : PSF_ERR_PARAM;

@@ -19,6 +19,7 @@
 #include "psf_chol_kernels.hpp"
 #include "psf_gemm_kernels.hpp"
 #include "psf_sdma.hpp"
+#include "psf_ntt_api.hpp"
 
 #define PSFP_FLAG_NO_PERTURB 1u   // internal: handle used as the Z_q / f_a engine of PSFGPV(Ring); no sqrt(Sigma_2) buffers
 // PSFP_FLAG_STRUCTURED_SQRT (2u) is public: include/psf_mi355x.h

@@ -104,6 +104,25 @@ def poly_mul_negacyclic(a, b, q, device=0, method=None):
     return out[0] if single else out
 
 
+def poly_mul_negacyclic_dev(d_a, d_b, d_out, q, n, count, io_bits=64, device=0, stream=None):
+    """psf_poly_mul_negacyclic_dev: the same product on device buffers (raw pointers, e.g. torch `data_ptr()`), in `stream`, nothing allocated.
+    io_bits 64: a uint64 / b int64 / out uint64; io_bits 16: a uint16 in [0, q) / b int16 in (-q, q) / out uint16 (NTT primes q < 2^14)."""
+    check(lib().psf_poly_mul_negacyclic_dev(C.c_int(device), C.c_uint64(q), C.c_size_t(n), C.c_size_t(count), C.c_void_p(d_a), C.c_void_p(d_b),
+                                            C.c_void_p(d_out), C.c_int(io_bits), C.c_void_p(stream or 0)), "poly_mul_negacyclic_dev")
+
+
+def ntt_forward_dev(d_a, d_hat, q, n, count, io_bits=64, device=0, stream=None):
+    """psf_ntt_forward_dev: transform `count` polynomials once; d_hat receives count * n 32-bit words (opaque images for poly_mul_hat_dev)."""
+    check(lib().psf_ntt_forward_dev(C.c_int(device), C.c_uint64(q), C.c_size_t(n), C.c_size_t(count), C.c_void_p(d_a), C.c_int(io_bits),
+                                    C.c_void_p(d_hat), C.c_void_p(stream or 0)), "ntt_forward_dev")
+
+
+def poly_mul_hat_dev(d_hat, hat_stride, d_b, d_out, q, n, count, io_bits=64, device=0, stream=None):
+    """psf_poly_mul_hat_dev: d_out[c] = image[c * hat_stride] * d_b[c]; hat_stride 0 = one image (a key polynomial) for every product."""
+    check(lib().psf_poly_mul_hat_dev(C.c_int(device), C.c_uint64(q), C.c_size_t(n), C.c_size_t(count), C.c_void_p(d_hat), C.c_size_t(hat_stride),
+                                     C.c_void_p(d_b), C.c_void_p(d_out), C.c_int(io_bits), C.c_void_p(stream or 0)), "poly_mul_hat_dev")
+
+
 def gen_trapdoor(gp, a_bar, tag=None, seed=0, device=0):
     """gen_trapdoor (gadget_classical.rs:56-68): caller-supplied A_bar and tag H; returns (A, R), R <- PlusMinusOneZero from `seed`."""
     c = gp.c if hasattr(gp, "c") else gp
