@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include "../../tools_amd/csrc/psf_host.hpp"
 #include "../../tools_amd/csrc/psf_ntt_core.hpp"
@@ -69,7 +70,28 @@ struct HostWave {
   static U cadd(U x, uint32_t q) { for (auto& e : x.v) e = e + (q & (uint32_t)((int32_t)e >> 31)); return x; }
   template <class V> static V tab(Tab t, I idx, int off) { V r; for (int l = 0; l < 64; ++l) r.v[l] = (decltype(r.v[0]))t[idx.v[l] + off]; return r; }
   template <class V> static V tab_const(Tab t, int idx) { V r; for (int l = 0; l < 64; ++l) r.v[l] = (decltype(r.v[0]))t[idx]; return r; }
+  static I umin(I a, I b) { I r; for (int l = 0; l < 64; ++l) r.v[l] = (uint32_t)a.v[l] < (uint32_t)b.v[l] ? a.v[l] : b.v[l]; return r; }
+  template <class V> static void tab_pair(Tab t, int zoff, I idx, int off, V& pk, V& zq) {
+    for (int l = 0; l < 64; ++l) { pk.v[l] = (int32_t)t[zoff + 2 * (idx.v[l] + off)]; zq.v[l] = (int32_t)t[zoff + 2 * (idx.v[l] + off) + 1]; }
+  }
+  template <class V> static void tab_pair_const(Tab t, int zoff, int idx, V& pk, V& zq) { tab_pair<V>(t, zoff, I(0), idx, pk, zq); }
+  static I dot2mont(I x, I zq, I pk) {
+    for (int l = 0; l < 64; ++l) {
+      const int32_t xv = x.v[l];
+      if (xv < -32768 || xv > 32767) { std::fprintf(stderr, "dot-product form: operand %d outside 16 bits\n", xv); std::abort(); }
+      const int16_t m = (int16_t)(uint16_t)((uint16_t)xv * (uint16_t)zq.v[l]);
+      const long long S = (long long)xv * (int16_t)(pk.v[l] & 0xffff) + (long long)m * (int16_t)((uint32_t)pk.v[l] >> 16);
+      if (S & 0xffff) { std::fprintf(stderr, "dot-product form: not exact\n"); std::abort(); }
+      if (S < -(1ll << 31) || S >= (1ll << 31)) { std::fprintf(stderr, "dot-product form: overflow\n"); std::abort(); }
+      x.v[l] = (int32_t)(S >> 16);
+    }
+    return x;
+  }
   template <class V> static V sel_odd(I lane, V a, V b) { V r; for (int l = 0; l < 64; ++l) r.v[l] = (lane.v[l] & 1) ? a.v[l] : b.v[l]; return r; }
+  template <int K, int C, int J, class V> static void exchange(V (&x)[C]) {
+    for (int r = 0; r < C; ++r)
+      if (!((r >> J) & 1)) swap<K>(x[r], x[r | (1 << J)]);
+  }
   template <int K, class V> static void swap(V& a, V& b) {
     V na, nb;
     for (int l = 0; l < 64; ++l) {
@@ -120,10 +142,11 @@ template <int LOGN, int LD, int QB> static int run_case(uint64_t q, bool extreme
   std::vector<uint64_t> got(N);
   const auto lane = W::lane();
   if constexpr (QB != 0) {
-    using M = Mod16<W, QB>;
+    using M = std::conditional_t<QB == 12, Mod16D<W>, Mod16<W, QB>>;
     using BD = Bounds16<QB, LOGN, LD>;
     using K = Core<W, M, BD, LOGN, LD>;
     M md; md.q = (int)q; md.nq = -(int)q; md.qinv = tb.qinv16;
+    if constexpr (QB == 12) md.zoff = 2 << pl.L;
     typename M::V x[C], y[C], c[C];
     for (int r = 0; r < C; ++r)
       for (int l = 0; l < 64; ++l) {

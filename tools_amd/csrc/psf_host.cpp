@@ -436,6 +436,14 @@ NttTables make_ntt_tables(const NttPlan& pl) {
     t.zetas[i] = ntt_form(mulmod_u64(pl.zetas[i], R, q), q, t.qb);
     t.zetas[cnt + i] = ntt_form(mulmod_u64(pl.zetas_inv[i], R, q), q, t.qb);
   }
+  if (t.qb == 12) {                                                   // dot-product form of the forward butterflies: [(z | -q), z q^-1 mod 2^16] per zeta
+    t.zetas.resize(4 * cnt);
+    for (size_t i = 0; i < cnt; ++i) {
+      const uint32_t z = t.zetas[i] & 0xffffu;
+      t.zetas[2 * cnt + 2 * i] = z | ((uint32_t)(0x10000u - (uint32_t)q) << 16);
+      t.zetas[2 * cnt + 2 * i + 1] = (z * (uint32_t)(uint16_t)t.qinv16) & 0xffffu;
+    }
+  }
   return t;
 }
 uint32_t ntt_final_scale(const NttTables& t, const NttPlan& pl, int e) {

@@ -77,7 +77,7 @@ struct NttPlan { bool ok = false; uint32_t n = 0, L = 0, d = 0; uint64_t q = 0, 
 NttPlan make_ntt_plan(uint64_t q, uint32_t n);
 // The same plan in the form the wave-level kernels of psf_ntt_core.hpp read: which arithmetic (qb = 12 / 14: signed 16-bit Montgomery form for
 // q < 2^12 / 2^14; qb = 0: 32-bit Montgomery form), the constants of the reduction, and the zetas (forward [2^L] | inverse [2^L]) multiplied by
-// R = 2^16 (centred, as int32 bits) or 2^32.  wave = false when the shape has no wave kernel (n outside 128 ... 1024, leaf degree above 4 or wider than a lane).
+// R = 2^16 (centred, as int32 bits) or 2^32; qb = 12 appends the pairs of the dot-product form (psf_ntt_core.hpp, Mod16D).  wave = false when the shape has no wave kernel (n outside 128 ... 1024, leaf degree above 4 or wider than a lane).
 struct NttTables { bool wave = false; int logn = 0, ld = 0, qb = 0; uint32_t q = 0; int32_t qinv16 = 0; uint32_t nqinv32 = 0, r2 = 0; std::vector<uint32_t> zetas; };
 NttTables make_ntt_tables(const NttPlan& pl);
 // 2^-L R^(e+1) mod q in the tables' form: the last multiplication of a product that carries e factors R^-1

@@ -2,6 +2,7 @@
 // PolynomialRingZq multiplication under gadget_ring.rs:78 and gpv_ring.rs:243-247; the kernels are in psf_ntt_kernels.hpp / psf_ntt_core.hpp.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -29,7 +30,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_ntt_polymul_lds(NttDev p, uint32_t n, uint32_t L, uint32_t d, const uint64_t* __restrict__ A, const int64_t* __restrict__ Bp,
                                                          uint64_t* __restrict__ out, size_t count) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_smem[];   // zetas fwd [2^L] | inv [2^L] | a[n] | b[n] | c[n]
-  const Mod32<DevWave> md = make_policy<0>(p);
+  const Mod32<DevWave> md = make_policy<0>(p, 0);
   uint32_t* zf = lds_smem;
   uint32_t* zi = zf + (1u << L);
   uint32_t* sa = zi + (1u << L);
@@ -138,8 +139,9 @@ NttDev dev_args(const Plan* P, int e, int e_fa) {
   return a;
 }
 unsigned wave_grid(size_t count) {                                       // four products per workgroup at a time, at most 8 workgroups per CU
+  static const size_t cap = [] { const char* e = std::getenv("PSF_NTT_GRID"); const long v = e ? std::atol(e) : 0; return (size_t)(v > 0 ? v : 2048); }();
   const size_t g = (count + 3) / 4;
-  return (unsigned)(g < 1 ? 1 : g > 2048 ? 2048 : g);
+  return (unsigned)(g < 1 ? 1 : g > cap ? cap : g);
 }
 
 }  // namespace
@@ -231,7 +233,7 @@ psf_status ntt_ring_fa_dev(int device, uint64_t q, size_t n, uint32_t K, const u
   psf_status rc;
   Plan* P = plan_for(device, q, n, &rc);
   if (!P) return rc != PSF_OK ? rc : PSF_ERR_UNSUPPORTED;
-  const size_t smem = ((2u << P->pl.L) + (size_t)K * n) * sizeof(uint32_t);
+  const size_t smem = (((P->tb.qb == 12 ? 4u : 2u) << P->pl.L) + (size_t)K * n) * sizeof(uint32_t);
   if (P->route != 2 || smem > 64 * 1024) return PSF_ERR_UNSUPPORTED;
   if (B == 0) return PSF_OK;
   NTT_TRY(hipSetDevice(device));

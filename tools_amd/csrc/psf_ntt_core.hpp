@@ -121,10 +121,34 @@ template <class W, int QB_> struct Mod16 {
   PSF_NTT_FN V add(V a, V b) const { return a + b; }
   PSF_NTT_FN V sub(V a, V b) const { return a - b; }
   PSF_NTT_FN V neg(V a) const { return W::izero() - a; }
-  PSF_NTT_FN V canon(V x) const { return x + (W::sra(x, 31) & q); }            // x in (-q, q)
+  PSF_NTT_FN V canon(V x) const { return W::umin(x, x + q); }                  // x in (-q, q): as unsigned numbers the smaller of x and x + q
   // sums of products reduced once (leaf products): t = a b (+ c d ...)
   PSF_NTT_FN V prod(V a, V b) const { return W::mul24(a, b); }
   PSF_NTT_FN V prod_add(V a, V b, V t) const { return W::mad24(a, b, t); }
+  // the zeta of a forward butterfly and its product with the upper element
+  using FZ = V;
+  PSF_NTT_FN FZ fz(const typename W::Tab& zf, typename W::I idx, int off) const { return W::template tab<V>(zf, idx, off); }
+  PSF_NTT_FN FZ fz_const(const typename W::Tab& zf, int idx) const { return W::template tab_const<V>(zf, idx); }
+  PSF_NTT_FN V mulfz(FZ z, V x) const { return mul(z, x); }
+};
+// q < 2^12 with seven levels: every operand of a forward butterfly stays below 2^15 (Bounds16: xf = 20 839), so the product and its reduction are
+// ONE two-element dot product:  z x - m q = (x | m) . (z | -q)  with m = the low half of x (z q^-1), written into the upper half of x's register.
+// Two instructions per Montgomery product instead of three.  The table holds (z | -q) and z q^-1 mod 2^16 per zeta behind the plain tables.
+template <class W> struct Mod16D : Mod16<W, 12> {
+  using V = typename W::I;
+  int zoff;                               // words in front of the pairs: forward [2^L] | inverse [2^L]
+  struct FZ { V pk, zq; };
+  PSF_NTT_FN FZ fz(const typename W::Tab& zf, typename W::I idx, int off) const {
+    FZ z;
+    W::template tab_pair<V>(zf, zoff, idx, off, z.pk, z.zq);
+    return z;
+  }
+  PSF_NTT_FN FZ fz_const(const typename W::Tab& zf, int idx) const {
+    FZ z;
+    W::template tab_pair_const<V>(zf, zoff, idx, z.pk, z.zq);
+    return z;
+  }
+  PSF_NTT_FN V mulfz(const FZ& z, V x) const { return W::dot2mont(x, z.zq, z.pk); }
 };
 template <class W> struct Mod32 {
   static constexpr bool lazy = false;
@@ -141,6 +165,10 @@ template <class W> struct Mod32 {
   PSF_NTT_FN V sub(V a, V b) const { return W::cadd(a - b, q); }               // a - b wraps below zero: add q back
   PSF_NTT_FN V neg(V a) const { return W::cadd(W::uzero() - a, q); }
   PSF_NTT_FN V canon(V x) const { return x; }
+  using FZ = V;
+  PSF_NTT_FN FZ fz(const typename W::Tab& zf, typename W::I idx, int off) const { return W::template tab<V>(zf, idx, off); }
+  PSF_NTT_FN FZ fz_const(const typename W::Tab& zf, int idx) const { return W::template tab_const<V>(zf, idx); }
+  PSF_NTT_FN V mulfz(FZ z, V x) const { return mul(z, x); }
 };
 
 // ---- the transforms -------------------------------------------------------------------------------------------------------------------------------
@@ -151,12 +179,7 @@ template <class W, class M, class BD, int LOGN, int LD> struct Core {
   static constexpr int C = S::C, RB = S::RB, L = LOGN - LD;
   static_assert(LD >= 0 && LD <= 2 && LD <= RB, "leaf degree 1, 2 or 4, inside a lane");
 
-  template <int P> static PSF_NTT_FN void exchange(V (&x)[C]) {
-    constexpr int J = S::jof(P);
-#pragma unroll
-    for (int r = 0; r < C; ++r)
-      if (!((r >> J) & 1)) W::template swap<P>(x[r], x[r | (1 << J)]);
-  }
+  template <int P> static PSF_NTT_FN void exchange(V (&x)[C]) { W::template exchange<P, C, S::jof(P)>(x); }
   static PSF_NTT_FN void reduce_all(V (&x)[C], const M& md) {
 #pragma unroll
     for (int r = 0; r < C; ++r) x[r] = md.mont(x[r]);
@@ -178,8 +201,10 @@ template <class W, class M, class BD, int LOGN, int LD> struct Core {
 #pragma unroll
     for (int r = 0; r < C; ++r)
       if (!((r >> J) & 1)) {
-        const V z = zeta_at<P>(zf, zl, r);
-        const V t = md.mul(z, x[r | (1 << J)]);
+        typename M::FZ z;
+        if constexpr (P >= 6) z = md.fz_const(zf, (1 << (LOGN - 1 - P)) + (r >> (P - 5)));
+        else z = md.fz(zf, zl, S::regpart(r, P));
+        const V t = md.mulfz(z, x[r | (1 << J)]);
         x[r | (1 << J)] = md.sub(x[r], t);
         x[r] = md.add(x[r], t);
       }

@@ -43,33 +43,89 @@ struct DevWave {
   template <class V> static __device__ __forceinline__ V tab(Tab t, I idx, int off) { return (V)t[idx + off]; }
   template <class V> static __device__ __forceinline__ V tab_const(Tab t, int idx) { return (V)t[idx]; }
   template <class V> static __device__ __forceinline__ V sel_odd(I lane, V a, V b) { return (lane & 1) ? a : b; }
+  static __device__ __forceinline__ I umin(I a, I b) { return (I)((U)a < (U)b ? (U)a : (U)b); }
+  // pairs [(z | -q), z q^-1] behind `zoff` words of plain tables: one 8-byte LDS read
+  template <class V> static __device__ __forceinline__ void tab_pair(Tab t, int zoff, I idx, int off, V& pk, V& zq) {
+    const uint2 v = *reinterpret_cast<const uint2*>(t + zoff + 2 * (idx + off));
+    pk = (V)v.x; zq = (V)v.y;
+  }
+  template <class V> static __device__ __forceinline__ void tab_pair_const(Tab t, int zoff, int idx, V& pk, V& zq) {
+    const uint2 v = *reinterpret_cast<const uint2*>(t + zoff + 2 * idx);
+    pk = (V)v.x; zq = (V)v.y;
+  }
+  // (z x - m q) >> 16 with m = low half of x (z q^-1): m goes into the upper half of x's register (SDWA, lower half preserved), then one dot product
+  // of the halves with (z | -q).  Wait states by hand (asm is opaque to the hazard recogniser): one between an SDWA write of a half and its reader,
+  // three between a dot product and a vector read of its result.
+  static __device__ __forceinline__ I dot2mont(I x, I zq, I pk) {
+    asm("v_mul_lo_u16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\ts_nop 0\n\t"
+        "v_dot2_i32_i16 %0, %0, %2, 0\n\ts_nop 2"
+        : "+v"(x) : "v"(zq), "v"(pk));
+    return x >> 16;
+  }
 
   // 2 x 2 transpose of (register pair (a, b), lane bit K): afterwards a holds [a where bit K = 0 | b of the partner lane where bit K = 1],
-  // b holds [a of the partner lane where bit K = 0 | b where bit K = 1]
+  // b holds [a of the partner lane where bit K = 0 | b where bit K = 1].  Bits 5 and 4 are true swaps (v_permlane32_swap / v_permlane16_swap: one
+  // instruction per pair); bits 3 ... 0 are two v_cndmask_b32_dpp per pair -- the partner's value comes in through the DPP operand (row_ror:8, row
+  // shifts by 4, quad permutes), the lane-bit mask through VCC.  Asm statements: hipcc has no cndmask-with-DPP builtin and lowers the same selection to
+  // v_mov_b32_dpp + v_cndmask + copies (twice the instructions of a kernel that is bound by vector issue); `s_nop 1` covers the two wait states
+  // between a vector write of an operand and its DPP read, which the hazard recogniser cannot see inside an asm statement.
+  template <int K> struct BitMask { static constexpr unsigned long long v = K == 3 ? 0xff00ff00ff00ff00ull : K == 2 ? 0xf0f0f0f0f0f0f0f0ull : K == 1 ? 0xccccccccccccccccull : 0xaaaaaaaaaaaaaaaaull; };
+#define PSF_NTT_DPP_PAIR(CTRL_A, CTRL_B)                                                                                                              \
+  asm("s_nop 1\n\ts_mov_b64 vcc, %4\n\tv_cndmask_b32_dpp %0, %3, %2, vcc " CTRL_A " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                       \
+      "s_mov_b64 vcc, %5\n\tv_cndmask_b32_dpp %1, %2, %3, vcc " CTRL_B " row_mask:0xf bank_mask:0xf bound_ctrl:0"                                      \
+      : "=&v"(na), "=&v"(nb) : "v"(a), "v"(b), "s"(~BitMask<K>::v), "s"(BitMask<K>::v) : "vcc")
+#define PSF_NTT_DPP_TWO(CTRL_A, CTRL_B)                                                                                                               \
+  asm("s_nop 1\n\ts_mov_b64 vcc, %8\n\tv_cndmask_b32_dpp %0, %5, %4, vcc " CTRL_A " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                       \
+      "v_cndmask_b32_dpp %2, %7, %6, vcc " CTRL_A " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                                                      \
+      "s_mov_b64 vcc, %9\n\tv_cndmask_b32_dpp %1, %4, %5, vcc " CTRL_B " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                                  \
+      "v_cndmask_b32_dpp %3, %6, %7, vcc " CTRL_B " row_mask:0xf bank_mask:0xf bound_ctrl:0"                                                          \
+      : "=&v"(na), "=&v"(nb), "=&v"(nc), "=&v"(nd) : "v"(a), "v"(b), "v"(c), "v"(d), "s"(~BitMask<K>::v), "s"(BitMask<K>::v) : "vcc")
   template <int K> static __device__ __forceinline__ void swap(U& a, U& b) {
     if constexpr (K == 5) { const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r.x; b = r.y; }
     else if constexpr (K == 4) { const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r.x; b = r.y; }
-    else if constexpr (K == 3) {
-      const U na = (U)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x128, 0xf, 0xc, false);      // row_ror:8 into lanes 8-15 of every row
-      const U nb = (U)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x128, 0xf, 0x3, false);      // ... into lanes 0-7
+    else {
+      U na, nb;
+      if constexpr (K == 3) PSF_NTT_DPP_PAIR("row_ror:8", "row_ror:8");
+      else if constexpr (K == 2) PSF_NTT_DPP_PAIR("row_shr:4", "row_shl:4");
+      else if constexpr (K == 1) PSF_NTT_DPP_PAIR("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]");
+      else PSF_NTT_DPP_PAIR("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]");
       a = na; b = nb;
-    } else if constexpr (K == 2) {
-      const U na = (U)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x114, 0xf, 0xa, false);      // row_shr:4 into banks 1, 3
-      const U nb = (U)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x104, 0xf, 0x5, false);      // row_shl:4 into banks 0, 2
-      a = na; b = nb;
-    } else {
-      constexpr int ctrl = K == 1 ? 0x4e : 0xb1;                                                // quad_perm [2,3,0,1] / [1,0,3,2]
-      const U pb = (U)__builtin_amdgcn_update_dpp(0, (int)b, ctrl, 0xf, 0xf, false);
-      const U pa = (U)__builtin_amdgcn_update_dpp(0, (int)a, ctrl, 0xf, 0xf, false);
-      const bool hi = ((U)__lane_id() >> K) & 1u;
-      a = hi ? pb : a;
-      b = hi ? b : pa;
     }
   }
+  template <int K> static __device__ __forceinline__ void swap2(U& a, U& b, U& c, U& d) {       // two pairs behind one pair of mask moves
+    U na, nb, nc, nd;
+    if constexpr (K == 3) PSF_NTT_DPP_TWO("row_ror:8", "row_ror:8");
+    else if constexpr (K == 2) PSF_NTT_DPP_TWO("row_shr:4", "row_shl:4");
+    else if constexpr (K == 1) PSF_NTT_DPP_TWO("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]");
+    else PSF_NTT_DPP_TWO("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]");
+    a = na; b = nb; c = nc; d = nd;
+  }
+#undef PSF_NTT_DPP_PAIR
+#undef PSF_NTT_DPP_TWO
   template <int K> static __device__ __forceinline__ void swap(I& a, I& b) {
     U ua = (U)a, ub = (U)b;
     swap<K>(ua, ub);
     a = (I)ua; b = (I)ub;
+  }
+  // lane bit K against register bit J of the C registers of a lane
+  template <int K, int C, int J, class V> static __device__ __forceinline__ void exchange(V (&x)[C]) {
+    if constexpr (K >= 4 || C < 4) {
+#pragma unroll
+      for (int r = 0; r < C; ++r)
+        if (!((r >> J) & 1)) swap<K>(x[r], x[r | (1 << J)]);
+    } else {
+      int lo[C / 2];
+      int np = 0;
+#pragma unroll
+      for (int r = 0; r < C; ++r)
+        if (!((r >> J) & 1)) lo[np++] = r;
+#pragma unroll
+      for (int i = 0; i < C / 2; i += 2) {
+        U a = (U)x[lo[i]], b = (U)x[lo[i] | (1 << J)], c = (U)x[lo[i + 1]], d = (U)x[lo[i + 1] | (1 << J)];
+        swap2<K>(a, b, c, d);
+        x[lo[i]] = (V)a; x[lo[i] | (1 << J)] = (V)b; x[lo[i + 1]] = (V)c; x[lo[i + 1] | (1 << J)] = (V)d;
+      }
+    }
   }
 };
 
@@ -85,12 +141,14 @@ struct NttDev {
 };
 
 template <int QB> struct PolicyOf { using M = Mod16<DevWave, QB>; template <int LOGN, int LD> using BD = Bounds16<QB, LOGN, LD>; };
+template <> struct PolicyOf<12> { using M = Mod16D<DevWave>; template <int LOGN, int LD> using BD = Bounds16<12, LOGN, LD>; };
 template <> struct PolicyOf<0> { using M = Mod32<DevWave>; template <int LOGN, int LD> using BD = NoBounds; };
 
-template <int QB> __device__ __forceinline__ typename PolicyOf<QB>::M make_policy(const NttDev& p) {
+template <int QB> __device__ __forceinline__ typename PolicyOf<QB>::M make_policy(const NttDev& p, int levels) {
   typename PolicyOf<QB>::M md;
   if constexpr (QB != 0) { md.q = (int)p.q; md.nq = -(int)p.q; md.qinv = p.qinv16; }
   else { md.q = p.q; md.nqinv = p.nqinv32; }
+  if constexpr (QB == 12) md.zoff = 2 << levels;
   return md;
 }
 
@@ -116,12 +174,16 @@ template <int QB, class M> __device__ __forceinline__ typename M::V reduce_u64(u
   }
 }
 
+// the wave's number inside its workgroup as a SCALAR: row addresses are then computed once per wave, in SGPRs
+static __device__ __forceinline__ unsigned wave_in_block() { return (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 template <int LOGN, int LD, int QB> struct Kern {
   using M = typename PolicyOf<QB>::M;
   using BD = typename PolicyOf<QB>::template BD<LOGN, LD>;
   using K = Core<DevWave, M, BD, LOGN, LD>;
   using V = typename M::V;
-  static constexpr int C = K::C, N = 1 << LOGN, L = LOGN - LD, ZN = 2 << L;
+  static constexpr int C = K::C, N = 1 << LOGN, L = LOGN - LD, ZN = (QB == 12 ? 4 : 2) << L;     // forward | inverse (| forward pairs of the dot-product form)
+  static_assert(QB != 12 || (BD::r.xf < 32768 && BD::r.nrf == 0), "dot-product form: 16-bit operands in every forward butterfly");
   static constexpr int E = 1 + 2 * BD::r.nrf + BD::r.nri;            // powers of R^-1 a product carries before the final scale
 
   static __device__ __forceinline__ void load_tables(uint32_t* zt, const NttDev& p) {
@@ -158,14 +220,14 @@ template <int LOGN, int LD, int QB, int IO>
 __global__ __launch_bounds__(256) void k_ntt_polymul(NttDev p, const void* __restrict__ A, const void* __restrict__ B, void* __restrict__ out, size_t count) {
   using KN = Kern<LOGN, LD, QB>;
   using V = typename KN::V;
-  __shared__ uint32_t zt[KN::ZN];
+  __shared__ __attribute__((aligned(16))) uint32_t zt[KN::ZN];
   KN::load_tables(zt, p);
-  const auto md = make_policy<QB>(p);
+  const auto md = make_policy<QB>(p, KN::L);
   const int lane = DevWave::lane();
   const size_t waves = (size_t)gridDim.x * (blockDim.x >> 6);
   const uint32_t* zf = zt;
   const uint32_t* zi = zt + (1 << KN::L);
-  for (size_t pr = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); pr < count; pr += waves) {
+  for (size_t pr = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block(); pr < count; pr += waves) {
     V a[KN::C], b[KN::C], c[KN::C];
     KN::template load<IO, false>(a, A, pr, lane, md, p);
     KN::template load<IO, true>(b, B, pr, lane, md, p);
@@ -183,12 +245,12 @@ template <int LOGN, int LD, int QB, int IO, bool SIGNED>
 __global__ __launch_bounds__(256) void k_ntt_forward(NttDev p, const void* __restrict__ A, uint32_t* __restrict__ hat, size_t count) {
   using KN = Kern<LOGN, LD, QB>;
   using V = typename KN::V;
-  __shared__ uint32_t zt[KN::ZN];
+  __shared__ __attribute__((aligned(16))) uint32_t zt[KN::ZN];
   KN::load_tables(zt, p);
-  const auto md = make_policy<QB>(p);
+  const auto md = make_policy<QB>(p, KN::L);
   const int lane = DevWave::lane();
   const size_t waves = (size_t)gridDim.x * (blockDim.x >> 6);
-  for (size_t pr = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); pr < count; pr += waves) {
+  for (size_t pr = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block(); pr < count; pr += waves) {
     V a[KN::C];
     KN::template load<IO, SIGNED>(a, A, pr, lane, md, p);
     KN::K::forward(a, md, zt, lane);
@@ -202,14 +264,14 @@ template <int LOGN, int LD, int QB, int IO>
 __global__ __launch_bounds__(256) void k_ntt_mul_hat(NttDev p, const uint32_t* __restrict__ hat, size_t hat_stride, const void* __restrict__ B, void* __restrict__ out, size_t count) {
   using KN = Kern<LOGN, LD, QB>;
   using V = typename KN::V;
-  __shared__ uint32_t zt[KN::ZN];
+  __shared__ __attribute__((aligned(16))) uint32_t zt[KN::ZN];
   KN::load_tables(zt, p);
-  const auto md = make_policy<QB>(p);
+  const auto md = make_policy<QB>(p, KN::L);
   const int lane = DevWave::lane();
   const size_t waves = (size_t)gridDim.x * (blockDim.x >> 6);
   const uint32_t* zf = zt;
   const uint32_t* zi = zt + (1 << KN::L);
-  for (size_t pr = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); pr < count; pr += waves) {
+  for (size_t pr = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block(); pr < count; pr += waves) {
     V a[KN::C], b[KN::C], c[KN::C];
 #pragma unroll
     for (int r = 0; r < KN::C; ++r) a[r] = (V)hat[pr * hat_stride + (size_t)r * 64 + lane];
@@ -233,12 +295,12 @@ __global__ __launch_bounds__(256) void k_ring_fa(NttDev p, const uint32_t* __res
   uint32_t* ah = fa_smem + KN::ZN;
   for (uint32_t i = threadIdx.x; i < K * (uint32_t)KN::N; i += blockDim.x) ah[i] = hat[i];
   KN::load_tables(zt, p);
-  const auto md = make_policy<QB>(p);
+  const auto md = make_policy<QB>(p, KN::L);
   const int lane = DevWave::lane();
   const size_t waves = (size_t)gridDim.x * (blockDim.x >> 6);
   const uint32_t* zf = zt;
   const uint32_t* zi = zt + (1 << KN::L);
-  for (size_t pr = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); pr < count; pr += waves) {
+  for (size_t pr = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block(); pr < count; pr += waves) {
     V acc[KN::C];
 #pragma unroll
     for (int r = 0; r < KN::C; ++r) acc[r] = 0;
