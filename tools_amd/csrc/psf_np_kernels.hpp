@@ -322,9 +322,11 @@ __device__ inline size_t j0_of(size_t J) { return J * NP_NB; }
 // consumed); all eight waves of a workgroup are resident by construction, so the spin-waits always make progress.
 // COH (unused since round 4, when the one-launch walk k_np_walk was removed: it spilled and bought 3 %, profiles/r03_notes.md): the running projections read and
 // the drawn z written with agent-scope accesses, for a launch in which they come from / go to workgroups on other XCDs
-template <int G, bool COH = false>
+// WALK (k_np_walk: one launch for the whole walk): the z of the block above are the wave's own draws of the previous call of this function (zr_io, in
+// registers) instead of a read-back from memory, and they are handed on the same way.
+template <int G, bool COH = false, bool WALK = false>
 __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned wg, const NpSampleArgs& a, size_t dim, size_t J, uint64_t seed, uint32_t tag,
-                                               uint64_t first_index, size_t B) {
+                                               uint64_t first_index, size_t B, long long* zr_io = nullptr) {
   constexpr int LPD = 64 / G, BPS = LPD / 4;
   static_assert(G == 1 || G == 2, "one or two preimages per wave pair");
   // carved from the launch's dynamic LDS (shared with the update tiles of the same launch): 16 + 2 + 8 + 32 + 4 KiB + counters < 64 KiB
@@ -510,7 +512,8 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
     for (int s = 0; s < G; ++s) {
       const int kk = s * LPD + lam;
       const size_t i = j0 + NP_NB + (size_t)kk;
-      zs[sg * NP_NB + kk] = (live && i < dim) ? a.Zf[((b / TR_BN) * a.nkb + i / 16) * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(i % 16))] : 0.0;
+      if (WALK) zs[sg * NP_NB + kk] = (live && i < dim) ? (double)zr_io[s] : 0.0;
+      else zs[sg * NP_NB + kk] = (live && i < dim) ? a.Zf[((b / TR_BN) * a.nkb + i / 16) * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(i % 16))] : 0.0;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -788,6 +791,10 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
     }
   }
   int use1 = 0, use2 = 0, big = 0;
+  if (WALK) {
+#pragma unroll
+    for (int s = 0; s < G; ++s) zr_io[s] = zr[s];
+  }
   if (live) {
     const size_t plane = a.zplane;
 #pragma unroll
@@ -932,6 +939,161 @@ __global__ __launch_bounds__(512, 4) void k_np_step(NpSampleArgs a, size_t dim, 
     if (id < jobs.ntiles[q]) { np_update_tile(reinterpret_cast<double*>(np_smem), id, jobs.job[q], nbj, Gp, a.Zf, a.nkb, Tm, a.ldt); return; }
     id -= jobs.ntiles[q];
   }
+}
+
+// ---- the whole walk in ONE launch (k_np_walk) -----------------------------------------------------------------------------------------------------------
+// k_np_step pays, per block of 64 steps, a dependent launch (~5 us) and the wait for the slowest of ALL sampler waves of the batch (rare exact decisions and generic
+// rounds: a fifth of a launch at C2, profiles/r04_notes.md).  The data dependence does not ask for either: block J of a preimage needs the draws of the blocks
+// above it for THAT preimage only.  Here the batch is cut into column groups of NP_GW = 64 preimages that never synchronise with each other:
+//   sampler workgroups (one per CU: 4 wave pairs = 4 G preimages) walk J = nblk-1 ... 0 without leaving the kernel; after block J a workgroup publishes its
+//       z (write-through stores, then one counter add) and, before block J, waits for the running projections of that block's rows;
+//   updater workgroups (the second workgroup of every CU) OWN the running projections T of their group: updater u of a group keeps the 64-row blocks
+//       u, u + ug, u + 2 ug, ... x 64 preimages in ACCUMULATOR REGISTERS for the whole walk (16 x 64 per wave and slot, at most three slots: 96 VGPRs), so T never
+//       moves except once to the samplers.  Per block J it waits for the group's z, stages them in LDS and applies t = fma(-z_j, g[j][.], t), j ascending -- the
+//       same v_mfma_f64_16x16x4_f64 K loop as np_update_tile, A operand straight from the fragment-ordered panels -- to every block it owns below J - 1 (block J - 1
+//       takes Z_J inside the sampler, as before).  Block J - 2 is then complete up to its neighbour: its owner does it first, stores its 64 x 64 values
+//       (write-through) and raises the block's flag, a full block time before the samplers ask for it.
+// Same chains, same order (blocks descending, j ascending inside a block): the same bits as the launch-per-block walk and the oracle.
+// Hand-offs follow the write-through form of the CDNA4 guide (Guideline 16, R1): every handed-off value is an agent-scope (sc1) store, every storing wave drains
+// (s_waitcnt vmcnt(0)) before ONE lane signals, the consumer polls relaxed and reads the values with agent-scope loads only.  Every spin is bounded: a wait that
+// runs out raises the abort word, every workgroup leaves at its next wait and the call reports PSF_ERR_SAMPLER (flags[0]); nothing is relaunched.
+constexpr int NP_GW = 64;                     // preimages per column group
+constexpr int NP_WALK_SLOTS = 3;              // 64-row blocks x 64 preimages of T per updater WAVE QUARTET: a workgroup owns at most 2 * NP_WALK_SLOTS blocks
+struct NpWalkSync {
+  unsigned* zcount;                           // [group][block]: sampler workgroups of the group that have published the block's z
+  unsigned* tready;                           // [group][block]: the block's running projections are complete up to the block after next
+  unsigned* abort;                            // [0] raised by a wait that ran out
+  unsigned nblk_stride;
+};
+constexpr unsigned NP_WALK_SPINS = 1u << 22;  // x s_sleep(2) ~ seconds: a walk lasts milliseconds
+
+// one lane polls, the workgroup learns the outcome through LDS; false = abort
+__device__ __forceinline__ bool np_walk_wait(const unsigned* word, unsigned target, unsigned* abort_word, int* s_flag) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+      if (spins >= NP_WALK_SPINS) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  const int ok = *s_flag;
+  __syncthreads();
+  return ok != 0;
+}
+
+template <int G>
+__device__ __forceinline__ void np_walk_sampler(unsigned char* smem, unsigned wg, const NpSampleArgs& a, size_t dim, size_t nblk, uint64_t seed, uint32_t tag,
+                                                uint64_t first_index, size_t B, const NpWalkSync& sy) {
+  int* s_flag = reinterpret_cast<int*>(smem + 65536 - 16);
+  const unsigned grp = wg / (unsigned)(NP_GW / (4 * G));
+  long long zr[G];
+#pragma unroll
+  for (int s = 0; s < G; ++s) zr[s] = 0;
+  for (size_t J = nblk; J-- > 0;) {
+    if (J + 2 < nblk) {                       // the two top blocks come from the initial projection alone
+      if (!np_walk_wait(sy.tready + (size_t)grp * sy.nblk_stride + J, 1u, sy.abort, s_flag)) return;
+    }
+    np_sample_body<G, true, true>(smem, wg, a, dim, J, seed, tag, first_index, B, zr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave drains its write-through stores of z ...
+    __syncthreads();
+    if (threadIdx.x == 0 && J >= 2) __hip_atomic_fetch_add(sy.zcount + (size_t)grp * sy.nblk_stride + J, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then ONE lane signals
+  }
+}
+
+// updater `ul` of `ug` in group `grp`: blocks ul, ul + ug, ... (below nblk - 2); block number k of the workgroup lives in slot k / 2 of the waves 4 (k & 1) ... + 3,
+// wave w holding its rows 16 (w & 3) ... + 15 x the group's 64 preimages as four 16 x 16 accumulator fragments
+__device__ __forceinline__ void np_walk_updater(unsigned char* smem, unsigned grp, unsigned ul, unsigned ug, unsigned need, const NpSampleArgs& a, size_t nblk,
+                                                const double* __restrict__ Gp, double* __restrict__ T, const NpWalkSync& sy) {
+  double* s_z = reinterpret_cast<double*>(smem);                         // z of the block: [k-step 16][fragment 4][lane 64] = 32 KiB
+  int* s_flag = reinterpret_cast<int*>(smem + 65536 - 16);
+  int* s_arr = reinterpret_cast<int*>(smem + 65536 - 32);               // arrivals of the four waves that hand a block over
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t col0 = (size_t)grp * NP_GW;
+  const size_t ldt = a.ldt;
+  d4 acc[NP_WALK_SLOTS][4];
+  long blk[NP_WALK_SLOTS];                                              // the block of each slot, -1: none
+#pragma unroll
+  for (int sl = 0; sl < NP_WALK_SLOTS; ++sl) {
+    const long k = 2 * sl + (wave >> 2);
+    const long Jb = (long)ul + k * (long)ug;
+    blk[sl] = Jb + 2 < (long)nblk ? Jb : -1;
+    const size_t row0 = (size_t)(blk[sl] < 0 ? 0 : blk[sl]) * NP_NB + (size_t)(wave & 3) * 16;
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[sl][nf][r] = blk[sl] < 0 ? 0.0 : T[(row0 + (lane >> 4) + 4 * r) * ldt + col0 + nf * 16 + (lane & 15)];
+  }
+  if (tid == 0) *s_arr = 0;
+  for (size_t J = nblk; J-- > 2;) {
+    if (!np_walk_wait(sy.zcount + (size_t)grp * sy.nblk_stride + J, need, sy.abort, s_flag)) return;
+    {  // the block's z for the group's 64 preimages: rows k = 64 J + 16 kc + 4 ks + (lane >> 4), preimage 16 nf + (lane & 15); chunk stream (bj, kb) of Zf
+      const size_t bj = col0 / TR_BN;
+      const int t0 = (int)((col0 % TR_BN) / 16);                         // first of the four 16-preimage tiles of the group inside the 128-wide chunk
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = i * 8 + wave;                                      // 64 (k-step, fragment) pairs of 64 lanes
+        const int kstep = e >> 2, nf = e & 3, kc = kstep >> 2, ks = kstep & 3;
+        const double* src = a.Zf + (bj * a.nkb + J * (NP_NB / 16) + (size_t)kc) * TR_CHUNK + (size_t)((ks * 8 + t0 + nf) * 64 + lane);
+        s_z[e * 64 + lane] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    // the block after next first: its owner hands it to the samplers
+    const long Ju = (long)J - 2;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int sl = 0; sl < NP_WALK_SLOTS; ++sl) {
+        const bool urgent = blk[sl] == Ju;
+        if (blk[sl] < 0 || blk[sl] > Ju || urgent != (pass == 0)) continue;
+        const size_t i0 = (size_t)blk[sl] * NP_NB + (size_t)(wave & 3) * 16;
+        const double* ga = Gp + (np_panel_base(J) + (i0 / 128) * 4) * TR_CHUNK + ((i0 % 128) / 16) * 64 + lane;
+#pragma unroll
+        for (int kstep = 0; kstep < 16; ++kstep) {
+          const double av = -ga[(size_t)(kstep >> 2) * TR_CHUNK + (kstep & 3) * 512];
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) acc[sl][nf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, s_z[(kstep * 4 + nf) * 64 + lane], acc[sl][nf], 0, 0, 0);
+        }
+        if (urgent) {
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              __hip_atomic_store(T + (i0 + (lane >> 4) + 4 * r) * ldt + col0 + nf * 16 + (lane & 15), acc[sl][nf][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) {
+            const int prev = __hip_atomic_fetch_add(s_arr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((prev & 3) == 3) __hip_atomic_store(sy.tready + (size_t)grp * sy.nblk_stride + (size_t)Ju, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+    __syncthreads();                                                     // the staged z are free
+  }
+}
+
+// grid: nS sampler workgroups, then the updater workgroups (ug per group); two workgroups per CU, all resident at once
+template <int G>
+__global__ __launch_bounds__(512, 4) void k_np_walk(NpSampleArgs a, size_t dim, size_t nblk, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, unsigned nS,
+                                                    unsigned ngroups, unsigned ug, const double* __restrict__ Gp, double* __restrict__ Tm, NpWalkSync sy) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char np_smem[];
+  unsigned id = blockIdx.x;
+  if (id < nS) {
+    np_walk_sampler<G>(np_smem, id, a, dim, nblk, seed, tag, first_index, B, sy);
+  } else {
+    id -= nS;
+    const unsigned grp = id / ug, ul = id % ug;
+    if (grp >= ngroups) return;
+    const unsigned per = (unsigned)(NP_GW / (4 * G));                     // sampler workgroups of a full group
+    const unsigned first = grp * per, need = nS - first < per ? nS - first : per;
+    np_walk_updater(np_smem, grp, ul, ug, need, a, nblk, Gp, Tm, sy);
+  }
+  if (threadIdx.x == 0 && __hip_atomic_load(sy.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicOr(a.flags, 1);   // (the workgroup that gave up gets here)
 }
 
 // E[b][j] (+)= scale * sum_i Z8[i][b] B8[j][i] on the int8 matrix cores (v_mfma_i32_16x16x64_i8): Z as the A operand (rows = preimages),

@@ -36,6 +36,10 @@ struct psfgpv_handle {
   double* dBfull = nullptr;           // b~_i on every coordinate, fragment order (A operand of the second projection)
   double* dC1 = nullptr;              // -e1, chunk stream (ld / 128) x nkd
   int64_t* dE1 = nullptr;             // e1, bcap x dim
+  unsigned* dWalk = nullptr;          // k_np_walk: [group][block] counters of published z | [group][block] flags of completed rows | abort word
+  size_t walk_words = 0;
+  int np_walk = -1;                   // PSF_NP_WALK: 0 = one launch per block (k_np_step), 1 = the whole walk in one launch where the batch fits (k_np_walk); -1 = 1
+  int cus = 0;                        // compute units of the device
   int np_g = 0;                       // PSF_NP_G: preimages per wave of the sampler (0 = by batch size)
   int np_immediate = -1;              // PSF_NP_IMMEDIATE: 1 = every block updates all the rows below it in the launch that follows, 0 = panel-deferred far update, -1 = by batch size
   bool has_key = false;
@@ -152,8 +156,8 @@ static psf_status gpv_build_solver(psfgpv_handle* g) {
 }
 
 static void free_np_batch(psfgpv_handle* g) {
-  hipFree(g->dTm); hipFree(g->dZf); hipFree(g->dZ8); hipFree(g->dC0p); hipFree(g->dSol); hipFree(g->dC1); hipFree(g->dE1);
-  g->dTm = g->dZf = g->dC0p = g->dC1 = nullptr; g->dZ8 = nullptr; g->dSol = nullptr; g->dE1 = nullptr;
+  hipFree(g->dTm); hipFree(g->dZf); hipFree(g->dZ8); hipFree(g->dC0p); hipFree(g->dSol); hipFree(g->dC1); hipFree(g->dE1); hipFree(g->dWalk);
+  g->dTm = g->dZf = g->dC0p = g->dC1 = nullptr; g->dZ8 = nullptr; g->dSol = nullptr; g->dE1 = nullptr; g->dWalk = nullptr;
   g->bcap = 0;
 }
 static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
@@ -172,12 +176,16 @@ static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
     HIP_TRY(hipMalloc(&g->dC1, ld * g->nkd * 16 * sizeof(double)));
     HIP_TRY(hipMalloc(&g->dE1, B * g->dim * sizeof(int64_t)));
   }
+  g->walk_words = round_up(2 * (ld / NP_GW) * g->nblk + 4, 4);
+  HIP_TRY(hipMalloc(&g->dWalk, g->walk_words * sizeof(unsigned)));
   HIP_TRY(hipMemset(g->dTm, 0, g->dpad * ld * sizeof(double)));
   HIP_TRY(hipMemset(g->dZf, 0, ld * g->nkb * 16 * sizeof(double)));      // padding rows / columns of the operands stay zero for good
   HIP_TRY(hipMemset(g->dZ8, 0, 3 * g->zplane));
   g->bcap = B;
   return PSF_OK;
 }
+
+static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size_t B, int64_t* d_e, int pass);
 
 // MatZ::sample_d_precomputed_gso for the whole batch (gpv.rs:160): the launch sequence of psf_np_kernels.hpp, one stream
 // pass 0: centre -sol on the pivot columns (K = n), e = sum z b + sol; pass 1 (two-pass mode): centre -e1 on every coordinate (K = d), e = sum z b + e1
@@ -191,6 +199,24 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
   int G = g->np_g;
   if (G != 1 && G != 2) G = B <= 1536 ? 1 : 2;      // one or two wave pairs per SIMD of the chip (1024 SIMDs)
   NpSampleArgs a{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, flags};
+  // The whole walk in one launch (k_np_walk) where every workgroup can be resident at once: one sampler workgroup per CU at most (B <= 4 G CUs) beside one
+  // updater workgroup per CU, and at most 2 * NP_WALK_SLOTS blocks of T per updater.  Otherwise one launch per block (k_np_step).
+  if (g->np_walk != 0 && g->cus > 0 && g->nblk >= 3) {
+    const int Gw = B <= 4 * (size_t)g->cus ? 1 : 2;
+    const unsigned nSw = (unsigned)((B + 4 * (size_t)Gw - 1) / (4 * (size_t)Gw));
+    const unsigned per = (unsigned)(NP_GW / (4 * Gw)), ngroups = (nSw + per - 1) / per;
+    unsigned ug = ngroups ? (unsigned)g->cus / ngroups : 0;
+    if (ug > g->nblk - 2) ug = (unsigned)(g->nblk - 2);
+    if ((g->np_g == 0 || g->np_g == Gw) && nSw <= (unsigned)g->cus && ug >= 1 && (size_t)2 * NP_WALK_SLOTS * ug >= g->nblk - 2) {
+      NpWalkSync sy{g->dWalk, g->dWalk + (size_t)ngroups * g->nblk, g->dWalk + (size_t)2 * ngroups * g->nblk, (unsigned)g->nblk};
+      hipMemsetAsync(g->dWalk, 0, g->walk_words * sizeof(unsigned), st);
+      NpSampleArgs aw{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, flags};
+      const unsigned ntot = nSw + ngroups * ug;
+      if (Gw == 1) hipLaunchKernelGGL((k_np_walk<1>), dim3(ntot), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, nSw, ngroups, ug, g->dGp, g->dTm, sy);
+      else hipLaunchKernelGGL((k_np_walk<2>), dim3(ntot), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, nSw, ngroups, ug, g->dGp, g->dTm, sy);
+      return launch_np_recombination(g, st, B, d_e, pass);
+    }
+  }
   const unsigned nS = (unsigned)((B + 4 * (size_t)G - 1) / (4 * (size_t)G));
   const size_t W = NP_PANEL;
   // small batches: a rank-64 update of every row below costs less than the sampler's 64 steps, and the T matrix stays in the Infinity Cache (measured
@@ -225,7 +251,13 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
     if (G == 1) hipLaunchKernelGGL((k_np_step<1>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, g->dTm);
     else hipLaunchKernelGGL((k_np_step<2>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, g->dTm);
   }
-  // e = sum_i z_i b_i + sol
+  return launch_np_recombination(g, st, B, d_e, pass);
+}
+
+// e = sum_i z_i b_i + sol (pass 1 of the two-pass walk: + e1)
+static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size_t B, int64_t* d_e, int pass) {
+  const size_t ld = g->ld;
+  int* const flags = g->dFlags + 4 * pass;
   const psfp_handle* b = g->base;
   const dim3 cgrid((unsigned)((B + 127) / 128), (unsigned)(g->dpad / 128));
   const int nk128 = (int)(g->dpad / 128);
@@ -324,6 +356,10 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_project), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  { int cu = 0; HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, g->base->prm.device)); g->cus = cu; }
+  if (const char* e = std::getenv("PSF_NP_WALK")) g->np_walk = std::atoi(e);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
