@@ -1015,6 +1015,13 @@ __device__ __forceinline__ void np_walk_updater(unsigned char* smem, unsigned gr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t col0 = (size_t)grp * NP_GW;
   const size_t ldt = a.ldt;
+  // every address below is a wave-uniform base (SGPRs) plus ONE 32-bit lane offset: nothing per slot, row or fragment is kept in vector registers
+  // (the 96 accumulator registers leave 32; address pairs hoisted out of the block loop were the kernel's scratch spills)
+  const uint32_t t_lane = (uint32_t)(((size_t)(lane >> 4) * ldt + (size_t)(lane & 15)) * sizeof(double));   // element (lane >> 4, lane & 15) of a 16 x 16 fragment of T
+  const uint32_t f_lane = (uint32_t)(lane * sizeof(double));                                                 // lane of a 512-byte operand fragment
+  auto t_at = [&](size_t row, size_t col) -> double* {                   // (row, col) wave-uniform
+    return reinterpret_cast<double*>(reinterpret_cast<char*>(T + row * ldt + col) + t_lane);
+  };
   d4 acc[NP_WALK_SLOTS][4];
   long blk[NP_WALK_SLOTS];                                              // the block of each slot, -1: none
 #pragma unroll
@@ -1026,19 +1033,20 @@ __device__ __forceinline__ void np_walk_updater(unsigned char* smem, unsigned gr
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[sl][nf][r] = blk[sl] < 0 ? 0.0 : T[(row0 + (lane >> 4) + 4 * r) * ldt + col0 + nf * 16 + (lane & 15)];
+      for (int r = 0; r < 4; ++r) acc[sl][nf][r] = blk[sl] < 0 ? 0.0 : *t_at(row0 + 4 * r, col0 + nf * 16);
   }
   if (tid == 0) *s_arr = 0;
+  const size_t bj = col0 / TR_BN;
+  const int t0 = (int)((col0 % TR_BN) / 16);                             // first of the four 16-preimage tiles of the group inside the 128-wide chunk
   for (size_t J = nblk; J-- > 2;) {
     if (!np_walk_wait(sy.zcount + (size_t)grp * sy.nblk_stride + J, need, sy.abort, s_flag)) return;
     {  // the block's z for the group's 64 preimages: rows k = 64 J + 16 kc + 4 ks + (lane >> 4), preimage 16 nf + (lane & 15); chunk stream (bj, kb) of Zf
-      const size_t bj = col0 / TR_BN;
-      const int t0 = (int)((col0 % TR_BN) / 16);                         // first of the four 16-preimage tiles of the group inside the 128-wide chunk
+      const double* zsrc = a.Zf + (bj * a.nkb + J * (NP_NB / 16)) * TR_CHUNK;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int e = i * 8 + wave;                                      // 64 (k-step, fragment) pairs of 64 lanes
         const int kstep = e >> 2, nf = e & 3, kc = kstep >> 2, ks = kstep & 3;
-        const double* src = a.Zf + (bj * a.nkb + J * (NP_NB / 16) + (size_t)kc) * TR_CHUNK + (size_t)((ks * 8 + t0 + nf) * 64 + lane);
+        const double* src = reinterpret_cast<const double*>(reinterpret_cast<const char*>(zsrc + (size_t)kc * TR_CHUNK + (size_t)((ks * 8 + t0 + nf) * 64)) + f_lane);
         s_z[e * 64 + lane] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -1052,10 +1060,10 @@ __device__ __forceinline__ void np_walk_updater(unsigned char* smem, unsigned gr
         const bool urgent = blk[sl] == Ju;
         if (blk[sl] < 0 || blk[sl] > Ju || urgent != (pass == 0)) continue;
         const size_t i0 = (size_t)blk[sl] * NP_NB + (size_t)(wave & 3) * 16;
-        const double* ga = Gp + (np_panel_base(J) + (i0 / 128) * 4) * TR_CHUNK + ((i0 % 128) / 16) * 64 + lane;
+        const double* ga = Gp + (np_panel_base(J) + (i0 / 128) * 4) * TR_CHUNK + ((i0 % 128) / 16) * 64;     // wave-uniform
 #pragma unroll
         for (int kstep = 0; kstep < 16; ++kstep) {
-          const double av = -ga[(size_t)(kstep >> 2) * TR_CHUNK + (kstep & 3) * 512];
+          const double av = -*reinterpret_cast<const double*>(reinterpret_cast<const char*>(ga + (size_t)(kstep >> 2) * TR_CHUNK + (kstep & 3) * 512) + f_lane);
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) acc[sl][nf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, s_z[(kstep * 4 + nf) * 64 + lane], acc[sl][nf], 0, 0, 0);
         }
@@ -1063,8 +1071,8 @@ __device__ __forceinline__ void np_walk_updater(unsigned char* smem, unsigned gr
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              __hip_atomic_store(T + (i0 + (lane >> 4) + 4 * r) * ldt + col0 + nf * 16 + (lane & 15), acc[sl][nf][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int r = 0; r < 4; ++r)      // (rows from the loop's own J: from blk[sl] the sixteen addresses are loop invariants that hipcc keeps in registers and spills)
+              __hip_atomic_store(t_at((size_t)Ju * NP_NB + (size_t)(wave & 3) * 16 + 4 * r, col0 + nf * 16), acc[sl][nf][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
             const int prev = __hip_atomic_fetch_add(s_arr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

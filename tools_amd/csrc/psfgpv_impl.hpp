@@ -202,12 +202,12 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
   // The whole walk in one launch (k_np_walk) where every workgroup can be resident at once: one sampler workgroup per CU at most (B <= 4 G CUs) beside one
   // updater workgroup per CU, and at most 2 * NP_WALK_SLOTS blocks of T per updater.  Otherwise one launch per block (k_np_step).
   if (g->np_walk != 0 && g->cus > 0 && g->nblk >= 3) {
-    const int Gw = B <= 4 * (size_t)g->cus ? 1 : 2;
+    const int Gw = (g->np_g == 1 || g->np_g == 2) ? g->np_g : (B <= 4 * (size_t)g->cus ? 1 : 2);
     const unsigned nSw = (unsigned)((B + 4 * (size_t)Gw - 1) / (4 * (size_t)Gw));
     const unsigned per = (unsigned)(NP_GW / (4 * Gw)), ngroups = (nSw + per - 1) / per;
     unsigned ug = ngroups ? (unsigned)g->cus / ngroups : 0;
     if (ug > g->nblk - 2) ug = (unsigned)(g->nblk - 2);
-    if ((g->np_g == 0 || g->np_g == Gw) && nSw <= (unsigned)g->cus && ug >= 1 && (size_t)2 * NP_WALK_SLOTS * ug >= g->nblk - 2) {
+    if (nSw <= (unsigned)g->cus && ug >= 1 && (size_t)2 * NP_WALK_SLOTS * ug >= g->nblk - 2) {
       NpWalkSync sy{g->dWalk, g->dWalk + (size_t)ngroups * g->nblk, g->dWalk + (size_t)2 * ngroups * g->nblk, (unsigned)g->nblk};
       hipMemsetAsync(g->dWalk, 0, g->walk_words * sizeof(unsigned), st);
       NpSampleArgs aw{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, flags};
