@@ -154,6 +154,8 @@ def main():
     latency = None
     if rank == 0 and scheme == "PSFPerturbation" and not args.no_latency and not args.structured:
         latency = single_call_latency(psf, u, e, m, first_index, stream, args.config)
+    elif rank == 0 and not args.no_latency:
+        latency = nearest_plane_call_latency(psf, u, m, first_index, stream, args.config)
 
     # correctness gate on the last step's output: A e == u and check_domain for every row
     u2 = torch.empty_like(u)
@@ -246,10 +248,38 @@ def main():
         sys.exit(4)
 
 
+def nearest_plane_call_latency(psf, u, m, first_index, stream, cfg, reps=15):
+    """One PSFGPV / PSFGPVRing samp_p call with 1 and 16 preimages (gpv.rs:152-161, gpv_ring.rs:160-212; what benches/psf.rs:26-39 times at n = 8) through the
+    device-pointer entry point: median of `reps` synchronised HIP-event times.  The call is d dependent draws per preimage whatever the batch -- a latency
+    chain, not a throughput problem -- so the figure beside it is the time per serial step."""
+    import torch
+    out = {"bound": "serial chain of d draws", "serial_steps": int(m), "entry_point": "samp_p_dev (device pointers)", "reps": reps}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e = torch.empty((min(16, u.shape[0]), m), dtype=torch.int64, device=u.device)
+    for B in (1, 16):
+        if B > u.shape[0]:
+            continue
+        call = lambda: psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=77, first_index=first_index, stream=stream)
+        call(); call()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            ev0.record(); call(); ev1.record()
+            torch.cuda.synchronize()
+            ts.append(ev0.elapsed_time(ev1))
+        ts.sort()
+        out[f"{cfg}_b{B}_ms"] = round(ts[len(ts) // 2], 4)
+        out[f"{cfg}_b{B}_min_ms"] = round(ts[0], 4)
+        out[f"us_per_serial_step_b{B}"] = round(ts[len(ts) // 2] * 1e3 / m, 4)
+    if psf.last_status() != 0:
+        out["status"] = "sampler failure"
+    return out
+
+
 def single_call_latency(psf, u, e, m, first_index, stream, cfg="c3", reps=30):
     """One samp_p call at batch 1 / 16 / 64 through the device-pointer entry point: median of `reps` HIP-event times, each call synchronised on both
     sides (a latency, not a throughput), plus the per-kernel HIP-event times of one call.  The product of these calls is k_trmm_stream, bound by
-    reading the factor (m(m+1)/2 doubles) from HBM once: `frac` = those bytes / its launch time / 8 TB/s."""
+    reading the factor (m(m+1)/2 doubles) from HBM once: `product_frac_b1` = those bytes / its launch time / 8 TB/s, `call_frac_b1` the same for the whole call."""
     import torch
     key_bytes = m * (m + 1) // 2 * 8
     out = {"bound": "hbm", "bytes": key_bytes, "peak_GBps": PEAK_HBM_GBS, "entry_point": "psfp_samp_p_dev (device pointers)", "reps": reps}
@@ -278,7 +308,7 @@ def single_call_latency(psf, u, e, m, first_index, stream, cfg="c3", reps=30):
             gbps = key_bytes / (tm["k_trmm_f64"] * 1e-3) / 1e9
             out["product_ms_b1"] = round(tm["k_trmm_f64"], 4)
             out["achieved_GBps"] = round(gbps, 1)
-            out["frac"] = round(gbps / PEAK_HBM_GBS, 4)                 # of the 8 TB/s spec; ~6.3 TB/s is what a streaming read achieves (MI355X_MICROARCH.md)
+            out["product_frac_b1"] = round(gbps / PEAK_HBM_GBS, 4)      # the product KERNEL against the 8 TB/s spec; ~6.3 TB/s is what a streaming read achieves (MI355X_MICROARCH.md)
             out["call_frac_b1"] = round(key_bytes / (out[f"{cfg}_b1_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)   # the whole call against the same roof
     if psf.last_status() != 0:
         out["status"] = "sampler failure"

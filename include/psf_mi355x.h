@@ -222,7 +222,11 @@ psf_status psfp_samp_p(psfp_handle*, uint64_t seed, uint64_t first_index, size_t
 /* The same, asynchronous: returns once the work is enqueued (u has been staged and may be reused); e[] is complete when psfp_wait returns.  At most
  * two calls are in flight per handle (a third waits for the first).  The rows of call i cross PCIe (narrowed to int32 on the device, widened into e by
  * worker threads) while call i + 1 computes, so a loop of asynchronous calls runs at the device-resident rate; psfp_samp_p = psfp_samp_p_async +
- * psfp_wait.  psfp_wait returns the first non-OK status of the outstanding calls, oldest first (PSF_ERR_SAMPLER as psfp_samp_p would). */
+ * psfp_wait.  psfp_wait returns the first non-OK status of the outstanding calls, oldest first (PSF_ERR_SAMPLER as psfp_samp_p would).
+ * RULE: every other entry point that rewrites the key (psfp_trap_gen, psfp_load_key, psfp_load_trapdoor, psfp_compute_sqrt_sigma_2(_dense)) or uses the
+ * handle's per-batch buffers (psfp_samp_p_dev, psfp_samp_d(_dev), psfp_f_a(_dev), psfp_samp_p_stages) first waits for the asynchronous calls in flight --
+ * they never see a half-replaced key or share buffers with the new call -- and returns their status if one of them failed.  A handle is driven by one
+ * thread at a time. */
 psf_status psfp_samp_p_async(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
 psf_status psfp_wait(psfp_handle*);
 /* PSF::f_a (mp_perturbation.rs:366-369): u[b] = A e[b] mod q; PSF_ERR_DOMAIN (u still written) if any

@@ -238,11 +238,11 @@ pub struct GpuPSFPerturbation {
     held: RefCell<Held>,
 }
 
-/// What the device handle holds, identified by FINGERPRINTS of the caller's matrices (`key_print`): dimensions plus a 64-bit hash of the first row,
-/// the last row and -- for square matrices -- the diagonal.  Comparing a caller's key with the held one therefore costs O(m) entry reads per
-/// `samp_p`, not the O(m^2) deep comparison (4.7e8 `fmpq` + 2.4e8 `fmpz` comparisons per preimage at n = 512) and the second copy of a multi-GB
-/// `MatQ` that a clone-and-compare cache needs.  A fingerprint is an identity check against accidental key changes, not a cryptographic binding:
-/// callers that mutate single entries of a key in place must call `install_key` again.
+/// What the device handle holds, identified by FINGERPRINTS of the caller's matrices.  A (n x m) and R (m_bar x nk) are hashed ENTRY BY ENTRY
+/// (`full_print`: small integers, O(n m) reads -- far below the upload they save); sqrt(Sigma_2) (m x m rationals, 4.7e8 `fmpq` at n = 512) is hashed
+/// through its dimensions, first and last row, diagonal and a strided sample of eight entries per row (`sampled_print`).  The reference's
+/// `samp_p(a, td, u)` is a pure function of its arguments: a caller's A or R that differs anywhere is re-installed; a sqrt(Sigma_2) that differs
+/// only outside the sample is not noticed -- callers that edit single entries of a factor in place call `install_key` again.
 #[derive(Clone, PartialEq)]
 enum Held {
     Nothing,
@@ -256,8 +256,19 @@ fn fnv(h: u64, v: u64) -> u64 {
     (h ^ v).wrapping_mul(0x100000001b3)
 }
 
-/// dimensions + first row + last row (+ diagonal of a square matrix), through `entry` -> u64
-fn key_print(rows: i64, cols: i64, entry: &dyn Fn(i64, i64) -> u64) -> u64 {
+/// every entry, row by row
+fn full_print(rows: i64, cols: i64, entry: &dyn Fn(i64, i64) -> u64) -> u64 {
+    let mut h = fnv(fnv(0xcbf29ce484222325, rows as u64), cols as u64);
+    for i in 0..rows {
+        for j in 0..cols {
+            h = fnv(h, entry(i, j));
+        }
+    }
+    h
+}
+
+/// dimensions + first row + last row + diagonal of a square matrix + eight strided entries of every row
+fn sampled_print(rows: i64, cols: i64, entry: &dyn Fn(i64, i64) -> u64) -> u64 {
     let mut h = fnv(fnv(0xcbf29ce484222325, rows as u64), cols as u64);
     if rows == 0 || cols == 0 {
         return h;
@@ -273,17 +284,34 @@ fn key_print(rows: i64, cols: i64, entry: &dyn Fn(i64, i64) -> u64) -> u64 {
             h = fnv(h, entry(i, i));
         }
     }
+    for i in 0..rows {
+        for t in 0..8i64 {
+            h = fnv(h, entry(i, (i * 7 + t * (cols / 8 + 1)) % cols));
+        }
+    }
     h
 }
 
+/// an integer entry as 64 hash bits: its value when it fits, a hash of its decimal digits otherwise (entries beyond 64 bits must not all collide)
+fn z_bits(z: &Z) -> u64 {
+    match i64::try_from(z) {
+        Ok(v) => v as u64,
+        Err(_) => z.to_string().bytes().fold(0x9e3779b97f4a7c15u64, |h, b| fnv(h, b as u64)),
+    }
+}
+
 fn print_matzq(a: &MatZq) -> u64 {
-    key_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let z: Z = a.get_entry(i, j).unwrap(); i64::try_from(&z).unwrap_or(0) as u64 })
+    full_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let z: Z = a.get_entry(i, j).unwrap(); z_bits(&z) })
 }
 fn print_matz(a: &MatZ) -> u64 {
-    key_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let z: Z = a.get_entry(i, j).unwrap(); i64::try_from(&z).unwrap_or(0) as u64 })
+    full_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let z: Z = a.get_entry(i, j).unwrap(); z_bits(&z) })
+}
+/// a d x d short basis (38 M entries at n = 256, q = 3329): the sampled form, like its Gram-Schmidt matrix
+fn print_basis(a: &MatZ) -> u64 {
+    sampled_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let z: Z = a.get_entry(i, j).unwrap(); z_bits(&z) })
 }
 fn print_matq(a: &MatQ) -> u64 {
-    key_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let q: Q = a.get_entry(i, j).unwrap(); f64::from(&q).to_bits() })
+    sampled_print(a.get_num_rows(), a.get_num_columns(), &|i, j| { let q: Q = a.get_entry(i, j).unwrap(); f64::from(&q).to_bits() })
 }
 
 impl GpuPSFPerturbation {
@@ -360,25 +388,40 @@ impl GpuPSFPerturbation {
     }
 }
 
-/// The rows of an asynchronous batch: owns the buffers the library reads from / writes into until `GpuPSFPerturbation::wait_batches` has returned.
-pub struct PendingBatch {
+/// The rows of an asynchronous batch.  It owns the buffers the library reads from and its worker threads write into, and it BORROWS the handle: the
+/// handle cannot be dropped while a batch is pending, and the rows can only be taken through `into_matz`, which waits (`psfp_wait`) first.  Dropping a
+/// pending batch waits as well, so the buffers are never freed under the workers.
+pub struct PendingBatch<'a> {
+    owner: &'a GpuPSFPerturbation,
     rows: i64,
     cols: i64,
     _u: Vec<u64>,
     e: Vec<i64>,
+    waited: Cell<bool>,
 }
 
-impl PendingBatch {
-    /// the preimages, one per row; only meaningful after `wait_batches`
+impl<'a> PendingBatch<'a> {
+    /// the preimages, one per row; waits for the handle's outstanding batches first and panics with the first failure (oldest batch first)
     pub fn into_matz(self) -> MatZ {
+        check(unsafe { ffi::psfp_wait(self.owner.handle) }, "psfp_wait");
+        self.waited.set(true);
         matz_from_rows(self.rows, self.cols, &self.e)
+    }
+}
+
+impl<'a> Drop for PendingBatch<'a> {
+    fn drop(&mut self) {
+        if !self.waited.get() {
+            // nothing may write into `e` once it is freed; the status of an abandoned batch is discarded
+            let _ = unsafe { ffi::psfp_wait(self.owner.handle) };
+        }
     }
 }
 
 impl GpuPSFPerturbation {
     /// `samp_p_batch` without waiting (`psfp_samp_p_async`): at most two batches in flight per handle; the rows of batch i cross PCIe and are widened
-    /// by worker threads while batch i + 1 computes.  Call `wait_batches` before `into_matz`.
-    pub fn samp_p_batch_async(&self, a: &MatZq, td: &<Self as PSF>::Trapdoor, targets: &MatZq) -> PendingBatch {
+    /// by worker threads while batch i + 1 computes.  `into_matz` (or dropping the batch) waits.
+    pub fn samp_p_batch_async<'a>(&'a self, a: &MatZq, td: &<Self as PSF>::Trapdoor, targets: &MatZq) -> PendingBatch<'a> {
         let (n, _, _, m) = self.dims();
         self.ensure_key(a, td);
         let b = targets.get_num_rows();
@@ -387,7 +430,7 @@ impl GpuPSFPerturbation {
         let mut e = vec![0i64; (b * m) as usize];
         let seed = next_seed(&self.seed, &self.calls);
         check(unsafe { ffi::psfp_samp_p_async(self.handle, seed, 0, b as usize, u.as_ptr(), e.as_mut_ptr()) }, "psfp_samp_p_async");
-        PendingBatch { rows: b, cols: m, _u: u, e }
+        PendingBatch { owner: self, rows: b, cols: m, _u: u, e, waited: Cell::new(false) }
     }
 
     /// every asynchronous batch of this handle has completed (`psfp_wait`); panics with the first failure, oldest batch first
@@ -501,7 +544,7 @@ pub struct GpuPSFGPV {
     handle: *mut ffi::psfgpv_handle,
     seed: Cell<u64>,
     calls: Cell<u64>,
-    /// fingerprints (`key_print`) of the (A, basis, GSO) the handle holds: an O(m) identity check per call instead of a deep comparison of two
+    /// fingerprints of the (A, basis, GSO) the handle holds (A entry by entry, the two d x d matrices sampled: `Held`) instead of a deep comparison of two
     /// d x d matrices and a second copy of them (d = 6208 at n = 256, q = 3329)
     held: RefCell<Option<(u64, u64, u64)>>,
 }
@@ -530,11 +573,11 @@ impl GpuPSFGPV {
         let (av, bt, gt) = (matzq_to_rows(a), matz_to_rows_t_i32(basis), matq_to_rows_t(gso));
         *self.held.borrow_mut() = None;
         check(unsafe { ffi::psfgpv_load_key(self.handle, av.as_ptr(), bt.as_ptr(), gt.as_ptr()) }, "psfgpv_load_key");
-        *self.held.borrow_mut() = Some((print_matzq(a), print_matz(basis), print_matq(gso)));
+        *self.held.borrow_mut() = Some((print_matzq(a), print_basis(basis), print_matq(gso)));
     }
 
     fn ensure_key(&self, a: &MatZq, basis: &MatZ, gso: &MatQ) {
-        let want = Some((print_matzq(a), print_matz(basis), print_matq(gso)));
+        let want = Some((print_matzq(a), print_basis(basis), print_matq(gso)));
         if *self.held.borrow() != want {
             self.install_key(a, basis, gso);
         }
@@ -582,7 +625,7 @@ impl PSF for GpuPSFGPV {
             }
         }
         let gso = matq_from_rows(m, m, &gt, true);
-        *self.held.borrow_mut() = Some((print_matzq(&a_mat), print_matz(&basis), print_matq(&gso)));
+        *self.held.borrow_mut() = Some((print_matzq(&a_mat), print_basis(&basis), print_matq(&gso)));
         (a_mat, (basis, gso))
     }
 

@@ -85,3 +85,34 @@ def test_c5_per_gpu_shape_is_valid_and_matches_the_oracle_on_a_sample(oracle):
         assert (fx["z"] == st["z"][b]).all(), "gadget preimage differs"
         assert (fx["e"] == st["e"][b]).all(), "preimage differs"
     psf.close()
+
+
+@pytest.mark.timeout(1200)
+def test_c3_single_calls_match_the_oracle_in_every_stage(oracle):
+    """The streaming product of a SINGLE call (k_trmm_stream: 1 and 16 preimages, psf.rs:48-80 -- one reference call is one preimage) at the C3 shape
+    (n = 512, q = 2^30, m = 30 801): every stage bit for bit against the oracle, the centres through the oracle's ascending fma chain over the factor streamed
+    back in row blocks.  (The batch kernels at this shape are covered by the bench runs above, the single call at the C5 shape by the test above.)"""
+    import numpy as np
+    import tools_amd as T
+    n, q, r, s = 512, 2**30, 9.0, 512.0
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+    psf.trap_gen(11, export=False)
+    m = psf.m
+    A, R = psf.export_A_R()
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s, with_L=False)
+    orc.load_key(A, R)
+    for S, first in ((1, 123456), (16, 7)):
+        uh = oracle.uniform_targets(5, S, n, q)
+        st = psf.samp_p_stages(uh, seed=42, first_index=first)
+        assert (psf.samp_p(uh, seed=42, first_index=first) == st["e"]).all()
+        d_ref = np.array([oracle.normals(42, first + b, m) for b in range(S)])
+        assert (st["d"].view(np.uint64) == d_ref.view(np.uint64)).all(), "normals differ"
+        for row0 in (0, 4096, 16384, m - 2048):               # a few row blocks of the factor, the last one included
+            nr = min(2048, m - row0)
+            Lr = psf.export_sqrt_sigma2_rows(row0, nr)
+            x_ref = oracle.centres_rows(Lr, row0, nr, m, d_ref)
+            assert (st["x"][:, row0:row0 + nr].view(np.uint64) == x_ref.view(np.uint64)).all(), f"centres differ in rows {row0}.. at {S} preimages"
+        for b in range(S):
+            fx = orc.samp_p_from_x(42, first + b, uh[b], st["x"][b])
+            assert (fx["p"] == st["p"][b]).all() and (fx["v"] == st["v"][b]).all() and (fx["z"] == st["z"][b]).all() and (fx["e"] == st["e"][b]).all()
+    psf.close()

@@ -131,24 +131,6 @@ def test_fused_one_launch_call_gives_the_oracles_rows(T, oracle, monkeypatch, n,
     psf.close()
 
 
-def test_fused_call_with_a_general_base(T, oracle):
-    """base 3 / 5 gadgets (gadget_classical.rs:169-229 digits in base b) through the fused kernel"""
-    for n, k, base, q in [(4, 5, 3, 243), (3, 4, 5, 600)]:
-        m_bar = n * int(np.ceil(np.log2(q))) + 7
-        gp = T.GadgetParameters(n, k, m_bar, base, q)
-        r = 3.0
-        s = r * np.sqrt(base * base + 1) * (np.sqrt(m_bar) + np.sqrt(n * k) + 4.0) * 1.5
-        psf = T.PSFPerturbation(gp, r, s)
-        assert psf.m <= 256
-        A, (R, Lp, _) = psf.trap_gen(8)
-        orc = oracle.PSFPerturbation(oracle.GadgetParams(n, k, m_bar, base, q), r, s)
-        orc.load_key(A, R, Lp)
-        u = oracle.uniform_targets(2, 9, n, q)
-        e = psf.samp_p(u, seed=19)
-        assert (e == orc.samp_p(19, u)).all() and (psf.f_a(e) == u).all()
-        psf.close()
-
-
 @pytest.mark.parametrize("B", [1, 2, 3, 4])
 def test_streaming_stage_kernels_of_a_handful_of_preimages_equal_the_matrix_core_ones(pair, oracle, B):
     """Up to four preimages e = p + [R; I] z streams R once (k_recombine_small), one preimage also streams A for v = u - A p (k_syndrome_small), up to

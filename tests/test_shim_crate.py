@@ -48,7 +48,7 @@ def test_impls_only_use_defined_functions_and_cover_the_trait():
     # a macro, a keyword, nor a tuple-struct / enum constructor (capitalised)
     calls = set(m.group(1) for m in re.finditer(r"(?<![\w.:!])([a-z_][a-z0-9_]*)\(", re.sub(r"//[^\n]*", "", lib)))
     calls -= {"if", "while", "for", "match", "fn", "unsafe", "loop", "return", "drop", "assert", "panic", "vec", "format", "check_domain", "allow", "cfg", "test",
-              "derive", "entry"}      # an attribute; the `&dyn Fn` parameter of key_print
+              "derive", "entry"}      # an attribute; the `&dyn Fn` parameter of full_print / sampled_print
     undefined = sorted(c for c in calls if c not in defined)
     assert not undefined, undefined
     for helper in ("matzq_from_rows", "matq_lower_from_packed", "ensure_key", "next_seed", "dims"):      # the helpers round 1 left undefined
@@ -91,3 +91,10 @@ def test_one_state_for_what_the_handle_holds():
     ensure = inherent[inherent.index("fn ensure_key(&self"):]
     ensure = ensure[:ensure.index("\n    }\n") + 7]
     assert ".clone()" not in ensure and "==" not in ensure.replace("!=", "")             # no deep comparison, no second copy of the key
+    # A and R are hashed entry by entry (a key that differs in a middle row is re-installed), entries beyond 64 bits do not all collide,
+    # and a pending asynchronous batch borrows the handle and waits when it is consumed or dropped (no use-after-free from safe Rust)
+    assert "fn full_print(" in lib and "full_print(a.get_num_rows()" in lib[lib.index("fn print_matzq"):lib.index("fn print_basis")]
+    assert "unwrap_or(0)" not in lib
+    pend = lib[lib.index("pub struct PendingBatch<'a>"):lib.index("impl Drop for GpuPSFPerturbation")]
+    assert "owner: &'a GpuPSFPerturbation" in pend and "impl<'a> Drop for PendingBatch<'a>" in pend
+    assert pend[pend.index("pub fn into_matz(self)"):].index("ffi::psfp_wait") < pend[pend.index("pub fn into_matz(self)"):].index("matz_from_rows")

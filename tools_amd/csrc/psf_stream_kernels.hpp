@@ -1,3 +1,4 @@
+#pragma once
 // psf_stream_kernels.hpp -- the SINGLE-CALL / SMALL-BATCH form of x = sqrt(Sigma_2) d  (mp_perturbation.rs:315; psf.rs:48-80: one `samp_p` call is
 // one preimage, and that is what benches/psf.rs:38,63-65,90-92 time).
 //
@@ -20,7 +21,6 @@
 // the 6-bit vmcnt allows 63 loads in flight, so PD <= 63 / (RT + NB) + 1.  Eight waves per CU with eight k-steps each already saturate what a CU
 // takes from HBM (tools/probe_stream.hip: PD 8 / 16 / 32 within 4 %); what a wave must not do is spend issue cycles per k-step beside its loads.
 constexpr size_t TS_SLACK_DOUBLES = 4 * 32 * 512;      // doubles (512 KiB) the host allocates behind the factor's and the normals' streams: PD k-steps of over-read, at most 8 x 64 fragments x 512 B for the compact normals stream at 1024 preimages
-#pragma once
 #include <type_traits>
 #include "psf_kernels.hpp"
 

@@ -41,6 +41,10 @@ static inline unsigned grid_for(size_t total, unsigned block = 256, unsigned cap
   return (unsigned)(g > cap ? cap : g);
 }
 static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// Rule of the handle (include/psf_mi355x.h, "Asynchronous calls"): an entry point that rewrites key material or reuses the handle's per-batch buffers first waits
+// for the asynchronous samp_p calls in flight (psfp_wait) and returns their status if one failed -- they run on a non-blocking stream and would otherwise read a
+// half-replaced key or share dP / dX / dV / the failure words with the new call.
+#define PSFP_QUIESCE(h) do { const psf_status rw__ = psfp_wait(h); if (rw__ != PSF_OK) return rw__; } while (0)
 
 struct TimingSlot { std::string name; hipEvent_t e0, e1; };
 
@@ -454,7 +458,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
 }
 
 static void hp_release(psfp_handle* h);
-static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_words);
+static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_words, bool from_prewarm = false);
 // A key whose batches will cross PCIe (m >= 8192: a preimage is >= 64 KiB) gets the batch-independent part of the host-pointer machinery -- streams, the DMA path,
 // one slot's pinned rings -- when the key is installed, next to a factorisation that takes a quarter of a second, instead of inside the first samp_p call
 // (PSF_HOST_PREWARM=0: on first use, as for small keys).
@@ -463,7 +467,7 @@ static void hp_prewarm(psfp_handle* h) {
   if (const char* env = std::getenv("PSF_HOST_PREWARM")) if (std::atoi(env) == 0) return;
   if (h->hp_warm.joinable()) h->hp_warm.join();
   try {
-    h->hp_warm = std::thread([h]() { if (hipSetDevice(h->prm.device) == hipSuccess) (void)hp_ensure(h, 0, 0, 0); });      // beside the factorisation, not behind it
+    h->hp_warm = std::thread([h]() { if (hipSetDevice(h->prm.device) == hipSuccess) (void)hp_ensure(h, 0, 0, 0, true); });      // beside the factorisation, not behind it
   } catch (...) { }                                         // no thread: on first use then
 }
 void psfp_destroy(psfp_handle* h) {
@@ -834,6 +838,7 @@ psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
   if (!h) return PSF_ERR_PARAM;
   if (h->prm.flags & PSFP_FLAG_NO_PERTURB) return PSF_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(h->prm.device));
+  PSFP_QUIESCE(h);
   const psf_status rcg = gen_A_R(h, seed);
   if (rcg != PSF_OK) return rcg;
   h->has_pub = h->has_R = true;
@@ -851,6 +856,7 @@ psf_status psfp_compute_sqrt_sigma_2(psfp_handle* h, double s_cov) {
   // the handle's s.  A factor for another s_cov would therefore be paired with the wrong constants after an export / load round trip, silently; refused.
   if (h->structured && s_cov != h->prm.s) return PSF_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(h->prm.device));
+  PSFP_QUIESCE(h);
   const psf_status rc = build_sqrt_sigma2(h, s_cov);
   h->has_key = rc == PSF_OK;
   return rc;
@@ -862,6 +868,7 @@ psf_status psfp_compute_sqrt_sigma_2_dense(psfp_handle* h, const double* sigma_l
   if (!h->has_R || (h->prm.flags & PSFP_FLAG_NO_PERTURB)) return PSF_ERR_NO_KEY;
   if (h->structured) return PSF_ERR_UNSUPPORTED;           // the structured factor exists for Sigma = s^2 I only
   HIP_TRY(hipSetDevice(h->prm.device));
+  PSFP_QUIESCE(h);
   double* dsg = nullptr;
   const size_t np = h->m * (h->m + 1) / 2;
   HIP_TRY(hipMalloc(&dsg, np * sizeof(double)));
@@ -875,6 +882,7 @@ psf_status psfp_compute_sqrt_sigma_2_dense(psfp_handle* h, const double* sigma_l
 psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, const double* Lp) {
   if (!h || !A || (!R && Lp)) return PSF_ERR_PARAM;
   HIP_TRY(hipSetDevice(h->prm.device));
+  PSFP_QUIESCE(h);
   h->has_key = h->has_R = h->has_pub = false;
   HIP_TRY(hipMemcpy(h->dA, A, h->n * h->m * sizeof(uint64_t), hipMemcpyHostToDevice));
   split_A(h);
@@ -918,6 +926,7 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
 psf_status psfp_load_trapdoor(psfp_handle* h, const uint64_t* A, const int8_t* R) {
   if (!h || !R) return PSF_ERR_PARAM;
   HIP_TRY(hipSetDevice(h->prm.device));
+  PSFP_QUIESCE(h);
   h->has_key = h->has_R = false;
   if (A) {
     h->has_pub = false;
@@ -1019,6 +1028,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // shape, PSF_COMPACT_D=0 the chunk-stream layout of the normals (experiments; same bits).
   size_t stream_max = 1024;      // measured at C3 (profiles/r04_notes.md): the streaming form wins up to ~1024 preimages, k_trmm_f64_big beyond
   if (const char* e = std::getenv("PSF_TRMM_STREAM_MAX")) stream_max = (size_t)std::atol(e);
+  if (stream_max > 2048) stream_max = 2048;      // 128 column fragments: beyond, the over-read of the compact normals stream would leave TS_SLACK_DOUBLES
   const bool stream = B <= stream_max;
   // tile shape per wave (RT 16-row tiles x NB fragments of 16 preimages) and workgroup form, from tools/probe_stream.hip at the C3 shape
   // (profiles/r04_probe_stream.log): <= 16 preimages the launch is bound by reading the factor, beyond that by the longest MFMA chain
@@ -1227,6 +1237,7 @@ psf_status psfp_samp_p_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, 
   if (!h->has_key || !h->has_pub) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
+  PSFP_QUIESCE(h);
   psf_status rc = ensure_batch(h, B);
   if (rc != PSF_OK) return rc;
   if (h->timing) clear_slots(h);       // once per public call: the slices of a host-pointer call add up in psfp_get_timing
@@ -1344,8 +1355,8 @@ static void hp_release(psfp_handle* h) {
 
 // streams, transport and the rings of call slot `slot` (which the caller has joined).  Everything is allocated on first use and per slot: a caller that only ever
 // makes synchronous calls pays for one slot (pinning memory is the expensive part of a handle's first host-pointer call).
-static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_words) {
-  if (h->hp_warm.joinable() && std::this_thread::get_id() != h->hp_warm.get_id()) h->hp_warm.join();
+static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_words, bool from_prewarm) {
+  if (!from_prewarm && h->hp_warm.joinable()) h->hp_warm.join();      // (the prewarm worker itself never looks at h->hp_warm: the owner may still be assigning it)
   auto& hp = h->hp;
   constexpr int NW = psfp_handle::HostPipe::NW;
   if (!hp.common_ready) {
@@ -1414,6 +1425,7 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   if (!h || (B && (!u || !e))) return PSF_ERR_PARAM;
   if (!h->has_key || !h->has_pub) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
+  if (h->pipeline) return PSF_ERR_UNSUPPORTED;              // PSF_PIPELINE=1 alternates two sets of failure words per call: the synchronous forms only (as psfp_samp_p does)
   HIP_TRY(hipSetDevice(h->prm.device));
   auto& hp = h->hp;
   const size_t m = h->m, total = B * m;
@@ -1684,6 +1696,7 @@ psf_status psfp_samp_d_dev(psfp_handle* h, uint64_t seed, uint64_t first_index, 
   if (!h || (B && !d_e)) return PSF_ERR_PARAM;
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
+  PSFP_QUIESCE(h);
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(h->dFail, 0, sizeof(int), st);
   hipLaunchKernelGGL(k_samp_d, dim3(grid_for(B * h->m, 256, 256 * 32)), dim3(256), 0, st, seed, first_index, h->m, B, h->szSR, d_e, h->dFail);
@@ -1730,6 +1743,7 @@ psf_status psfp_f_a_dev(psfp_handle* h, size_t B, const int64_t* d_e, uint64_t* 
   if (!h->has_pub) return PSF_ERR_NO_KEY;                     // f_a needs the public matrix only (mp_perturbation.rs:366-369)
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(h->prm.device));
+  PSFP_QUIESCE(h);
   psf_status rc = ensure_batch(h, B);
   if (rc != PSF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
