@@ -314,6 +314,12 @@ psf_status psfgpv_export_key(const psfgpv_handle*, uint64_t* A, int8_t* R, int32
 psf_status psfgpv_samp_d(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, int64_t* e);         /* gpv.rs:113-116 */
 psf_status psfgpv_samp_p(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
 psf_status psfgpv_samp_p_dev(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, void* stream);
+/* gpv.rs:152-161 on host buffers without waiting (the transport of psfp_samp_p_async: rows narrowed to int32 on the device, chunk transfers by the DMA engines into
+ * per-call pinned rings, widened into e by worker threads): returns once the work is enqueued (u may be reused), e[] is complete when psfgpv_wait returns.  At most two
+ * calls in flight per handle; the rows of call i cross PCIe while call i + 1 walks.  psfgpv_wait returns the first non-OK status of the outstanding calls, oldest first:
+ * PSF_ERR_SAMPLER as psfgpv_samp_p would; PSF_ERR_UNSUPPORTED if a row entry did not fit 32 bits (the synchronous call copies 64-bit rows in that case). */
+psf_status psfgpv_samp_p_async(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
+psf_status psfgpv_wait(psfgpv_handle*);
 psf_status psfgpv_f_a(psfgpv_handle*, size_t B, const int64_t* e, uint64_t* u);                               /* gpv.rs:190-193 */
 psf_status psfgpv_f_a_dev(psfgpv_handle*, size_t B, const int64_t* d_e, uint64_t* d_u, uint8_t* d_ok, void* stream);
 psf_status psfgpv_check_domain(psfgpv_handle*, size_t B, const int64_t* e, size_t len, uint8_t* ok);         /* gpv.rs:219-224 */
@@ -362,6 +368,9 @@ psf_status psfring_export_key(const psfring_handle*, uint64_t* a, int64_t* r, in
 psf_status psfring_samp_d(psfring_handle*, uint64_t seed, uint64_t first_index, size_t B, int64_t* sigma);            /* :118-122 */
 psf_status psfring_samp_p(psfring_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* sigma);
 psf_status psfring_samp_p_dev(psfring_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_sigma, void* stream);
+/* gpv_ring.rs:160-212 without waiting: as psfgpv_samp_p_async / psfgpv_wait */
+psf_status psfring_samp_p_async(psfring_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* sigma);
+psf_status psfring_wait(psfring_handle*);
 psf_status psfring_f_a(psfring_handle*, size_t B, const int64_t* sigma, uint64_t* u);                                  /* :243-247 */
 psf_status psfring_f_a_dev(psfring_handle*, size_t B, const int64_t* d_sigma, uint64_t* d_u, uint8_t* d_ok, void* stream);
 psf_status psfring_check_domain(psfring_handle*, size_t B, const int64_t* sigma, size_t len, uint8_t* ok);            /* :274-283 */

@@ -149,6 +149,13 @@ class PSFGPV {
     check(psfgpv_samp_p(h_, seed, first_index, B, u.data(), e.data()), "samp_p");
     return e;
   }
+  // the same, asynchronous: e (B * m entries, caller-owned) is complete after wait(); at most two calls in flight per handle
+  void samp_p_async(const MatZq& u, MatZ& e, uint64_t seed, uint64_t first_index = 0) {
+    const size_t B = u.size() / n();
+    e.resize(B * m());
+    check(psfgpv_samp_p_async(h_, seed, first_index, B, u.data(), e.data()), "samp_p_async");
+  }
+  void wait() { check(psfgpv_wait(h_), "wait"); }
   MatZq f_a(const MatZ& sigma) {                                                                   // :190-193
     if (sigma.empty() || sigma.size() % m() != 0) throw PsfError(PSF_ERR_DOMAIN, "f_a");
     const size_t B = sigma.size() / m();
@@ -202,6 +209,12 @@ class PSFGPVRing {
     check(psfring_samp_p(h_, seed, first_index, B, u.data(), sg.data()), "samp_p");
     return sg;
   }
+  void samp_p_async(const MatZq& u, MatZ& sg, uint64_t seed, uint64_t first_index = 0) {           // sg is complete after wait()
+    const size_t B = u.size() / n();
+    sg.resize(B * polys() * n());
+    check(psfring_samp_p_async(h_, seed, first_index, B, u.data(), sg.data()), "samp_p_async");
+  }
+  void wait() { check(psfring_wait(h_), "wait"); }
   MatZq f_a(const MatZ& sigma) {                                                                    // :243-247
     const size_t d = polys() * n();
     if (sigma.empty() || sigma.size() % d != 0) throw PsfError(PSF_ERR_DOMAIN, "f_a");

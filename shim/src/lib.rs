@@ -392,7 +392,7 @@ impl GpuPSFPerturbation {
 /// handle cannot be dropped while a batch is pending, and the rows can only be taken through `into_matz`, which waits (`psfp_wait`) first.  Dropping a
 /// pending batch waits as well, so the buffers are never freed under the workers.
 pub struct PendingBatch<'a> {
-    owner: &'a GpuPSFPerturbation,
+    owner: Owner<'a>,
     rows: i64,
     cols: i64,
     _u: Vec<u64>,
@@ -400,10 +400,25 @@ pub struct PendingBatch<'a> {
     waited: Cell<bool>,
 }
 
+/// the handle a pending batch belongs to (and waits on)
+enum Owner<'a> {
+    Perturbation(&'a GpuPSFPerturbation),
+    Gpv(&'a GpuPSFGPV),
+}
+
+impl<'a> Owner<'a> {
+    fn wait(&self) -> std::os::raw::c_int {
+        match self {
+            Owner::Perturbation(p) => unsafe { ffi::psfp_wait(p.handle) },
+            Owner::Gpv(g) => unsafe { ffi::psfgpv_wait(g.handle) },
+        }
+    }
+}
+
 impl<'a> PendingBatch<'a> {
     /// the preimages, one per row; waits for the handle's outstanding batches first and panics with the first failure (oldest batch first)
     pub fn into_matz(self) -> MatZ {
-        check(unsafe { ffi::psfp_wait(self.owner.handle) }, "psfp_wait");
+        check(self.owner.wait(), "wait");
         self.waited.set(true);
         matz_from_rows(self.rows, self.cols, &self.e)
     }
@@ -413,7 +428,7 @@ impl<'a> Drop for PendingBatch<'a> {
     fn drop(&mut self) {
         if !self.waited.get() {
             // nothing may write into `e` once it is freed; the status of an abandoned batch is discarded
-            let _ = unsafe { ffi::psfp_wait(self.owner.handle) };
+            let _ = self.owner.wait();
         }
     }
 }
@@ -430,7 +445,7 @@ impl GpuPSFPerturbation {
         let mut e = vec![0i64; (b * m) as usize];
         let seed = next_seed(&self.seed, &self.calls);
         check(unsafe { ffi::psfp_samp_p_async(self.handle, seed, 0, b as usize, u.as_ptr(), e.as_mut_ptr()) }, "psfp_samp_p_async");
-        PendingBatch { owner: self, rows: b, cols: m, _u: u, e, waited: Cell::new(false) }
+        PendingBatch { owner: Owner::Perturbation(self), rows: b, cols: m, _u: u, e, waited: Cell::new(false) }
     }
 
     /// every asynchronous batch of this handle has completed (`psfp_wait`); panics with the first failure, oldest batch first
@@ -593,6 +608,24 @@ impl GpuPSFGPV {
         let mut e = vec![0i64; (b * m) as usize];
         check(unsafe { ffi::psfgpv_samp_p(self.handle, next_seed(&self.seed, &self.calls), 0, b as usize, u.as_ptr(), e.as_mut_ptr()) }, "psfgpv_samp_p");
         matz_from_rows(b, m, &e)
+    }
+
+    /// `samp_p_batch` without waiting (`psfgpv_samp_p_async`): at most two batches in flight per handle, the rows of batch i cross PCIe while batch i + 1
+    /// walks.  `PendingBatch::into_matz` (or dropping the batch) waits.
+    pub fn samp_p_batch_async<'a>(&'a self, a: &MatZq, td: &(MatZ, MatQ), targets: &MatZq) -> PendingBatch<'a> {
+        let (n, m) = self.dims();
+        self.ensure_key(a, &td.0, &td.1);
+        let b = targets.get_num_rows();
+        assert_eq!(targets.get_num_columns(), n);
+        let u = matzq_to_rows(targets);
+        let mut e = vec![0i64; (b * m) as usize];
+        check(unsafe { ffi::psfgpv_samp_p_async(self.handle, next_seed(&self.seed, &self.calls), 0, b as usize, u.as_ptr(), e.as_mut_ptr()) }, "psfgpv_samp_p_async");
+        PendingBatch { owner: Owner::Gpv(self), rows: b, cols: m, _u: u, e, waited: Cell::new(false) }
+    }
+
+    /// every asynchronous batch of this handle has completed (`psfgpv_wait`)
+    pub fn wait_batches(&self) {
+        check(unsafe { ffi::psfgpv_wait(self.handle) }, "psfgpv_wait");
     }
 }
 

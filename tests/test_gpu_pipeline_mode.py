@@ -284,3 +284,48 @@ def test_batch_host_calls_of_the_nearest_plane_types_equal_the_straight_form(ora
         assert (fast == straight).all(), B
         assert (psf.f_a(fast) == u).all()
     psf.close()
+
+
+def test_overlapped_async_calls_of_the_nearest_plane_types(oracle):
+    """psfgpv_samp_p_async / psfring_samp_p_async + _wait (gpv.rs:152-161, gpv_ring.rs:160-212 on host buffers): two calls in flight return the rows of two
+    synchronous calls, a third waits for the first inside the library; the rows equal the oracle's; a small synchronous call in between waits for what is in flight."""
+    import math
+    import numpy as np
+    import tools_amd as T
+    n, q, s = 12, 2**9, 60.0
+    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+    A, (Bt, Gt) = psf.trap_gen(6)
+    Bs = [700, 520, 900]
+    us = [oracle.uniform_targets(40 + i, B, n, q) for i, B in enumerate(Bs)]
+    sync = [psf.samp_p(u, seed=80 + i, first_index=500 * i) for i, u in enumerate(us)]
+    outs = [np.full((B, psf.m), -7, dtype=np.int64) for B in Bs]
+    for i, u in enumerate(us):
+        psf.samp_p_async(u, outs[i], seed=80 + i, first_index=500 * i)
+    psf.wait()
+    for i in range(3):
+        assert (outs[i] == sync[i]).all(), i
+    assert (psf.f_a(outs[2]) == us[2]).all() and psf.check_domain(outs[2]).all()
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    orc.load_key(A, Bt, Gt)
+    assert (outs[1][:24] == orc.samp_p(81, us[1][:24], first_index=500)).all()
+    psf.samp_p_async(us[0], outs[0], seed=95)
+    small = psf.samp_p(us[1][:2], seed=96)
+    assert (small == orc.samp_p(96, us[1][:2])).all()
+    psf.wait()
+    assert (outs[0] == psf.samp_p(us[0], seed=95)).all()
+    psf.close()
+    # the ring type
+    nr, qr = 16, 3329
+    sr = ((2 * 2 * 1.005 * math.sqrt(nr) + 1) * 2) * 4
+    ring = T.PSFGPVRing(T.GadgetParametersRing.init_default(nr, qr), sr, 1.005)
+    ring.trap_gen(7)
+    ur = [oracle.uniform_targets(50 + i, B, nr, qr) for i, B in enumerate((600, 450))]
+    syncr = [ring.samp_p(u, seed=60 + i, first_index=33 * i) for i, u in enumerate(ur)]
+    outr = [np.full((u.shape[0], ring.K, ring.n), -7, dtype=np.int64) for u in ur]
+    for i, u in enumerate(ur):
+        ring.samp_p_async(u, outr[i], seed=60 + i, first_index=33 * i)
+    ring.wait()
+    for i in range(2):
+        assert (outr[i] == syncr[i]).all(), i
+    assert (ring.f_a(outr[0]) == ur[0]).all()
+    ring.close()

@@ -96,5 +96,5 @@ def test_one_state_for_what_the_handle_holds():
     assert "fn full_print(" in lib and "full_print(a.get_num_rows()" in lib[lib.index("fn print_matzq"):lib.index("fn print_basis")]
     assert "unwrap_or(0)" not in lib
     pend = lib[lib.index("pub struct PendingBatch<'a>"):lib.index("impl Drop for GpuPSFPerturbation")]
-    assert "owner: &'a GpuPSFPerturbation" in pend and "impl<'a> Drop for PendingBatch<'a>" in pend
-    assert pend[pend.index("pub fn into_matz(self)"):].index("ffi::psfp_wait") < pend[pend.index("pub fn into_matz(self)"):].index("matz_from_rows")
+    assert "owner: Owner<'a>" in pend and "Perturbation(&'a GpuPSFPerturbation)" in pend and "impl<'a> Drop for PendingBatch<'a>" in pend
+    assert pend[pend.index("pub fn into_matz(self)"):].index("self.owner.wait()") < pend[pend.index("pub fn into_matz(self)"):].index("matz_from_rows")

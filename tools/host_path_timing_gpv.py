@@ -29,6 +29,18 @@ def run(name, psf, B, m, n, q):
     e = psf.samp_p(u, seed=7, out=e)
     psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=7, stream=st); torch.cuda.synchronize()
     same = bool((ed.cpu().numpy().reshape(-1) == np.asarray(e).reshape(-1)).all())
+    # a loop of overlapped asynchronous calls (samp_p_async / wait): two output buffers in turn
+    outs = [np.empty_like(e), np.empty_like(e)]
+    NC = 16
+    psf.samp_p_async(u, outs[0], seed=50); psf.samp_p_async(u, outs[1], seed=51); psf.wait()
+    t0 = time.perf_counter()
+    for i in range(NC):
+        psf.samp_p_async(u, outs[i & 1], seed=100 + i, first_index=3 * i)
+    psf.wait()
+    da = (time.perf_counter() - t0) / NC
+    psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=100 + NC - 1, first_index=3 * (NC - 1), stream=st); torch.cuda.synchronize()
+    same_async = bool((ed.cpu().numpy().reshape(-1) == outs[(NC - 1) & 1].reshape(-1)).all())
+    print(f"{name}: {NC} overlapped asynchronous calls {da*1e3:.2f} ms per call = {dd/da:.3f} of device-resident, last call's rows equal the device path's: {same_async}", flush=True)
     print(f"{name}: device pointers {dd*1e3:.2f} ms per call, host pointers {min(ts)*1e3:.2f} ms (median {sorted(ts)[3]*1e3:.2f}), same rows {same}", flush=True)
 
 gpv = T.PSFGPV(T.GadgetParameters.init_default(256, 3329), 1024.0); gpv.trap_gen(3, export=False)

@@ -384,6 +384,7 @@ psf_status psfgpv_trap_gen(psfgpv_handle* g, uint64_t seed) {
   if (!g) return PSF_ERR_PARAM;
   psfp_handle* b = g->base;
   HIP_TRY(hipSetDevice(b->prm.device));
+  PSFP_QUIESCE(b);
   g->has_key = false;
   psf_status rc = gen_A_R(b, seed);                                          // :84-88
   if (rc != PSF_OK) return rc;
@@ -413,6 +414,7 @@ psf_status psfgpv_load_key(psfgpv_handle* g, const uint64_t* A, const int32_t* b
   if (!g || !A || !basis_t || !gso_t) return PSF_ERR_PARAM;
   psfp_handle* b = g->base;
   HIP_TRY(hipSetDevice(b->prm.device));
+  PSFP_QUIESCE(b);
   g->has_key = false;
   HIP_TRY(hipMemcpy(b->dA, A, b->n * b->m * sizeof(uint64_t), hipMemcpyHostToDevice));
   split_A(b);
@@ -440,10 +442,16 @@ psf_status psfgpv_export_key(const psfgpv_handle* g, uint64_t* A, int8_t* R, int
 }
 
 // gpv.rs:152-161
+static psf_status gpv_samp_p_enqueue(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, void* stream);
 psf_status psfgpv_samp_p_dev(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, void* stream) {
   if (!g || (B && (!d_u || !d_e))) return PSF_ERR_PARAM;
   if (!g->has_key) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
+  HIP_TRY(hipSetDevice(g->base->prm.device));
+  PSFP_QUIESCE(g->base);                // the walk's buffers are shared with the asynchronous calls in flight (which enqueue through gpv_samp_p_enqueue themselves)
+  return gpv_samp_p_enqueue(g, seed, first_index, B, d_u, d_e, stream);
+}
+static psf_status gpv_samp_p_enqueue(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_e, void* stream) {
   psfp_handle* b = g->base;
   HIP_TRY(hipSetDevice(b->prm.device));
   hipStream_t st = (hipStream_t)stream;
@@ -572,6 +580,30 @@ psf_status psfgpv_samp_p(psfgpv_handle* g, uint64_t seed, uint64_t first_index, 
   return (hf[1 + 0] || hf[1 + 4]) ? PSF_ERR_SAMPLER : PSF_OK;
 }
 
+// gpv.rs:152-161 on host buffers without waiting (the machinery of psfp_samp_p_async on the inner handle: int32 narrowing, per-slot pinned rings, chunk transfers by the
+// DMA engines, widening workers): returns once the work is enqueued; e is complete when psfgpv_wait returns.  At most two calls in flight; the rows of call i cross
+// PCIe while call i + 1 walks.  A row entry beyond 32 bits (the synchronous call copies 64-bit rows then) makes psfgpv_wait return PSF_ERR_UNSUPPORTED.
+psf_status psfgpv_samp_p_async(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
+  if (!g || (B && (!u || !e))) return PSF_ERR_PARAM;
+  if (!g->has_key) return PSF_ERR_NO_KEY;
+  if (B == 0) return PSF_OK;
+  psfp_handle* h = g->base;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  if (B > g->bcap) {                                        // ensure_np_batch reallocates the walk's buffers: nothing may be in flight
+    const psf_status rw = psfp_wait(h);
+    if (rw != PSF_OK) return rw;
+    const psf_status rb = ensure_np_batch(g, B);
+    if (rb != PSF_OK) return rb;
+  }
+  return hp_async(h, B, u, e, false, false, g->dFlags, [&](size_t off, size_t cnt, const uint64_t* d_u, int64_t* d_e, hipStream_t cs) -> psf_status {
+    return gpv_samp_p_enqueue(g, seed, first_index + off, cnt, d_u, d_e, cs);
+  });
+}
+psf_status psfgpv_wait(psfgpv_handle* g) {
+  if (!g) return PSF_ERR_PARAM;
+  return psfp_wait(g->base);
+}
+
 psf_status psfgpv_samp_d(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, int64_t* e) {
   return g ? psfp_samp_d(g->base, seed, first_index, B, e) : PSF_ERR_PARAM;
 }
@@ -652,6 +684,7 @@ static psf_status ring_install(psfring_handle* h) {
   psfgpv_handle* g = h->g;
   psfp_handle* b = g->base;
   HIP_TRY(hipSetDevice(b->prm.device));
+  PSFP_QUIESCE(b);
   g->has_key = false;
   HIP_TRY(hipMemcpy(b->dA, A_emb.data(), A_emb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   split_A(b);
@@ -906,6 +939,10 @@ psf_status psfring_samp_d(psfring_handle* h, uint64_t seed, uint64_t first_index
 psf_status psfring_samp_p(psfring_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* sigma) {
   return h ? psfgpv_samp_p(h->g, seed, first_index, B, u, sigma) : PSF_ERR_PARAM;
 }
+psf_status psfring_samp_p_async(psfring_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* sigma) {
+  return h ? psfgpv_samp_p_async(h->g, seed, first_index, B, u, sigma) : PSF_ERR_PARAM;
+}
+psf_status psfring_wait(psfring_handle* h) { return h ? psfgpv_wait(h->g) : PSF_ERR_PARAM; }
 psf_status psfring_samp_p_dev(psfring_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_sigma, void* stream) {
   return h ? psfgpv_samp_p_dev(h->g, seed, first_index, B, d_u, d_sigma, stream) : PSF_ERR_PARAM;
 }

@@ -1307,8 +1307,13 @@ static void widen_rows(int64_t* __restrict__ dst, const int32_t* __restrict__ sr
 // The flags of an asynchronous call: cleared and sent to pinned host memory by one-wave kernels in stream order.  (hipMemsetAsync / hipMemcpyAsync on the
 // compute stream go through the runtime's copy path, where they queue behind the chunk copies of the call before: the next call's kernels then waited for them.)
 __global__ void k_host_flags_clear(int* __restrict__ fail, int* __restrict__ ovf) { if (threadIdx.x < 2) { fail[threadIdx.x] = 0; ovf[threadIdx.x] = 0; } }
-__global__ void k_host_flags_send(const int* __restrict__ fail, const int* __restrict__ ovf, int* __restrict__ host_flags) {
-  if (threadIdx.x == 0) { host_flags[0] = fail[0]; host_flags[1] = fail[1]; host_flags[2] = ovf[0]; host_flags[3] = 0; __threadfence_system(); }
+// extra: the eight flag words of a PSFGPV / PSFGPVRing call (psfgpv_impl.hpp: [0] and [4] = a sampler failure of the first / second pass), or nullptr
+__global__ void k_host_flags_send(const int* __restrict__ fail, const int* __restrict__ ovf, const int* __restrict__ extra, int* __restrict__ host_flags) {
+  if (threadIdx.x == 0) {
+    host_flags[0] = fail[0] | (extra ? (extra[0] | extra[4]) : 0);
+    host_flags[1] = fail[1]; host_flags[2] = ovf[0]; host_flags[3] = extra ? 1 : 0;        // [3]: a nearest-plane call (an overflow of the narrowing is not a sampler failure there)
+    __threadfence_system();
+  }
 }
 
 // wait for the asynchronous call in `slot` (its workers have copied and widened every row), release it, return its status
@@ -1319,7 +1324,10 @@ static psf_status hp_join(psfp_handle* h, int slot) {
   hp.workers[slot].clear();
   hp.busy[slot] = false;
   psf_status rc = (psf_status)hp.status[slot].load();
-  if (rc == PSF_OK && (hp.hFlags[slot][0] || hp.hFlags[slot][2])) rc = PSF_ERR_SAMPLER;
+  if (rc == PSF_OK && hp.hFlags[slot][0]) rc = PSF_ERR_SAMPLER;
+  // an entry beyond 32 bits: impossible for PSFPerturbation (every entry is checked on the device: a sampler failure); a PSFGPV / PSFGPVRing row of that size
+  // needs the synchronous call, which copies 64-bit rows then
+  if (rc == PSF_OK && hp.hFlags[slot][2]) rc = hp.hFlags[slot][3] ? PSF_ERR_UNSUPPORTED : PSF_ERR_SAMPLER;
   return rc;
 }
 
@@ -1421,11 +1429,27 @@ static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_w
 // and |R z| <= w 2^15, both checked on the device), copied in chunks to pinned memory on a second stream and widened into `e` by NW worker threads --
 // while the compute stream is already in the next slice or the next call.  A single call therefore ends one short slice after its product
 // (slices: all but the last ~1024 rows, then the rest), and back-to-back calls run at the device-resident rate.
+// What an asynchronous host-pointer call of any of the three types is made of: `compute(off, cnt, d_u, d_e, cs)` enqueues the samp_p pipeline of the rows
+// [off, off + cnt) on the stream cs (targets d_u: cnt x n, preimages d_e: cnt x m, both on the device); everything around it -- slots, staging of the targets,
+// int32 narrowing, chunk transfers by the DMA engines, widening workers, the flags -- is the same.  defer_u: the targets are uploaded when the pipeline asks for them
+// (h->before_u, PSFPerturbation: behind the product); otherwise at the head of the call.  extra_flags: see k_host_flags_send.
+using HpCompute = std::function<psf_status(size_t, size_t, const uint64_t*, int64_t*, hipStream_t)>;
+static psf_status hp_async(psfp_handle* h, size_t B, const uint64_t* u, int64_t* e, bool defer_u, bool allow_slices, const int* extra_flags, const HpCompute& compute);
+
 psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {
   if (!h || (B && (!u || !e))) return PSF_ERR_PARAM;
   if (!h->has_key || !h->has_pub) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
   if (h->pipeline) return PSF_ERR_UNSUPPORTED;              // PSF_PIPELINE=1 alternates two sets of failure words per call: the synchronous forms only (as psfp_samp_p does)
+  struct FailGuard { psfp_handle* h; size_t B; ~FailGuard() { h->keep_fail = false; h->nbj = round_up(B, TR_BN) / TR_BN; } } guard{h, B};
+  return hp_async(h, B, u, e, true, true, nullptr, [&](size_t off, size_t cnt, const uint64_t* d_u, int64_t* d_e, hipStream_t cs) -> psf_status {
+    h->keep_fail = true;                                    // the slices of a call share its failure words (cleared once, in front of the first)
+    h->nbj = round_up(cnt, TR_BN) / TR_BN;
+    return run_samp_p(h, seed, first_index + off, cnt, d_u, d_e, cs);
+  });
+}
+
+static psf_status hp_async(psfp_handle* h, size_t B, const uint64_t* u, int64_t* e, bool defer_u, bool allow_slices, const int* extra_flags, const HpCompute& compute) {
   HIP_TRY(hipSetDevice(h->prm.device));
   auto& hp = h->hp;
   const size_t m = h->m, total = B * m;
@@ -1453,7 +1477,7 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
     return PSF_OK;
   };
   struct GateGuard { psfp_handle* h; ~GateGuard() { h->before_u = nullptr; } } gate_guard{h};      // (an error return must not leave a callback with dead captures behind)
-  if (hp.copy_mode != 1) {                                  // the copy kernel is ordered by the compute stream only: at the head of the call, as before
+  if (hp.copy_mode != 1 || !defer_u) {                      // the copy kernel is ordered by the compute stream only: at the head of the call, as before
     auto f = std::move(h->before_u); h->before_u = nullptr;
     rc = f();
     if (rc != PSF_OK) return rc;
@@ -1468,26 +1492,23 @@ psf_status psfp_samp_p_async(psfp_handle* h, uint64_t seed, uint64_t first_index
   if (const char* env = std::getenv("PSF_HOST_TAIL")) { const long v = std::atol(env); if (v >= 128) tail = (size_t)v; }
   bool cut = hp.slice_tail;                                 // the synchronous form only: behind an asynchronous call the next call's compute covers the transfer
   if (const char* env = std::getenv("PSF_HOST_ASYNC_SLICE")) cut = cut || std::atoi(env) != 0;      // experiments: 1 = asynchronous calls cut the tail slice too
-  if (cut && !h->no_slice && !h->pipeline && B >= 2 * tail) { cuts[1] = B - tail; cuts[2] = B; nsl = 2; }
+  if (cut && allow_slices && !h->no_slice && !h->pipeline && B >= 2 * tail) { cuts[1] = B - tail; cuts[2] = B; nsl = 2; }
   if (const char* env = std::getenv("PSF_HOST_SLICE")) {    // experiments: equal slices of this many rows (at most four)
     const long v = std::atol(env);
-    if (v >= 128 && !h->no_slice && !h->pipeline && (size_t)v < B) {
+    if (v >= 128 && allow_slices && !h->no_slice && !h->pipeline && (size_t)v < B) {
       nsl = 0;
       for (size_t off = 0; off < B && nsl < 4; off += (size_t)v) cuts[nsl++] = off;
       cuts[nsl] = B;
     }
   }
-  struct FailGuard { psfp_handle* h; size_t B; ~FailGuard() { h->keep_fail = false; h->nbj = round_up(B, TR_BN) / TR_BN; } } guard{h, B};
   hipLaunchKernelGGL(k_host_flags_clear, dim3(1), dim3(64), 0, cs, h->dFail, hp.dOvf);
-  h->keep_fail = true;
   for (int j = 0; j < nsl; ++j) {
     const size_t off = cuts[j], cnt = cuts[j + 1] - cuts[j];
-    h->nbj = round_up(cnt, TR_BN) / TR_BN;
-    rc = run_samp_p(h, seed, first_index + off, cnt, dUcall + off * h->n, h->dE + off * m, cs);
+    rc = compute(off, cnt, dUcall + off * h->n, h->dE + off * m, cs);
     if (rc != PSF_OK) return rc;
     hipLaunchKernelGGL(k_narrow_rows, dim3(grid_for(cnt * m / 2 + 1, 256, 256 * 16)), dim3(256), 0, cs, h->dE + off * m, hp.dE32[slot] + off * m, cnt * m, hp.dOvf);
     if (j == nsl - 1) {                                     // the call's flags travel with its last slice
-      hipLaunchKernelGGL(k_host_flags_send, dim3(1), dim3(64), 0, cs, h->dFail, hp.dOvf, hp.hFlags[slot]);
+      hipLaunchKernelGGL(k_host_flags_send, dim3(1), dim3(64), 0, cs, h->dFail, hp.dOvf, extra_flags, hp.hFlags[slot]);
     }
     HIP_TRY(hipEventRecord(hp.evSlice[slot][j], cs));
   }

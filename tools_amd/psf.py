@@ -358,6 +358,24 @@ class PSFGPV:
                                         _p(ok, C.c_uint8)), "check_domain")
         return bool(ok[0]) if single else ok.astype(bool)
 
+    def samp_p_async(self, u, out, seed=0, first_index=0):
+        """psfgpv_samp_p_async: enqueue B samp_p calls on host buffers and return; `out` ((B, m) int64, C-contiguous) is complete after wait().
+        At most two calls are in flight per handle; `out` must stay alive (and untouched) until wait() -- the wrapper keeps a reference."""
+        u2 = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, self.n)
+        B = u2.shape[0]
+        assert out.dtype == np.int64 and out.shape == (B, self.m) and out.flags.c_contiguous
+        check(lib().psfgpv_samp_p_async(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64), _p(out, C.c_int64)),
+              "samp_p_async")
+        self._inflight = getattr(self, "_inflight", []) + [out]
+        return out
+
+    def wait(self):
+        """psfgpv_wait: every asynchronous call of this handle has completed; raises PsfError with the first failure (oldest call first)."""
+        try:
+            check(lib().psfgpv_wait(self._h), "wait")
+        finally:
+            self._inflight = []
+
     # device-resident API
     def samp_p_dev(self, d_u_ptr, d_e_ptr, B, seed=0, first_index=0, stream=None):
         check(lib().psfgpv_samp_p_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), C.c_void_p(d_u_ptr),
@@ -487,6 +505,22 @@ class PSFGPVRing:
         check(lib().psfring_check_domain(self._h, C.c_size_t(s2.shape[0]), _p(s2, C.c_int64), C.c_size_t(s2.shape[1]),
                                          _p(ok, C.c_uint8)), "check_domain")
         return bool(ok[0]) if single else ok.astype(bool)
+
+    def samp_p_async(self, u, out, seed=0, first_index=0):
+        """psfring_samp_p_async: as PSFGPV.samp_p_async; `out` is (B, k+2, n) int64, complete after wait()."""
+        u2 = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, self.n)
+        B = u2.shape[0]
+        assert out.dtype == np.int64 and out.shape == (B, self.K, self.n) and out.flags.c_contiguous
+        check(lib().psfring_samp_p_async(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64), _p(out, C.c_int64)),
+              "samp_p_async")
+        self._inflight = getattr(self, "_inflight", []) + [out]
+        return out
+
+    def wait(self):
+        try:
+            check(lib().psfring_wait(self._h), "wait")
+        finally:
+            self._inflight = []
 
     def samp_p_dev(self, d_u_ptr, d_sigma_ptr, B, seed=0, first_index=0, stream=None):
         check(lib().psfring_samp_p_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), C.c_void_p(d_u_ptr),
