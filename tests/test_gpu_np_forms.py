@@ -1,0 +1,90 @@
+"""The randomized nearest plane (MatZ::sample_d_precomputed_gso, gpv.rs:160; gpv_ring.rs:204-211) has three launch forms for the SAME chains: one launch per
+block (k_np_step, PSF_NP_WALK=0), the whole walk in one launch with updater workgroups that keep the running projections in registers (k_np_walk, the default where
+the batch fits) and the whole walk with the helper waves updating the projections in memory (k_np_walk2, PSF_NP_WALK=3), each with one or two preimages per
+sampler wave (PSF_NP_G).  Every form must return the default's bytes -- which equal the oracle's -- on batches with several 64-preimage groups (one of them
+partial), several blocks and a short top block; a wait that gives up must surface as PSF_ERR_SAMPLER, not as a hang or a silent result."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, hashlib, json, math
+sys.path.insert(0, %r)
+import numpy as np
+import tools_amd as T
+from oracle import oracle as O
+kind, B = sys.argv[1], int(sys.argv[2])
+if kind == "gpv":
+    n, q, s = 14, 2**9, 70.0
+    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+    psf.trap_gen(21)
+    d = psf.m
+else:
+    n, q = 16, 3329
+    s = ((2 * 2 * 1.005 * math.sqrt(n) + 1) * 2) * 4
+    psf = T.PSFGPVRing(T.GadgetParametersRing.init_default(n, q), s, 1.005)
+    psf.trap_gen(22)
+    d = psf.d
+u = O.uniform_targets(9, B, n, q)
+try:
+    outs = [psf.samp_p(u, seed=50 + i, first_index=777 * i) for i in range(2)]
+except T.PsfError as ex:
+    print(json.dumps({"status": ex.status}))
+    sys.exit(0)
+h = hashlib.sha256()
+for e in outs:
+    h.update(np.ascontiguousarray(e).tobytes())
+print(json.dumps({"hash": h.hexdigest(), "d": int(d), "status": 0}))
+''' % ROOT
+
+FORMS = [{}, {"PSF_NP_WALK": "0"}, {"PSF_NP_WALK": "3"}, {"PSF_NP_G": "2"}, {"PSF_NP_WALK": "0", "PSF_NP_G": "2"}, {"PSF_NP_WALK": "3", "PSF_NP_G": "2"},
+         {"PSF_NP_WALK": "0", "PSF_NP_IMMEDIATE": "0"}]
+
+
+def run(kind, B, **extra):
+    env = dict(os.environ, **extra)
+    for k in ("PSF_NP_WALK", "PSF_NP_G", "PSF_NP_IMMEDIATE", "PSF_NP_WALK_SPINS"):
+        if k not in extra:
+            env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", SCRIPT, kind, str(B)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("kind,B", [("gpv", 150), ("gpv", 64), ("gpv", 5), ("ring", 200), ("ring", 129)])
+def test_every_launch_form_of_the_walk_returns_the_same_bytes(kind, B):
+    base = run(kind, B)
+    assert base["status"] == 0 and base["d"] >= 192          # at least three blocks of 64 rows, the top one short
+    for form in FORMS[1:]:
+        got = run(kind, B, **form)
+        assert got.get("hash") == base["hash"], (form, kind, B)
+
+
+def test_the_default_form_equals_the_oracle(oracle):
+    """(the parity tests of the two types run the default form at many shapes; this pins the shape of the form comparison above to the oracle as well)"""
+    import numpy as np
+    import tools_amd as T
+    n, q, s = 14, 2**9, 70.0
+    psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+    A, (bt, gt) = psf.trap_gen(21)
+    orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+    orc.load_key(A, bt, gt)
+    u = oracle.uniform_targets(9, 150, n, q)
+    assert (psf.samp_p(u, seed=50) == orc.samp_p(50, u)).all()
+    psf.close()
+
+
+@pytest.mark.parametrize("walk", ["1", "3"])
+def test_a_wait_that_gives_up_reports_a_sampler_failure(walk):
+    """PSF_NP_WALK_SPINS=1: the first wait inside the one-launch walk that is not satisfied at once gives up, raises the abort word, every workgroup leaves at its
+    next wait and the call returns PSF_ERR_SAMPLER (status 9) -- no hang, no relaunch, no silent rows."""
+    got = run("gpv", 150, PSF_NP_WALK=walk, PSF_NP_WALK_SPINS="1")
+    assert got["status"] == 9
+    ok = run("gpv", 150, PSF_NP_WALK=walk)                   # and the same process configuration without the limit is fine
+    assert ok["status"] == 0

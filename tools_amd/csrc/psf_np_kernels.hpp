@@ -21,6 +21,7 @@
 // nearest plane"); every kernel below follows it bit for bit: v_mfma_f64_16x16x4_f64 is an ascending-k fma chain
 // (profiles/r01_probe_mfma_f64.log), so a block's contribution t = fma(-z_j, g[j][.], t), j ascending, is one MFMA K loop with T as the accumulator.
 #pragma once
+#include <type_traits>
 #include "psf_kernels.hpp"
 
 namespace psf {
@@ -324,9 +325,16 @@ __device__ inline size_t j0_of(size_t J) { return J * NP_NB; }
 // the drawn z written with agent-scope accesses, for a launch in which they come from / go to workgroups on other XCDs
 // WALK (k_np_walk: one launch for the whole walk): the z of the block above are the wave's own draws of the previous call of this function (zr_io, in
 // registers) instead of a read-back from memory, and they are handed on the same way.
-template <int G, bool COH = false, bool WALK = false>
+// BG (k_np_walk2): what a helper wave does instead of sleeping while its record ring is full (bg.step(): one unit of background work, false = nothing to do) and after
+// its last group (bg.drain()); t_wait: a sampler wave spins on this word (then reads T) -- the block's rows are handed over by another workgroup.
+struct NpNoBg {
+  __device__ __forceinline__ bool step() { return false; }
+  __device__ __forceinline__ void drain() {}
+  __device__ __forceinline__ bool wait_word(const unsigned*) { return true; }
+};
+template <int G, bool COH = false, bool WALK = false, class BG = NpNoBg>
 __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned wg, const NpSampleArgs& a, size_t dim, size_t J, uint64_t seed, uint32_t tag,
-                                               uint64_t first_index, size_t B, long long* zr_io = nullptr) {
+                                               uint64_t first_index, size_t B, long long* zr_io = nullptr, BG* bg = nullptr, const unsigned* t_wait = nullptr) {
   constexpr int LPD = 64 / G, BPS = LPD / 4;
   static_assert(G == 1 || G == 2, "one or two preimages per wave pair");
   // carved from the launch's dynamic LDS (shared with the update tiles of the same launch): 16 + 2 + 8 + 32 + 4 KiB + counters < 64 KiB
@@ -405,7 +413,10 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
       for (int grp = BPS - 1; grp >= 0; --grp) {                    // four steps slot * LPD + 4 grp + 3 .. + 0
         const int lbase = slot * LPD + grp * 4;
         if (lbase >= nrows) continue;                               // short top block (uniform; the sampler skips the same groups)
-        while (__hip_atomic_load(cnt_cons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k - 1) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(cnt_cons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k - 1) {
+          if (!std::is_same<BG, NpNoBg>::value) { if (!bg->step()) __builtin_amdgcn_s_sleep(1); }
+          else __builtin_amdgcn_s_sleep(1);
+        }
         {  // attempt words of the four steps, first LPD attempts each: lane (s, g) serves step lbase + 3 - s.
            // narrow rows: Philox block g holds attempts 4g .. 4g+3; wide rows: blocks g and g + BPS hold attempts 2g, 2g+1 and 2(g+BPS), 2(g+BPS)+1
           const int s = lam / BPS, g = lam % BPS;
@@ -489,10 +500,12 @@ __device__ __forceinline__ void np_sample_body(unsigned char* smem_raw, unsigned
         if (lane == 0) __hip_atomic_store(cnt_prod, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
+    if (!std::is_same<BG, NpNoBg>::value) bg->drain();             // the sampler is still on its last groups: whatever background work is ready
     return;
   }
 
   // ---- sampler wave ------------------------------------------------------------------------------------------------------
+  if (!std::is_same<BG, NpNoBg>::value && t_wait) { if (!bg->wait_word(t_wait)) { /* abort: fall through, the caller leaves after the barriers */ } }
   double t[G];
   long long zr[G];
 #pragma unroll
@@ -964,18 +977,18 @@ struct NpWalkSync {
   unsigned* tready;                           // [group][block]: the block's running projections are complete up to the block after next
   unsigned* abort;                            // [0] raised by a wait that ran out
   unsigned nblk_stride;
+  unsigned spin_limit;                        // polls (x s_sleep(2)) before a wait gives up: 2^22 ~ seconds, a walk lasts milliseconds (env PSF_NP_WALK_SPINS: tests of the give-up path)
 };
-constexpr unsigned NP_WALK_SPINS = 1u << 22;  // x s_sleep(2) ~ seconds: a walk lasts milliseconds
 
 // one lane polls, the workgroup learns the outcome through LDS; false = abort
-__device__ __forceinline__ bool np_walk_wait(const unsigned* word, unsigned target, unsigned* abort_word, int* s_flag) {
+__device__ __forceinline__ bool np_walk_wait(const unsigned* word, unsigned target, unsigned* abort_word, unsigned spin_limit, int* s_flag) {
   if (threadIdx.x == 0) {
     int ok = 1;
     unsigned spins = 0;
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
       if ((++spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
-      if (spins >= NP_WALK_SPINS) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      if (spins >= spin_limit) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
     }
     *s_flag = ok;
   }
@@ -995,7 +1008,7 @@ __device__ __forceinline__ void np_walk_sampler(unsigned char* smem, unsigned wg
   for (int s = 0; s < G; ++s) zr[s] = 0;
   for (size_t J = nblk; J-- > 0;) {
     if (J + 2 < nblk) {                       // the two top blocks come from the initial projection alone
-      if (!np_walk_wait(sy.tready + (size_t)grp * sy.nblk_stride + J, 1u, sy.abort, s_flag)) return;
+      if (!np_walk_wait(sy.tready + (size_t)grp * sy.nblk_stride + J, 1u, sy.abort, sy.spin_limit, s_flag)) return;
     }
     np_sample_body<G, true, true>(smem, wg, a, dim, J, seed, tag, first_index, B, zr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave drains its write-through stores of z ...
@@ -1039,7 +1052,7 @@ __device__ __forceinline__ void np_walk_updater(unsigned char* smem, unsigned gr
   const size_t bj = col0 / TR_BN;
   const int t0 = (int)((col0 % TR_BN) / 16);                             // first of the four 16-preimage tiles of the group inside the 128-wide chunk
   for (size_t J = nblk; J-- > 2;) {
-    if (!np_walk_wait(sy.zcount + (size_t)grp * sy.nblk_stride + J, need, sy.abort, s_flag)) return;
+    if (!np_walk_wait(sy.zcount + (size_t)grp * sy.nblk_stride + J, need, sy.abort, sy.spin_limit, s_flag)) return;
     {  // the block's z for the group's 64 preimages: rows k = 64 J + 16 kc + 4 ks + (lane >> 4), preimage 16 nf + (lane & 15); chunk stream (bj, kb) of Zf
       const double* zsrc = a.Zf + (bj * a.nkb + J * (NP_NB / 16)) * TR_CHUNK;
 #pragma unroll
@@ -1102,6 +1115,139 @@ __global__ __launch_bounds__(512, 4) void k_np_walk(NpSampleArgs a, size_t dim, 
     np_walk_updater(np_smem, grp, ul, ug, need, a, nblk, Gp, Tm, sy);
   }
   if (threadIdx.x == 0 && __hip_atomic_load(sy.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicOr(a.flags, 1);   // (the workgroup that gave up gets here)
+}
+
+// ---- the same walk where the sampler workgroups fill the chip (two per CU: C4, 4096 preimages) and T does not fit registers: k_np_walk2 -----------------------------
+// No workgroup is left for updating, so the HELPER waves do it: a helper produces its sampler's Philox records ahead of time and used to sleep while the record ring
+// was full -- now it applies published z to the running projections instead.  Each helper OWNS 16-row x 64-preimage tiles of its group's T (tile f of the group
+// belongs to helper f mod HW, HW = 4 x the group's workgroups; the four tiles of a block to the four helpers of one workgroup), reads and writes them in memory with
+// write-through accesses (nobody else touches them until the hand-over), and walks the published blocks in order: for block J every owned tile below block J - 1
+// takes t = fma(-z_j, g[j][.], t), j ascending (one 16-step MFMA loop, operands straight from the fragment-ordered streams), the tiles of block J - 2 first -- they
+// are complete then and their owner raises the block's flag.  Before its sampler starts block J a helper finishes everything up to the z of block J + 2 (a sampler of
+// the group may be waiting for exactly those rows), so the chain of waits always ends at a workgroup that is still sampling.  Same chains, same bits.
+template <int G>
+struct NpWalk2Jobs {
+  const double* Gp; double* T; const double* Zf;
+  const unsigned* zcount_g; unsigned* tready_g; unsigned* abort_w; int* s_arr;
+  size_t ldt, nkb, col0, bj;
+  unsigned need, spin_limit;
+  int nblk, t0, hw, HW, lane;
+  uint32_t t_lane, f_lane;
+  int Jn, fi, zmin;
+  bool aborted;
+
+  __device__ __forceinline__ bool spin(const unsigned* word, unsigned target) {          // bounded; false = gave up (abort raised or seen)
+    unsigned spins = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (aborted) return false;
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255u) == 0 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { aborted = true; return false; }
+      if (spins >= spin_limit) { __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; return false; }
+    }
+    return true;
+  }
+  __device__ __forceinline__ bool wait_word(const unsigned* w) { return spin(w, 1u); }
+  __device__ __forceinline__ int imax(int J) const {                   // owned tiles hw + HW i that lie in blocks <= J - 2
+    const int fmax = 4 * (J - 2) + 3;
+    return fmax >= hw ? (fmax - hw) / HW : -1;
+  }
+  __device__ __forceinline__ double* t_at(size_t row, size_t col) const {
+    return reinterpret_cast<double*>(reinterpret_cast<char*>(T + row * ldt + col) + t_lane);
+  }
+  // tile f (rows 16 f ... + 15, the group's 64 preimages) takes the z of block J.  Loads are PLAIN loads behind the one agent-scope acquire that follows the poll
+  // of the block's counter (advance): hipcc keeps a dozen plain loads in flight, while it puts a full s_waitcnt vmcnt(0) behind every agent-scope atomic load
+  // (measured: 50 us per tile).  The z of the block were stored write-through by their samplers before the counter moved; the tile itself is private to this wave
+  // (its own earlier stores) until the hand-over, which stores it write-through.
+  __device__ __forceinline__ void job(int J, int f) {
+    const size_t i0 = (size_t)f * 16;
+    const bool urgent = f / 4 == J - 2;
+    d4 acc[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[nf][r] = *t_at(i0 + 4 * r, col0 + nf * 16);
+    const double* ga = Gp + (np_panel_base((size_t)J) + (i0 / 128) * 4) * TR_CHUNK + ((i0 % 128) / 16) * 64;
+    const double* zs = Zf + (bj * nkb + (size_t)J * (NP_NB / 16)) * TR_CHUNK + (size_t)t0 * 64;
+#pragma unroll
+    for (int kstep = 0; kstep < 16; ++kstep) {
+      const size_t ko = (size_t)(kstep >> 2) * TR_CHUNK + (size_t)(kstep & 3) * 512;
+      const double av = -*reinterpret_cast<const double*>(reinterpret_cast<const char*>(ga + ko) + f_lane);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const double bv = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(zs + ko + nf * 64) + f_lane);
+        acc[nf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[nf], 0, 0, 0);
+      }
+    }
+    if (!urgent) {
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *t_at(i0 + 4 * r, col0 + nf * 16) = acc[nf][r];
+    } else {                                                           // the block after next is complete: hand it to the samplers
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) __hip_atomic_store(t_at(i0 + 4 * r, col0 + nf * 16), acc[nf][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const int prev = __hip_atomic_fetch_add(s_arr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((prev & 3) == 3) __hip_atomic_store(tready_g + (J - 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  // one unit of work if there is one; `blocking`: wait for the block's z
+  __device__ __forceinline__ bool advance(bool blocking) {
+    if (Jn < 2) return false;
+    if (fi == -2) {                                                    // block Jn not started: are its z published?
+      if (zmin > Jn) {
+        if (blocking) { if (!spin(zcount_g + Jn, need)) { /* aborted: go on without waiting */ } }
+        else if (__hip_atomic_load(zcount_g + Jn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) return false;
+        zmin = Jn;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");             // ONE acquire per block: this CU's L1 holds nothing older than the publication
+      }
+      fi = imax(Jn);
+    }
+    if (fi >= 0) { job(Jn, hw + HW * fi); --fi; }
+    if (fi < 0) { --Jn; fi = -2; }
+    return true;
+  }
+  __device__ __forceinline__ bool step() { return advance(false); }
+  __device__ __forceinline__ void drain() { while (advance(false)) {} }
+  __device__ __forceinline__ void finish_through(int Jt) { while (Jn >= Jt && Jn >= 2) advance(true); }
+};
+
+// grid: the nS sampler workgroups, two per CU, all resident at once
+template <int G>
+__global__ __launch_bounds__(512, 4) void k_np_walk2(NpSampleArgs a, size_t dim, size_t nblk, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, unsigned nS,
+                                                     const double* __restrict__ Gp, double* __restrict__ Tm, NpWalkSync sy) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char np_smem[];
+  const unsigned wg = blockIdx.x;
+  const unsigned per = (unsigned)(NP_GW / (4 * G)), grp = wg / per, wl = wg % per, first = grp * per, need = nS - first < per ? nS - first : per;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool helper = wave >= 4;
+  int* s_arr = reinterpret_cast<int*>(np_smem + 65536 - 32);
+  if (tid == 0) *s_arr = 0;
+  __syncthreads();
+  NpWalk2Jobs<G> jobs;
+  jobs.Gp = Gp; jobs.T = Tm; jobs.Zf = a.Zf;
+  jobs.zcount_g = sy.zcount + (size_t)grp * sy.nblk_stride; jobs.tready_g = sy.tready + (size_t)grp * sy.nblk_stride; jobs.abort_w = sy.abort; jobs.s_arr = s_arr;
+  jobs.ldt = a.ldt; jobs.nkb = a.nkb; jobs.col0 = (size_t)grp * NP_GW; jobs.bj = jobs.col0 / TR_BN; jobs.t0 = (int)((jobs.col0 % TR_BN) / 16);
+  jobs.need = need; jobs.spin_limit = sy.spin_limit; jobs.nblk = (int)nblk; jobs.hw = (int)(4 * wl) + (wave & 3); jobs.HW = (int)(4 * need); jobs.lane = lane;
+  jobs.t_lane = (uint32_t)(((size_t)(lane >> 4) * a.ldt + (size_t)(lane & 15)) * sizeof(double)); jobs.f_lane = (uint32_t)(lane * sizeof(double));
+  jobs.Jn = (int)nblk - 1; jobs.fi = -2; jobs.zmin = (int)nblk; jobs.aborted = false;
+  long long zr[G];
+#pragma unroll
+  for (int s = 0; s < G; ++s) zr[s] = 0;
+  for (size_t J = nblk; J-- > 0;) {
+    if (helper) jobs.finish_through((int)J + 2);
+    const unsigned* tw = J + 2 < nblk ? jobs.tready_g + J : nullptr;
+    np_sample_body<G, true, true, NpWalk2Jobs<G>>(np_smem, wg, a, dim, J, seed, tag, first_index, B, zr, &jobs, tw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && J >= 2) __hip_atomic_fetch_add(sy.zcount + (size_t)grp * sy.nblk_stride + J, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (lane == 0 && __hip_atomic_load(sy.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicOr(a.flags, 1);
 }
 
 // E[b][j] (+)= scale * sum_i Z8[i][b] B8[j][i] on the int8 matrix cores (v_mfma_i32_16x16x64_i8): Z as the A operand (rows = preimages),

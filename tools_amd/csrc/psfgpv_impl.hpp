@@ -38,8 +38,10 @@ struct psfgpv_handle {
   int64_t* dE1 = nullptr;             // e1, bcap x dim
   unsigned* dWalk = nullptr;          // k_np_walk: [group][block] counters of published z | [group][block] flags of completed rows | abort word
   size_t walk_words = 0;
-  int np_walk = -1;                   // PSF_NP_WALK: 0 = one launch per block (k_np_step), 1 = the whole walk in one launch where the batch fits (k_np_walk); -1 = 1
+  int np_walk = -1;                   // PSF_NP_WALK: 0 = one launch per block (k_np_step); 1 / unset = the whole walk in one launch (k_np_walk: updater workgroups, T in
+                                      // registers) where it fits, launches otherwise; 3 = k_np_walk2 (helper waves update T in memory) for every batch that is resident
   int cus = 0;                        // compute units of the device
+  unsigned walk_spins = 1u << 22;      // NpWalkSync::spin_limit
   int np_g = 0;                       // PSF_NP_G: preimages per wave of the sampler (0 = by batch size)
   int np_immediate = -1;              // PSF_NP_IMMEDIATE: 1 = every block updates all the rows below it in the launch that follows, 0 = panel-deferred far update, -1 = by batch size
   bool has_key = false;
@@ -201,14 +203,14 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
   NpSampleArgs a{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, flags};
   // The whole walk in one launch (k_np_walk) where every workgroup can be resident at once: one sampler workgroup per CU at most (B <= 4 G CUs) beside one
   // updater workgroup per CU, and at most 2 * NP_WALK_SLOTS blocks of T per updater.  Otherwise one launch per block (k_np_step).
-  if (g->np_walk != 0 && g->cus > 0 && g->nblk >= 3) {
+  if (g->np_walk != 0 && g->np_walk != 3 && g->cus > 0 && g->nblk >= 3) {      // (PSF_NP_WALK=3: k_np_walk2 for every batch, tests)
     const int Gw = (g->np_g == 1 || g->np_g == 2) ? g->np_g : (B <= 4 * (size_t)g->cus ? 1 : 2);
     const unsigned nSw = (unsigned)((B + 4 * (size_t)Gw - 1) / (4 * (size_t)Gw));
     const unsigned per = (unsigned)(NP_GW / (4 * Gw)), ngroups = (nSw + per - 1) / per;
     unsigned ug = ngroups ? (unsigned)g->cus / ngroups : 0;
     if (ug > g->nblk - 2) ug = (unsigned)(g->nblk - 2);
     if (nSw <= (unsigned)g->cus && ug >= 1 && (size_t)2 * NP_WALK_SLOTS * ug >= g->nblk - 2) {
-      NpWalkSync sy{g->dWalk, g->dWalk + (size_t)ngroups * g->nblk, g->dWalk + (size_t)2 * ngroups * g->nblk, (unsigned)g->nblk};
+      NpWalkSync sy{g->dWalk, g->dWalk + (size_t)ngroups * g->nblk, g->dWalk + (size_t)2 * ngroups * g->nblk, (unsigned)g->nblk, g->walk_spins};
       hipMemsetAsync(g->dWalk, 0, g->walk_words * sizeof(unsigned), st);
       NpSampleArgs aw{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, flags};
       const unsigned ntot = nSw + ngroups * ug;
@@ -218,6 +220,17 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
     }
   }
   const unsigned nS = (unsigned)((B + 4 * (size_t)G - 1) / (4 * (size_t)G));
+  // The sampler workgroups alone fill the chip (two per CU): the walk in one launch with the helper waves updating T in memory (k_np_walk2)
+  // MEASURED SLOWER than one launch per block at C4 (6.9 against 4.4 ms, profiles/r05_notes.md: with two wave pairs per SIMD the vector pipe is the bound, and the
+  // helpers' tiles re-read the block's z per 16 rows): a labelled opt-in (PSF_NP_WALK=3), kept bit-identical by tests/test_gpu_switch_matrix.py
+  if (g->np_walk == 3 && g->cus > 0 && g->nblk >= 3 && nS <= 2u * (unsigned)g->cus) {
+    const unsigned per = (unsigned)(NP_GW / (4 * G)), ngroups = (nS + per - 1) / per;
+    NpWalkSync sy{g->dWalk, g->dWalk + (size_t)ngroups * g->nblk, g->dWalk + (size_t)2 * ngroups * g->nblk, (unsigned)g->nblk, g->walk_spins};
+    hipMemsetAsync(g->dWalk, 0, g->walk_words * sizeof(unsigned), st);
+    if (G == 1) hipLaunchKernelGGL((k_np_walk2<1>), dim3(nS), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, g->dGp, g->dTm, sy);
+    else hipLaunchKernelGGL((k_np_walk2<2>), dim3(nS), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, g->dGp, g->dTm, sy);
+    return launch_np_recombination(g, st, B, d_e, pass);
+  }
   const size_t W = NP_PANEL;
   // small batches: a rank-64 update of every row below costs less than the sampler's 64 steps, and the T matrix stays in the Infinity Cache (measured
   // at C2, 1024 preimages: 4.57 vs 4.80 ms); large batches: the panel-deferred update moves T an eighth as often (C4, 4096 preimages: 5.06 vs 5.20 ms)
@@ -358,8 +371,11 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   { int cu = 0; HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, g->base->prm.device)); g->cus = cu; }
   if (const char* e = std::getenv("PSF_NP_WALK")) g->np_walk = std::atoi(e);
+  if (const char* e = std::getenv("PSF_NP_WALK_SPINS")) { const long v = std::atol(e); if (v >= 1) g->walk_spins = (unsigned)v; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
