@@ -1660,7 +1660,10 @@ __global__ __launch_bounds__(256, 2) void k_recombine_mfma(const int8_t* __restr
 // global loads into registers + ds_write_b128: 1.08 / 1.08 / 1.13 ms); double-buffered fragment reads change nothing (1.08).
 constexpr int RCB_STAGE = 65536;
 constexpr int RCB_LDS = 2 * RCB_STAGE;
-__global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int n2,
+// packed != 0: R is the tile-packed copy (k_pack_R8: [row tile of 64][k step of 64][row][64 bytes, k groups rotated as in the LDS image]): the R half of a stage is
+// thirty-two CONTIGUOUS 1 KiB pieces instead of 512 row segments of 64 bytes (tools/probe_ldsdma_l2.hip: LDS-DMA fills from L2 run at 65 GB/s per CU contiguous,
+// 44 GB/s with the 64-byte segments of the row-major fetch; 76 GB/s is what this tile needs to keep its MFMAs busy)
+__global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __restrict__ R, int packed, size_t ldr, size_t mbar, int n2,
                                                                const int8_t* __restrict__ Zlo, size_t ld, const int* __restrict__ flags,
                                                                const int32_t* __restrict__ P, size_t B, int64_t* __restrict__ E, size_t m,
                                                                unsigned nbx, unsigned nby) {
@@ -1689,14 +1692,17 @@ __global__ __launch_bounds__(512, 1) void k_recombine_mfma_big(const int8_t* __r
   for (int j = 0; j < 4; ++j) {
     const int p = (wave * 4 + j) * 64 + lane;
     const int kk = p >> 10, row = (p >> 2) & 255, col = ((p & 3) - (row >> 2)) & 3;
-    srcR[j] = R + (i0 + (size_t)row) * ldr + (size_t)(kk * 64 + col * 16);
+    const int q = wave * 4 + j;                        // piece q of the stage's R half = LDS bytes [q KiB, q + 1 KiB): (k half q / 16, row tile (q / 4) % 4, quarter q % 4)
+    srcR[j] = packed ? R + ((i0 / 64 + (size_t)((q >> 2) & 3)) * (ldr / 64) + (size_t)(q >> 4)) * 4096 + (size_t)(q & 3) * 1024 + (size_t)lane * 16
+                     : R + (i0 + (size_t)row) * ldr + (size_t)(kk * 64 + col * 16);
     srcZ[j] = Zlo + ((size_t)(p >> 8) * ld + b0 + (size_t)(p & 255)) * 16;
   }
+  const size_t rstep = packed ? 8192 : 128;            // a K step of 128: two 4 KiB tiles of the packed copy / 128 bytes of a row
   auto stage_load = [&](int ks2, int buf) {
     unsigned char* base = rcb_smem + buf * RCB_STAGE;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds(srcR[j] + (size_t)ks2 * 128, (lds_void_ptr)(base + (wave * 4 + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(srcR[j] + (size_t)ks2 * rstep, (lds_void_ptr)(base + (wave * 4 + j) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(srcZ[j] + (size_t)ks2 * 8 * ld * 16, (lds_void_ptr)(base + 32768 + (wave * 4 + j) * 1024), 16, 0, 0);
     }
   };

@@ -65,7 +65,8 @@ struct psfp_handle {
   // structured sqrt(Sigma_2) (PSFP_FLAG_STRUCTURED_SQRT): x_top = L_1 d_1 - g R d_2, x_bot = h d_2
   bool structured = false;
   size_t mL = 0, nbiL = 0;     // order of the stored triangular factor (m, or m_bar) and its row blocks
-  int8_t* dR8 = nullptr;       // R tile-packed for k_rd2_mfma, round_up(m_bar, 64) x ldr
+  int8_t* dR8 = nullptr;       // R tile-packed (k_pack_R8: 4 KiB tiles of 64 rows x 64 columns, contiguous) for k_recombine_mfma_big and k_rd2_mfma, mb_pad x ldr
+  bool r8_valid = false;       // dR8 follows dR (ensure_R8)
   double g_const = 0, h_const = 0;
   // gadget tables
   int32_t* dRng = nullptr;
@@ -147,6 +148,18 @@ struct psfp_handle {
   const std::chrono::steady_clock::time_point* multi_t0 = nullptr;
   double multi_launched_ms = -1.0, multi_done_ms = -1.0;
 };
+
+// PSF_RECOMBINE_PACKED=0: k_recombine_mfma_big fetches its R tiles from the row-major matrix as in rounds 2-4 (comparison arm; same bits)
+static bool rcb_packed() {
+  static const bool on = [] { const char* e = std::getenv("PSF_RECOMBINE_PACKED"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+// the tile-packed copy of R, rebuilt on `st` when R has changed since
+static void ensure_R8(psfp_handle* h, hipStream_t st) {
+  if (h->r8_valid || !h->dR8) return;
+  hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(h->mb_pad * h->ldr, 256, 256 * 64)), dim3(256), 0, st, h->dR, h->ldr, h->mb, h->w, h->mb_pad, h->ldr, h->dR8);
+  h->r8_valid = true;
+}
 
 static size_t gadget_lds_bytes(size_t k) { return k * k * 8 + k * 8 + k * sizeof(SampleZParams) + k * k * 4 + k * 256 * 4; }
 
@@ -392,7 +405,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipMalloc(&h->dR, h->mb_pad * h->ldr));
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dLt, (tr_total_chunks(h->nbiL) * TR_CHUNK + TS_SLACK_DOUBLES) * sizeof(double)));
-  if (h->structured) HIP_TRY(hipMalloc(&h->dR8, round_up(h->mb, 64) * h->ldr));
+  if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dR8, h->mb_pad * h->ldr));      // tile-packed copy of R: k_recombine_mfma_big, k_rd2_mfma
   for (auto& t : h->sets) {                             // [0] sampler failure, [1] some |z| > 127
     HIP_TRY(hipMalloc(&t.dFail, 2 * sizeof(int)));
     HIP_TRY(hipMemset(t.dFail, 0, 2 * sizeof(int)));
@@ -618,7 +631,7 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     b2p1 = kappa * (alpha / beta);                                   // the R R^t block of the Schur-complemented top-left corner
     h->g_const = (std::sqrt(nf_r2) * kappa) / std::sqrt(beta);
     h->h_const = std::sqrt(nf_r2 * beta);
-    hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(round_up(h->mb, 64) * h->ldr, 256, 256 * 64)), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, round_up(h->mb, 64), h->ldr, h->dR8);
+    ensure_R8(h, nullptr);
   }
   {
     // "stream": left-looking on the key's chunk stream, no dense matrix (C5: 10.1 s against 21.1 s, and 121 GB less memory; C3: 0.28 s either way); "gemm": left-looking on a
@@ -771,6 +784,7 @@ static psf_status gen_A_R(psfp_handle* h, uint64_t seed) {
   if (gadget_too_short(h->prm.gp.base, h->k, h->q)) return PSF_ERR_MODULUS;
   // mp_perturbation.rs:222 / gpv.rs:84 ; gadget_classical.rs:62-64
   hipLaunchKernelGGL(k_sample_abar, dim3(grid_for(h->n * h->mb)), dim3(256), 0, 0, seed, h->n, h->mb, h->m, h->q, h->dA);
+  h->r8_valid = false;
   hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);
   // gadget_classical.rs:66
   launch_zq_trapdoor(h);
@@ -805,9 +819,11 @@ static psf_status gen_trapdoor_core(int device, const psf_gadget_params* gp, con
       if (R_in[i] > 127 || R_in[i] < -127) return fail(PSF_ERR_UNSUPPORTED);
       r8[i] = (int8_t)R_in[i];
     }
+    h->r8_valid = false;
     if (hipMemset(h->dR, 0, h->mb_pad * h->ldr) != hipSuccess) return fail(PSF_ERR_HIP);
     if (hipMemcpy2D(h->dR, h->ldr, r8.data(), h->w, h->w, h->mb, hipMemcpyHostToDevice) != hipSuccess) return fail(PSF_ERR_HIP);
   } else {
+    h->r8_valid = false;
     hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);    // gadget_classical.rs:62-64
   }
   launch_zq_trapdoor(h, dtag);                                                                                            // :66
@@ -890,6 +906,7 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
   HIP_TRY(hipDeviceSynchronize());
   h->has_pub = true;
   if (!R) return PSF_OK;                                    // public key only: the verifier's handle (f_a, check_domain, samp_d)
+  h->r8_valid = false;
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
   h->has_R = true;
@@ -910,7 +927,7 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
     if (!(beta > 0.0)) { hipFree(dp); return PSF_ERR_NOT_PD; }
     h->g_const = (std::sqrt(nf_r2) * kappa) / std::sqrt(beta);
     h->h_const = std::sqrt(nf_r2 * beta);
-    hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(round_up(h->mb, 64) * h->ldr, 256, 256 * 64)), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, round_up(h->mb, 64), h->ldr, h->dR8);
+    ensure_R8(h, nullptr);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
@@ -935,6 +952,7 @@ psf_status psfp_load_trapdoor(psfp_handle* h, const uint64_t* A, const int8_t* R
     HIP_TRY(hipGetLastError());
     h->has_pub = true;
   }
+  h->r8_valid = false;
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
@@ -1172,7 +1190,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       if (big) {
         const unsigned nbx = (unsigned)(Bh / 256), nby = (unsigned)(h->mb_pad / 256);
         const unsigned nsup = ((nbx + 3) / 4) * ((nby + 7) / 8);                 // super-tiles of 4 x 8 tiles, dealt to the XCDs in rounds of eight
-        hipLaunchKernelGGL(k_recombine_mfma_big, dim3(((nsup + 7) / 8) * 8 * 32), dim3(512), RCB_LDS, sx, h->dR, h->ldr, h->mb,
+        ensure_R8(h, sx);
+        hipLaunchKernelGGL(k_recombine_mfma_big, dim3(((nsup + 7) / 8) * 8 * 32), dim3(512), RCB_LDS, sx, rcb_packed() ? h->dR8 : h->dR, rcb_packed() ? 1 : 0, h->ldr, h->mb,
                            (int)(h->ldr / 128), h->dZlo + 16 * b0, ld, h->dFail, h->dP + b0, Bh, d_e + b0 * m, m, nbx, nby);
       }
       // few preimages: cut K over blockIdx.z (an even number of K steps each, at least 8) until ~2048 workgroups; the partial sums are added into a zeroed E
