@@ -176,3 +176,32 @@ def test_streaming_syndrome_with_wide_moduli(T, oracle, q):
         assert (e == orc.samp_p(12, u, first_index=4)).all()
         assert (psf.f_a(e) == u).all()
     psf.close()
+
+
+@pytest.mark.parametrize("ternary", [True, False])
+def test_compact_key_copies_of_small_calls_give_the_same_rows(T, oracle, ternary):
+    """A call with a handful of preimages reads a two-bit copy of R (k_recombine_small2; only a {-1, 0, 1} trapdoor has one) and a 32-bit copy of A
+    (k_syndrome_small32, q <= 2^32).  The copies are built behind the first small call after a key change -- that call still reads the full-size matrices -- and
+    taken over by the calls after it; a trapdoor with other entries (psfp_load_key) keeps the int8 kernel.  Every call must return the oracle's rows."""
+    import torch
+    n, q, r, s = 40, 2**16, 4.0, 120.0
+    gp = T.GadgetParameters.init_default(n, q)
+    psf = T.PSFPerturbation(gp, r, s if ternary else 3 * s)
+    A, (R, Lp, _) = psf.trap_gen(33)
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s if ternary else 3 * s)
+    if not ternary:                                             # a caller's own trapdoor with entries beyond {-1, 0, 1}: A = [A_bar | G - A_bar R] for this R
+        rng = np.random.default_rng(3)
+        R2 = rng.integers(-2, 3, size=R.shape).astype(np.int8)
+        A2 = T.gadget.gen_trapdoor_with_r(gp, A[:, :psf.m_bar], R2)
+        psf.load_trapdoor(R2, A2)
+        psf.compute_sqrt_sigma_2(3 * s)
+        A, (R, Lp, _) = psf.export_key()
+    orc.load_key(A, R, Lp)
+    for B in (1, 3, 4, 2):
+        u = oracle.uniform_targets(60 + B, B, n, q)
+        want = orc.samp_p(700 + B, u, first_index=5)
+        for rep in range(3):                                    # first call after the key change: full-size matrices; later calls: the compact copies
+            got = psf.samp_p(u, seed=700 + B, first_index=5)
+            torch.cuda.synchronize()
+            assert (got == want).all(), (B, rep, ternary)
+    psf.close()

@@ -516,12 +516,187 @@ __global__ __launch_bounds__(512) void k_recombine_small(const int8_t* __restric
   }
 }
 
+// The same product on a TWO-BIT copy of R (59 MB instead of 237 MB at C3): a trapdoor drawn from PlusMinusOneZero (trapdoor_distribution.rs:82-97) has entries
+// in {-1, 0, 1}.  k_pack_R2 stores one 32-bit word per 16-byte group of the int8 matrix: bit e = "entry e is +1", bit 16 + e = "entry e is -1", and raises *bad for
+// any other entry (a caller's own R through psfp_load_key / psf_gen_trapdoor_with_r: the int8 kernel above serves it).  A lane's 16-byte piece is four words = 64
+// entries; a nibble of a mask (four entries) becomes four {0, 1} bytes by ONE 24-bit multiply (n * 0x204081 puts bit t at bit 8 t, no two terms overlap) and meets
+// the digits of z in a v_dot4: e = p + (sum over +1) - (sum over -1).  Integer sums: any order is exact, the same e as the int8 kernel.  The upper digit plane of z
+// is skipped when it is zero (every |z| <= 127: the common call).
+__global__ void k_pack_R2(const int8_t* __restrict__ R, size_t ldr, size_t mbar, uint32_t* __restrict__ R2, int* __restrict__ bad) {
+  const size_t ng = ldr / 16, total = mbar * ng;
+  int b = 0;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / ng, gg = g % ng;
+    const int8_t* src = R + i * ldr + gg * 16;
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int v = src[e];
+      if (v > 1 || v < -1) b = 1;
+      if (v == 1) w |= 1u << e;
+      if (v == -1) w |= 1u << (16 + e);
+    }
+    R2[g] = w;
+  }
+  if (b) atomicOr(bad, 1);
+}
+
+template <int NB>
+__global__ __launch_bounds__(512) void k_recombine_small2(const uint32_t* __restrict__ R2, size_t ldr, size_t mbar, size_t w, const int8_t* __restrict__ Zlo,
+                                                          const int8_t* __restrict__ Zhi, size_t ld, const int32_t* __restrict__ P, size_t B, int64_t* __restrict__ E, size_t m) {
+  extern __shared__ int4 s_zd[];                                // [b][plane][group]
+  __shared__ int s_hi;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ng = (int)(ldr / 16);
+  if (tid == 0) s_hi = 0;
+  __syncthreads();
+  int any_hi = 0;
+  for (int e = tid; e < (int)B * 2 * ng; e += 512) {
+    const int g = e % ng, pl = (e / ng) & 1, b = e / (2 * ng);
+    const int4 v = *reinterpret_cast<const int4*>((pl ? Zhi : Zlo) + ((size_t)g * ld + (size_t)b) * 16);
+    s_zd[e] = v;
+    if (pl) any_hi |= v.x | v.y | v.z | v.w;
+  }
+  if (any_hi) s_hi = 1;
+  __syncthreads();
+  const bool use_hi = s_hi != 0;                                 // (workgroup-uniform)
+  const int8_t* zb = reinterpret_cast<const int8_t*>(s_zd);
+  for (size_t g = (size_t)blockIdx.x * 512 + tid; g < w * B; g += (size_t)gridDim.x * 512) {      // identity block
+    const size_t b = g / w, c = g % w;
+    const size_t at = ((b * 2) * (size_t)ng + (c >> 4)) * 16 + (c & 15);
+    E[b * m + mbar + c] = (int64_t)P[(mbar + c) * ld + b] + (int64_t)zb[at] + 256 * (int64_t)zb[at + (size_t)ng * 16];
+  }
+  const int np = ng / 4;                                         // 16-byte pieces (four groups) per row; ldr is a multiple of 64
+  for (size_t i = (size_t)blockIdx.x * 8 + wave; i < mbar; i += (size_t)gridDim.x * 8) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4u* row = reinterpret_cast<const v4u*>(R2 + i * (size_t)ng);
+    int accp[NB][2], accn[NB][2];                               // [preimage][digit plane]: sums over the +1 / the -1 entries
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { accp[b][0] = accp[b][1] = accn[b][0] = accn[b][1] = 0; }
+    for (int p0 = 0; p0 < np; p0 += 4 * 64) {
+      v4u r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pc = p0 + u * 64 + lane;
+        r[u] = pc < np ? __builtin_nontemporal_load(row + pc) : v4u{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (p0 + u * 64 >= np) break;                            // (wave-uniform)
+        const int pc = p0 + u * 64 + lane;
+        const int g4 = (pc < np ? pc : 0) * 4;                   // (a lane beyond the row holds r = 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                            // group g4 + k = word k of the piece
+          const unsigned int wv = r[u][k];
+          int pos[4], neg[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            pos[j] = (int)(__umul24((wv >> (4 * j)) & 0xfu, 0x204081u) & 0x01010101u);
+            neg[j] = (int)(__umul24((wv >> (16 + 4 * j)) & 0xfu, 0x204081u) & 0x01010101u);
+          }
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            if (b >= (int)B) break;
+            {
+              const int4 z = s_zd[(b * 2) * ng + g4 + k];
+              const int zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                accp[b][0] = __builtin_amdgcn_sdot4(pos[j], zz[j], accp[b][0], false);
+                accn[b][0] = __builtin_amdgcn_sdot4(neg[j], zz[j], accn[b][0], false);
+              }
+            }
+            if (use_hi) {
+              const int4 z = s_zd[(b * 2 + 1) * ng + g4 + k];
+              const int zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                accp[b][1] = __builtin_amdgcn_sdot4(pos[j], zz[j], accp[b][1], false);
+                accn[b][1] = __builtin_amdgcn_sdot4(neg[j], zz[j], accn[b][1], false);
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b >= (int)B) break;
+      long long v = (long long)(accp[b][0] - accn[b][0]) + 256 * (long long)(accp[b][1] - accn[b][1]);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) E[(size_t)b * m + i] = (int64_t)P[i * ld + (size_t)b] + (int64_t)v;
+    }
+  }
+}
+
 // A p mod q (the sum of v = u - A p, mp_perturbation.rs:318) for a handful of preimages (B <= NB <= 4): A is read ONCE as 64-bit words, row by row, by one
 // wave per (row, K range); the range's entries of p (int32, |p| < 2^23) sit in LDS.  A word a < 2^62 meets p as two signed 64-bit sums (low and high 32 bits of a:
 // at most SYN_KLEN / 64 = 32 terms of < 2^55 per lane), joined in 128 bits, reduced over the wave and taken mod q once -- integer arithmetic, exact in any order.
 // The residues go where the matrix-core product puts its per-split residues ([split][n_pad][ld]); k_zq_combine_wave finishes v as before.  The int8 matrix-core
 // path (digit planes of p, LDS-staged tiles, 46 + 6 us at C3 for one preimage) is bound by its staging; this one by reading A's 126 MB.
 constexpr int SYN_KLEN = 2048;
+// q <= 2^32: the same from a 32-bit copy of A (k_narrow_A32: half the bytes, 63 MB at C3).  A lane takes two consecutive entries per 8-byte load; one signed
+// 64-bit sum per preimage (32 terms of < 2^55 per lane), reduced over the wave, one division per (row, range).
+__global__ void k_narrow_A32(const uint64_t* __restrict__ A, size_t total, uint32_t* __restrict__ A32) {
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) A32[g] = (uint32_t)A[g];
+}
+template <int NB>
+__global__ __launch_bounds__(512) void k_syndrome_small32(const uint32_t* __restrict__ A32, size_t n, size_t m, const int32_t* __restrict__ P, size_t ld, size_t B, uint64_t q,
+                                                          int rows_per_wg, uint64_t* __restrict__ part, size_t n_pad, size_t col0) {
+  __shared__ int s_p[NB * SYN_KLEN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t j0 = (size_t)blockIdx.x * SYN_KLEN;
+  const int klen = (int)(m - j0 < (size_t)SYN_KLEN ? m - j0 : (size_t)SYN_KLEN);
+  for (int e = tid; e < NB * SYN_KLEN; e += 512) {
+    const int b = e / SYN_KLEN, jj = e % SYN_KLEN;
+    s_p[e] = (b < (int)B && jj < klen) ? P[(j0 + (size_t)jj) * ld + col0 + (size_t)b] : 0;
+  }
+  __syncthreads();
+  const size_t i_end = ((size_t)blockIdx.y + 1) * (size_t)rows_per_wg < n ? ((size_t)blockIdx.y + 1) * (size_t)rows_per_wg : n;
+  for (size_t i = (size_t)blockIdx.y * (size_t)rows_per_wg + wave; i < i_end; i += 8) {
+    const uint32_t* a = A32 + i * m + j0;                        // (row starts are 4-byte aligned only: m may be odd -- two 4-byte loads per lane, adjacent addresses)
+    long long acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0;
+#pragma unroll 1
+    for (int h0 = 0; h0 < SYN_KLEN / 128; h0 += 8) {
+      if (h0 * 128 >= klen) break;
+      uint32_t av[8][2];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int jj = (h0 + u) * 128 + 2 * lane;
+        av[u][0] = jj < klen ? __builtin_nontemporal_load(a + jj) : 0u;
+        av[u][1] = jj + 1 < klen ? __builtin_nontemporal_load(a + jj + 1) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int jj = (h0 + u) * 128 + 2 * lane;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          acc[b] += (long long)av[u][0] * (long long)s_p[b * SYN_KLEN + jj];
+          acc[b] += (long long)av[u][1] * (long long)s_p[b * SYN_KLEN + jj + 1];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b >= (int)B) break;
+      __int128 v = (__int128)acc[b];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long ol = __shfl_xor((unsigned long long)v, off);
+        const long long oh = __shfl_xor((long long)(v >> 64), off);
+        v += (((__int128)oh) << 64) | (__int128)ol;
+      }
+      if (lane == 0) {
+        __int128 r = v % (__int128)q;
+        if (r < 0) r += (__int128)q;
+        part[((size_t)blockIdx.x * n_pad + i) * ld + col0 + (size_t)b] = (uint64_t)r;
+      }
+    }
+  }
+}
 template <int NB>
 __global__ __launch_bounds__(512) void k_syndrome_small(const uint64_t* __restrict__ A, size_t n, size_t m, const int32_t* __restrict__ P, size_t ld, size_t B, uint64_t q,
                                                         int rows_per_wg, uint64_t* __restrict__ part, size_t n_pad, size_t col0) {

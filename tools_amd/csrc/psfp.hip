@@ -67,6 +67,10 @@ struct psfp_handle {
   size_t mL = 0, nbiL = 0;     // order of the stored triangular factor (m, or m_bar) and its row blocks
   int8_t* dR8 = nullptr;       // R tile-packed (k_pack_R8: 4 KiB tiles of 64 rows x 64 columns, contiguous) for k_recombine_mfma_big and k_rd2_mfma, mb_pad x ldr
   bool r8_valid = false;       // dR8 follows dR (ensure_R8)
+  // compact copies of the key for calls with a handful of preimages, where reading A and R once IS the time of their stages (psf_stream_kernels.hpp):
+  // R as two bits per entry (k_recombine_small2; only a {-1, 0, 1} trapdoor has one), A as 32-bit words (k_syndrome_small32; q <= 2^32)
+  uint32_t* dR2 = nullptr; uint32_t* dA32 = nullptr; int* dR2bad = nullptr; int* hR2bad = nullptr; hipEvent_t evSmall = nullptr;
+  int small_state = 0;         // 0: stale (the key changed); 1: being built (evSmall); 2: usable; 3: usable, R is not ternary (A32 only)
   double g_const = 0, h_const = 0;
   // gadget tables
   int32_t* dRng = nullptr;
@@ -148,6 +152,29 @@ struct psfp_handle {
   const std::chrono::steady_clock::time_point* multi_t0 = nullptr;
   double multi_launched_ms = -1.0, multi_done_ms = -1.0;
 };
+
+// The compact copies follow the key without ever blocking a call: the first small call after a key change launches the two packers on its stream and goes on with
+// the full-size matrices; a later call finds their event complete and switches over.  PSF_SMALL_COMPACT=0: never.
+static void ensure_small_copies(psfp_handle* h, hipStream_t st) {
+  static const bool on = [] { const char* e = std::getenv("PSF_SMALL_COMPACT"); return !e || std::atoi(e) != 0; }();
+  if (!on || (h->prm.flags & PSFP_FLAG_NO_PERTURB) || h->small_state >= 2) return;
+  if (h->small_state == 1) {
+    if (hipEventQuery(h->evSmall) == hipSuccess) h->small_state = *h->hR2bad ? 3 : 2;
+    return;
+  }
+  const size_t ng = h->ldr / 16;
+  if (!h->dR2) {
+    if (hipMalloc(&h->dR2, h->mb * ng * sizeof(uint32_t)) != hipSuccess || hipMalloc(&h->dR2bad, sizeof(int)) != hipSuccess ||
+        hipHostMalloc(&h->hR2bad, sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&h->evSmall, hipEventDisableTiming) != hipSuccess) { h->small_state = 4; return; }
+    if (h->q <= (1ull << 32) && hipMalloc(&h->dA32, h->n * h->m * sizeof(uint32_t)) != hipSuccess) { h->small_state = 4; return; }
+  }
+  hipMemsetAsync(h->dR2bad, 0, sizeof(int), st);
+  hipLaunchKernelGGL(k_pack_R2, dim3(grid_for(h->mb * ng, 256, 256 * 32)), dim3(256), 0, st, h->dR, h->ldr, h->mb, h->dR2, h->dR2bad);
+  if (h->dA32) hipLaunchKernelGGL(k_narrow_A32, dim3(grid_for(h->n * h->m, 256, 256 * 32)), dim3(256), 0, st, h->dA, h->n * h->m, h->dA32);
+  hipMemcpyAsync(h->hR2bad, h->dR2bad, sizeof(int), hipMemcpyDeviceToHost, st);
+  hipEventRecord(h->evSmall, st);
+  h->small_state = 1;
+}
 
 // PSF_RECOMBINE_PACKED=0: k_recombine_mfma_big fetches its R tiles from the row-major matrix as in rounds 2-4 (comparison arm; same bits)
 static bool rcb_packed() {
@@ -461,6 +488,9 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rd2_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (1 + kFixPlanes) * 4096));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
@@ -493,7 +523,9 @@ void psfp_destroy(psfp_handle* h) {
   free_batch(h);
   clear_slots(h);
   if (h->aux) hipStreamDestroy(h->aux);
-  hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dR8);
+  hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dR8); hipFree(h->dR2); hipFree(h->dA32); hipFree(h->dR2bad);
+  if (h->hR2bad) hipHostFree(h->hR2bad);
+  if (h->evSmall) hipEventDestroy(h->evSmall);
   for (auto& t : h->sets) hipFree(t.dFail);
   if (h->s1) hipStreamDestroy(h->s1);
   for (int i = 0; i < 2; ++i) { if (h->evT[i]) hipEventDestroy(h->evT[i]); if (h->evP[i]) hipEventDestroy(h->evP[i]); }
@@ -747,6 +779,12 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
     if (mode == ZQ_SYNDROME && P == h->dP && ncols <= small_max && splits <= h->zq_split_cap && splits <= 64) {
       const int rows_per_wg = 16;
       dim3 grid((unsigned)splits, (unsigned)((h->n + rows_per_wg - 1) / rows_per_wg));
+      ensure_small_copies(h, st);
+      if (h->dA32 && (h->small_state == 2 || h->small_state == 3)) {
+        if (ncols == 1) hipLaunchKernelGGL(k_syndrome_small32<1>, grid, dim3(512), 0, st, h->dA32, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
+        else if (ncols == 2) hipLaunchKernelGGL(k_syndrome_small32<2>, grid, dim3(512), 0, st, h->dA32, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
+        else hipLaunchKernelGGL(k_syndrome_small32<4>, grid, dim3(512), 0, st, h->dA32, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
+      } else
       if (ncols == 1) hipLaunchKernelGGL(k_syndrome_small<1>, grid, dim3(512), 0, st, h->dA, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
       else if (ncols == 2) hipLaunchKernelGGL(k_syndrome_small<2>, grid, dim3(512), 0, st, h->dA, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
       else hipLaunchKernelGGL(k_syndrome_small<4>, grid, dim3(512), 0, st, h->dA, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
@@ -784,7 +822,7 @@ static psf_status gen_A_R(psfp_handle* h, uint64_t seed) {
   if (gadget_too_short(h->prm.gp.base, h->k, h->q)) return PSF_ERR_MODULUS;
   // mp_perturbation.rs:222 / gpv.rs:84 ; gadget_classical.rs:62-64
   hipLaunchKernelGGL(k_sample_abar, dim3(grid_for(h->n * h->mb)), dim3(256), 0, 0, seed, h->n, h->mb, h->m, h->q, h->dA);
-  h->r8_valid = false;
+  h->r8_valid = false; h->small_state = 0;
   hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);
   // gadget_classical.rs:66
   launch_zq_trapdoor(h);
@@ -819,11 +857,11 @@ static psf_status gen_trapdoor_core(int device, const psf_gadget_params* gp, con
       if (R_in[i] > 127 || R_in[i] < -127) return fail(PSF_ERR_UNSUPPORTED);
       r8[i] = (int8_t)R_in[i];
     }
-    h->r8_valid = false;
+    h->r8_valid = false; h->small_state = 0;
     if (hipMemset(h->dR, 0, h->mb_pad * h->ldr) != hipSuccess) return fail(PSF_ERR_HIP);
     if (hipMemcpy2D(h->dR, h->ldr, r8.data(), h->w, h->w, h->mb, hipMemcpyHostToDevice) != hipSuccess) return fail(PSF_ERR_HIP);
   } else {
-    h->r8_valid = false;
+    h->r8_valid = false; h->small_state = 0;
     hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);    // gadget_classical.rs:62-64
   }
   launch_zq_trapdoor(h, dtag);                                                                                            // :66
@@ -906,7 +944,7 @@ psf_status psfp_load_key(psfp_handle* h, const uint64_t* A, const int8_t* R, con
   HIP_TRY(hipDeviceSynchronize());
   h->has_pub = true;
   if (!R) return PSF_OK;                                    // public key only: the verifier's handle (f_a, check_domain, samp_d)
-  h->r8_valid = false;
+  h->r8_valid = false; h->small_state = 0;
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
   h->has_R = true;
@@ -952,7 +990,7 @@ psf_status psfp_load_trapdoor(psfp_handle* h, const uint64_t* A, const int8_t* R
     HIP_TRY(hipGetLastError());
     h->has_pub = true;
   }
-  h->r8_valid = false;
+  h->r8_valid = false; h->small_state = 0;
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   HIP_TRY(hipMemcpy2D(h->dR, h->ldr, R, h->w, h->w, h->mb, hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
@@ -1180,6 +1218,13 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       const size_t small_lds = 32 * (h->ldr / 16) * Bh;
       if (Bh <= small_max && small_lds <= 150 * 1024) {
         const unsigned wgs = (unsigned)std::min<size_t>((h->mb + 7) / 8, small_lds > 64 * 1024 ? 256 : 512);
+        ensure_small_copies(h, sx);
+        if (h->small_state == 2) {
+          if (Bh == 1) hipLaunchKernelGGL(k_recombine_small2<1>, dim3(wgs), dim3(512), small_lds, sx, h->dR2, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
+          else if (Bh == 2) hipLaunchKernelGGL(k_recombine_small2<2>, dim3(wgs), dim3(512), small_lds, sx, h->dR2, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
+          else hipLaunchKernelGGL(k_recombine_small2<4>, dim3(wgs), dim3(512), small_lds, sx, h->dR2, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
+          return;
+        }
         if (Bh == 1) hipLaunchKernelGGL(k_recombine_small<1>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
         else if (Bh == 2) hipLaunchKernelGGL(k_recombine_small<2>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
         else hipLaunchKernelGGL(k_recombine_small<4>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
