@@ -62,6 +62,11 @@ __global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, s
   double* __restrict__ sCol = ch_smem + CH_NB * LD;
   const int tid = threadIdx.x, ti = tid & 127, th = tid >> 7;
   if (*info != 0) return;
+#ifndef CHOL_NO_SETPRIO
+  // This workgroup is a chain of 128 dependent steps and runs beside the product kernels of the look-ahead (their workgroups share its CU): alone it takes
+  // 0.19 ms, under them 0.88 ms, on the critical path of most panels (profiles/r04_notes.md).  Instruction-issue priority over the co-resident waves.
+  __builtin_amdgcn_s_setprio(3);
+#endif
   for (int e = tid; e < nb * CH_NB; e += 256) {
     const int r = e >> 7, c = e & 127;
     if (c < nb) sG[r * LD + c] = (c <= r) ? A[(off + r) * ld + off + c] : 0.0;

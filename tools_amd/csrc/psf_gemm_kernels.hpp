@@ -211,6 +211,9 @@ __global__ __launch_bounds__(256) void k_ldl_inverse(const double* __restrict__ 
   double* __restrict__ sG = ldl_smem;
   double* __restrict__ sCol = ldl_smem + GM_T * LD;
   const int tid = threadIdx.x, ti = tid & 127, th = tid >> 7;
+#ifndef CHOL_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(3);      // a chain of 128 dependent steps in one workgroup: ahead of whatever else shares its CU (k_chol_diag_inv)
+#endif
   for (int e = tid; e < p * GM_T; e += 256) { const int r = e >> 7, c = e & 127; if (c < p) sG[r * LD + c] = Gm[(size_t)r * ldg + c]; }
   __syncthreads();
   double* __restrict__ myrow = sG + ti * LD;
