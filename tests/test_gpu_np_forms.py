@@ -1,7 +1,8 @@
 """The randomized nearest plane (MatZ::sample_d_precomputed_gso, gpv.rs:160; gpv_ring.rs:204-211) has three launch forms for the SAME chains: one launch per
 block (k_np_step, PSF_NP_WALK=0), the whole walk in one launch with updater workgroups that keep the running projections in registers (k_np_walk, the default where
 the batch fits) and the whole walk with the helper waves updating the projections in memory (k_np_walk2, PSF_NP_WALK=3), each with one or two preimages per
-sampler wave (PSF_NP_G).  Every form must return the default's bytes -- which equal the oracle's -- on batches with several 64-preimage groups (one of them
+sampler wave (PSF_NP_G); the recombination e = sum z b behind it runs as one launch over the occupied tiles of the digit planes (default) or as one launch per
+digit pair (PSF_NP_COMBINE=0).  Every form must return the default's bytes -- which equal the oracle's -- on batches with several 64-preimage groups (one of them
 partial), several blocks and a short top block; a wait that gives up must surface as PSF_ERR_SAMPLER, not as a hang or a silent result."""
 import json
 import os
@@ -44,12 +45,12 @@ print(json.dumps({"hash": h.hexdigest(), "d": int(d), "status": 0}))
 ''' % ROOT
 
 FORMS = [{}, {"PSF_NP_WALK": "0"}, {"PSF_NP_WALK": "3"}, {"PSF_NP_G": "2"}, {"PSF_NP_WALK": "0", "PSF_NP_G": "2"}, {"PSF_NP_WALK": "3", "PSF_NP_G": "2"},
-         {"PSF_NP_WALK": "0", "PSF_NP_IMMEDIATE": "0"}]
+         {"PSF_NP_WALK": "0", "PSF_NP_IMMEDIATE": "0"}, {"PSF_NP_COMBINE": "0"}]
 
 
 def run(kind, B, **extra):
     env = dict(os.environ, **extra)
-    for k in ("PSF_NP_WALK", "PSF_NP_G", "PSF_NP_IMMEDIATE", "PSF_NP_WALK_SPINS"):
+    for k in ("PSF_NP_WALK", "PSF_NP_G", "PSF_NP_IMMEDIATE", "PSF_NP_WALK_SPINS", "PSF_NP_COMBINE"):
         if k not in extra:
             env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", SCRIPT, kind, str(B)], capture_output=True, text=True, env=env, timeout=900)

@@ -1322,6 +1322,156 @@ __global__ __launch_bounds__(256, 2) void k_np_combine8(const int8_t* __restrict
       }
 }
 
+// ---- the recombination in ONE launch (round 5) ---------------------------------------------------------------------------------------------
+// Six digit-pair products (three z digits x two basis digits) used to be six launches, each a read-modify-write of the whole of E; measured at C2 five of
+// them ran at full length although the second basis digit holds a handful of entries (|b| > 127 is a 5-sigma event of R W) and the third z digit a few rows.
+// k_np_occ_* record which 128 x 128 tiles of the digit planes hold anything at all (the basis once per key, z digits 1 and 2 once per call; digit 0 is
+// taken as dense); k_np_combine8_fused walks, per output tile, the list of (pair, K block) items whose two tiles are both occupied, ordered by the
+// pair's scale 2^(8 (zi + bi)), folds the int32 accumulator into 64 bits whenever the scale changes and writes E once.  Same integers as the six
+// launches: every skipped item is a product with an all-zero tile.
+__global__ __launch_bounds__(256) void k_np_occ_z(const int8_t* __restrict__ Z8, size_t zplane, size_t ld, int nk128, unsigned char* __restrict__ occ /*[2][ld / 128][nk128]; the grid covers the column blocks in use*/) {
+  const int ks2 = (int)(blockIdx.x % (unsigned)nk128), bblk = (int)(blockIdx.x / (unsigned)nk128);
+  const int8_t* src = Z8 + (size_t)(blockIdx.y + 1) * zplane;
+  int any = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = j * 256 + (int)threadIdx.x, kg = p >> 7, bb = p & 127;
+    const v4i v = *reinterpret_cast<const v4i*>(src + (((size_t)ks2 * 8 + kg) * ld + (size_t)bblk * 128 + bb) * 16);
+    any |= v[0] | v[1] | v[2] | v[3];
+  }
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) occ[(size_t)blockIdx.y * (ld / 128) * nk128 + blockIdx.x] = any != 0;
+}
+__global__ __launch_bounds__(256) void k_np_occ_basis(const int8_t* __restrict__ B8, size_t dpad, int nk128, unsigned char* __restrict__ occ /*[2][dpad / 128][nk128]*/) {
+  const int ks2 = (int)(blockIdx.x % (unsigned)nk128), iblk = (int)(blockIdx.x / (unsigned)nk128);
+  const int8_t* src = B8 + (size_t)blockIdx.y * dpad * dpad;
+  int any = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = j * 256 + (int)threadIdx.x, row = p >> 3, seg = p & 7;
+    const v4i v = *reinterpret_cast<const v4i*>(src + ((size_t)iblk * 128 + row) * dpad + (size_t)ks2 * 128 + seg * 16);
+    any |= v[0] | v[1] | v[2] | v[3];
+  }
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) occ[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = any != 0;
+}
+
+__global__ __launch_bounds__(256, 2) void k_np_combine8_fused(const int8_t* __restrict__ B8, size_t ldb, size_t d, int nk128, int nbdig, const unsigned char* __restrict__ bocc,
+                                                              const int8_t* __restrict__ Z8, size_t zplane, size_t ld, size_t B, const unsigned char* __restrict__ zocc,
+                                                              int64_t* __restrict__ E, size_t lde) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];      // two stages of 32 KiB, then the item list of one chunk of 64 K blocks
+  unsigned short* const list = reinterpret_cast<unsigned short*>(rc_smem + 65536);
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const size_t b0 = (size_t)blockIdx.x * 128, i0 = (size_t)blockIdx.y * 128;
+  const size_t nbb = ld / 128, nrb = ldb / 128;
+  v4i acc[4][4];
+  long long tot[4][4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      acc[x][y] = v4i{0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[x][y][r] = 0;
+    }
+  // pair p: z digit / basis digit, ordered by scale zi + bi
+  auto zi_of = [](int p) { return (0x212010 >> (4 * p)) & 3; };      // 0 1 0 2 1 2
+  auto bi_of = [](int p) { return (0x110100 >> (4 * p)) & 1; };      // 0 0 1 0 1 1
+  const int r16 = lane & 15, g = lane >> 4;
+  for (int c0 = 0; c0 < nk128; c0 += 64) {
+    if (wave == 0) {
+      const int ks = c0 + lane;
+      const bool in = ks < nk128;
+      unsigned long long zm[3], bm[2];
+      zm[0] = __builtin_amdgcn_ballot_w64(in);
+      zm[1] = __builtin_amdgcn_ballot_w64(in && zocc[((size_t)0 * nbb + blockIdx.x) * nk128 + ks] != 0);
+      zm[2] = __builtin_amdgcn_ballot_w64(in && zocc[((size_t)1 * nbb + blockIdx.x) * nk128 + ks] != 0);
+      bm[0] = __builtin_amdgcn_ballot_w64(in && bocc[((size_t)0 * nrb + blockIdx.y) * nk128 + ks] != 0);
+      bm[1] = nbdig > 1 ? __builtin_amdgcn_ballot_w64(in && bocc[((size_t)1 * nrb + blockIdx.y) * nk128 + ks] != 0) : 0ull;
+      int base = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const unsigned long long m = zm[zi_of(p)] & bm[bi_of(p)];
+        if ((m >> lane) & 1ull) list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned short)((p << 8) | lane);
+        base += __builtin_popcountll(m);
+      }
+      if (lane == 0) s_n = base;
+    }
+    __syncthreads();
+    const int n = s_n;
+    auto stage_load = [&](int item, int buf) {
+      const int p = item >> 8, ks2 = c0 + (item & 255);
+      const int8_t* Bp = B8 + (size_t)bi_of(p) * ldb * ldb;
+      const int8_t* Zp = Z8 + (size_t)zi_of(p) * zplane;
+      unsigned char* base = rc_smem + buf * 32768;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = (wave * 4 + j) * 64 + lane;                  // 16-byte piece, 0..1023
+        const int kk = q >> 9, row = (q >> 2) & 127, col = ((q & 3) - (row >> 2)) & 3;      // as k_np_combine8
+        __builtin_amdgcn_global_load_lds(Bp + (i0 + (size_t)row) * ldb + (size_t)ks2 * 128 + kk * 64 + col * 16, (lds_void_ptr)(base + (wave * 4 + j) * 1024), 16, 0, 0);
+        const int kg = q >> 7, bb = q & 127;
+        __builtin_amdgcn_global_load_lds(Zp + (((size_t)ks2 * 8 + kg) * ld + b0 + (size_t)bb) * 16, (lds_void_ptr)(base + 16384 + (wave * 4 + j) * 1024), 16, 0, 0);
+      }
+    };
+    if (n > 0) {
+      int item = __builtin_amdgcn_readfirstlane((int)list[0]);
+      stage_load(item, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int t = 0; t < n; ++t) {
+        const int cb = t & 1;
+        const int next = t + 1 < n ? __builtin_amdgcn_readfirstlane((int)list[t + 1]) : -1;
+        if (next >= 0) stage_load(next, cb ^ 1);
+        const unsigned char* sR = rc_smem + cb * 32768;
+        const unsigned char* sL = sR + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          v4i fr[4], fl[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            fr[u] = *reinterpret_cast<const v4i*>(sR + kk * 8192 + ((wc * 64 + u * 16 + r16) * 64 + i8_slot(wc * 64 + u * 16 + r16, g) * 16));
+            fl[u] = *reinterpret_cast<const v4i*>(sL + (((kk * 4 + g) * 128 + wr * 64 + u * 16 + r16) * 16));
+          }
+#pragma unroll
+          for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[bt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fl[bt], fr[it], acc[bt][it], 0, 0, 0);
+        }
+        const int sc = zi_of(item >> 8) + bi_of(item >> 8);
+        const int scn = next >= 0 ? zi_of(next >> 8) + bi_of(next >> 8) : -1;
+        if (sc != scn) {      // at most 64 K blocks x 2 pairs x 128 terms of |z b| <= 2^14 since the last fold: 2^28, exact in int32
+          const long long scale = 1ll << (8 * sc);
+#pragma unroll
+          for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) tot[bt][it][r] += scale * (long long)acc[bt][it][r];
+              acc[bt][it] = v4i{0, 0, 0, 0};
+            }
+        }
+        item = next;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+    __syncthreads();      // the list is rebuilt by the next chunk
+  }
+  // C/D map: column (coordinate j) = lane & 15, row (preimage) = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t bb = b0 + wr * 64 + bt * 16 + 4 * g + r, jj = i0 + wc * 64 + it * 16 + r16;
+        if (bb < B && jj < d) E[bb * lde + jj] = tot[bt][it][r];
+      }
+}
+
 // e[b][piv[r]] += sol[r][b]  (gpv.rs:160: sol + sample; e = -(c0 - sum z b) with c0 = -sol)
 __global__ void k_np_add_sol(const uint64_t* __restrict__ Sol, const uint32_t* __restrict__ piv, size_t n, size_t B, size_t ld, int64_t* __restrict__ E, size_t lde) {
   const size_t total = n * B;

@@ -27,6 +27,9 @@ struct psfgpv_handle {
   double* dTm = nullptr;              // running projections, dpad x ld
   double* dZf = nullptr;              // z as f64, chunk stream (ld / 128) x nkb
   int8_t* dZ8 = nullptr; size_t zplane = 0;          // three digit planes of z, [dpad / 16][ld][16] each
+  unsigned char* dBocc = nullptr;     // which 128 x 128 tiles of the basis digit planes hold anything: [2][nrb][nrb] (k_np_occ_basis, per key)
+  unsigned char* dZocc = nullptr;     // the same for z digits 1 and 2: [2][ld / 128][nrb] (k_np_occ_z, per call)
+  int np_combine = 1;                 // PSF_NP_COMBINE: 1 / unset = one fused launch over the occupied tiles (k_np_combine8_fused), 0 = one launch per digit pair
   double* dC0p = nullptr;             // -sol on the pivots, chunk stream (ld / 128) x nkc
   uint64_t* dSol = nullptr;           // n x ld
   int* dFlags = nullptr;              // [0] sampler failure [1] second digit of some z in use [2] third digit [3] |z| beyond three digits; [4..7]: the same for the second pass
@@ -110,6 +113,8 @@ static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
     hipFree(dinfo);
     g->basis_generic = info[0] != 0;
     g->basis_hi = info[1] != 0;
+    hipLaunchKernelGGL(k_np_occ_basis, dim3((unsigned)(g->nrb * g->nrb), 2), dim3(256), 0, 0, g->dB8, g->dpad, (int)g->nrb, g->dBocc);
+    HIP_TRY(hipGetLastError());
   }
   return PSF_OK;
 }
@@ -158,7 +163,8 @@ static psf_status gpv_build_solver(psfgpv_handle* g) {
 }
 
 static void free_np_batch(psfgpv_handle* g) {
-  hipFree(g->dTm); hipFree(g->dZf); hipFree(g->dZ8); hipFree(g->dC0p); hipFree(g->dSol); hipFree(g->dC1); hipFree(g->dE1); hipFree(g->dWalk);
+  hipFree(g->dTm); hipFree(g->dZf); hipFree(g->dZ8); hipFree(g->dC0p); hipFree(g->dSol); hipFree(g->dC1); hipFree(g->dE1); hipFree(g->dWalk); hipFree(g->dZocc);
+  g->dZocc = nullptr;
   g->dTm = g->dZf = g->dC0p = g->dC1 = nullptr; g->dZ8 = nullptr; g->dSol = nullptr; g->dE1 = nullptr; g->dWalk = nullptr;
   g->bcap = 0;
 }
@@ -172,6 +178,7 @@ static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
   HIP_TRY(hipMalloc(&g->dZf, ld * g->nkb * 16 * sizeof(double)));
   g->zplane = g->dpad * ld;
   HIP_TRY(hipMalloc(&g->dZ8, 3 * g->zplane));
+  HIP_TRY(hipMalloc(&g->dZocc, 2 * (ld / 128) * g->nrb));
   HIP_TRY(hipMalloc(&g->dC0p, ld * g->nkc * 16 * sizeof(double)));
   HIP_TRY(hipMalloc(&g->dSol, g->n * ld * sizeof(uint64_t)));
   if (g->two_pass) {
@@ -275,8 +282,13 @@ static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size
   const dim3 cgrid((unsigned)((B + 127) / 128), (unsigned)(g->dpad / 128));
   const int nk128 = (int)(g->dpad / 128);
   const size_t plane = g->dpad * g->dpad;
-  if (!g->basis_generic) {
-    // z = z0 + 256 z1 + 65536 z2, b = b0 + 256 b1: one pass per digit pair in use (the z digits beyond the first are gated on the device)
+  if (!g->basis_generic && g->np_combine != 0) {
+    // z = z0 + 256 z1 + 65536 z2, b = b0 + 256 b1: every digit pair in one launch, over the tiles of the digit planes that hold anything
+    hipLaunchKernelGGL(k_np_occ_z, dim3((unsigned)(cgrid.x * g->nrb), 2), dim3(256), 0, st, g->dZ8, g->zplane, ld, nk128, g->dZocc);
+    hipLaunchKernelGGL(k_np_combine8_fused, cgrid, dim3(256), 65536 + 768, st, g->dB8, g->dpad, g->dim, nk128, g->basis_hi ? 2 : 1, g->dBocc, g->dZ8, g->zplane, ld, B, g->dZocc, d_e, g->dim);
+    if (pass == 0) hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dSol, g->dPiv, g->n, B, ld, d_e, g->dim);
+  } else if (!g->basis_generic) {
+    // the same sum as one pass per digit pair in use (the z digits beyond the first are gated on the device): PSF_NP_COMBINE=0, kept for the switch matrix
     const int8_t* zp[3] = {g->dZ8, g->dZ8 + g->zplane, g->dZ8 + 2 * g->zplane};
     const int* gate[3] = {nullptr, flags + 1, flags + 2};
     bool first = true;
@@ -357,6 +369,7 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipMalloc(&g->dRows, g->nblk * NP_NB * sizeof(NpRow)));
   HIP_TRY(hipMalloc(&g->dBpiv, g->nrb * g->nkc * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipMalloc(&g->dB8, 2 * g->dpad * g->dpad));
+  HIP_TRY(hipMalloc(&g->dBocc, 2 * g->nrb * g->nrb));
   HIP_TRY(hipMalloc(&g->dFlags, 8 * sizeof(int)));
   HIP_TRY(hipMemset(g->dFlags, 0, 8 * sizeof(int)));
   // large moduli: q sqrt(n) > 2^13 s (relative centre error of a single pass above 2^-40, see include/psf_mi355x.h "Precision of the centres"); PSF_NP_TWO_PASS=0/1 forces
@@ -378,6 +391,8 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   if (const char* e = std::getenv("PSF_NP_WALK_SPINS")) { const long v = std::atol(e); if (v >= 1) g->walk_spins = (unsigned)v; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 768));
+  if (const char* e = std::getenv("PSF_NP_COMBINE")) g->np_combine = std::atoi(e);
   for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
   return PSF_OK;
 }
@@ -387,7 +402,7 @@ void psfgpv_destroy(psfgpv_handle* g) {
   hipSetDevice(g->base->prm.device);
   free_np_batch(g);
   hipFree(g->dSt); hipFree(g->dGt); hipFree(g->dNorm2); hipFree(g->dSz); hipFree(g->dT); hipFree(g->dPiv);
-  hipFree(g->dGp); hipFree(g->dGin); hipFree(g->dGnx); hipFree(g->dRows); hipFree(g->dBpiv); hipFree(g->dB8); hipFree(g->dFlags); hipFree(g->dBfull);
+  hipFree(g->dGp); hipFree(g->dGin); hipFree(g->dGnx); hipFree(g->dRows); hipFree(g->dBpiv); hipFree(g->dB8); hipFree(g->dBocc); hipFree(g->dFlags); hipFree(g->dBfull);
   for (auto& e : g->ev) if (e) hipEventDestroy(e);
   psfp_destroy(g->base);
   delete g;
