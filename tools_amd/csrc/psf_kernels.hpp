@@ -725,6 +725,97 @@ __global__ __launch_bounds__(256) void k_perturb_round_lean(uint64_t seed, uint6
   if (f) atomicOr(fail, 1);
 }
 
+// k_perturb_round_lean with the table screen of psf_rng.hpp (sz_screen16_tab) in place of the fp32 screen: same attempts, same exact decisions, same values.
+__global__ __launch_bounds__(256) void k_perturb_round_tab(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
+                                                            const double* __restrict__ X, SampleZParams sp, int32_t* __restrict__ P,
+                                                            int* __restrict__ fail, uint32_t seg, SzTable tb) {
+  __shared__ double s_win[4][PRL_WIN];
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];      // the screen table of this s: rows x F words
+  const int lane = threadIdx.x & 63;
+  double* win = s_win[threadIdx.x >> 6];
+  const size_t total = m * B;
+  const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * seg;
+  for (uint32_t e = threadIdx.x; e < tb.rows * tb.F; e += 256) s_tab[e] = tb.t[e];
+  __syncthreads();
+  if (seg0 >= total) return;                                   // (no workgroup barrier below: a wave may leave alone)
+  const uint32_t nseg = (uint32_t)(total - seg0 < (size_t)seg ? total - seg0 : (size_t)seg);
+  const uint32_t coord0 = (uint32_t)(seg0 / B), b00 = (uint32_t)(seg0 % B), B32 = (uint32_t)B;
+  const bool few_wraps = B32 >= seg;                           // then an offset wraps at most once
+  auto locate = [&](uint32_t off, uint32_t* coord, uint32_t* bb) {
+    const uint32_t o = b00 + off;
+    if (few_wraps) { const bool wrap = o >= B32; *coord = coord0 + (wrap ? 1u : 0u); *bb = wrap ? o - B32 : o; }
+    else { *coord = coord0 + o / B32; *bb = o % B32; }
+  };
+  auto gload = [&](uint32_t off) -> double {
+    if (off >= nseg) return 0.0;
+    uint32_t cc, bb;
+    locate(off, &cc, &bb);
+    return X[(size_t)cc * ld + bb];
+  };
+  // ring: offsets [loaded - 256, loaded) sit at index (offset & 255); pf holds the block [loaded, loaded + 64)
+  win[lane] = gload(lane); win[64 + lane] = gload(64 + lane); win[128 + lane] = gload(128 + lane);
+  uint32_t loaded = 192;
+  double pf = gload(192 + lane);
+  uint32_t my = (uint32_t)lane, next_free = 64;
+  bool active = my < nseg;
+  const double Fd = (double)tb.F;
+  const int c6_32 = (int)sp.c6;
+  double c = 0.0; uint32_t coord = 0, b = 0, idx_lo = 0, tw = 0, t = 0, bin = 0;
+  SzRange rg{0, 1, 0, 16};
+  bool generic = false;
+  auto take = [&](uint32_t off) {                               // a lane adopts sample `off`: everything that depends on the sample only
+    c = win[off & (PRL_WIN - 1)];
+    locate(off, &coord, &b);
+    const uint64_t index = first_index + b;
+    idx_lo = (uint32_t)index;
+    tw = tag_word(TAG_PERTURB, index);
+    generic = !(fabs(c) < 0x1.0p30);
+    if (generic) rg = sz_range(c, sp);
+    else {                                                      // sz_range with the range start formed in 32 bits (|c| < 2^30, ceil(6 s) <= 2048)
+      const double cc = ceil(c);
+      const bool integral = cc == c;
+      rg.lo = (long long)((int)cc - c6_32);
+      rg.N = integral ? sp.n_int : sp.n_int - 1;
+      rg.thr = integral ? sp.thr_int : sp.thr_frac;
+      rg.sh = 16;
+      const uint32_t bq = (uint32_t)((cc - c) * Fd);           // delta in [0, 1): its bin (the table's bins overlap by 1e-9, psfp.hip)
+      bin = bq < tb.F ? bq : tb.F - 1;
+    }
+    t = 0;
+  };
+  if (active) take(my);
+  int f = 0;
+  while (__ballot(active)) {
+    bool accept = false;
+    long long x = 0;
+    if (active) {
+      accept = generic ? sz_group4(seed, coord, idx_lo, tw, t, rg, c, sp.inv_s, &x)
+                       : sz_group4_tab(seed, coord, idx_lo, tw, t, rg, c, sp.inv_s, s_tab + bin, tb.F, &x);
+      if (!accept && ++t >= kMaxAttempts / 4) { accept = true; f = 1; x = (long long)floor(c + 0.5); }
+      if (accept) {
+        if (x > kDigitRangeP || x < -kDigitRangeP) f = 1;       // the syndrome product needs |p| < 2^23 (k_split_P)
+        P[(size_t)coord * ld + b] = (int32_t)x;
+      }
+    }
+    const uint64_t mask = __ballot(accept);
+    if (mask) {
+      const uint32_t nid = next_free + (uint32_t)lane_rank(mask);
+      next_free += (uint32_t)__popcll(mask);
+      while (loaded < next_free + 64 && loaded < nseg) {        // uniform: keep every offset below next_free + 64 in the ring
+        win[(loaded + lane) & (PRL_WIN - 1)] = pf;
+        loaded += 64;
+        pf = gload(loaded + lane);
+      }
+      if (accept) {
+        my = nid;
+        active = nid < nseg;
+        if (active) take(nid);
+      }
+    }
+  }
+  if (f) atomicOr(fail, 1);
+}
+
 // ---- integer products over Z_q ---------------------------------------------------------------------------
 // S[i][c] = sum_t a[i][t] * p[t][c]  (a in [0,q) as u64, p small signed), reduced mod q, then an epilogue:
 //   ZQ_SYNDROME : out[i][c] = (u[c][i] - S) mod q      out n x ld   (mp_perturbation.rs:318)

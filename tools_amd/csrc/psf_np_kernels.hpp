@@ -168,7 +168,24 @@ __global__ void k_np_solve(const uint64_t* __restrict__ Tt, size_t n, size_t nk1
     const size_t r = g % nk16, b = g / nk16;
     uint64_t acc = 0;
     if (r < n && b < B) {
-      if (q <= 0x7fffffffull) {                     // products below 2^62: sum them in 128 bits, reduce once
+      if (q < (1ull << 24) && n <= 65536) {         // products below 2^48, the sum below 2^64: one v_mad_u64_u32 per term, reduced once (C2 / C4: q = 3329)
+        const uint32_t* T32 = reinterpret_cast<const uint32_t*>(Tt);
+        uint64_t s0 = 0, s1 = 0;
+        size_t t = 0;
+        for (; t + 2 <= n; t += 2) {
+          uint64_t u0 = U[b * n + t], u1 = U[b * n + t + 1];
+          if (u0 >= q) u0 %= q;
+          if (u1 >= q) u1 %= q;
+          s0 += (uint64_t)T32[2 * (t * n + r)] * (uint32_t)u0;
+          s1 += (uint64_t)T32[2 * ((t + 1) * n + r)] * (uint32_t)u1;
+        }
+        if (t < n) {
+          uint64_t u0 = U[b * n + t];
+          if (u0 >= q) u0 %= q;
+          s0 += (uint64_t)T32[2 * (t * n + r)] * (uint32_t)u0;
+        }
+        acc = (s0 % q + s1 % q) % q;
+      } else if (q <= 0x7fffffffull) {              // products below 2^62: sum them in 128 bits, reduce once
         Acc128 s{0, 0};
         for (size_t t = 0; t < n; ++t) {
           uint64_t uq = U[b * n + t];

@@ -286,6 +286,54 @@ __device__ inline bool sz_group4_narrow(uint64_t seed, uint32_t coord, uint32_t 
 }
 #endif
 
+// ---- table screen (round 5) ---------------------------------------------------------------------------------------------------------------------
+// For one s the acceptance threshold floor(rho 2^16) of a narrow attempt depends on the candidate index and on delta = ceil(c) - c only:
+// a = (idx - ceil(6 s) + delta) / s.  The host tabulates, per (idx, bin of delta) with F bins, two 16-bit bounds that hold for EVERY delta of the bin --
+// certainly accepted below A, certainly rejected above R (one unit of slack on either side of the extreme floors covers the rounding of the exact
+// evaluation) -- packed as R << 16 | A.  An attempt is then: 24-bit multiply, Lemire test, one LDS word, two 16-bit compares; what falls between A and R
+// (a 1 / F share of the accepted mass: 3e-4 of the attempts at F = 64) is settled by sz_decide as before, so the accepted attempt and its value are
+// those of the exact sampler.  The fp32 screen it replaces spends ~14 more vector instructions per attempt on conversions, the exponential and margins.
+struct SzTable { const uint32_t* t; uint32_t F; uint32_t rows; };      // t[idx * F + bin], rows = n_int, F a power of two
+#if defined(__HIPCC__)
+__device__ inline int sz_screen16_tab(uint32_t word, const SzRange rg, const uint32_t* __restrict__ tab_bin /* LDS: table + bin */, uint32_t F, uint32_t* idx_out) {
+  const uint32_t prod = __umul24(word >> 16, rg.N);
+  const bool valid = (prod & 0xffffu) >= rg.thr;
+  const uint32_t idx = prod >> 16;
+  const uint32_t T = tab_bin[__umul24(idx, F)];
+  const uint32_t wb = word & 0xffffu;
+  const bool sure = wb < (T & 0xffffu);
+  const bool maybe = wb <= (T >> 16);
+  *idx_out = idx;
+  return (valid && maybe) ? (sure ? 1 : 2) : 0;
+}
+__device__ inline bool sz_group4_tab(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t g, const SzRange rg, double center,
+                                     double inv_s, const uint32_t* __restrict__ tab_bin, uint32_t F, long long* x_out) {
+  const U4 w = philox(seed, coord, idx_lo, g, tw);
+  const uint32_t word[4] = {w.x, w.y, w.z, w.w};
+  int tm = -1, cls = 0;
+  uint32_t idxm = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t idx = 0;
+    const int cj = sz_screen16_tab(word[j], rg, tab_bin, F, &idx);
+    if (tm < 0 && cj) { tm = j; idxm = idx; cls = cj; }
+  }
+  if (tm < 0) return false;
+  long long x = rg.lo + (long long)idxm;
+  *x_out = x;
+  if (cls == 1) return true;
+  const uint32_t wbm = word[tm] & 0xffffu;
+  bool accept = sz_decide(seed, coord, idx_lo, tw, 4 * g + (uint32_t)tm, x, wbm, center, inv_s, 16);
+  if (!accept) {
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      if (!accept && j > tm) accept = sz_attempt(seed, coord, idx_lo, tw, 4 * g + (uint32_t)j, word[j] >> 16, word[j] & 0xffffu, rg, center, inv_s, &x);
+    *x_out = x;
+  }
+  return accept;
+}
+#endif
+
 __host__ __device__ inline long long sample_z(uint64_t seed, uint32_t tag, uint64_t index, uint32_t coord, double center,
                                               const SampleZParams sp, int* fail) {
   const SzRange rg = sz_range(center, sp);

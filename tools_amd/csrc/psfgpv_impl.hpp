@@ -58,6 +58,7 @@ struct psfgpv_handle {
 // operands of the blocked nearest plane
 static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
   const size_t d = g->dim;
+  KeygenClock kc("psfgpv");
   if (compute_gso) {
     hipLaunchKernelGGL(k_i32_to_f64, dim3(grid_for(d * d)), dim3(256), 0, 0, g->dSt, g->dGt, d * d);
     // blocked Gram-Schmidt with re-orthogonalisation on the FP64 matrix cores (psf_gemm_kernels.hpp)
@@ -70,6 +71,7 @@ static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
     hipFree(dinfo);
     if (ge != hipSuccess) return PSF_ERR_HIP;
     if (info != 0) return PSF_ERR_PARAM;                                 // linearly dependent "basis"
+    kc.mark("  gso_blocked");
   }
   hipLaunchKernelGGL(k_row_norm2_chain, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, 0, g->dGt, d, g->dNorm2);
   HIP_TRY(hipGetLastError());
@@ -90,6 +92,7 @@ static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
     }
     HIP_TRY(hipMemcpy(g->dRows, rows.data(), rows.size() * sizeof(NpRow), hipMemcpyHostToDevice));
   }
+  kc.mark("  norms, SampleZ rows");
   {  // g[j][i] = <b_j, b~_i>, then its two packed forms
     double* dGd = nullptr;
     HIP_TRY(hipMalloc(&dGd, d * d * sizeof(double)));
@@ -103,6 +106,7 @@ static psf_status gpv_finish_basis(psfgpv_handle* g, bool compute_gso) {
     HIP_TRY(hipDeviceSynchronize());
     hipFree(dGd);
   }
+  kc.mark("  gram + packing");
   {
     int* dinfo = nullptr;
     HIP_TRY(hipMalloc(&dinfo, 2 * sizeof(int)));
@@ -417,8 +421,10 @@ psf_status psfgpv_trap_gen(psfgpv_handle* g, uint64_t seed) {
   HIP_TRY(hipSetDevice(b->prm.device));
   PSFP_QUIESCE(b);
   g->has_key = false;
+  KeygenClock kc("psfgpv");
   psf_status rc = gen_A_R(b, seed);                                          // :84-88
   if (rc != PSF_OK) return rc;
+  kc.mark("A, R");
   // gen_short_basis_for_trapdoor (:90, short_basis_classical.rs:54-110), assembled transposed on the device
   int8_t* dBT = nullptr;
   const size_t ldw = b->ldr;
@@ -432,10 +438,13 @@ psf_status psfgpv_trap_gen(psfgpv_handle* g, uint64_t seed) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   hipFree(dBT);
+  kc.mark("short basis");
   rc = gpv_finish_basis(g, true);                                             // :91 gso
   if (rc != PSF_OK) return rc;
+  kc.mark("gso + walk operands");
   rc = gpv_build_solver(g);
   if (rc != PSF_OK) return rc;
+  kc.mark("solve operator");
   b->has_key = true; b->has_pub = true;
   g->has_key = true;
   return PSF_OK;

@@ -21,6 +21,19 @@
 #include "psf_sdma.hpp"
 #include "psf_ntt_api.hpp"
 
+// PSF_KEYGEN_TIMING=1: wall time of the phases of key generation on stderr (each mark drains the device first; off, a mark is one branch)
+struct KeygenClock {
+  bool on; const char* what; std::chrono::steady_clock::time_point t0, last;
+  explicit KeygenClock(const char* w) : on(std::getenv("PSF_KEYGEN_TIMING") != nullptr), what(w) { if (on) { hipDeviceSynchronize(); t0 = last = std::chrono::steady_clock::now(); } }
+  void mark(const char* phase) {
+    if (!on) return;
+    hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[keygen %s] %-28s %8.2f ms (at %8.2f)\n", what, phase, std::chrono::duration<double, std::milli>(now - last).count(), std::chrono::duration<double, std::milli>(now - t0).count());
+    last = now;
+  }
+};
+
 #define PSFP_FLAG_NO_PERTURB 1u   // internal: handle used as the Z_q / f_a engine of PSFGPV(Ring); no sqrt(Sigma_2) buffers
 // PSFP_FLAG_STRUCTURED_SQRT (2u) is public: include/psf_mi355x.h
 
@@ -80,6 +93,7 @@ struct psfp_handle {
   ZqConsts zc;
   std::vector<int64_t> hSk; std::vector<double> hGso;
   SampleZParams szR, szSR;
+  uint32_t* dSzTab = nullptr; uint32_t szF = 0;      // table screen of the rounding sampler (psf_rng.hpp, k_perturb_round_tab); szF = 0: none (wide words, or the table would not fit)
   // batch work buffers
   size_t Bcap = 0, ld = 0, nbj = 0;
   double* dDt = nullptr; double* dX = nullptr; int32_t* dP = nullptr; uint64_t* dV = nullptr;
@@ -376,6 +390,36 @@ psf_status psf_find_solution_gadget_mat(int device, const uint64_t* value, size_
 // ------------------------------------------------------------------------------------------------------------
 static psf_status psfp_init(psfp_handle* h, const psfp_params* prm);
 
+// The screen table of one s (psf_rng.hpp "table screen"): for every candidate index and every bin of delta = ceil(c) - c the 16-bit bounds between which an
+// attempt has to be settled exactly.  rho is monotone on either side of a = 0 and a = (idx - ceil(6 s) + delta) / s changes sign only at integers, so the
+// extremes over a bin are at its ends; the bins overlap by 1e-9 (the kernel's delta carries one rounding) and the floors get one unit of slack on either side.
+static bool build_sz_table(const SampleZParams& sp, std::vector<uint32_t>& T, uint32_t* F_out) {
+  if (sp.sh != 16 || sp.n_int < 2) return false;
+  uint32_t F = 64;
+  while (F >= 8 && (size_t)sp.n_int * F * sizeof(uint32_t) > 40 * 1024) F >>= 1;
+  if (F < 8) return false;
+  T.assign((size_t)sp.n_int * F, 0);
+  auto rs_at = [&](double idx, double delta) {
+    const double a = (idx - (double)sp.c6 + delta) * sp.inv_s;
+    return det_exp(-3.14159265358979323846 * (a * a)) * 65536.0;
+  };
+  for (uint32_t idx = 0; idx < sp.n_int; ++idx)
+    for (uint32_t b = 0; b < F; ++b) {
+      double d0 = (double)b / F - 1e-9, d1 = (double)(b + 1) / F + 1e-9;
+      if (d0 < 0.0) d0 = 0.0;
+      if (d1 > 1.0) d1 = 1.0;
+      const double r0 = rs_at((double)idx, d0), r1 = rs_at((double)idx, d1);
+      double lo = r0 < r1 ? r0 : r1, hi = r0 < r1 ? r1 : r0;
+      if ((double)idx - (double)sp.c6 + d0 <= 0.0 && (double)idx - (double)sp.c6 + d1 >= 0.0) hi = 65536.0;      // a = 0 inside the bin
+      long long A = (long long)std::floor(lo) - 1, R = (long long)std::floor(hi) + 1;
+      if (A < 0) A = 0;
+      if (R > 65535) R = 65535;
+      T[(size_t)idx * F + b] = ((uint32_t)R << 16) | (uint32_t)A;
+    }
+  *F_out = F;
+  return true;
+}
+
 psf_status psfp_create(const psfp_params* prm, psfp_handle** out) {
   if (!prm || !out) return PSF_ERR_PARAM;
   const psf_gadget_params& gp = prm->gp;
@@ -427,6 +471,15 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   }
   HIP_TRY(hipMalloc(&h->dA8, (size_t)h->NA * h->n_pad * h->K_pad));
   h->szR = make_sample_z_params(prm->r);
+  {
+    std::vector<uint32_t> T;
+    uint32_t F = 0;
+    if (!(prm->flags & PSFP_FLAG_NO_PERTURB) && build_sz_table(h->szR, T, &F)) {
+      HIP_TRY(hipMalloc(&h->dSzTab, T.size() * sizeof(uint32_t)));
+      HIP_TRY(hipMemcpy(h->dSzTab, T.data(), T.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      h->szF = F;
+    }
+  }
   h->szSR = make_sample_z_params(prm->s * prm->r);                    // mp_perturbation.rs:266
   HIP_TRY(hipMalloc(&h->dA, h->n * h->m * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dR, h->mb_pad * h->ldr));
@@ -530,7 +583,7 @@ void psfp_destroy(psfp_handle* h) {
   if (h->s1) hipStreamDestroy(h->s1);
   for (int i = 0; i < 2; ++i) { if (h->evT[i]) hipEventDestroy(h->evT[i]); if (h->evP[i]) hipEventDestroy(h->evP[i]); }
   if (h->evIn) hipEventDestroy(h->evIn);
-  hipFree(h->dA8);
+  hipFree(h->dA8); hipFree(h->dSzTab);
   hipFree(h->dRng);
   hipFree(h->dSk); hipFree(h->dGso); hipFree(h->dNorm2); hipFree(h->dSz); hipFree(h->dGvec);
   delete h;
@@ -893,13 +946,17 @@ psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
   if (h->prm.flags & PSFP_FLAG_NO_PERTURB) return PSF_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(h->prm.device));
   PSFP_QUIESCE(h);
+  KeygenClock kc("psfp");
   const psf_status rcg = gen_A_R(h, seed);
   if (rcg != PSF_OK) return rcg;
+  kc.mark("A, R");
   h->has_pub = h->has_R = true;
   const psf_status rc = build_sqrt_sigma2(h, h->prm.s);            // mp_perturbation.rs:227-231
   if (rc != PSF_OK) { h->has_key = false; return rc; }
+  kc.mark("sqrt(Sigma_2)");
   h->has_key = true;
   hp_prewarm(h);
+  kc.mark("prewarm (returns at once)");
   return PSF_OK;
 }
 
@@ -1168,6 +1225,14 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       if (h->szR.sh == 16 && !(renv && !std::strcmp(renv, "wave"))) {
         const uint32_t seg = prl_segment(m * Bh);
         const size_t waves = (m * Bh + seg - 1) / seg;
+        if (h->szF && !(renv && !std::strcmp(renv, "lean"))) {     // the table screen ("lean": the fp32 screen of rounds 3-4, comparison arm; same bits)
+          // a segment that is one row of the [coordinate][preimage] matrix never wraps: the sample's position is its offset (no division per sample)
+          uint32_t segt = seg;
+          if (Bh % 64 == 0 && Bh <= (size_t)PRL_SEG && (size_t)seg > Bh) segt = (uint32_t)Bh;
+          const size_t wavest = (m * Bh + segt - 1) / segt;
+          hipLaunchKernelGGL(k_perturb_round_tab, dim3((unsigned)((wavest + 3) / 4)), dim3(256), (size_t)h->szR.n_int * h->szF * sizeof(uint32_t), sx, seed, first_index + b0, m, Bh, ld,
+                             h->dX + b0, h->szR, h->dP + b0, h->dFail, segt, SzTable{h->dSzTab, h->szF, h->szR.n_int});
+        } else
         hipLaunchKernelGGL(k_perturb_round_lean, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, m, Bh, ld, h->dX + b0, h->szR, h->dP + b0, h->dFail, seg);
       } else {
         const size_t waves = (m * Bh + PR_SEG - 1) / PR_SEG;
