@@ -150,7 +150,15 @@ __global__ __launch_bounds__(256) void k_normals_wave(uint64_t seed, uint64_t fi
         const double u = (double)(((((uint64_t)w.y << 32) | w.x) >> 11) + 1) * 0x1.0p-53;
         const uint64_t vv = (((uint64_t)w.w << 32) | w.z) >> 12;
         const double x = (((double)(2 * vv + 1) * 0x1.0p-52 - 1.0) * 0.8577638849607068) / u;
-        accept = u <= det_exp(-0.25 * (x * x));
+        {
+          // fp32 screen of u <= exp(-x^2 / 4) (round 5): v_exp_f32 of the fp32-rounded argument is within 1e-5 relative of det_exp for x^2 / 4 <= 88, u converts with
+          // 6e-8; beyond, both sides of the comparison are decided by the flush to zero (u >= 2^-53).  Only the 2e-4 band around the threshold pays the f64 exponential.
+          const float xf = (float)x, uf = (float)u;
+          const float e32 = __builtin_amdgcn_exp2f(-0.36067376f * (xf * xf));
+          const bool sure = uf <= e32 * 0.9998f, never = uf > e32 * 1.0002f;
+          accept = sure;
+          if (!sure && !never) accept = u <= det_exp(-0.25 * (x * x));
+        }
         v = x;
         if (!accept && ++t >= kMaxAttempts) { accept = true; f = 1; v = 0.0; }
         if (accept && fx.planes && coord >= fx.split) {              // fixed-point coordinate of the structured factor
@@ -1467,6 +1475,12 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
   size_t myb = 0;
   double cen = 0.0;
   SampleZParams sp = s_sz[0];
+  // everything of an attempt group that depends on the problem's current step only is formed when a lane takes the problem (round 5): the Philox key words,
+  // the range in 32 bits and the fp32 offsets of the narrow screen (sz_group4_narrow) -- a group is then one Philox block and four screens
+  SzRange rg{0, 1, 0, 16};
+  uint32_t idx_lo = 0, tw = 0, coord = 0;
+  float c_rel = 0.f, inv_s_f = 0.f;
+  bool narrow = false;
 
   while (done < nprob) {
     // ---- idle lanes take READY problems
@@ -1486,6 +1500,21 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
           else { myj = pj0 + o / B32; myb = o % B32; }
           t = 0;
           has = true;
+          const uint64_t index = first_index + myb;
+          idx_lo = (uint32_t)index;
+          tw = tag_word(TAG_GADGET, index);
+          coord = myj * k + (uint32_t)mystep;
+          narrow = sp.sh == 16 && fabs(cen) < 0x1.0p30;
+          if (narrow) {
+            const double cc = ceil(cen);
+            const bool integral = cc == cen;
+            rg.lo = (long long)((int)cc - (int)sp.c6);
+            rg.N = integral ? sp.n_int : sp.n_int - 1;
+            rg.thr = integral ? sp.thr_int : sp.thr_frac;
+            rg.sh = 16;
+            c_rel = (float)((double)rg.lo - cen);
+            inv_s_f = (float)sp.inv_s;
+          } else rg = sz_range(cen, sp);
         }
       }
       rhead = (rhead + take) & (P - 1);
@@ -1495,11 +1524,8 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
     bool accept = false;
     long long x = 0;
     if (has) {
-      const uint64_t index = first_index + myb;
-      const uint32_t tw = tag_word(TAG_GADGET, index);
-      const uint32_t coord = myj * k + (uint32_t)mystep;
-      const SzRange rg = sz_range(cen, sp);
-      accept = sz_group4(seed, coord, (uint32_t)index, tw, t, rg, cen, sp.inv_s, &x);
+      accept = narrow ? sz_group4_narrow(seed, coord, idx_lo, tw, t, rg, cen, sp.inv_s, c_rel, inv_s_f, &x)
+                      : sz_group4(seed, coord, idx_lo, tw, t, rg, cen, sp.inv_s, &x);
       if (!accept && ++t >= kMaxAttempts / 4) { accept = true; f = 1; x = (long long)floor(cen + 0.5); }
     }
     {
