@@ -1033,11 +1033,13 @@ __device__ inline uint64_t zq_term(int32_t T, uint64_t pw, uint64_t q, uint64_t 
 // grid = (column tiles, row tiles, K splits).  A split covers at most 256 K-steps (16384 coordinates), so its int32 class
 // accumulators never overflow and are folded into a residue exactly once, after the loop; the per-split residues go to
 // `part[split][i][c]` and k_zq_combine adds them.  (Folding inside the K loop made hipcc spill accumulators to scratch.)
-template <int NA, bool FOLD128>
+// POW2 (round 5): q is a power of two that the NA digits of A cover (8 NA >= log2 q), so 256^c = 0 mod q for every class c >= NA and the digit pairs
+// that only feed those classes are not multiplied at all (q = 2^30: 9 of the 12 pairs) -- the same residues.
+template <int NA, bool FOLD128, bool POW2 = false>
 __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, size_t n_pad, size_t K_pad, const int8_t* __restrict__ P8, size_t ld,
                                                  int ks_per_split, ZqConsts zc, int wide, uint64_t* __restrict__ part, size_t col0) {
   constexpr int STAGE = (NA + 3) * 4096;
-  constexpr int NC = NA + 2;
+  constexpr int NC = POW2 ? NA : NA + 2;                 // live classes
   extern __shared__ __attribute__((aligned(16))) unsigned char zq_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1094,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, 
         for (int x = 0; x < 2; ++x)
 #pragma unroll
           for (int y = 0; y < 2; ++y)
-            acc[d + e][x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[d][x], fp[e][y], acc[d + e][x][y], 0, 0, 0);
+            if (d + e < NC) acc[d + e < NC ? d + e : 0][x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[d][x], fp[e][y], acc[d + e < NC ? d + e : 0][x][y], 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }

@@ -853,12 +853,14 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
   dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64), (unsigned)splits);
   int fold128 = zq_ks <= 32 ? 1 : 0;                                  // short splits (few preimages): one 128-bit fold per output; long ones: the per-class fold
   if (const char* e = std::getenv("PSF_ZQ_FOLD128")) fold128 = std::atoi(e);
+  // a power-of-two modulus covered by the digits of A: the classes from NA on vanish mod q (pw[NA] = 0) and their digit pairs are skipped (PSF_ZQ_POW2=0: multiplied anyway)
+  bool pow2 = (h->q & (h->q - 1)) == 0 && h->NA <= 8 && h->zc.pw[h->NA] == 0;
+  if (const char* e = std::getenv("PSF_ZQ_POW2")) pow2 = pow2 && std::atoi(e) != 0;
+#define ZQL(NA_, F_, P_) hipLaunchKernelGGL((k_zq_mfma<NA_, F_, P_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc, (int)h->wide, h->dPart, col0)
 #define ZQM(NA_)                                                                                                        \
   case NA_:                                                                                                             \
-    if (fold128) hipLaunchKernelGGL((k_zq_mfma<NA_, true>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc,  \
-                       (int)h->wide, h->dPart, col0);                                                                   \
-    else hipLaunchKernelGGL((k_zq_mfma<NA_, false>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc,  \
-                       (int)h->wide, h->dPart, col0);                                                                   \
+    if (fold128) { if (pow2) ZQL(NA_, true, true); else ZQL(NA_, true, false); }                                         \
+    else { if (pow2) ZQL(NA_, false, true); else ZQL(NA_, false, false); }                                               \
     break;
   switch (h->NA) { ZQM(1) ZQM(2) ZQM(3) ZQM(4) ZQM(5) ZQM(6) ZQM(7) ZQM(8) default: break; }
   if (splits >= 16 && h->n * ncols <= 16384)      // a single call: few outputs, many splits -- one wave per output
@@ -868,6 +870,7 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
     hipLaunchKernelGGL(k_zq_combine, dim3(grid_for(h->n * ncols, 256, 256 * 32)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols,
                        h->q, U, out, ldo, col0);
 #undef ZQM
+#undef ZQL
 }
 
 // A_bar <- U(Z_q^{n x m_bar}), R <- PlusMinusOneZero, A = [A_bar | G - A_bar R] (gen_trapdoor, gadget_classical.rs:56-68, tag = I)
