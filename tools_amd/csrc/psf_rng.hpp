@@ -262,19 +262,26 @@ __device__ inline bool sz_group4_narrow(uint64_t seed, uint32_t coord, uint32_t 
                                         double inv_s, float c_rel, float inv_s_f, long long* x_out) {
   const U4 w = philox(seed, coord, idx_lo, g, tw);
   const uint32_t word[4] = {w.x, w.y, w.z, w.w};
-  int tm = -1, cls = 0;
-  uint32_t idxm = 0;
+  // sz_screen16 with its two questions apart (round 5): "not certainly rejected" for the four attempts, "certainly accepted" once, for the first survivor
+  uint32_t prod[4];
+  float rho[4];
+  bool maybe[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    uint32_t idx = 0;
-    const int cj = sz_screen16(word[j], rg, c_rel, inv_s_f, &idx);
-    if (tm < 0 && cj) { tm = j; idxm = idx; cls = cj; }
+    prod[j] = __umul24(word[j] >> 16, rg.N);
+    const float a = ((float)(prod[j] >> 16) + c_rel) * inv_s_f;
+    rho[j] = __builtin_amdgcn_exp2f(-4.53236014f * (a * a));
+    maybe[j] = (prod[j] & 0xffffu) >= rg.thr && (float)(word[j] & 0xffffu) <= (rho[j] * 1.001f + 1e-9f) * 65536.0f;
   }
-  if (tm < 0) return false;
-  long long x = rg.lo + (long long)idxm;
+  if (!(maybe[0] || maybe[1] || maybe[2] || maybe[3])) return false;
+  const int tm = maybe[0] ? 0 : maybe[1] ? 1 : maybe[2] ? 2 : 3;
+  const float rm = maybe[0] ? rho[0] : maybe[1] ? rho[1] : maybe[2] ? rho[2] : rho[3];
+  const uint32_t pm = maybe[0] ? prod[0] : maybe[1] ? prod[1] : maybe[2] ? prod[2] : prod[3];
+  const uint32_t wm = maybe[0] ? word[0] : maybe[1] ? word[1] : maybe[2] ? word[2] : word[3];
+  long long x = rg.lo + (long long)(pm >> 16);
   *x_out = x;
-  if (cls == 1) return true;                       // the first surviving attempt is a certain accept: no f64 evaluation at all
-  const uint32_t wbm = word[tm] & 0xffffu;
+  const uint32_t wbm = wm & 0xffffu;
+  if ((float)wbm + 1.0f <= rm * 0.999f * 65536.0f) return true;      // certainly accepted: no f64 evaluation at all
   bool accept = sz_decide(seed, coord, idx_lo, tw, 4 * g + (uint32_t)tm, x, wbm, center, inv_s, 16);
   if (!accept) {
 #pragma unroll
@@ -295,34 +302,29 @@ __device__ inline bool sz_group4_narrow(uint64_t seed, uint32_t coord, uint32_t 
 // those of the exact sampler.  The fp32 screen it replaces spends ~14 more vector instructions per attempt on conversions, the exponential and margins.
 struct SzTable { const uint32_t* t; uint32_t F; uint32_t rows; };      // t[idx * F + bin], rows = n_int, F a power of two
 #if defined(__HIPCC__)
-__device__ inline int sz_screen16_tab(uint32_t word, const SzRange rg, const uint32_t* __restrict__ tab_bin /* LDS: table + bin */, uint32_t F, uint32_t* idx_out) {
-  const uint32_t prod = __umul24(word >> 16, rg.N);
-  const bool valid = (prod & 0xffffu) >= rg.thr;
-  const uint32_t idx = prod >> 16;
-  const uint32_t T = tab_bin[__umul24(idx, F)];
-  const uint32_t wb = word & 0xffffu;
-  const bool sure = wb < (T & 0xffffu);
-  const bool maybe = wb <= (T >> 16);
-  *idx_out = idx;
-  return (valid && maybe) ? (sure ? 1 : 2) : 0;
-}
+// (the class of the FIRST surviving attempt is all a group needs: "maybe" is evaluated for the four attempts, "sure" once, for the one selected)
 __device__ inline bool sz_group4_tab(uint64_t seed, uint32_t coord, uint32_t idx_lo, uint32_t tw, uint32_t g, const SzRange rg, double center,
-                                     double inv_s, const uint32_t* __restrict__ tab_bin, uint32_t F, long long* x_out) {
+                                     double inv_s, const uint32_t* __restrict__ tab_bin /* LDS: table + bin */, uint32_t F, long long* x_out) {
   const U4 w = philox(seed, coord, idx_lo, g, tw);
   const uint32_t word[4] = {w.x, w.y, w.z, w.w};
-  int tm = -1, cls = 0;
-  uint32_t idxm = 0;
+  uint32_t T[4], prod[4];
+  bool maybe[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    uint32_t idx = 0;
-    const int cj = sz_screen16_tab(word[j], rg, tab_bin, F, &idx);
-    if (tm < 0 && cj) { tm = j; idxm = idx; cls = cj; }
+    prod[j] = __umul24(word[j] >> 16, rg.N);
+    T[j] = tab_bin[__umul24(prod[j] >> 16, F)];
   }
-  if (tm < 0) return false;
-  long long x = rg.lo + (long long)idxm;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) maybe[j] = (prod[j] & 0xffffu) >= rg.thr && (word[j] & 0xffffu) <= (T[j] >> 16);      // Lemire: void below the threshold; not certainly rejected
+  if (!(maybe[0] || maybe[1] || maybe[2] || maybe[3])) return false;
+  const int tm = maybe[0] ? 0 : maybe[1] ? 1 : maybe[2] ? 2 : 3;
+  const uint32_t Tm = maybe[0] ? T[0] : maybe[1] ? T[1] : maybe[2] ? T[2] : T[3];
+  const uint32_t pm = maybe[0] ? prod[0] : maybe[1] ? prod[1] : maybe[2] ? prod[2] : prod[3];
+  const uint32_t wm = maybe[0] ? word[0] : maybe[1] ? word[1] : maybe[2] ? word[2] : word[3];
+  long long x = rg.lo + (long long)(pm >> 16);
   *x_out = x;
-  if (cls == 1) return true;
-  const uint32_t wbm = word[tm] & 0xffffu;
+  const uint32_t wbm = wm & 0xffffu;
+  if (wbm < (Tm & 0xffffu)) return true;            // certainly accepted: no f64 evaluation at all
   bool accept = sz_decide(seed, coord, idx_lo, tw, 4 * g + (uint32_t)tm, x, wbm, center, inv_s, 16);
   if (!accept) {
 #pragma unroll
