@@ -1387,7 +1387,8 @@ struct GadgetTablesQ {
 };
 constexpr int GQ_WAVES = 4;
 
-// slots per wave (a power of two).  256 measured slower at k = 30 (LDS limits occupancy); 64 at k = 60 (two workgroups per CU
+// slots per wave (a power of two).  256 measured slower at k = 30 (LDS limits occupancy), 64 and 32 at k = 30 too (round 5: 3.54 / 6.20 ms against 2.49 at C3: the
+// READY / PENDING rings need the depth); 64 at k = 60 (two workgroups per CU
 // instead of one) measured 0.155 ns per draw against 0.124 with 128
 __host__ __device__ inline int gq_problems_per_wave(uint32_t k) { (void)k; return 128; }
 // Few problems in all (a single call: n of them, one preimage): a problem is a chain of k dependent draws, so the launch lasts as long as one chain
