@@ -38,6 +38,9 @@ COPY = {
     "midsize.log": "r05_midsize.log", "traffic_c3.json": "r05_traffic_c3.json", "traffic_c2.json": "r05_traffic_c2.json", "traffic_c4.json": "r05_traffic_c4.json",
     "traffic_single_b16.json": "r05_traffic_single_b16.json", "host_path.log": "r05_host_path.log", "host_path_gpv.log": "r05_host_path_gpv.log",
     "host_async_stress_gpv.log": "r05_host_async_stress_gpv.log", "ring_fa.log": "r05_ring_fa.log", "probe_ldsdma_l2.log": "r05_probe_ldsdma_l2.log", "keygen.log": "r05_keygen.log",
+    "keygen_phases.log": "r05_keygen_phases.log", "keygen_timeline_c3.txt": "r05_keygen_timeline_c3.txt", "keygen_timeline_c2.txt": "r05_keygen_timeline_c2.txt",
+    "bench_c3_round4_stages.json": "r05_bench_c3_round4_stages.json", "bench_c2_combine_per_pair.json": "r05_bench_c2_combine_per_pair.json",
+    "bench_c4_combine_per_pair.json": "r05_bench_c4_combine_per_pair.json",
 }
 for cfg in ("c3", "c2", "c4"):
     r = last_json(os.path.join(SRC, f"rocprof_{cfg}.log"), "metric")

@@ -13,6 +13,10 @@ if has bench; then
   done
   PSF_NP_WALK=0 timeout 600 python3 bench.py --config c2 --no-cpu-baseline --no-latency > $O/bench_c2_launch_per_block.log 2>&1; tail -1 $O/bench_c2_launch_per_block.log > $O/bench_c2_launch_per_block.json
   PSF_NP_WALK=3 timeout 600 python3 bench.py --config c4 --no-cpu-baseline --no-latency > $O/bench_c4_walk2.log 2>&1; tail -1 $O/bench_c4_walk2.log > $O/bench_c4_walk2.json
+  # comparison arms in the same box: the samplers / syndrome product of round 4 (fp32 screen, every digit pair), one recombination launch per digit pair
+  PSF_ROUND=lean PSF_ZQ_POW2=0 timeout 600 python3 bench.py --config c3 --no-cpu-baseline --no-latency > $O/bench_c3_round4_stages.log 2>&1; tail -1 $O/bench_c3_round4_stages.log > $O/bench_c3_round4_stages.json
+  PSF_NP_COMBINE=0 timeout 600 python3 bench.py --config c2 --no-cpu-baseline --no-latency > $O/bench_c2_combine_per_pair.log 2>&1; tail -1 $O/bench_c2_combine_per_pair.log > $O/bench_c2_combine_per_pair.json
+  PSF_NP_COMBINE=0 timeout 600 python3 bench.py --config c4 --no-cpu-baseline --no-latency > $O/bench_c4_combine_per_pair.log 2>&1; tail -1 $O/bench_c4_combine_per_pair.log > $O/bench_c4_combine_per_pair.json
   timeout 300 python3 bench.py --config c3 --structured > $O/bench_c3s.log 2>&1; tail -1 $O/bench_c3s.log > $O/bench_c3_structured.json
   timeout 900 python3 bench.py --config c5 --steps 2 --warmup 1 > $O/bench_c5.log 2>&1; tail -1 $O/bench_c5.log > $O/bench_c5_one_gpu.json
 fi
@@ -48,5 +52,8 @@ if has misc; then
   timeout 300 python3 tools/time_ring_fa.py > $O/ring_fa.log 2>&1; PSF_RING_FA=matmul timeout 300 python3 tools/time_ring_fa.py >> $O/ring_fa.log 2>&1
   timeout 300 tools/bin/probe_ldsdma_l2 > $O/probe_ldsdma_l2.log 2>&1
   timeout 600 python3 tools/keygen_time.py c3 c2 c4 > $O/keygen.log 2>&1
+  PSF_KEYGEN_TIMING=1 timeout 600 python3 tools/keygen_time.py c3 c2 c4 > $O/keygen_phases.log 2>&1
+  bash tools/keygen_timeline.sh c3 r5final > /dev/null 2>&1; cp gpurun_out/r5final_keygen_timeline_c3.txt $O/keygen_timeline_c3.txt 2>/dev/null
+  bash tools/keygen_timeline.sh c2 r5final > /dev/null 2>&1; cp gpurun_out/r5final_keygen_timeline_c2.txt $O/keygen_timeline_c2.txt 2>/dev/null
 fi
 ls -la $O | tail -40; tail -1 $O/bench_c3.json 2>/dev/null | cut -c1-600
