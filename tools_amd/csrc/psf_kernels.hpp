@@ -734,18 +734,16 @@ __global__ __launch_bounds__(256) void k_perturb_round_lean(uint64_t seed, uint6
 }
 
 // k_perturb_round_lean with the table screen of psf_rng.hpp (sz_screen16_tab) in place of the fp32 screen: same attempts, same exact decisions, same values.
-// PRT_WAVES = waves per workgroup: the 28 KB table is per workgroup, so eight waves share it in full batches (3 workgroups = 24 wave slots per CU by LDS, 20 by registers); four in small launches
-template <int PRT_WAVES>
-__global__ __launch_bounds__(64 * PRT_WAVES) void k_perturb_round_tab(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
+__global__ __launch_bounds__(256) void k_perturb_round_tab(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
                                                             const double* __restrict__ X, SampleZParams sp, int32_t* __restrict__ P,
                                                             int* __restrict__ fail, uint32_t seg, SzTable tb) {
-  __shared__ double s_win[PRT_WAVES][PRL_WIN];
+  __shared__ double s_win[4][PRL_WIN];
   extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];      // the screen table of this s: rows x F words
   const int lane = threadIdx.x & 63;
   double* win = s_win[threadIdx.x >> 6];
   const size_t total = m * B;
-  const size_t seg0 = ((size_t)blockIdx.x * PRT_WAVES + (threadIdx.x >> 6)) * seg;
-  for (uint32_t e = threadIdx.x; e < tb.rows * tb.F; e += 64 * PRT_WAVES) s_tab[e] = tb.t[e];
+  const size_t seg0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * seg;
+  for (uint32_t e = threadIdx.x; e < tb.rows * tb.F; e += 256) s_tab[e] = tb.t[e];
   __syncthreads();
   if (seg0 >= total) return;                                   // (no workgroup barrier below: a wave may leave alone)
   const uint32_t nseg = (uint32_t)(total - seg0 < (size_t)seg ? total - seg0 : (size_t)seg);
@@ -1400,31 +1398,17 @@ __host__ inline int gq_problems_for(uint32_t k, size_t total) {
   while (P > 1 && total / (size_t)P < 2048) P >>= 1;
   return P;
 }
-__host__ inline size_t gadget_queue_lds_bytes(size_t k, int problems = 0, int waves = GQ_WAVES) {
+__host__ inline size_t gadget_queue_lds_bytes(size_t k, int problems = 0) {
   const size_t P = (size_t)(problems > 0 ? problems : gq_problems_per_wave((uint32_t)k));
   const size_t tables = k * k * 8 + k * 8 + k * sizeof(SampleZParams) + 4 * k * 4 + k * k * 2;
-  const size_t per_wave = (k * P * 2 + P * 8 + P * 4 + P * 2 + P * 2 + P * 2 + 7) & ~(size_t)7;      // c | centre | z | ready | pending | step (int8, padded to P * 2)
-  return tables + (size_t)waves * per_wave + 64;
-}
-// waves per workgroup (round 5): the kernel is bound by the LDS round trips of its queues, so what counts is how many waves a CU holds -- the tables are per workgroup,
-// the queues per wave: 4 waves x 3 workgroups at k = 30 (12 waves per CU), 7 x 2 (14) fit as well.  The count that maximises resident waves (160 KB of LDS, at most 8 per
-// workgroup, at most 16 per CU by registers), ties to the smaller workgroup.
-__host__ inline int gq_waves_for(size_t k, int problems) {
-  int best = GQ_WAVES; size_t best_res = 0;
-  for (int w = 2; w <= 8; ++w) {
-    const size_t b = gadget_queue_lds_bytes(k, problems, w);
-    if (b > 160 * 1024) break;
-    size_t res = (160 * 1024 / b) * (size_t)w;
-    if (res > 16) res = 16;
-    if (res > best_res) { best_res = res; best = w; }
-  }
-  return best;
+  const size_t per_wave = k * P * 2 + P * 8 + P * 4 + P * 4 + P * 2 + P * 2;
+  return tables + GQ_WAVES * per_wave + 64;
 }
 
 // FIXED: 128 problems per wave as a compile-time constant (full batches: the ring masks and strides fold; a run-time P cost 4 % there);
 // otherwise Prt (a power of two below 128) for mid-size batches, see gq_problems_for
 template <bool FIXED>
-__global__ __launch_bounds__(512) void k_gadget_queue(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q,
+__global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q,
                                                       uint64_t base, size_t B, size_t ld, const uint64_t* __restrict__ V,
                                                       GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
                                                       int* __restrict__ fail, int Prt) {
@@ -1438,23 +1422,22 @@ __global__ __launch_bounds__(512) void k_gadget_queue(uint64_t seed, uint64_t fi
   unsigned char* wave_base = reinterpret_cast<unsigned char*>(s_Sk + (size_t)k * k);
   wave_base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(wave_base) + 7) & ~(uintptr_t)7);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const size_t per_wave = ((size_t)k * P * 2 + (size_t)P * 8 + P * 4 + P * 2 + P * 2 + P * 2 + 7) & ~(size_t)7;
+  const size_t per_wave = (size_t)k * P * 2 + (size_t)P * 8 + P * 4 + P * 4 + P * 2 + P * 2;
   unsigned char* wb = wave_base + (size_t)wave * per_wave;
   double* s_cen = reinterpret_cast<double*>(wb);                           // P
   int32_t* s_z = reinterpret_cast<int32_t*>(s_cen + P);                    // P
-  uint16_t* s_ready = reinterpret_cast<uint16_t*>(s_z + P);                // P (ring)
+  int32_t* s_step = s_z + P;                                               // P
+  uint16_t* s_ready = reinterpret_cast<uint16_t*>(s_step + P);             // P (ring)
   uint16_t* s_pend = s_ready + P;                                          // P (ring)
-  int8_t* s_step = reinterpret_cast<int8_t*>(s_pend + P);                  // P (k <= 64), padded to 2 P bytes
-  int16_t* s_c = reinterpret_cast<int16_t*>(s_step + 2 * P);               // k * P, [row][problem]
-  const uint32_t nthr = blockDim.x;                                         // 64 x (waves per workgroup), chosen by the host (gq_waves_for)
+  int16_t* s_c = reinterpret_cast<int16_t*>(s_pend + P);                   // k * P, [row][problem]
 
-  for (uint32_t e = tid; e < k * k; e += nthr) { s_gso[e] = tb.gso[e]; s_Sk[e] = (int16_t)tb.Sk[e]; }
-  for (uint32_t e = tid; e < k; e += nthr) { s_norm2[e] = tb.norm2[e]; s_sz[e] = tb.sz[e]; }
-  for (uint32_t e = tid; e < 4 * k; e += nthr) s_rng[e] = tb.rng[e];
+  for (uint32_t e = tid; e < k * k; e += 256) { s_gso[e] = tb.gso[e]; s_Sk[e] = (int16_t)tb.Sk[e]; }
+  for (uint32_t e = tid; e < k; e += 256) { s_norm2[e] = tb.norm2[e]; s_sz[e] = tb.sz[e]; }
+  for (uint32_t e = tid; e < 4 * k; e += 256) s_rng[e] = tb.rng[e];
   __syncthreads();
 
   const size_t total = (size_t)n * B;
-  const size_t seg0 = ((size_t)blockIdx.x * (nthr >> 6) + wave) * (size_t)P;
+  const size_t seg0 = ((size_t)blockIdx.x * GQ_WAVES + wave) * (size_t)P;
   if (seg0 >= total) return;
   const int nprob = (int)(total - seg0 < (size_t)P ? total - seg0 : (size_t)P);
   int f = 0, anyhi = 0;
@@ -1479,7 +1462,7 @@ __global__ __launch_bounds__(512) void k_gadget_queue(uint64_t seed, uint64_t fi
       else { d = v % base; v = (v - d) / base; }
       s_c[r * P + p] = (int16_t)(-(int)d);
     }
-    s_step[p] = (int8_t)((int)k - 1);
+    s_step[p] = (int)k - 1;
     s_cen[p] = centre(p, (int)k - 1);
     s_ready[p] = (uint16_t)p;
   }
@@ -1579,7 +1562,7 @@ __global__ __launch_bounds__(512) void k_gadget_queue(uint64_t seed, uint64_t fi
           s_c[r * P + p] = (int16_t)nv;
         }
         --i;
-        s_step[p] = (int8_t)i;
+        s_step[p] = i;
         if (i >= 0) {
           s_cen[p] = centre(p, i);
           to_ready = true;

@@ -546,8 +546,8 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rd2_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (1 + kFixPlanes) * 4096));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k, 0, 8) <= 160 * 1024 ? (int)gadget_queue_lds_bytes(h->k, 0, 8) : 160 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k, 0, 8) <= 160 * 1024 ? (int)gadget_queue_lds_bytes(h->k, 0, 8) : 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   if (const char* env = std::getenv("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
   for (int64_t v : h->hSk) if (v > 32767 || v < -32768) h->gadget_queue = false;      // the queue kernel keeps S_k in int16
   return PSF_OK;
@@ -1233,14 +1233,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
           uint32_t segt = seg;
           if (Bh % 64 == 0 && Bh >= 1024 && Bh <= (size_t)PRL_SEG && (size_t)seg > Bh) segt = (uint32_t)Bh;      // (short rows: every workgroup loads the table, 0.14 against 0.09 ms at 64 preimages)
           const size_t wavest = (m * Bh + segt - 1) / segt;
-          int prw = wavest >= 8192 ? 8 : 4;
-          if (const char* e = std::getenv("PSF_ROUND_WAVES")) prw = std::atoi(e) == 8 ? 8 : 4;
-          if (prw == 8)
-            hipLaunchKernelGGL(k_perturb_round_tab<8>, dim3((unsigned)((wavest + 7) / 8)), dim3(512), (size_t)h->szR.n_int * h->szF * sizeof(uint32_t), sx, seed, first_index + b0, m, Bh, ld,
-                               h->dX + b0, h->szR, h->dP + b0, h->dFail, segt, SzTable{h->dSzTab, h->szF, h->szR.n_int});
-          else
-            hipLaunchKernelGGL(k_perturb_round_tab<4>, dim3((unsigned)((wavest + 3) / 4)), dim3(256), (size_t)h->szR.n_int * h->szF * sizeof(uint32_t), sx, seed, first_index + b0, m, Bh, ld,
-                               h->dX + b0, h->szR, h->dP + b0, h->dFail, segt, SzTable{h->dSzTab, h->szF, h->szR.n_int});
+          hipLaunchKernelGGL(k_perturb_round_tab, dim3((unsigned)((wavest + 3) / 4)), dim3(256), (size_t)h->szR.n_int * h->szF * sizeof(uint32_t), sx, seed, first_index + b0, m, Bh, ld,
+                             h->dX + b0, h->szR, h->dP + b0, h->dFail, segt, SzTable{h->dSzTab, h->szF, h->szR.n_int});
         } else
         hipLaunchKernelGGL(k_perturb_round_lean, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, m, Bh, ld, h->dX + b0, h->szR, h->dP + b0, h->dFail, seg);
       } else {
@@ -1270,14 +1264,12 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       } else if (h->gadget_queue) {
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         const int P = gq_problems_for((uint32_t)h->k, h->n * Bh);
-        int W = gq_waves_for(h->k, P);
-        if (const char* e = std::getenv("PSF_GQ_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 8 && gadget_queue_lds_bytes(h->k, P, v) <= 160 * 1024) W = v; }
-        const size_t per_wg = (size_t)W * P;
+        const size_t per_wg = (size_t)GQ_WAVES * P;
         if (P == 128)
-          hipLaunchKernelGGL(k_gadget_queue<true>, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(64 * W), gadget_queue_lds_bytes(h->k, P, W), sx, seed,
+          hipLaunchKernelGGL(k_gadget_queue<true>, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k, P), sx, seed,
                              first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail, P);
         else
-          hipLaunchKernelGGL(k_gadget_queue<false>, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(64 * W), gadget_queue_lds_bytes(h->k, P, W), sx, seed,
+          hipLaunchKernelGGL(k_gadget_queue<false>, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k, P), sx, seed,
                              first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q, h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail, P);
       } else {
         GadgetTables tb{h->dSk, h->dGso, h->dNorm2, h->dSz};
