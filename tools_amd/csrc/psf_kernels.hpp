@@ -988,7 +988,7 @@ __global__ void k_split_A(const uint64_t* __restrict__ A, size_t lda, size_t n, 
 __global__ void k_split_P(const int32_t* __restrict__ P, size_t K, size_t ld, size_t ngroups, int8_t* __restrict__ P8, int* __restrict__ fail, size_t col0, size_t cw) {
   const size_t total = ngroups * cw;
   const size_t plane = ngroups * ld * 16;
-  int f = 0;
+  int f = 0, hi2 = 0;
   for (size_t g0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < total; g0 += (size_t)gridDim.x * blockDim.x) {
     const size_t kg = g0 / cw, b = col0 + g0 % cw;
     const size_t g = kg * ld + b;
@@ -1003,6 +1003,7 @@ __global__ void k_split_P(const int32_t* __restrict__ P, size_t K, size_t ld, si
       const int32_t e1 = (int32_t)(int8_t)(p1 & 0xff);
       const int32_t e2 = (p1 - e1) >> 8;
       if (e2 > 127 || e2 < -128) f = 1;
+      if (e2) hi2 = 1;
       w0[j >> 2] |= (e0 & 0xff) << (8 * (j & 3));
       w1[j >> 2] |= (e1 & 0xff) << (8 * (j & 3));
       w2[j >> 2] |= (e2 & 0xff) << (8 * (j & 3));
@@ -1013,6 +1014,8 @@ __global__ void k_split_P(const int32_t* __restrict__ P, size_t K, size_t ld, si
     *reinterpret_cast<v4i*>(P8 + 2 * plane + g * 16) = o2;
   }
   if (f) atomicOr(fail, 1);
+  // fail[2]: the third digit plane holds something (|p| >= 2^15 somewhere): k_zq_mfma multiplies it only then.  Sticky within a call (cleared with the failure words).
+  if (__syncthreads_or(hi2) && threadIdx.x == 0 && __hip_atomic_load(fail + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(fail + 2, 1);
 }
 
 struct ZqConsts { uint64_t q, two64; uint64_t pw[12]; };   // pw[c] = 256^c mod q
@@ -1037,7 +1040,7 @@ __device__ inline uint64_t zq_term(int32_t T, uint64_t pw, uint64_t q, uint64_t 
 // that only feed those classes are not multiplied at all (q = 2^30: 9 of the 12 pairs) -- the same residues.
 template <int NA, bool FOLD128, bool POW2 = false>
 __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, size_t n_pad, size_t K_pad, const int8_t* __restrict__ P8, size_t ld,
-                                                 int ks_per_split, ZqConsts zc, int wide, uint64_t* __restrict__ part, size_t col0) {
+                                                 int ks_per_split, ZqConsts zc, int wide, uint64_t* __restrict__ part, size_t col0, const int* __restrict__ flags) {
   constexpr int STAGE = (NA + 3) * 4096;
   constexpr int NC = POW2 ? NA : NA + 2;                 // live classes
   extern __shared__ __attribute__((aligned(16))) unsigned char zq_smem[];
@@ -1060,46 +1063,53 @@ __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, 
   const int pA = wave * 64 + lane;   // 16-byte piece of a 4 KiB tile
   const int8_t* srcA = A8 + (size_t)blockIdx.y * (K_pad / 64) * 4096 + (size_t)pA * 16;   // tile-packed planes, see k_split_A
   const int8_t* srcP = P8 + ((size_t)(pA >> 6) * ld + b0 + (size_t)(pA & 63)) * 16;
-  auto stage_load = [&](int ks, int buf) {
-    unsigned char* base = zq_smem + buf * STAGE + wave * 1024;
+  // the K loop, for NP = 3 digit planes of p or -- when k_split_P found the third one empty (flags[2] == 0: |p| < 2^15 everywhere, the usual case) -- for two
+  auto k_loop = [&](auto np_tag) {
+    constexpr int NP = decltype(np_tag)::value;
+    auto stage_load = [&](int ks, int buf) {
+      unsigned char* base = zq_smem + buf * STAGE + wave * 1024;
 #pragma unroll
-    for (int d = 0; d < NA; ++d)
-      __builtin_amdgcn_global_load_lds(srcA + (size_t)d * planeA + (size_t)ks * 4096, (lds_void_ptr)(base + d * 4096), 16, 0, 0);
+      for (int d = 0; d < NA; ++d)
+        __builtin_amdgcn_global_load_lds(srcA + (size_t)d * planeA + (size_t)ks * 4096, (lds_void_ptr)(base + d * 4096), 16, 0, 0);
 #pragma unroll
-    for (int e = 0; e < 3; ++e)
-      __builtin_amdgcn_global_load_lds(srcP + (size_t)e * planeP + (size_t)ks * 4 * ld * 16, (lds_void_ptr)(base + (NA + e) * 4096), 16, 0, 0);
+      for (int e = 0; e < NP; ++e)
+        __builtin_amdgcn_global_load_lds(srcP + (size_t)e * planeP + (size_t)ks * 4 * ld * 16, (lds_void_ptr)(base + (NA + e) * 4096), 16, 0, 0);
+    };
+    if (ks0 < ks1) {
+      stage_load(ks0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const int r16 = lane & 15, g = lane >> 4;
+    for (int ks = ks0; ks < ks1; ++ks) {
+      const int cur = (ks - ks0) & 1;
+      if (ks + 1 < ks1) stage_load(ks + 1, cur ^ 1);
+      const unsigned char* sb = zq_smem + cur * STAGE;
+      v4i fa[NA][2], fp[NP][2];
+#pragma unroll
+      for (int d = 0; d < NA; ++d)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) fa[d][x] = *reinterpret_cast<const v4i*>(sb + d * 4096 + ((wr * 32 + x * 16 + r16) * 64 + i8_slot(wr * 32 + x * 16 + r16, g) * 16));
+#pragma unroll
+      for (int e = 0; e < NP; ++e)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) fp[e][y] = *reinterpret_cast<const v4i*>(sb + (NA + e) * 4096 + ((g * 64 + wc * 32 + y * 16 + r16) * 16));
+#pragma unroll
+      for (int d = 0; d < NA; ++d)
+#pragma unroll
+        for (int e = 0; e < NP; ++e)
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+              if (d + e < NC) acc[d + e < NC ? d + e : 0][x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[d][x], fp[e][y], acc[d + e < NC ? d + e : 0][x][y], 0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   };
-  if (ks0 < ks1) {
-    stage_load(ks0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
+  if (flags[2] != 0) k_loop(std::integral_constant<int, 3>{});
+  else k_loop(std::integral_constant<int, 2>{});
   const int r16 = lane & 15, g = lane >> 4;
-  for (int ks = ks0; ks < ks1; ++ks) {
-    const int cur = (ks - ks0) & 1;
-    if (ks + 1 < ks1) stage_load(ks + 1, cur ^ 1);
-    const unsigned char* sb = zq_smem + cur * STAGE;
-    v4i fa[NA][2], fp[3][2];
-#pragma unroll
-    for (int d = 0; d < NA; ++d)
-#pragma unroll
-      for (int x = 0; x < 2; ++x) fa[d][x] = *reinterpret_cast<const v4i*>(sb + d * 4096 + ((wr * 32 + x * 16 + r16) * 64 + i8_slot(wr * 32 + x * 16 + r16, g) * 16));
-#pragma unroll
-    for (int e = 0; e < 3; ++e)
-#pragma unroll
-      for (int y = 0; y < 2; ++y) fp[e][y] = *reinterpret_cast<const v4i*>(sb + (NA + e) * 4096 + ((g * 64 + wc * 32 + y * 16 + r16) * 16));
-#pragma unroll
-    for (int d = 0; d < NA; ++d)
-#pragma unroll
-      for (int e = 0; e < 3; ++e)
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y)
-            if (d + e < NC) acc[d + e < NC ? d + e : 0][x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[d][x], fp[e][y], acc[d + e < NC ? d + e : 0][x][y], 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
   // fold the classes: residue = sum_c (T_c mod q) 256^c mod q.  C/D map: column (preimage) = lane & 15, row (i) = 4 * (lane >> 4) + reg
   uint64_t* dst = part + (size_t)blockIdx.z * n_pad * ld;
 #pragma unroll

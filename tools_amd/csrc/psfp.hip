@@ -487,8 +487,8 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dLt, (tr_total_chunks(h->nbiL) * TR_CHUNK + TS_SLACK_DOUBLES) * sizeof(double)));
   if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dR8, h->mb_pad * h->ldr));      // tile-packed copy of R: k_recombine_mfma_big, k_rd2_mfma
   for (auto& t : h->sets) {                             // [0] sampler failure, [1] some |z| > 127
-    HIP_TRY(hipMalloc(&t.dFail, 2 * sizeof(int)));
-    HIP_TRY(hipMemset(t.dFail, 0, 2 * sizeof(int)));
+    HIP_TRY(hipMalloc(&t.dFail, 4 * sizeof(int)));
+    HIP_TRY(hipMemset(t.dFail, 0, 4 * sizeof(int)));
   }
   h->dFail = h->sets[0].dFail;
   {  // the FP64 product gets the high-priority queue, the sampling stages the low one
@@ -848,6 +848,10 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
   size_t cw = round_up(ncols, 64);                                    // the product works on 64-column tiles
   if (col0 + cw > ld) cw = ld - col0;
   hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * cw, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, P8, h->dFail, col0, cw);
+  {  // PSF_ZQ_PLANES3=1: the third digit plane of p is multiplied whether or not it holds anything (comparison arm; same residues)
+    static const bool force3 = [] { const char* e = std::getenv("PSF_ZQ_PLANES3"); return e && std::atoi(e) != 0; }();
+    if (force3) hipMemsetAsync(h->dFail + 2, 1, sizeof(int), st);
+  }
   const int nks = (int)(h->K_pad / 64);
   const int splits = zq_plan(h, ncols, h->zq_split_cap), zq_ks = (nks + splits - 1) / splits;
   dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64), (unsigned)splits);
@@ -856,7 +860,7 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
   // a power-of-two modulus covered by the digits of A: the classes from NA on vanish mod q (pw[NA] = 0) and their digit pairs are skipped (PSF_ZQ_POW2=0: multiplied anyway)
   bool pow2 = (h->q & (h->q - 1)) == 0 && h->NA <= 8 && h->zc.pw[h->NA] == 0;
   if (const char* e = std::getenv("PSF_ZQ_POW2")) pow2 = pow2 && std::atoi(e) != 0;
-#define ZQL(NA_, F_, P_) hipLaunchKernelGGL((k_zq_mfma<NA_, F_, P_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc, (int)h->wide, h->dPart, col0)
+#define ZQL(NA_, F_, P_) hipLaunchKernelGGL((k_zq_mfma<NA_, F_, P_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc, (int)h->wide, h->dPart, col0, h->dFail)
 #define ZQM(NA_)                                                                                                        \
   case NA_:                                                                                                             \
     if (fold128) { if (pow2) ZQL(NA_, true, true); else ZQL(NA_, true, false); }                                         \
@@ -1118,7 +1122,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     st = h->s1;
     s2 = h->aux;
   }
-  if (!h->keep_fail) hipMemsetAsync(h->dFail, 0, 2 * sizeof(int), st);
+  if (!h->keep_fail) hipMemsetAsync(h->dFail, 0, 4 * sizeof(int), st);      // [0] sampler failure, [1] some |z| > 127, [2] some |p| >= 2^15 (third digit plane of the syndrome product in use)
   psf_status gate_rc = PSF_OK;
   auto u_gate = [&]() { if (h->before_u) { auto f = std::move(h->before_u); h->before_u = nullptr; gate_rc = f(); } };
   {  // small parameter sets, few preimages (the reference's own benchmarks: n = 8, one call; benches/psf.rs:51-66): the whole call in ONE launch, one
@@ -1438,7 +1442,7 @@ static void widen_rows(int64_t* __restrict__ dst, const int32_t* __restrict__ sr
 
 // The flags of an asynchronous call: cleared and sent to pinned host memory by one-wave kernels in stream order.  (hipMemsetAsync / hipMemcpyAsync on the
 // compute stream go through the runtime's copy path, where they queue behind the chunk copies of the call before: the next call's kernels then waited for them.)
-__global__ void k_host_flags_clear(int* __restrict__ fail, int* __restrict__ ovf) { if (threadIdx.x < 2) { fail[threadIdx.x] = 0; ovf[threadIdx.x] = 0; } }
+__global__ void k_host_flags_clear(int* __restrict__ fail, int* __restrict__ ovf) { if (threadIdx.x < 4) fail[threadIdx.x] = 0; if (threadIdx.x < 2) ovf[threadIdx.x] = 0; }
 // extra: the eight flag words of a PSFGPV / PSFGPVRing call (psfgpv_impl.hpp: [0] and [4] = a sampler failure of the first / second pass), or nullptr
 __global__ void k_host_flags_send(const int* __restrict__ fail, const int* __restrict__ ovf, const int* __restrict__ extra, int* __restrict__ host_flags) {
   if (threadIdx.x == 0) {
