@@ -16,7 +16,7 @@ for f in glob.glob('gpurun_out/pmc_sq/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('psf::', '')
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
-want = ['k_trmm_f64_big', 'k_perturb_round_lean', 'k_perturb_round_wave', 'k_gadget_queue', 'k_normals_wave', 'k_recombine_mfma', 'k_zq_mfma<4>']
+want = ['k_trmm_f64_big', 'k_perturb_round_tab', 'k_perturb_round_lean', 'k_perturb_round_wave', 'k_gadget_queue', 'k_normals_wave', 'k_recombine_mfma', 'k_zq_mfma<4>', 'k_gadget_queue<true>', 'k_zq_mfma<4, false, true>']
 for k in want:
     if k not in agg: continue
     c = {n: sum(v) / len(v) for n, v in agg[k].items()}

@@ -1576,21 +1576,9 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
         if (i >= 0) {
           s_cen[p] = centre(p, i);
           to_ready = true;
-        } else {
-          const size_t pid = seg0 + p;
-          const uint32_t j = (uint32_t)(pid / B);
-          const size_t b = pid % B;
-          for (uint32_t r = 0; r < k; ++r) {
-            const int32_t zz = -(int32_t)s_c[r * P + p];
-            const int32_t zl = (int32_t)(int8_t)(zz & 0xff);
-            const int32_t zh = (zz - zl) >> 8;
-            const size_t c = (size_t)j * k + r;
-            const size_t addr = ((c >> 4) * ld + b) * 16 + (c & 15);
-            Zlo[addr] = (int8_t)zl;
-            Zhi[addr] = (int8_t)zh;
-            if (zh) anyhi = 1;
-          }
         }
+        // (a finished problem keeps its column of c in LDS; the digits are written once, behind the loop, with every lane at work -- round 5: written from here the
+        // k-step store loop ran in nine passes of ten, for the one or two lanes whose problem had just finished, and was a third of the kernel's vector instructions)
       }
       const uint64_t rmask = __ballot(to_ready);
       if (to_ready) s_ready[(rhead + rcount + lane_rank(rmask)) & (P - 1)] = (uint16_t)p;
@@ -1601,6 +1589,24 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
       pcount -= cnt;
       GQ_FENCE();
       if (!starving) break;                 // with lanes still sampling, one pass per iteration keeps everybody busy
+    }
+  }
+  // ---- the digits z = -c of every problem of the wave
+  GQ_FENCE();
+  for (int p = lane; p < nprob; p += 64) {
+    const uint32_t o = pb0 + (uint32_t)p;                     // seg0 + p = pj0 * B + o
+    uint32_t j; size_t b;
+    if (B32 >= (uint32_t)P) { const bool wrap = o >= B32; j = pj0 + (wrap ? 1u : 0u); b = wrap ? o - B32 : o; }
+    else { j = pj0 + o / B32; b = o % B32; }
+    for (uint32_t r = 0; r < k; ++r) {
+      const int32_t zz = -(int32_t)s_c[r * P + p];
+      const int32_t zl = (int32_t)(int8_t)(zz & 0xff);
+      const int32_t zh = (zz - zl) >> 8;
+      const size_t c = (size_t)j * k + r;
+      const size_t addr = ((c >> 4) * ld + b) * 16 + (c & 15);
+      Zlo[addr] = (int8_t)zl;
+      Zhi[addr] = (int8_t)zh;
+      if (zh) anyhi = 1;
     }
   }
 #undef GQ_FENCE
