@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
   uint32_t t = 0, myj = 0;
   size_t myb = 0;
   double cen = 0.0;
-  SampleZParams sp = s_sz[0];
+  double inv_s = 0.0;                     // 1 / s of the problem's current step (the exact decisions); the other SampleZ parameters are used when the problem is taken only
   // everything of an attempt group that depends on the problem's current step only is formed when a lane takes the problem (round 5): the Philox key words,
   // the range in 32 bits and the fp32 offsets of the narrow screen (sz_group4_narrow) -- a group is then one Philox block and four screens
   SzRange rg{0, 1, 0, 16};
@@ -1507,7 +1507,8 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
           myp = s_ready[(rhead + rk) & (P - 1)];
           mystep = s_step[myp];
           cen = s_cen[myp];
-          sp = s_sz[mystep];
+          const SampleZParams sp = s_sz[mystep];
+          inv_s = sp.inv_s;
           const uint32_t o = pb0 + (uint32_t)myp;               // seg0 + myp = pj0 * B + o
           if (B32 >= (uint32_t)P) { const bool wrap = o >= B32; myj = pj0 + (wrap ? 1u : 0u); myb = wrap ? o - B32 : o; }
           else { myj = pj0 + o / B32; myb = o % B32; }
@@ -1537,8 +1538,8 @@ __global__ __launch_bounds__(256) void k_gadget_queue(uint64_t seed, uint64_t fi
     bool accept = false;
     long long x = 0;
     if (has) {
-      accept = narrow ? sz_group4_narrow(seed, coord, idx_lo, tw, t, rg, cen, sp.inv_s, c_rel, inv_s_f, &x)
-                      : sz_group4(seed, coord, idx_lo, tw, t, rg, cen, sp.inv_s, &x);
+      accept = narrow ? sz_group4_narrow(seed, coord, idx_lo, tw, t, rg, cen, inv_s, c_rel, inv_s_f, &x)
+                      : sz_group4(seed, coord, idx_lo, tw, t, rg, cen, inv_s, &x);
       if (!accept && ++t >= kMaxAttempts / 4) { accept = true; f = 1; x = (long long)floor(cen + 0.5); }
     }
     {
