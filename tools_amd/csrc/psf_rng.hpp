@@ -283,10 +283,14 @@ __device__ inline bool sz_group4_narrow(uint64_t seed, uint32_t coord, uint32_t 
   const uint32_t wbm = wm & 0xffffu;
   if ((float)wbm + 1.0f <= rm * 0.999f * 65536.0f) return true;      // certainly accepted: no f64 evaluation at all
   bool accept = sz_decide(seed, coord, idx_lo, tw, 4 * g + (uint32_t)tm, x, wbm, center, inv_s, 16);
-  if (!accept) {
+  if (!accept) {                                    // the later attempts of the group: the screen has already discarded those with maybe[j] == false
 #pragma unroll
     for (int j = 1; j < 4; ++j)
-      if (!accept && j > tm) accept = sz_attempt(seed, coord, idx_lo, tw, 4 * g + (uint32_t)j, word[j] >> 16, word[j] & 0xffffu, rg, center, inv_s, &x);
+      if (!accept && j > tm && maybe[j]) {
+        const uint32_t wbj = word[j] & 0xffffu;
+        const long long xj = rg.lo + (long long)(prod[j] >> 16);
+        if ((float)wbj + 1.0f <= rho[j] * 0.999f * 65536.0f || sz_decide(seed, coord, idx_lo, tw, 4 * g + (uint32_t)j, xj, wbj, center, inv_s, 16)) { accept = true; x = xj; }
+      }
     *x_out = x;
   }
   return accept;
@@ -326,10 +330,14 @@ __device__ inline bool sz_group4_tab(uint64_t seed, uint32_t coord, uint32_t idx
   const uint32_t wbm = wm & 0xffffu;
   if (wbm < (Tm & 0xffffu)) return true;            // certainly accepted: no f64 evaluation at all
   bool accept = sz_decide(seed, coord, idx_lo, tw, 4 * g + (uint32_t)tm, x, wbm, center, inv_s, 16);
-  if (!accept) {
+  if (!accept) {                                    // the later attempts of the group: the screen has already discarded those with maybe[j] == false
 #pragma unroll
     for (int j = 1; j < 4; ++j)
-      if (!accept && j > tm) accept = sz_attempt(seed, coord, idx_lo, tw, 4 * g + (uint32_t)j, word[j] >> 16, word[j] & 0xffffu, rg, center, inv_s, &x);
+      if (!accept && j > tm && maybe[j]) {
+        const uint32_t wbj = word[j] & 0xffffu;
+        const long long xj = rg.lo + (long long)(prod[j] >> 16);
+        if (wbj < (T[j] & 0xffffu) || sz_decide(seed, coord, idx_lo, tw, 4 * g + (uint32_t)j, xj, wbj, center, inv_s, 16)) { accept = true; x = xj; }
+      }
     *x_out = x;
   }
   return accept;
