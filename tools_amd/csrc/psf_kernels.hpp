@@ -734,6 +734,9 @@ __global__ __launch_bounds__(256) void k_perturb_round_lean(uint64_t seed, uint6
 }
 
 // k_perturb_round_lean with the table screen of psf_rng.hpp (sz_screen16_tab) in place of the fp32 screen: same attempts, same exact decisions, same values.
+// ROW: a segment is exactly one row of the [coordinate][preimage] matrices (seg == B, the host's choice from 1024 preimages on): the coordinate is the wave's, the preimage
+// the offset, and the loads and stores go through the row's base address
+template <bool ROW>
 __global__ __launch_bounds__(256) void k_perturb_round_tab(uint64_t seed, uint64_t first_index, size_t m, size_t B, size_t ld,
                                                             const double* __restrict__ X, SampleZParams sp, int32_t* __restrict__ P,
                                                             int* __restrict__ fail, uint32_t seg, SzTable tb) {
@@ -749,13 +752,17 @@ __global__ __launch_bounds__(256) void k_perturb_round_tab(uint64_t seed, uint64
   const uint32_t nseg = (uint32_t)(total - seg0 < (size_t)seg ? total - seg0 : (size_t)seg);
   const uint32_t coord0 = (uint32_t)(seg0 / B), b00 = (uint32_t)(seg0 % B), B32 = (uint32_t)B;
   const bool few_wraps = B32 >= seg;                           // then an offset wraps at most once
+  const double* __restrict__ Xrow = X + (size_t)coord0 * ld;
+  int32_t* __restrict__ Prow = P + (size_t)coord0 * ld;
   auto locate = [&](uint32_t off, uint32_t* coord, uint32_t* bb) {
+    if constexpr (ROW) { *coord = coord0; *bb = off; return; }
     const uint32_t o = b00 + off;
     if (few_wraps) { const bool wrap = o >= B32; *coord = coord0 + (wrap ? 1u : 0u); *bb = wrap ? o - B32 : o; }
     else { *coord = coord0 + o / B32; *bb = o % B32; }
   };
   auto gload = [&](uint32_t off) -> double {
     if (off >= nseg) return 0.0;
+    if constexpr (ROW) return Xrow[off];
     uint32_t cc, bb;
     locate(off, &cc, &bb);
     return X[(size_t)cc * ld + bb];
@@ -802,7 +809,8 @@ __global__ __launch_bounds__(256) void k_perturb_round_tab(uint64_t seed, uint64
       if (!accept && ++t >= kMaxAttempts / 4) { accept = true; f = 1; x = (long long)floor(c + 0.5); }
       if (accept) {
         if (x > kDigitRangeP || x < -kDigitRangeP) f = 1;       // the syndrome product needs |p| < 2^23 (k_split_P)
-        P[(size_t)coord * ld + b] = (int32_t)x;
+        if constexpr (ROW) Prow[b] = (int32_t)x;
+        else P[(size_t)coord * ld + b] = (int32_t)x;
       }
     }
     const uint64_t mask = __ballot(accept);

@@ -1237,8 +1237,12 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
           uint32_t segt = seg;
           if (Bh % 64 == 0 && Bh >= 1024 && Bh <= (size_t)PRL_SEG && (size_t)seg > Bh) segt = (uint32_t)Bh;      // (short rows: every workgroup loads the table, 0.14 against 0.09 ms at 64 preimages)
           const size_t wavest = (m * Bh + segt - 1) / segt;
-          hipLaunchKernelGGL(k_perturb_round_tab, dim3((unsigned)((wavest + 3) / 4)), dim3(256), (size_t)h->szR.n_int * h->szF * sizeof(uint32_t), sx, seed, first_index + b0, m, Bh, ld,
-                             h->dX + b0, h->szR, h->dP + b0, h->dFail, segt, SzTable{h->dSzTab, h->szF, h->szR.n_int});
+          if ((size_t)segt == Bh)
+            hipLaunchKernelGGL(k_perturb_round_tab<true>, dim3((unsigned)((wavest + 3) / 4)), dim3(256), (size_t)h->szR.n_int * h->szF * sizeof(uint32_t), sx, seed, first_index + b0, m, Bh, ld,
+                               h->dX + b0, h->szR, h->dP + b0, h->dFail, segt, SzTable{h->dSzTab, h->szF, h->szR.n_int});
+          else
+            hipLaunchKernelGGL(k_perturb_round_tab<false>, dim3((unsigned)((wavest + 3) / 4)), dim3(256), (size_t)h->szR.n_int * h->szF * sizeof(uint32_t), sx, seed, first_index + b0, m, Bh, ld,
+                               h->dX + b0, h->szR, h->dP + b0, h->dFail, segt, SzTable{h->dSzTab, h->szF, h->szR.n_int});
         } else
         hipLaunchKernelGGL(k_perturb_round_lean, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, m, Bh, ld, h->dX + b0, h->szR, h->dP + b0, h->dFail, seg);
       } else {
