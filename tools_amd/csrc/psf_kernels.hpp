@@ -1127,7 +1127,14 @@ __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         uint64_t t = 0;
-        if constexpr (FOLD128) {
+        if constexpr (POW2) {
+          // q = 2^e divides 2^64: the sum of the classes in wrap-around 64-bit arithmetic, then a mask -- no division (the general fold below spends two 64-bit
+          // divisions per class and output: half of this kernel's vector instructions at C3, SQ counters in profiles/r05_notes.md)
+          uint64_t S = 0;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) S += (uint64_t)(int64_t)acc[c][x][y][r] << (8 * c);
+          t = S & (zc.q - 1);
+        } else if constexpr (FOLD128) {
           // S = sum_c T_c 256^c as ONE signed 128-bit integer (|S| < 2^31 2^(8 (NC - 1))), then a single reduction mod q: a short split of a single call
           // spends more time in the per-class form below (two 64-bit divisions per class) than in its K loop
           Acc128 S{0, 0};
