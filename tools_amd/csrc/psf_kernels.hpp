@@ -1026,9 +1026,24 @@ __global__ void k_split_P(const int32_t* __restrict__ P, size_t K, size_t ld, si
   if (__syncthreads_or(hi2) && threadIdx.x == 0 && __hip_atomic_load(fail + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(fail + 2, 1);
 }
 
-struct ZqConsts { uint64_t q, two64; uint64_t pw[12]; };   // pw[c] = 256^c mod q
+struct ZqConsts { uint64_t q, two64; uint64_t pw[12]; double inv_q; double pwd[12]; };   // pw[c] = 256^c mod q; inv_q = 1 / q and pwd[c] = (double)pw[c] for the narrow fold (q < 2^31)
 
 // (T mod q) * pw mod q for |T| < 2^31
+// q < 2^31 (round 5): both reductions by a double-precision quotient estimate and at most two corrections instead of two 64-bit divisions -- |T| < 2^31 and
+// t pw < 2^62, so floor(T / q) and floor(t pw / q) < 2^31 are estimated within one unit by the 53-bit products below; the residues are exact.
+__device__ inline uint64_t zq_term_narrow(int32_t T, uint32_t pw, double pwd, uint32_t q, double inv_q) {
+  const int32_t q1 = (int32_t)floor((double)T * inv_q);
+  int64_t t = (int64_t)T - (int64_t)q1 * (int64_t)q;                // in (-q, 2 q)
+  if (t < 0) t += (int64_t)q;
+  if (t >= (int64_t)q) t -= (int64_t)q;
+  const uint32_t q2 = (uint32_t)((double)(uint32_t)t * pwd * inv_q);
+  int64_t r = (int64_t)((uint64_t)(uint32_t)t * pw - (uint64_t)q2 * q);
+  if (r < 0) r += (int64_t)q;
+  if (r < 0) r += (int64_t)q;
+  if (r >= (int64_t)q) r -= (int64_t)q;
+  if (r >= (int64_t)q) r -= (int64_t)q;
+  return (uint64_t)r;
+}
 __device__ inline uint64_t zq_term(int32_t T, uint64_t pw, uint64_t q, uint64_t two64, bool wide) {
   if (!wide) {
     int64_t t = (int64_t)T % (int64_t)q;
@@ -1166,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_zq_mfma(const int8_t* __restrict__ A8, 
               case 8: T = acc[8 < NC ? 8 : 0][x][y][r]; break;
               default: T = acc[9 < NC ? 9 : 0][x][y][r]; break;
             }
-            t += zq_term(T, zc.pw[c], zc.q, zc.two64, wide != 0);
+            t += wide ? zq_term(T, zc.pw[c], zc.q, zc.two64, true) : zq_term_narrow(T, (uint32_t)zc.pw[c], zc.pwd[c], (uint32_t)zc.q, zc.inv_q);
             if (t >= zc.q) t -= zc.q;
           }
         }

@@ -467,7 +467,8 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
     while (bound > 127) { bound = (bound + 128) >> 8; ++h->NA; }
     h->zc.q = gp.q; h->zc.two64 = h->two64;
     uint64_t pw = 1 % gp.q;
-    for (int c = 0; c < 12; ++c) { h->zc.pw[c] = pw; pw = mulmod_u64(pw, 256 % gp.q, gp.q); }
+    h->zc.inv_q = 1.0 / (double)gp.q;
+    for (int c = 0; c < 12; ++c) { h->zc.pw[c] = pw; h->zc.pwd[c] = (double)pw; pw = mulmod_u64(pw, 256 % gp.q, gp.q); }
   }
   HIP_TRY(hipMalloc(&h->dA8, (size_t)h->NA * h->n_pad * h->K_pad));
   h->szR = make_sample_z_params(prm->r);
