@@ -194,6 +194,7 @@ static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
   HIP_TRY(hipMemset(g->dTm, 0, g->dpad * ld * sizeof(double)));
   HIP_TRY(hipMemset(g->dZf, 0, ld * g->nkb * 16 * sizeof(double)));      // padding rows / columns of the operands stay zero for good
   HIP_TRY(hipMemset(g->dZ8, 0, 3 * g->zplane));
+  HIP_TRY(hipDeviceSynchronize());      // the clears run on the null stream, the walk possibly on a non-blocking one (see ensure_batch, psfp.hip)
   g->bcap = B;
   return PSF_OK;
 }

@@ -278,6 +278,10 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
   HIP_TRY(hipMalloc(&h->dU, B * h->n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&h->dE, B * h->m * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&h->dOk, B));
+  // The clears above run on the null stream; the calls that follow may run on non-blocking streams (the host-pointer path's compute stream, a caller's stream), which do
+  // not wait for it -- without this barrier a clear could land AFTER the first kernels had written the same buffer (found in round 5 by tools/host_vs_device_fuzz.py: one
+  // whole-batch mismatch in 240 000 first calls, small keys whose product finishes within the clear of dP)
+  HIP_TRY(hipDeviceSynchronize());
   select_set(h, 0);
   h->Bcap = B;
   return PSF_OK;
