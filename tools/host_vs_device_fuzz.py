@@ -1,6 +1,6 @@
 """Host-pointer samp_p against device-pointer samp_p_dev of the same seed on seeded random PSFPerturbation configurations (the menus of tests/test_gpu_random_configs.py,
 --wide as in tools/fuzz_configs.py): no oracle in the loop, so thousands of calls per minute; on a mismatch prints which rows / coordinates differ.
-    python3 tools/host_vs_device_fuzz.py <first case> <count> [--wide] [calls per key]"""
+    python3 tools/host_vs_device_fuzz.py <first case> <count> [--wide|--narrow] [calls per key] [--side-stream]"""
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -28,11 +28,16 @@ for case in range(first, first + count):
     m = m_bar + n * k
     u = np.random.default_rng(case).integers(0, q, size=(B, n), dtype=np.uint64)
     ud = torch.from_numpy(u.astype(np.int64)).to(dev); ed = torch.empty((B, m), dtype=torch.int64, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream() if "--side-stream" in sys.argv else None      # a non-blocking stream for the device-pointer calls, issued FIRST (the first call after key generation)
+    st = side.cuda_stream if side is not None else torch.cuda.current_stream().cuda_stream
     for c in range(calls):
         try:
-            e = psf.samp_p(u, seed=7 + case + 1000 * c, first_index=c)
-            psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=7 + case + 1000 * c, first_index=c, stream=st); torch.cuda.synchronize()
+            if side is not None:
+                psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=7 + case + 1000 * c, first_index=c, stream=st); torch.cuda.synchronize()
+                e = psf.samp_p(u, seed=7 + case + 1000 * c, first_index=c)
+            else:
+                e = psf.samp_p(u, seed=7 + case + 1000 * c, first_index=c)
+                psf.samp_p_dev(ud.data_ptr(), ed.data_ptr(), B, seed=7 + case + 1000 * c, first_index=c, stream=st); torch.cuda.synchronize()
         except T.PsfError as ex:
             print(f"case {case} call {c}: PsfError {ex.status} (n={n} q={q} base={base} k={k} m_bar={m_bar} r={r} s={s:.1f} B={B})", flush=True); break
         ncalls += 1
