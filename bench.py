@@ -38,7 +38,7 @@ PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix; measured 77.3 by t
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -50,9 +50,38 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the result (N>1)")
     ap.add_argument("--structured", action="store_true", help="PSFPerturbation with the structured square root of Sigma_2 (PSFP_FLAG_STRUCTURED_SQRT): a labelled, different algorithm; the headline stays on the dense path")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency legs (batch 1 / 16 / 64)")
-    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barriers, gather, reductions) on a one-rank RCCL group")
-    args = ap.parse_args()
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short c2 / c4 / c3prime legs the default invocation appends (\"other_configs\")")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (launcher, process group, barriers, gather, reductions) on a one-rank RCCL group")
+    ap.add_argument("--multi-handle", action="store_true", help="torch-free scaling mode: ONE process drives --gpus devices through psfp_samp_p_multi (host buffers, one worker thread per handle)")
+    ap.add_argument("--launch-timeout", type=float, default=0.0, help="seconds after which the self-launcher stops every rank (0 = none)")
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if args.multi_handle:
+        return multi_handle_main(args)
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
+        return launcher_main(args)                 # this process becomes the parent of N ranks and never touches the GPU
+    rank_main(args)
+
+
+def launcher_main(args):
+    """`python3 bench.py --gpus N` is a complete command: without an external launcher (no WORLD_SIZE in the environment) the parent starts N fresh
+    children of this script -- before anything here has imported torch.cuda or loaded the HIP library, and by subprocess, never exec -- one per GPU with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank 0's output (its JSON line is the last line of stdout) and exits
+    non-zero if any rank does.  `python -m torch.distributed.run ... bench.py --gpus N` keeps working: WORLD_SIZE is then set and this is skipped."""
+    from tools_amd import launch
+    have = launch.visible_gpu_count()
+    if have < args.gpus:
+        print(f"[bench] --gpus {args.gpus} but this host shows {have} GPU(s) (KFD topology / *_VISIBLE_DEVICES): not starting any rank", file=sys.stderr)
+        sys.exit(2)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    rc = launch.run_ranks(cmd, args.gpus, timeout=args.launch_timeout or None)
+    sys.exit(rc)
+
+
+def rank_main(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -63,9 +92,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: the launcher and the flag disagree", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("[bench] no GPU: tools_amd has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -77,14 +105,100 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
-    scheme, n, q, r, s, batch = CONFIGS[args.config]
-    B = args.batch or batch
-    key_seed = 3
-    t0 = time.time()
+    run = run_config(args.config, args.batch, args.steps, args.warmup, local_rank, rank, world, multi, dev, structured=args.structured,
+                     gather=multi and not args.no_gather, force_dist=args.force_dist)
+    psf, scheme, n, q, r, s, m, B, u, e = (run[k] for k in ("psf", "scheme", "n", "q", "r", "s", "m", "B", "u", "e"))
+    stream, first_index, kern_ms, elapsed, valid, do_gather = (run[k] for k in ("stream", "first_index", "kern_ms", "elapsed", "valid", "do_gather"))
+
+    # latency of ONE call with few preimages -- the reference's unit of work (psf.rs:48-80: one samp_p call = one preimage; benches/psf.rs:38,63-65,90-92)
+    # and the regime where reading the key from HBM once, not the FP64 pipe, is the roof.  Outside the timed region of the metric.
+    latency = None
+    if rank == 0 and scheme == "PSFPerturbation" and not args.no_latency and not args.structured:
+        latency = single_call_latency(psf, u, e, m, first_index, stream, args.config)
+    elif rank == 0 and not args.no_latency:
+        latency = nearest_plane_call_latency(psf, u, m, first_index, stream, args.config)
+
+    total = B * world * args.steps
+    value = total / elapsed
+    out = None
+    if rank == 0:
+        roof = roofline(scheme, psf, m, B, kern_ms, args.config, args.structured)
+        out = {
+            "metric": "preimages/sec (whole node) + HBM-BW% for samp_p, n=512 q~2^30 batch=4096",
+            "value": round(value, 2), "unit": "preimages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64+int64" if scheme == "PSFPerturbation" else "f64+int8+int64", "data": "synthetic",
+            "config": {"workload": f"{scheme} samp_p n={n} q={q} k={run['gp'].k} m={m} r={r} s={s} batch={B}/GPU ({args.config})",
+                       "global_batch": B * world, "parallelism": f"batch-sharded x{world}" + (" + overlapped RCCL gather of int32 rows to rank 0" if do_gather else "")},
+            "valid": valid, "kernels_ms": {k: round(v, 3) for k, v in kern_ms.items()}, "trap_gen_s": round(run["trap_gen_s"], 2),
+            "roofline": roof,
+        }
+        if multi:
+            # what the process group really was: ranks_seen is dist.get_world_size(), the per-rank step times are each rank's own clock over the same K steps
+            out["ranks_seen"] = run["ranks_seen"]
+            out["ms_per_step_ranks"] = {"min": round(min(run["rank_elapsed"]) / args.steps * 1e3, 3), "max": round(max(run["rank_elapsed"]) / args.steps * 1e3, 3),
+                                        "all": [round(x / args.steps * 1e3, 3) for x in run["rank_elapsed"]]}
+            out["launcher"] = "bench.py (self-spawned ranks, tools_amd/launch.py)" if os.environ.get("PSF_LAUNCHED_BY") else "external (torch.distributed.run or equivalent)"
+        if latency:
+            out["latency"] = latency
+        if args.config != "c3" or args.structured:
+            out["metric"] = f"preimages/sec for samp_p ({args.config}" + (", structured sqrt(Sigma_2): labelled opt-in, not the parity path" if args.structured else "") + ")"
+        if args.structured:
+            out["config"]["workload"] += " [PSFP_FLAG_STRUCTURED_SQRT]"
+        key_gb = (m * (m + 1) // 2) * 8 / 1e9 if scheme == "PSFPerturbation" else m * m * 12 / 1e9
+        if world == 1 and not args.no_cpu_baseline and key_gb > 16:
+            # the port would need the key twice in host memory (export buffer + its own copy): not timed at this size.  The same shape is
+            # checked against the oracle stage by stage, with the factor streamed in row blocks, by tests/test_gpu_full_size.py
+            out["cpu_baseline"] = {"value": None, "unit": "preimages/s", "cores": 0, "kind": "port",
+                                   "sample": f"not timed: the key is {key_gb:.0f} GB and the port holds it twice in host memory"}
+        elif world == 1 and not args.no_cpu_baseline and args.structured:
+            out["cpu_baseline"] = {"value": None, "unit": "preimages/s", "cores": 0, "kind": "port",
+                                   "sample": "not timed: the CPU leg measures the reference's algorithm (dense factor); see the line without --structured"}
+        elif world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, 1000 + args.warmup + args.steps - 1, args.cpu_sample)
+
+    # The other single-GPU configurations of BASELINE.json, a few steps each, so that the driver's record carries them too (default invocation only:
+    # the headline above is timed first and alone; these legs run after it, each with its own key, outside every timed region of the metric).
+    if (rank == 0 and world == 1 and not multi and args.config == "c3" and not args.structured and not args.no_other_configs and not args.batch):
+        del psf, u, e
+        run.clear()
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs(local_rank, dev)
+
+    def flush_c_stdio():                            # RCCL writes its version banner through C stdio (NCCL_DEBUG=VERSION on the GPU boxes)
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+
+    if multi:                                       # every rank empties its buffers, then the group is torn down, then rank 0 speaks last
+        flush_c_stdio()
+        dist.barrier()
+        dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        if world > 1:
+            time.sleep(0.5)                         # the other ranks have nothing buffered any more; let their last writes land
+        print(json.dumps(out), flush=True)
+    if not valid:
+        sys.exit(4)
+
+
+def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, structured=False, gather=False, force_dist=False, key_seed=3):
+    """Key generation (outside the timed region, benches/psf.rs:36,61,88), `warmup` untimed steps, then exactly `steps` samp_p passes over one batch of
+    uniform syndromes between two fences (device synchronise + barrier + device synchronise), and the correctness gate on the last step's rows."""
+    import torch
+    import torch.distributed as dist
+    import tools_amd as T
     from tools_amd._ffi import lib, check
+    from tools_amd.shard import shard_range, AsyncRowGather
+    scheme, n, q, r, s, cfg_batch = CONFIGS[cfg]
+    B = batch or cfg_batch
+    t0 = time.time()
     if scheme == "PSFPerturbation":
         gp = T.GadgetParameters.init_default(n, q)
-        psf = T.PSFPerturbation(gp, r, s, device=local_rank, structured=args.structured)
+        psf = T.PSFPerturbation(gp, r, s, device=local_rank, structured=structured)
         check(lib().psfp_trap_gen(psf._h, C.c_uint64(key_seed)), "trap_gen")   # every rank: same seed -> same key
         m = psf.m
     elif scheme == "PSFGPV":
@@ -103,13 +217,12 @@ def main():
     t_trapgen = time.time() - t0
 
     stream = torch.cuda.current_stream().cuda_stream
-    from tools_amd.shard import shard_range, AsyncRowGather
     first_index, _ = shard_range(rank, world, B)               # global preimage index of this rank's row 0
     u = torch.empty((B, n), dtype=torch.int64, device=dev)
     e = torch.empty((B, m), dtype=torch.int64, device=dev)
     psf.uniform_targets_dev(u.data_ptr(), B, seed=7, first_index=first_index, stream=stream)
-    do_gather = multi and not args.no_gather
-    gatherer = AsyncRowGather(B, m, dev, dst=0, force=args.force_dist) if do_gather else None     # step i's rows travel while step i+1 computes
+    do_gather = bool(gather)
+    gatherer = AsyncRowGather(B, m, dev, dst=0, force=force_dist) if do_gather else None     # step i's rows travel while step i+1 computes
 
     def step(i):
         psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=1000 + i, first_index=first_index, stream=stream)
@@ -122,40 +235,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     if do_gather:
         gatherer.finish()
     if psf.last_status() != 0:
         raise RuntimeError("device-side sampler failure during warmup")
     psf.enable_timing(True)
-    trmm_ms, kern_ms = [], {}
+    kern_ms = {}
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
     if do_gather:
         gatherer.finish()                  # every step's rows have reached rank 0 inside the timed region
     fence()
-    elapsed = time.perf_counter() - t0
+    own = elapsed = time.perf_counter() - t0
     # per-kernel HIP-event times of the last step (events were recorded on the launch stream, no host sync in the loop)
     tm = psf.get_timing()
     for nm, ms in (tm.items() if isinstance(tm, dict) else tm):
         kern_ms[nm] = ms
     psf.enable_timing(False)
     status = psf.last_status()
+    rank_elapsed, ranks_seen = [own], 1
     if multi:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # latency of ONE call with few preimages -- the reference's unit of work (psf.rs:48-80: one samp_p call = one preimage; benches/psf.rs:38,63-65,90-92)
-    # and the regime where reading the key from HBM once, not the FP64 pipe, is the roof.  Outside the timed region of the metric.
-    latency = None
-    if rank == 0 and scheme == "PSFPerturbation" and not args.no_latency and not args.structured:
-        latency = single_call_latency(psf, u, e, m, first_index, stream, args.config)
-    elif rank == 0 and not args.no_latency:
-        latency = nearest_plane_call_latency(psf, u, m, first_index, stream, args.config)
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([own], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(ranks_seen)]
+        dist.all_gather(every, mine)
+        rank_elapsed = [float(t.item()) for t in every]
+        elapsed = max(rank_elapsed)                  # MAX over ranks
 
     # correctness gate on the last step's output: A e == u and check_domain for every row
     u2 = torch.empty_like(u)
@@ -167,83 +276,131 @@ def main():
         vt = torch.tensor([1 if valid else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(vt, op=dist.ReduceOp.MIN)
         valid = bool(vt.item())
+    return {"psf": psf, "scheme": scheme, "n": n, "q": q, "r": r, "s": s, "m": m, "gp": gp, "B": B, "u": u, "e": e, "stream": stream,
+            "first_index": first_index, "kern_ms": kern_ms, "elapsed": elapsed, "valid": valid, "do_gather": do_gather, "trap_gen_s": t_trapgen,
+            "rank_elapsed": rank_elapsed, "ranks_seen": ranks_seen}
 
-    total = B * world * args.steps
-    value = total / elapsed
-    out = None
-    if rank == 0:
-        trmm = kern_ms.get("k_trmm_f64")
-        mL = psf.m_bar if (scheme == "PSFPerturbation" and args.structured) else m
-        flops_per_launch = float(mL) * (mL + 1) * B          # mL(mL+1)/2 fma per preimage (m^2 flop; structured: the m_bar x m_bar block)
-        roof = None
-        if trmm:
-            ach = flops_per_launch / (trmm * 1e-3) / 1e12
-            kname = {"2": "k_trmm_f64_big", "1": "k_trmm_f64_reg"}.get(os.environ.get("PSF_TRMM_VARIANT", "2"), "k_trmm_f64")      # the library's default and its two alternatives
-            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 3), "peak": PEAK_F64_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": load_traffic(args.config + (":structured" if args.structured else ""), B),
-                    "traffic_source": "profiles/trmm_traffic.json (rocprofv3 PMC passes; null when psf_kernels.hpp changed since)",
-                    "launch_ms": round(trmm, 3), "flops_per_launch": flops_per_launch,
-                    "clock_note": "peak is priced at the nominal 2.4 GHz; under this kernel the shader clock sits at 2.25-2.37 GHz (tools/trmm_clock_probe.py, profiles/r02_probe_trmm.log)"}
-            if roof["traffic"]:                      # the HBM side of the same launch, for the metric's "HBM-BW%"
-                roof["hbm_GBps"] = round(roof["traffic"] / (trmm * 1e-3) / 1e9, 1)
-                roof["hbm_frac_of_peak"] = round(roof["traffic"] / (trmm * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)
-        npl = kern_ms.get("nearest_plane")
-        if npl and roof is None:
-            # PSFGPV / PSFGPVRing: the nearest plane (gpv.rs:160) as a whole -- per block one k_np_step launch (sampler workgroups + FP64-MFMA
-            # update tiles), then the int8-MFMA recombination.  Algorithmic work per preimage: 2 d^2 FP64 flop (projection + update,
-            # SURVEY.md 8d); the walk itself is d sequential draws per preimage, so the phase is latency bound, not MFMA bound.
-            flops = 2.0 * float(m) * float(m) * B
-            ach = flops / (npl * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "nearest plane: k_np_project + d/64 x k_np_step + k_np_combine8", "achieved": round(ach, 3),
-                    "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4),
-                    "traffic": load_traffic(args.config, B, "np_traffic.json", ("psf_np_kernels.hpp",)),
-                    "traffic_source": "profiles/np_traffic.json: rocprofv3 PMC passes over tools/bin/np_harness (C++ over the C ABI), every k_np_* launch of one samp_p call; null when psf_np_kernels.hpp changed since",
-                    "launch_ms": round(npl, 3), "flops_per_launch": flops, "serial_steps": int(m),
-                    "us_per_serial_step": round(npl * 1e3 / m, 4),
-                    "note": "latency bound: d sequential SampleZ draws per preimage (one launch per 64 of them); frac is the FP64 share of the phase"}
-        out = {
-            "metric": "preimages/sec (whole node) + HBM-BW% for samp_p, n=512 q~2^30 batch=4096",
-            "value": round(value, 2), "unit": "preimages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64+int64" if scheme == "PSFPerturbation" else "f64+int8+int64", "data": "synthetic",
-            "config": {"workload": f"{scheme} samp_p n={n} q={q} k={gp.k} m={m} r={r} s={s} batch={B}/GPU ({args.config})",
-                       "global_batch": B * world, "parallelism": f"batch-sharded x{world}" + (" + overlapped RCCL gather of int32 rows to rank 0" if do_gather else "")},
-            "valid": valid, "kernels_ms": {k: round(v, 3) for k, v in kern_ms.items()}, "trap_gen_s": round(t_trapgen, 2),
-            "roofline": roof,
-        }
-        if latency:
-            out["latency"] = latency
-        if args.config != "c3" or args.structured:
-            out["metric"] = f"preimages/sec for samp_p ({args.config}" + (", structured sqrt(Sigma_2): labelled opt-in, not the parity path" if args.structured else "") + ")"
-        if args.structured:
-            out["config"]["workload"] += " [PSFP_FLAG_STRUCTURED_SQRT]"
-        key_gb = (m * (m + 1) // 2) * 8 / 1e9 if scheme == "PSFPerturbation" else m * m * 12 / 1e9
-        if world == 1 and not args.no_cpu_baseline and key_gb > 16:
-            # the port would need the key twice in host memory (export buffer + its own copy): not timed at this size.  The same shape is
-            # checked against the oracle stage by stage, with the factor streamed in row blocks, by tests/test_gpu_full_size.py
-            out["cpu_baseline"] = {"value": None, "unit": "preimages/s", "cores": 0, "kind": "port",
-                                   "sample": f"not timed: the key is {key_gb:.0f} GB and the port holds it twice in host memory"}
-        elif world == 1 and not args.no_cpu_baseline and args.structured:
-            out["cpu_baseline"] = {"value": None, "unit": "preimages/s", "cores": 0, "kind": "port",
-                                   "sample": "not timed: the CPU leg measures the reference's algorithm (dense factor); see the line without --structured"}
-        elif world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scheme, psf, n, q, r, s, u, e, first_index, 1000 + args.warmup + args.steps - 1, args.cpu_sample)
-    def flush_c_stdio():                            # RCCL writes its version banner through C stdio (NCCL_DEBUG=VERSION on the GPU boxes)
+
+def nearest_plane_form(psf):
+    """The kernels the last PSFGPV / PSFGPVRing samp_p call really launched for the walk of gpv.rs:160, from the handle (psfgpv_get_nearest_plane_form)."""
+    try:
+        form, G, blocks, fallbacks = psf.nearest_plane_form()
+    except Exception:
+        return "nearest plane", {}
+    walk = {1: f"k_np_walk<{G}> (one launch: sampler + updater workgroups)", 0: f"{blocks} x k_np_step<{G}> (one launch per 64-row block)"}.get(form, f"form {form}")
+    return f"nearest plane: k_np_project + {walk} + k_np_combine8_fused", {"form": "one launch" if form == 1 else "launch per block", "G": G, "blocks": blocks,
+                                                                           "calls_rerun_per_block": fallbacks}
+
+
+def roofline(scheme, psf, m, B, kern_ms, cfg, structured=False):
+    trmm = kern_ms.get("k_trmm_f64")
+    mL = psf.m_bar if (scheme == "PSFPerturbation" and structured) else m
+    flops_per_launch = float(mL) * (mL + 1) * B          # mL(mL+1)/2 fma per preimage (SURVEY.md 8d: m^2 flop; structured: the m_bar x m_bar block)
+    roof = None
+    if trmm:
+        ach = flops_per_launch / (trmm * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "k_trmm_f64_big", "achieved": round(ach, 3), "peak": PEAK_F64_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4), "traffic": load_traffic(cfg + (":structured" if structured else ""), B),
+                "traffic_source": "profiles/trmm_traffic.json (rocprofv3 PMC passes; null when psf_kernels.hpp changed since)",
+                "launch_ms": round(trmm, 3), "flops_per_launch": flops_per_launch,
+                "clock_note": "peak is priced at the nominal 2.4 GHz; under this kernel the shader clock sits at 2.25-2.37 GHz (tools/trmm_clock_probe.py, profiles/r02_probe_trmm.log)"}
+        if roof["traffic"]:                      # the HBM side of the same launch, for the metric's "HBM-BW%"
+            roof["hbm_GBps"] = round(roof["traffic"] / (trmm * 1e-3) / 1e9, 1)
+            roof["hbm_frac_of_peak"] = round(roof["traffic"] / (trmm * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)
+    npl = kern_ms.get("nearest_plane")
+    if npl and roof is None:
+        # PSFGPV / PSFGPVRing: the nearest plane (gpv.rs:160) as a whole -- the walk (sampler workgroups + FP64-MFMA update tiles), then the int8-MFMA
+        # recombination.  Algorithmic work per preimage: 2 d^2 FP64 flop (projection + update, SURVEY.md 8d); the walk itself is d sequential draws per
+        # preimage, so the phase is latency bound, not MFMA bound.
+        flops = 2.0 * float(m) * float(m) * B
+        ach = flops / (npl * 1e-3) / 1e12
+        kname, form = nearest_plane_form(psf)
+        roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 3),
+                "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4),
+                "traffic": load_traffic(cfg, B, "np_traffic.json", ("psf_np_kernels.hpp",)),
+                "traffic_source": "profiles/np_traffic.json: rocprofv3 PMC passes over tools/bin/np_harness (C++ over the C ABI), every k_np_* launch of one samp_p call; null when psf_np_kernels.hpp changed since",
+                "launch_ms": round(npl, 3), "flops_per_launch": flops, "serial_steps": int(m),
+                "us_per_serial_step": round(npl * 1e3 / m, 4), "walk": form,
+                "note": "latency bound: d sequential SampleZ draws per preimage; frac is the FP64 share of the phase"}
+    return roof
+
+
+def other_configs(local_rank, dev, steps=5, warmup=1):
+    """c2 (BASELINE configs[1]), c4 (configs[3]) and c3prime (configs[2] with a prime modulus): `steps` timed steps each, same fences and the same gate as
+    the headline, with the per-kernel HIP-event times and the roofline object of each.  About 2 s in all (three key generations of 0.2-0.4 s + 0.4 s of steps)."""
+    import torch
+    res = {}
+    for cfg in ("c2", "c4", "c3prime"):
+        t0 = time.time()
         try:
-            C.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
+            run = run_config(cfg, 0, steps, warmup, local_rank, 0, 1, False, dev)
+            scheme, B = run["scheme"], run["B"]
+            res[cfg] = {"workload": f"{scheme} n={run['n']} q={run['q']} m={run['m']} s={run['s']} batch={B}",
+                        "ms_per_step": round(run["elapsed"] / steps * 1e3, 3), "value": round(B * steps / run["elapsed"], 2), "unit": "preimages/s",
+                        "steps": steps, "warmup": warmup, "valid": run["valid"], "kernels_ms": {k: round(v, 3) for k, v in run["kern_ms"].items()},
+                        "trap_gen_s": round(run["trap_gen_s"], 2), "roofline": roofline(scheme, run["psf"], run["m"], B, run["kern_ms"], cfg)}
+            run["psf"].close()
+            run.clear()
+        except Exception as exc:                    # a failed side leg is reported in the line, it does not take the headline with it
+            res[cfg] = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.empty_cache()
+        res[cfg]["wall_s"] = round(time.time() - t0, 2)
+    return res
 
-    if multi:                                       # every rank empties its buffers, then the group is torn down, then rank 0 speaks last
-        flush_c_stdio()
-        dist.barrier()
-        dist.destroy_process_group()
-    flush_c_stdio()
-    if rank == 0:
-        if world > 1:
-            time.sleep(0.5)                         # the other ranks have nothing buffered any more; let their last writes land
-        print(json.dumps(out), flush=True)
+
+def multi_handle_main(args):
+    """The second N-GPU route, without torch and without a process group: ONE process holds one handle per device, every handle the same key (same
+    trap_gen seed), and psfp_samp_p_multi (include/psf_mi355x.h) cuts each step's rows into contiguous shares, one worker thread per handle -- the route a
+    Rust caller of the shim would take.  Host buffers: the targets are uploaded and the rows come back over PCIe inside the timed region, so `value` here
+    is the PCIe-inclusive rate of that entry point (said in the line), not the HBM-resident figure of the default mode."""
+    import numpy as np
+    import tools_amd as T
+    from tools_amd._ffi import lib, check
+    from tools_amd.psf import samp_p_multi, multi_timing
+    scheme, n, q, r, s, batch = CONFIGS[args.config]
+    if scheme != "PSFPerturbation":
+        print("[bench] --multi-handle drives psfp_samp_p_multi: PSFPerturbation configurations only", file=sys.stderr)
+        sys.exit(2)
+    name = C.create_string_buffer(64)
+    cus = C.c_int(0)
+    for d in range(args.gpus):                      # fail fast and clearly when the node has fewer devices
+        if lib().psf_device_info(d, name, 64, C.byref(cus)) != 0:
+            print(f"[bench] --multi-handle --gpus {args.gpus}: device {d} is not available", file=sys.stderr)
+            sys.exit(2)
+    B = (args.batch or batch) * args.gpus           # weak scaling: the config's batch per device
+    gp = T.GadgetParameters.init_default(n, q)
+    t0 = time.time()
+    handles = [T.PSFPerturbation(gp, r, s, device=d) for d in range(args.gpus)]
+    for h in handles:
+        check(lib().psfp_trap_gen(h._h, C.c_uint64(3)), "trap_gen")
+    t_trapgen = time.time() - t0
+    m = handles[0].m
+    rng = np.random.default_rng(7)
+    u = rng.integers(0, q, size=(B, n), dtype=np.uint64)
+    e = np.zeros((B, m), dtype=np.int64)
+    for i in range(args.warmup):
+        samp_p_multi(handles, u, seed=1000 + i, out=e)
+    windows = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        samp_p_multi(handles, u, seed=1000 + args.warmup + i, out=e)
+        windows.append([multi_timing(h) for h in handles])
+    elapsed = time.perf_counter() - t0
+    chk = min(B, 256)                                # A e = u on the first rows of every handle's share, the domain check on the same rows
+    rows = np.unique(np.concatenate([np.arange(d * (B // args.gpus), d * (B // args.gpus) + min(chk, B // args.gpus)) for d in range(args.gpus)]))
+    valid = bool((handles[0].f_a(e[rows]) == u[rows]).all()) and bool(handles[0].check_domain(e[rows]).all())
+    last = windows[-1]
+    out = {"metric": f"preimages/sec for samp_p ({args.config}, psfp_samp_p_multi: one process, host buffers, PCIe inclusive)",
+           "value": round(B * args.steps / elapsed, 2), "unit": "preimages/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64+int64", "data": "synthetic",
+           "config": {"workload": f"{scheme} samp_p n={n} q={q} k={gp.k} m={m} r={r} s={s} batch={B // args.gpus}/GPU ({args.config})", "global_batch": B,
+                      "parallelism": f"psfp_samp_p_multi over {args.gpus} handle(s), one worker thread per device, contiguous row shares (psf_shard_range)"},
+           "valid": valid, "trap_gen_s": round(t_trapgen, 2), "transport": "host buffers: u uploaded, e downloaded inside the timed region",
+           "handle_windows_ms": [{"device": d, "launched": round(w[0], 3), "done": round(w[1], 3)} for d, w in enumerate(last)],
+           "windows_overlap": bool(max(w[0] for w in last) < min(w[1] for w in last)) if all(w[1] >= 0 for w in last) else None,
+           "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
     if not valid:
         sys.exit(4)
 

@@ -333,6 +333,12 @@ psf_status psfgpv_get_timing(psfgpv_handle*, double* solve_ms, double* nearest_p
  * e = sum z_i b_i was recombined by the 64-bit integer kernel (1) instead of the int8 matrix-core planes (0) -- the former when a
  * basis entry or a drawn z_i does not fit two balanced base-256 digits (|.| > 32639); the result is the same either way */
 psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle*, size_t* blocks, size_t* generic_recombination);
+/* The walk of gpv.rs:160 has two launch forms with identical results: ONE launch (k_np_walk<G>: sampler workgroups and updater workgroups that hand blocks to each
+ * other through device memory; chosen when the device's occupancy figures say every workgroup is resident at once) and one launch per 64-row block (k_np_step<G>).
+ * form: 1 / 0 as launched by the last call; preimages_per_wave: G; reruns: walks of this handle since its creation in which a workgroup of the one-launch form gave
+ * up waiting for another (a GPU shared with other work) and the call was walked again, inside the same call, by a form without waits between workgroups
+ * (k_np_walk_solo).  Contention costs time, never the call: PSF_ERR_SAMPLER is reserved for SampleZ itself.  One-launch walks of one process take turns per device. */
+psf_status psfgpv_get_nearest_plane_form(psfgpv_handle*, int* form, int* preimages_per_wave, size_t* blocks, uint64_t* reruns);
 /* 1 if samp_p of this handle draws in two passes (large moduli, see "Precision of the centres" above), else 0 */
 int psfgpv_two_pass(const psfgpv_handle*);
 
@@ -378,6 +384,7 @@ psf_status psfring_uniform_targets_dev(psfring_handle*, uint64_t seed, uint64_t 
 psf_status psfring_last_status(psfring_handle*);
 psf_status psfring_enable_timing(psfring_handle*, int on);
 psf_status psfring_get_timing(psfring_handle*, double* solve_ms, double* nearest_plane_ms);
+psf_status psfring_get_nearest_plane_form(psfring_handle*, int* form, int* preimages_per_wave, size_t* blocks, uint64_t* reruns);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in include/ but not exported: {missing}"
 
 
-def test_default_parameters_through_abi(kats):
+def check_default_parameters_through_abi(kats):
     import tools_amd as T
     for c in kats["gadget_parameters/default_unchanged"]["cases"]:
         gp = T.GadgetParameters.init_default(c["n"], c["q"])
@@ -41,7 +41,7 @@ def test_default_parameters_through_abi(kats):
         T.GadgetParameters.init_default(4, 1)       # modulus must be > 1
 
 
-def test_host_helper_kats_through_abi(kats):
+def check_host_helper_kats_through_abi(kats):
     import tools_amd as T
     G = T.gadget
     for name in ("correctness_base_2", "correctness_base_5"):
@@ -69,6 +69,24 @@ def test_host_helper_kats_through_abi(kats):
     mat = np.array([[sub(v) for v in row] for row in k["mat"]], dtype=np.int64)
     exp = [[sub(v) for v in row] for row in k["expect"]]
     assert G.rot_minus_matrix(mat).tolist() == exp
+
+
+def test_default_parameters_through_abi(kats):
+    check_default_parameters_through_abi(kats)
+
+
+def test_host_helper_kats_through_abi(kats):
+    check_host_helper_kats_through_abi(kats)
+
+
+def test_ring_golden_records_through_abi(kats):
+    """the six ring records (compute_s x 4, working_sa_r, working_sa_l) through psf_gen_short_basis_for_trapdoor_ring, a host function: the bodies live in
+    tests/test_gpu_golden_product.py, which runs them again in the GPU suite"""
+    from tests import test_gpu_golden_product as G
+    for name in ("base_2_power_two", "base_2_arbitrary", "base_5_power_5", "base_5_arbitrary"):
+        G.test_ring_compute_s_through_the_product(kats, name)
+    G.test_ring_working_sa_r_through_the_product(kats)
+    G.test_ring_working_sa_l_through_the_product(kats)
 
 
 def test_no_cpu_fallback():

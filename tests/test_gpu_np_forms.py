@@ -3,7 +3,8 @@ block (k_np_step, PSF_NP_WALK=0), the whole walk in one launch with updater work
 the batch fits) and the whole walk with the helper waves updating the projections in memory (k_np_walk2, PSF_NP_WALK=3), each with one or two preimages per
 sampler wave (PSF_NP_G); the recombination e = sum z b behind it runs as one launch over the occupied tiles of the digit planes (default) or as one launch per
 digit pair (PSF_NP_COMBINE=0).  Every form must return the default's bytes -- which equal the oracle's -- on batches with several 64-preimage groups (one of them
-partial), several blocks and a short top block; a wait that gives up must surface as PSF_ERR_SAMPLER, not as a hang or a silent result."""
+partial), several blocks and a short top block; a wait of the default one-launch form that gives up (a GPU shared with other work) is walked again inside the
+call by k_np_walk_solo and costs time only."""
 import json
 import os
 import subprocess
@@ -81,10 +82,45 @@ def test_the_default_form_equals_the_oracle(oracle):
     psf.close()
 
 
-@pytest.mark.parametrize("walk", ["1", "3"])
+def test_a_wait_that_gives_up_is_walked_again_inside_the_call(oracle):
+    """A poll limit of 1 makes the first wait of the one-launch walk that is not satisfied at once give up: the abort word is raised, every workgroup leaves at its next
+    wait, and the launches enqueued behind the walk (a fresh projection + k_np_walk_solo, no waits between workgroups) walk the batch again.  The call returns
+    status 0 and the oracle's rows -- contention costs time, never the call (gpv.rs:152-161 never fails on a valid key) -- and the handle counts the re-run."""
+    import math
+    import tools_amd as T
+    for kind, B in (("gpv", 150), ("gpv", 5), ("ring", 200)):
+        if kind == "gpv":
+            n, q, s = 14, 2**9, 70.0
+            psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+            A, (bt, gt) = psf.trap_gen(21)
+            orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+            orc.load_key(A, bt, gt)
+        else:
+            n, q = 16, 3329
+            s = ((2 * 2 * 1.005 * math.sqrt(n) + 1) * 2) * 4
+            psf = T.PSFGPVRing(T.GadgetParametersRing.init_default(n, q), s, 1.005)
+            psf.trap_gen(22)
+            a, r, e, bt, gt = psf.export_key()
+            orc = oracle.PSFGPVRing(oracle.gadget_params_ring_default(n, q), s, 1.005)
+            orc.load_key(a, r, e, gso_t=gt)
+        u = oracle.uniform_targets(9, B, n, q)
+        want = psf.samp_p(u, seed=50, first_index=3)
+        assert psf.nearest_plane_form()[0] == 1 and psf.nearest_plane_form()[3] == 0          # the default form here is the one-launch walk; nothing re-run so far
+        assert (want == orc.samp_p(50, u, first_index=3)).all()
+        psf._debug_set_walk(1, spins=1)
+        got = psf.samp_p(u, seed=50, first_index=3)                                           # no PsfError: status 0
+        form, G, blocks, reruns = psf.nearest_plane_form()
+        assert form == 1 and reruns >= 1, (kind, B, form, reruns)
+        assert (got == want).all(), (kind, B)
+        psf._debug_set_walk(0)                                                                # and the launch-per-block form agrees, as ever
+        assert (psf.samp_p(u, seed=50, first_index=3) == want).all() and psf.nearest_plane_form()[0] == 0
+        psf.close()
+
+
+@pytest.mark.parametrize("walk", ["3"])
 def test_a_wait_that_gives_up_reports_a_sampler_failure(walk):
-    """PSF_NP_WALK_SPINS=1: the first wait inside the one-launch walk that is not satisfied at once gives up, raises the abort word, every workgroup leaves at its
-    next wait and the call returns PSF_ERR_SAMPLER (status 9) -- no hang, no relaunch, no silent rows."""
+    """the opt-in second one-launch form (PSF_NP_WALK=3, k_np_walk2: measured slower, kept for comparison) has no re-run behind it: PSF_NP_WALK_SPINS=1 makes its
+    first unsatisfied wait end the call with PSF_ERR_SAMPLER (status 9) -- no hang, no silent rows."""
     got = run("gpv", 150, PSF_NP_WALK=walk, PSF_NP_WALK_SPINS="1")
     assert got["status"] == 9
     ok = run("gpv", 150, PSF_NP_WALK=walk)                   # and the same process configuration without the limit is fine

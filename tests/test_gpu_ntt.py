@@ -164,3 +164,23 @@ np.save(sys.argv[3], u)
                 outs.append(np.load(f.name))
         assert (outs[0] == outs[1]).all(), (n, q)
         assert outs[0].any()
+
+
+@pytest.mark.parametrize("q,n", [(65537, 4096), (40961, 4096), (65537, 8192), (12289, 4096)])
+def test_large_rings_take_the_ntt_route(T, q, n):
+    """n = 4096 with a fully splitting prime and n = 8192: the generic LDS transform needs ((2 << L) + 3 n) words -- 96 to 160 KiB, above the 64 KiB a kernel gets
+    by default; gfx950 has 160 KiB per workgroup and the library raises the kernel's limit (these sizes fell back to the O(n^2) kernel, and method = 1
+    was refused although a plan existed).  NTT route == schoolbook kernel, explicitly (method 1) and by default."""
+    rng = np.random.default_rng(n + q)
+    count = 5
+    a = rng.integers(0, q, size=(count, n), dtype=np.uint64)
+    b = rng.integers(-q + 1, q, size=(count, n), dtype=np.int64)
+    a[0, :] = q - 1
+    b[0, :] = np.where(np.arange(n) % 2 == 0, q - 1, -(q - 1))
+    want = T.gadget.poly_mul_negacyclic(a, b, q, method=0)
+    assert (T.gadget.poly_mul_negacyclic(a, b, q, method=1) == want).all()
+    assert (T.gadget.poly_mul_negacyclic(a, b, q) == want).all()
+    # one coefficient of one product against exact integers
+    c = 7
+    exact = sum((int(a[1, i]) * int(b[1, (c - i) % n]) * (1 if i <= c else -1)) for i in range(n)) % q
+    assert int(want[1, c]) == exact

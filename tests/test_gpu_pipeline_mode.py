@@ -173,6 +173,46 @@ def test_bench_multi_rank_path_on_a_one_rank_group():
     line = r.stdout.strip().splitlines()[-1]
     d = json.loads(line)
     assert d["valid"] is True and d["n_gpus"] == 1 and d["steps"] == 2 and "RCCL gather" in d["config"]["parallelism"]
+    # --force-dist without WORLD_SIZE goes through bench.py's own launcher (tools_amd/launch.py): the rank is a child process, the line is relayed
+    assert d["ranks_seen"] == 1 and "self-spawned" in d["launcher"] and d["ms_per_step_ranks"]["min"] <= d["ms_per_step_ranks"]["max"]
+
+
+@pytest.mark.gpu
+def test_bench_under_an_external_launcher_still_works():
+    """python -m torch.distributed.run ... bench.py --gpus 1: WORLD_SIZE is set by the launcher, bench.py must not start ranks of its own."""
+    import json
+    try:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29581",
+                            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--config", "bench64", "--no-cpu-baseline", "--no-latency", "--steps", "2", "--warmup", "1"],
+                           cwd=ROOT, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        pytest.skip("torch.distributed.run did not come up within 300 s on this box (environment, not the library)")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["valid"] is True and d["ranks_seen"] == 1 and d["launcher"].startswith("external")
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_the_box_has_quickly():
+    import time
+    from tools_amd import launch
+    n = launch.visible_gpu_count()
+    assert n >= 1
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1)], cwd=ROOT, capture_output=True, text=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 2 and "not starting any rank" in r.stderr and time.time() - t0 < 60
+
+
+@pytest.mark.gpu
+def test_bench_multi_handle_mode():
+    """bench.py --multi-handle: the torch-free N-GPU route (psfp_samp_p_multi, one worker thread per handle) on the GPUs this box has (one)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--multi-handle", "--gpus", "1", "--config", "bench64", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["valid"] is True and d["n_gpus"] == 1 and len(d["handle_windows_ms"]) == 1 and d["handle_windows_ms"][0]["done"] > 0
 
 
 def test_overlapped_async_calls_return_the_rows_of_synchronous_ones(oracle):

@@ -211,9 +211,11 @@ __global__ void k_np_solve(const uint64_t* __restrict__ Tt, size_t n, size_t nk1
 // Initial projection T = A B on the FP64 matrix cores: 128 x 128 tile per workgroup, wave tile 64 x 64, K chunks of 16 staged by
 // LDS-DMA exactly as in k_trmm_f64 (both operands are fragment-ordered chunk streams).  The per-block updates of the walk are
 // np_update_tile below.
+// only_if: nullptr, or a device word -- the launch does nothing while it is 0 (the second projection of a walk that gave up, psfgpv_impl.hpp)
 __global__ __launch_bounds__(256, 2) void k_np_project(const double* __restrict__ Ach, size_t a_rb_stride, const double* __restrict__ Bch, size_t b_bj_stride,
-                                                       int nk, double* __restrict__ T, size_t ldt) {
+                                                       int nk, double* __restrict__ T, size_t ldt, const unsigned* __restrict__ only_if = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (only_if && __hip_atomic_load(only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   const int bi = blockIdx.y, bj = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1131,7 +1133,59 @@ __global__ __launch_bounds__(512, 4) void k_np_walk(NpSampleArgs a, size_t dim, 
     const unsigned first = grp * per, need = nS - first < per ? nS - first : per;
     np_walk_updater(np_smem, grp, ul, ug, need, a, nblk, Gp, Tm, sy);
   }
-  if (threadIdx.x == 0 && __hip_atomic_load(sy.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicOr(a.flags, 1);   // (the workgroup that gave up gets here)
+  // (a workgroup that gave up gets here with the abort word raised: the call is then re-run by k_np_walk_solo, enqueued right behind this launch)
+}
+
+// ---- the walk without any wait between workgroups (k_np_walk_solo): what runs when k_np_walk gave up -----------------------------------------------------------
+// k_np_walk needs every one of its workgroups resident at the same time; the host decides that from the device's occupancy figures, which hold when the launch has
+// the chip to itself.  A second tenant (another process, a long kernel of another stream, a CU mask) can keep part of the grid from being dispatched while the part
+// that is resident spins: after `spin_limit` polls the abort word is raised and everybody leaves.  The reference's sampler never fails on a valid key
+// (gpv.rs:152-161), so a wait that gave up must cost time, not the call: this kernel is enqueued behind every k_np_walk launch, returns at once while the abort
+// word is 0, and otherwise walks the whole batch again in a form in which no workgroup ever waits for another: a sampler workgroup (4 G preimages) applies the
+// updates of its OWN columns itself, left-looking -- before block J, the rows of block J take the blocks nblk-1 ... J+2 (descending; j ascending inside a block:
+// the contract's chain, as plain fma instead of the MFMA K loop, same bits), block J+1 inside the sampler as always.  T comes from a fresh initial projection
+// (k_np_project with the same predicate).  Slow (every workgroup reads all of g: ~10 ms at C2) and rare by construction.
+template <int G>
+__global__ __launch_bounds__(512, 4) void k_np_walk_solo(NpSampleArgs a, size_t dim, size_t nblk, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, const double* __restrict__ Gp,
+                                                         double* __restrict__ Tm, const unsigned* __restrict__ only_if, unsigned long long* __restrict__ reruns) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char np_smem[];
+  if (__hip_atomic_load(only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  const unsigned wg = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wg == 0 && tid == 0) atomicAdd(reruns, 1ull);
+  long long zr[G];
+#pragma unroll
+  for (int s = 0; s < G; ++s) zr[s] = 0;
+  // chain owner: wave w < 4 G holds preimage (4 wg) G + w, lane = row of the block
+  const size_t b = (size_t)wg * 4 * G + (size_t)wave;
+  const bool owner = wave < 4 * G && b < B;
+  for (size_t J = nblk; J-- > 0;) {
+    if (J + 2 < nblk) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // the z of the blocks above were stored write-through by this workgroup's samplers
+      if (owner) {
+        const size_t i = J * NP_NB + (size_t)lane;
+        double t = Tm[i * a.ldt + b];                                     // the initial projection: untouched so far (rows of block J are written below, once)
+        const double* zb = a.Zf + (b / TR_BN) * a.nkb * TR_CHUNK;
+        const int bc = (int)(b % TR_BN);
+        for (size_t Jb = nblk; Jb-- > J + 2;) {
+          const double* gp = Gp + (np_panel_base(Jb) + (i / 128) * 4) * TR_CHUNK;
+          const double* zp = zb + Jb * (NP_NB / 16) * TR_CHUNK;
+#pragma unroll 4
+          for (int kc = 0; kc < NP_NB / 16; ++kc)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+              t = fma(-zp[(size_t)kc * TR_CHUNK + tr_chunk_pos(bc, kk)], gp[(size_t)kc * TR_CHUNK + tr_chunk_pos((int)(i % 128), kk)], t);
+        }
+        __hip_atomic_store(Tm + i * a.ldt + b, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    np_sample_body<G, true, true>(np_smem, wg, a, dim, J, seed, tag, first_index, B, zr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 }
 
 // ---- the same walk where the sampler workgroups fill the chip (two per CU: C4, 4096 preimages) and T does not fit registers: k_np_walk2 -----------------------------

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <set>
 #include <mutex>
 #include <tuple>
 #include <type_traits>
@@ -166,7 +167,15 @@ psf_status ntt_polymul_dev(int device, uint64_t q, size_t n, size_t count, const
     if (io_bits != 64) return PSF_ERR_UNSUPPORTED;
     const NttDev a = dev_args(P, 1, 1);
     const size_t smem = ((2u << P->pl.L) + 3 * n) * sizeof(uint32_t);
-    if (smem > 64 * 1024) return PSF_ERR_UNSUPPORTED;
+    if (smem > 160 * 1024) return PSF_ERR_UNSUPPORTED;                   // gfx950: 160 KiB of LDS per workgroup (n = 8192 with a fully splitting prime needs 160 KiB exactly)
+    if (smem > 64 * 1024) {                                              // above the default limit the kernel's attribute is raised once per process and device
+      static std::mutex mu; static std::set<int> raised;
+      std::lock_guard<std::mutex> lk(mu);
+      if (!raised.count(device)) {
+        NTT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_polymul_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised.insert(device);
+      }
+    }
     hipLaunchKernelGGL(k_ntt_polymul_lds, dim3((unsigned)(count > 4096 ? 4096 : count)), dim3(256), smem, st, a, (uint32_t)n, P->pl.L, P->pl.d,
                        (const uint64_t*)d_a, (const int64_t*)d_b, (uint64_t*)d_out, count);
     NTT_TRY(hipGetLastError());
@@ -195,7 +204,7 @@ psf_status ntt_forward_dev(int device, uint64_t q, size_t n, size_t count, const
   if (P->route != 2 || (io_bits == 16 && P->tb.qb == 0)) return PSF_ERR_UNSUPPORTED;
   if (count == 0) return PSF_OK;
   NTT_TRY(hipSetDevice(device));
-  for_shape(P->tb.logn, P->tb.ld, P->tb.qb, [&](auto ln, auto ldv, auto qbv) {
+  const bool ok = for_shape(P->tb.logn, P->tb.ld, P->tb.qb, [&](auto ln, auto ldv, auto qbv) {
     constexpr int LN = decltype(ln)::value, LDV = decltype(ldv)::value, QBV = decltype(qbv)::value;
     const NttDev a = dev_args(P, 1, 1);
     if constexpr (QBV != 0) {
@@ -203,6 +212,7 @@ psf_status ntt_forward_dev(int device, uint64_t q, size_t n, size_t count, const
     }
     hipLaunchKernelGGL((k_ntt_forward<LN, LDV, QBV, 64, false>), dim3(wave_grid(count)), dim3(256), 0, st, a, d_a, d_hat, count);
   });
+  if (!ok) return PSF_ERR_UNSUPPORTED;                      // route 2 without an instantiated shape: nothing was launched
   NTT_TRY(hipGetLastError());
   return PSF_OK;
 }
@@ -216,7 +226,7 @@ psf_status ntt_mul_hat_dev(int device, uint64_t q, size_t n, size_t count, const
   if (P->route != 2 || (io_bits == 16 && P->tb.qb == 0)) return PSF_ERR_UNSUPPORTED;
   if (count == 0) return PSF_OK;
   NTT_TRY(hipSetDevice(device));
-  for_shape(P->tb.logn, P->tb.ld, P->tb.qb, [&](auto ln, auto ldv, auto qbv) {
+  const bool ok = for_shape(P->tb.logn, P->tb.ld, P->tb.qb, [&](auto ln, auto ldv, auto qbv) {
     constexpr int LN = decltype(ln)::value, LDV = decltype(ldv)::value, QBV = decltype(qbv)::value;
     const NttDev a = dev_args(P, Kern<LN, LDV, QBV>::E, Kern<LN, LDV, QBV>::E + 1);
     if constexpr (QBV != 0) {
@@ -224,6 +234,7 @@ psf_status ntt_mul_hat_dev(int device, uint64_t q, size_t n, size_t count, const
     }
     hipLaunchKernelGGL((k_ntt_mul_hat<LN, LDV, QBV, 64>), dim3(wave_grid(count)), dim3(256), 0, st, a, d_hat, hat_stride, d_b, d_out, count);
   });
+  if (!ok) return PSF_ERR_UNSUPPORTED;                      // route 2 without an instantiated shape: nothing was launched
   NTT_TRY(hipGetLastError());
   return PSF_OK;
 }
@@ -237,11 +248,12 @@ psf_status ntt_ring_fa_dev(int device, uint64_t q, size_t n, uint32_t K, const u
   if (P->route != 2 || smem > 64 * 1024) return PSF_ERR_UNSUPPORTED;
   if (B == 0) return PSF_OK;
   NTT_TRY(hipSetDevice(device));
-  for_shape(P->tb.logn, P->tb.ld, P->tb.qb, [&](auto ln, auto ldv, auto qbv) {
+  const bool ok = for_shape(P->tb.logn, P->tb.ld, P->tb.qb, [&](auto ln, auto ldv, auto qbv) {
     constexpr int LN = decltype(ln)::value, LDV = decltype(ldv)::value, QBV = decltype(qbv)::value;
     const NttDev a = dev_args(P, Kern<LN, LDV, QBV>::E, Kern<LN, LDV, QBV>::E + 1);
     hipLaunchKernelGGL((k_ring_fa<LN, LDV, QBV>), dim3(wave_grid(B)), dim3(256), smem, st, a, d_hat, K, d_sigma, d_u, B);
   });
+  if (!ok) return PSF_ERR_UNSUPPORTED;                      // route 2 without an instantiated shape: nothing was launched
   NTT_TRY(hipGetLastError());
   return PSF_OK;
 }

@@ -44,7 +44,9 @@ struct psfgpv_handle {
   int np_walk = -1;                   // PSF_NP_WALK: 0 = one launch per block (k_np_step); 1 / unset = the whole walk in one launch (k_np_walk: updater workgroups, T in
                                       // registers) where it fits, launches otherwise; 3 = k_np_walk2 (helper waves update T in memory) for every batch that is resident
   int cus = 0;                        // compute units of the device
+  int walk_slots[3] = {0, 0, 0};      // [G]: workgroups of k_np_walk<G> a compute unit holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor)
   unsigned walk_spins = 1u << 22;      // NpWalkSync::spin_limit
+  int last_form = 0, last_G = 0;      // what the last call launched for the walk: 1 = k_np_walk<G> (one launch), 0 = k_np_step<G> per block, 3 = k_np_walk2<G>
   int np_g = 0;                       // PSF_NP_G: preimages per wave of the sampler (0 = by batch size)
   int np_immediate = -1;              // PSF_NP_IMMEDIATE: 1 = every block updates all the rows below it in the launch that follows, 0 = panel-deferred far update, -1 = by batch size
   bool has_key = false;
@@ -201,6 +203,25 @@ static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
 
 static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size_t B, int64_t* d_e, int pass);
 
+// One one-launch walk at a time per device and process: the constructor makes `st` wait for the walk launched before (any handle, any stream), the destructor
+// records the event the next one will wait for.  Held across the launch only; costs one hipStreamWaitEvent + one hipEventRecord per call.
+struct WalkTurn {
+  static constexpr int MAX_DEV = 64;
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static hipEvent_t* events() { static hipEvent_t ev[MAX_DEV] = {}; return ev; }
+  static bool* recorded() { static bool r[MAX_DEV] = {}; return r; }
+  std::unique_lock<std::mutex> lk;
+  int dev; hipStream_t st;
+  WalkTurn(int device, hipStream_t s) : lk(mu()), dev(device), st(s) {
+    if (dev < 0 || dev >= MAX_DEV) { dev = -1; return; }
+    if (!events()[dev] && hipEventCreateWithFlags(&events()[dev], hipEventDisableTiming) != hipSuccess) { events()[dev] = nullptr; dev = -1; return; }
+    if (recorded()[dev]) hipStreamWaitEvent(st, events()[dev], 0);
+  }
+  ~WalkTurn() {
+    if (dev >= 0 && hipEventRecord(events()[dev], st) == hipSuccess) recorded()[dev] = true;
+  }
+};
+
 // MatZ::sample_d_precomputed_gso for the whole batch (gpv.rs:160): the launch sequence of psf_np_kernels.hpp, one stream
 // pass 0: centre -sol on the pivot columns (K = n), e = sum z b + sol; pass 1 (two-pass mode): centre -e1 on every coordinate (K = d), e = sum z b + e1
 static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e, int pass = 0) {
@@ -219,15 +240,31 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
     const int Gw = (g->np_g == 1 || g->np_g == 2) ? g->np_g : (B <= 4 * (size_t)g->cus ? 1 : 2);
     const unsigned nSw = (unsigned)((B + 4 * (size_t)Gw - 1) / (4 * (size_t)Gw));
     const unsigned per = (unsigned)(NP_GW / (4 * Gw)), ngroups = (nSw + per - 1) / per;
-    unsigned ug = ngroups ? (unsigned)g->cus / ngroups : 0;
+    // residency: the device holds walk_slots workgroups of this kernel per CU (occupancy API: registers and LDS, not an assumption about the chip being ours alone --
+    // that part no API can promise, hence k_np_walk_solo below); one sampler workgroup per CU at most, the updaters take what the samplers leave
+    const long slots = (long)g->cus * (long)g->walk_slots[Gw];
+    unsigned ug = 0;
+    if (ngroups && nSw <= (unsigned)g->cus && slots > (long)nSw) ug = (unsigned)std::min<long>((slots - (long)nSw) / (long)ngroups, (long)g->cus / (long)ngroups);
     if (ug > g->nblk - 2) ug = (unsigned)(g->nblk - 2);
     if (nSw <= (unsigned)g->cus && ug >= 1 && (size_t)2 * NP_WALK_SLOTS * ug >= g->nblk - 2) {
       NpWalkSync sy{g->dWalk, g->dWalk + (size_t)ngroups * g->nblk, g->dWalk + (size_t)2 * ngroups * g->nblk, (unsigned)g->nblk, g->walk_spins};
-      hipMemsetAsync(g->dWalk, 0, g->walk_words * sizeof(unsigned), st);
       NpSampleArgs aw{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, flags};
       const unsigned ntot = nSw + ngroups * ug;
-      if (Gw == 1) hipLaunchKernelGGL((k_np_walk<1>), dim3(ntot), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, nSw, ngroups, ug, g->dGp, g->dTm, sy);
-      else hipLaunchKernelGGL((k_np_walk<2>), dim3(ntot), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, nSw, ngroups, ug, g->dGp, g->dTm, sy);
+      unsigned long long* reruns = reinterpret_cast<unsigned long long*>(g->dFlags + 8);
+      {
+        // two walks at once on one device (two handles, two streams) could each hold half of the slots and wait for the other half for ever: walks of this process take
+        // turns per device -- each launch waits for the event behind the previous one.  (Another process is not covered by this; k_np_walk_solo is.)
+        WalkTurn turn(g->base->prm.device, st);
+        hipMemsetAsync(g->dWalk, 0, g->walk_words * sizeof(unsigned), st);
+        if (Gw == 1) hipLaunchKernelGGL((k_np_walk<1>), dim3(ntot), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, nSw, ngroups, ug, g->dGp, g->dTm, sy);
+        else hipLaunchKernelGGL((k_np_walk<2>), dim3(ntot), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, nSw, ngroups, ug, g->dGp, g->dTm, sy);
+      }
+      // a walk that gave up (the abort word) is walked again without waits between workgroups, from a fresh projection; both launches return at once otherwise
+      if (pass == 0) hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, g->dC0p, g->nkc, (int)g->nkc, g->dTm, ld, (const unsigned*)sy.abort);
+      else hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBfull, g->nkd, g->dC1, g->nkd, (int)g->nkd, g->dTm, ld, (const unsigned*)sy.abort);
+      if (Gw == 1) hipLaunchKernelGGL((k_np_walk_solo<1>), dim3(nSw), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, g->dGp, g->dTm, (const unsigned*)sy.abort, reruns);
+      else hipLaunchKernelGGL((k_np_walk_solo<2>), dim3(nSw), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, g->dGp, g->dTm, (const unsigned*)sy.abort, reruns);
+      g->last_form = 1; g->last_G = Gw;
       return launch_np_recombination(g, st, B, d_e, pass);
     }
   }
@@ -241,6 +278,7 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
     hipMemsetAsync(g->dWalk, 0, g->walk_words * sizeof(unsigned), st);
     if (G == 1) hipLaunchKernelGGL((k_np_walk2<1>), dim3(nS), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, g->dGp, g->dTm, sy);
     else hipLaunchKernelGGL((k_np_walk2<2>), dim3(nS), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, g->dGp, g->dTm, sy);
+    g->last_form = 3; g->last_G = G;
     return launch_np_recombination(g, st, B, d_e, pass);
   }
   const size_t W = NP_PANEL;
@@ -276,6 +314,7 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
     if (G == 1) hipLaunchKernelGGL((k_np_step<1>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, g->dTm);
     else hipLaunchKernelGGL((k_np_step<2>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, g->dTm);
   }
+  g->last_form = 0; g->last_G = G;
   return launch_np_recombination(g, st, B, d_e, pass);
 }
 
@@ -375,8 +414,8 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipMalloc(&g->dBpiv, g->nrb * g->nkc * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipMalloc(&g->dB8, 2 * g->dpad * g->dpad));
   HIP_TRY(hipMalloc(&g->dBocc, 2 * g->nrb * g->nrb));
-  HIP_TRY(hipMalloc(&g->dFlags, 8 * sizeof(int)));
-  HIP_TRY(hipMemset(g->dFlags, 0, 8 * sizeof(int)));
+  HIP_TRY(hipMalloc(&g->dFlags, 12 * sizeof(int)));                       // [0..7] per call (two passes), [8..9] a 64-bit count of walks re-run by k_np_walk_solo (never cleared)
+  HIP_TRY(hipMemset(g->dFlags, 0, 12 * sizeof(int)));
   // large moduli: q sqrt(n) > 2^13 s (relative centre error of a single pass above 2^-40, see include/psf_mi355x.h "Precision of the centres"); PSF_NP_TWO_PASS=0/1 forces
   g->two_pass = (double)g->base->q * std::sqrt((double)g->n) > g->s * 8192.0;
   { const char* ev = getenv("PSF_NP_TWO_PASS"); if (ev) g->two_pass = atoi(ev) != 0; }
@@ -392,6 +431,11 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   { int cu = 0; HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, g->base->prm.device)); g->cus = cu; }
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk_solo<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk_solo<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  // workgroups of the one-launch walk a compute unit really holds (registers, LDS): the residency test of launch_nearest_plane multiplies by the CU count
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&g->walk_slots[1], reinterpret_cast<const void*>(k_np_walk<1>), 512, 65536));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&g->walk_slots[2], reinterpret_cast<const void*>(k_np_walk<2>), 512, 65536));
   if (const char* e = std::getenv("PSF_NP_WALK")) g->np_walk = std::atoi(e);
   if (const char* e = std::getenv("PSF_NP_WALK_SPINS")) { const long v = std::atol(e); if (v >= 1) g->walk_spins = (unsigned)v; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -690,6 +734,29 @@ extern "C" psf_status psfgpv_debug_last_z(psfgpv_handle* g, size_t b, double* z_
   return PSF_OK;
 }
 
+// which kernels walked the last call (bench.py's roofline label; tests): form 1 = k_np_walk<G>, one launch; 0 = one k_np_step<G> launch per 64-row block; `reruns` = walks of
+// this handle since its creation that gave up waiting and were walked again by k_np_walk_solo (0 on a GPU that is not shared)
+psf_status psfgpv_get_nearest_plane_form(psfgpv_handle* g, int* form, int* preimages_per_wave, size_t* blocks, uint64_t* reruns) {
+  if (!g) return PSF_ERR_PARAM;
+  HIP_TRY(hipSetDevice(g->base->prm.device));
+  HIP_TRY(hipStreamSynchronize(g->last_stream));
+  unsigned long long r = 0;
+  HIP_TRY(hipMemcpy(&r, g->dFlags + 8, sizeof(r), hipMemcpyDeviceToHost));
+  if (form) *form = g->last_form;
+  if (preimages_per_wave) *preimages_per_wave = g->last_G;
+  if (blocks) *blocks = g->nblk;
+  if (reruns) *reruns = (uint64_t)r;
+  return PSF_OK;
+}
+// tests: force the form of the walk (-1 = by batch size, 0 = one launch per block, 1 = one launch where it fits) and the number of polls after which a wait of the
+// one-launch walk gives up (0 = keep; 1 makes every call take the k_np_walk_solo route)
+psf_status psfgpv_debug_set_walk(psfgpv_handle* g, int form, unsigned spins) {
+  if (!g || form < -1 || form > 1) return PSF_ERR_PARAM;
+  g->np_walk = form;
+  if (spins) g->walk_spins = spins;
+  return PSF_OK;
+}
+
 psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle* g, size_t* blocks, size_t* generic_recombination) {
   if (!g) return PSF_ERR_PARAM;
   HIP_TRY(hipStreamSynchronize(g->last_stream));
@@ -739,15 +806,16 @@ static psf_status ring_install(psfring_handle* h) {
   // the key side of f_a is transformed once: a -> the images of its k+2 polynomials
   h->fa_ntt = false;
   if (ntt_route(h->gp.q, n) == 2 && ((size_t)K * n + 4 * n) * sizeof(uint32_t) <= 64 * 1024) {
-    if (!h->dHat) HIP_TRY(hipMalloc(&h->dHat, K * n * sizeof(uint32_t)));
+    // (the key is installed and usable at this point: a failure below only means that f_a keeps the matrix-product route, it is not an error of the call)
     uint64_t* da = nullptr;
-    HIP_TRY(hipMalloc(&da, K * n * sizeof(uint64_t)));
-    psf_status rf = hipMemcpy(da, h->a.data(), K * n * sizeof(uint64_t), hipMemcpyHostToDevice) == hipSuccess ? PSF_OK : PSF_ERR_HIP;
+    psf_status rf = (h->dHat || hipMalloc(&h->dHat, K * n * sizeof(uint32_t)) == hipSuccess) ? PSF_OK : PSF_ERR_HIP;
+    if (rf == PSF_OK && hipMalloc(&da, K * n * sizeof(uint64_t)) != hipSuccess) rf = PSF_ERR_HIP;
+    if (rf == PSF_OK && hipMemcpy(da, h->a.data(), K * n * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) rf = PSF_ERR_HIP;
     if (rf == PSF_OK) rf = ntt_forward_dev(b->prm.device, h->gp.q, n, K, da, 64, h->dHat, nullptr);
     if (rf == PSF_OK && hipDeviceSynchronize() != hipSuccess) rf = PSF_ERR_HIP;
     hipFree(da);
-    if (rf != PSF_OK) return rf;
-    h->fa_ntt = true;
+    if (rf != PSF_OK) (void)hipGetLastError();
+    h->fa_ntt = rf == PSF_OK;
   }
   return PSF_OK;
 }
@@ -1038,5 +1106,9 @@ psf_status psfring_uniform_targets_dev(psfring_handle* h, uint64_t seed, uint64_
 psf_status psfring_last_status(psfring_handle* h) { return h ? psfgpv_last_status(h->g) : PSF_ERR_PARAM; }
 psf_status psfring_enable_timing(psfring_handle* h, int on) { return h ? psfgpv_enable_timing(h->g, on) : PSF_ERR_PARAM; }
 psf_status psfring_get_timing(psfring_handle* h, double* a, double* b) { return h ? psfgpv_get_timing(h->g, a, b) : PSF_ERR_PARAM; }
+psf_status psfring_get_nearest_plane_form(psfring_handle* h, int* form, int* preimages_per_wave, size_t* blocks, uint64_t* reruns) {
+  return h ? psfgpv_get_nearest_plane_form(h->g, form, preimages_per_wave, blocks, reruns) : PSF_ERR_PARAM;
+}
+psf_status psfring_debug_set_walk(psfring_handle* h, int form, unsigned spins) { return h ? psfgpv_debug_set_walk(h->g, form, spins) : PSF_ERR_PARAM; }
 
 }  // extern "C"

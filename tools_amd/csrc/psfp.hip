@@ -8,6 +8,7 @@
 #include <string>
 #include <thread>
 #include <atomic>
+#include <mutex>
 #include <functional>
 #include <vector>
 #include "../../include/psf_mi355x.h"
@@ -80,6 +81,8 @@ struct psfp_handle {
   size_t mL = 0, nbiL = 0;     // order of the stored triangular factor (m, or m_bar) and its row blocks
   int8_t* dR8 = nullptr;       // R tile-packed (k_pack_R8: 4 KiB tiles of 64 rows x 64 columns, contiguous) for k_recombine_mfma_big and k_rd2_mfma, mb_pad x ldr
   bool r8_valid = false;       // dR8 follows dR (ensure_R8)
+  bool r8_pending = false;     // the pack has been enqueued on r8_stream and is not known to have completed: other streams wait for evR8
+  hipEvent_t evR8 = nullptr; hipStream_t r8_stream = nullptr;
   // compact copies of the key for calls with a handful of preimages, where reading A and R once IS the time of their stages (psf_stream_kernels.hpp):
   // R as two bits per entry (k_recombine_small2; only a {-1, 0, 1} trapdoor has one), A as 32-bit words (k_syndrome_small32; q <= 2^32)
   uint32_t* dR2 = nullptr; uint32_t* dA32 = nullptr; int* dR2bad = nullptr; int* hR2bad = nullptr; hipEvent_t evSmall = nullptr;
@@ -196,10 +199,22 @@ static bool rcb_packed() {
   return on;
 }
 // the tile-packed copy of R, rebuilt on `st` when R has changed since
+// (as the compact copies above: the stream that packs is ordered behind the pack by itself; every OTHER stream that reads dR8 before the pack is known to have
+// completed waits for its event -- the halves of PSF_HALVES on s1 / aux, back-to-back device-pointer calls on different non-blocking streams)
 static void ensure_R8(psfp_handle* h, hipStream_t st) {
-  if (h->r8_valid || !h->dR8) return;
-  hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(h->mb_pad * h->ldr, 256, 256 * 64)), dim3(256), 0, st, h->dR, h->ldr, h->mb, h->w, h->mb_pad, h->ldr, h->dR8);
-  h->r8_valid = true;
+  if (!h->dR8) return;
+  if (!h->r8_valid) {
+    hipLaunchKernelGGL(k_pack_R8, dim3(grid_for(h->mb_pad * h->ldr, 256, 256 * 64)), dim3(256), 0, st, h->dR, h->ldr, h->mb, h->w, h->mb_pad, h->ldr, h->dR8);
+    h->r8_valid = true;
+    h->r8_pending = false;
+    if (!h->evR8 && hipEventCreateWithFlags(&h->evR8, hipEventDisableTiming) != hipSuccess) { h->evR8 = nullptr; hipStreamSynchronize(st); return; }
+    if (hipEventRecord(h->evR8, st) != hipSuccess) { hipStreamSynchronize(st); return; }
+    h->r8_pending = true; h->r8_stream = st;
+    return;
+  }
+  if (!h->r8_pending) return;
+  if (hipEventQuery(h->evR8) == hipSuccess) { h->r8_pending = false; return; }
+  if (st != h->r8_stream) hipStreamWaitEvent(st, h->evR8, 0);
 }
 
 static size_t gadget_lds_bytes(size_t k) { return k * k * 8 + k * 8 + k * sizeof(SampleZParams) + k * k * 4 + k * 256 * 4; }
@@ -584,6 +599,7 @@ void psfp_destroy(psfp_handle* h) {
   hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dR8); hipFree(h->dR2); hipFree(h->dA32); hipFree(h->dR2bad);
   if (h->hR2bad) hipHostFree(h->hR2bad);
   if (h->evSmall) hipEventDestroy(h->evSmall);
+  if (h->evR8) hipEventDestroy(h->evR8);
   for (auto& t : h->sets) hipFree(t.dFail);
   if (h->s1) hipStreamDestroy(h->s1);
   for (int i = 0; i < 2; ++i) { if (h->evT[i]) hipEventDestroy(h->evT[i]); if (h->evP[i]) hipEventDestroy(h->evP[i]); }
@@ -1219,6 +1235,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 4 * TR_CHUNK * sizeof(double), st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
   }
   if (h->structured) {  // x_top -= g R d_2 (exact integer sum on the int8 matrix cores)
+    ensure_R8(h, st);
     ScopedTimer t(h, st, "k_rd2_mfma");
     hipLaunchKernelGGL(k_rd2_mfma, dim3((unsigned)(ld / 64), (unsigned)(round_up(h->mb, 64) / 64)), dim3(256), 3 * (1 + kFixPlanes) * 4096, st, h->dR8, h->ldr, h->dD8, h->ldr * ld, ld,
                        h->mb, h->g_const, h->dX);

@@ -252,12 +252,14 @@ class PSFPerturbation:
         return list(zip(nm, list(ms)[:cnt.value]))
 
 
-def samp_p_multi(psfs, u, seed=0, first_index=0):
-    """psfp_samp_p_multi: one batch over several PSFPerturbation handles (one per GPU, same key), rows cut into contiguous shares."""
+def samp_p_multi(psfs, u, seed=0, first_index=0, out=None):
+    """psfp_samp_p_multi: one batch over several PSFPerturbation handles (one per GPU, same key), rows cut into contiguous shares.
+    out: a C-contiguous int64 array of B x m to fill (a loop of calls reuses it instead of touching a fresh gigabyte per step)."""
     n, m = psfs[0].n, psfs[0].m
     u2 = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, n)
     B = u2.shape[0]
-    e = np.zeros((B, m), dtype=np.int64)
+    e = np.zeros((B, m), dtype=np.int64) if out is None else out
+    assert e.dtype == np.int64 and e.shape == (B, m) and e.flags["C_CONTIGUOUS"]
     arr = (C.c_void_p * len(psfs))(*[p._h for p in psfs])
     check(lib().psfp_samp_p_multi(arr, C.c_int(len(psfs)), C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), _p(u2, C.c_uint64), _p(e, C.c_int64)),
           "samp_p_multi")
@@ -411,6 +413,17 @@ class PSFGPV:
         check(lib().psfgpv_get_timing(self._h, C.byref(a), C.byref(b)), "get_timing")
         return {"k_np_solve": a.value, "nearest_plane": b.value}
 
+    def nearest_plane_form(self):
+        """(form, G, blocks, reruns) of the last samp_p call: form 1 = the walk of gpv.rs:160 in one launch (k_np_walk<G>), 0 = one k_np_step<G> launch per 64-row
+        block; reruns = walks of this handle that gave up waiting on a shared GPU and were walked again by k_np_walk_solo (include/psf_mi355x.h)."""
+        f, g, b, r = C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_uint64(0)
+        check(lib().psfgpv_get_nearest_plane_form(self._h, C.byref(f), C.byref(g), C.byref(b), C.byref(r)), "nearest_plane_form")
+        return f.value, g.value, b.value, r.value
+
+    def _debug_set_walk(self, form=-1, spins=0):
+        """tests: force the walk's launch form (-1 by batch size, 0 per block, 1 one launch where it fits) / the poll limit of its waits (1: every wait gives up)"""
+        check(lib().psfgpv_debug_set_walk(self._h, C.c_int(form), C.c_uint(spins)), "debug_set_walk")
+
 
 class PSFGPVRing:
     """gpv_ring.rs:62-67 / impl PSF :69-284 on one MI355X.  Polynomials are coefficient rows (constant term first):
@@ -544,3 +557,14 @@ class PSFGPVRing:
         a, b = C.c_double(0), C.c_double(0)
         check(lib().psfring_get_timing(self._h, C.byref(a), C.byref(b)), "get_timing")
         return {"k_np_solve": a.value, "nearest_plane": b.value}
+
+    def nearest_plane_form(self):
+        """(form, G, blocks, reruns) of the last samp_p call: form 1 = the walk of gpv.rs:160 in one launch (k_np_walk<G>), 0 = one k_np_step<G> launch per 64-row
+        block; reruns = walks of this handle that gave up waiting on a shared GPU and were walked again by k_np_walk_solo (include/psf_mi355x.h)."""
+        f, g, b, r = C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_uint64(0)
+        check(lib().psfring_get_nearest_plane_form(self._h, C.byref(f), C.byref(g), C.byref(b), C.byref(r)), "nearest_plane_form")
+        return f.value, g.value, b.value, r.value
+
+    def _debug_set_walk(self, form=-1, spins=0):
+        """tests: force the walk's launch form (-1 by batch size, 0 per block, 1 one launch where it fits) / the poll limit of its waits (1: every wait gives up)"""
+        check(lib().psfring_debug_set_walk(self._h, C.c_int(form), C.c_uint(spins)), "debug_set_walk")
