@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency legs (batch 1 / 16 / 64)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short c2 / c4 / c3prime legs the default invocation appends (\"other_configs\")")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (launcher, process group, barriers, gather, reductions) on a one-rank RCCL group")
+    ap.add_argument("--emulate-world", type=int, default=0, help="with --force-dist: size the gather's buffers as rank 0 of a job of this many ranks would (C5 readiness: 8)")
     ap.add_argument("--multi-handle", action="store_true", help="torch-free scaling mode: ONE process drives --gpus devices through psfp_samp_p_multi (host buffers, one worker thread per handle)")
     ap.add_argument("--launch-timeout", type=float, default=0.0, help="seconds after which the self-launcher stops every rank (0 = none)")
     return ap.parse_args(argv)
@@ -106,7 +107,7 @@ def rank_main(args):
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     run = run_config(args.config, args.batch, args.steps, args.warmup, local_rank, rank, world, multi, dev, structured=args.structured,
-                     gather=multi and not args.no_gather, force_dist=args.force_dist)
+                     gather=multi and not args.no_gather, force_dist=args.force_dist, alloc_world=args.emulate_world)
     psf, scheme, n, q, r, s, m, B, u, e = (run[k] for k in ("psf", "scheme", "n", "q", "r", "s", "m", "B", "u", "e"))
     stream, first_index, kern_ms, elapsed, valid, do_gather = (run[k] for k in ("stream", "first_index", "kern_ms", "elapsed", "valid", "do_gather"))
 
@@ -139,6 +140,8 @@ def rank_main(args):
             out["ms_per_step_ranks"] = {"min": round(min(run["rank_elapsed"]) / args.steps * 1e3, 3), "max": round(max(run["rank_elapsed"]) / args.steps * 1e3, 3),
                                         "all": [round(x / args.steps * 1e3, 3) for x in run["rank_elapsed"]]}
             out["launcher"] = "bench.py (self-spawned ranks, tools_amd/launch.py)" if os.environ.get("PSF_LAUNCHED_BY") else "external (torch.distributed.run or equivalent)"
+            if run["gather_info"]:
+                out["gather"] = run["gather_info"]
         if latency:
             out["latency"] = latency
         if args.config != "c3" or args.structured:
@@ -185,7 +188,7 @@ def rank_main(args):
         sys.exit(4)
 
 
-def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, structured=False, gather=False, force_dist=False, key_seed=3):
+def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, structured=False, gather=False, force_dist=False, key_seed=3, alloc_world=0):
     """Key generation (outside the timed region, benches/psf.rs:36,61,88), `warmup` untimed steps, then exactly `steps` samp_p passes over one batch of
     uniform syndromes between two fences (device synchronise + barrier + device synchronise), and the correctness gate on the last step's rows."""
     import torch
@@ -222,7 +225,12 @@ def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, s
     e = torch.empty((B, m), dtype=torch.int64, device=dev)
     psf.uniform_targets_dev(u.data_ptr(), B, seed=7, first_index=first_index, stream=stream)
     do_gather = bool(gather)
-    gatherer = AsyncRowGather(B, m, dev, dst=0, force=force_dist) if do_gather else None     # step i's rows travel while step i+1 computes
+    gatherer = AsyncRowGather(B, m, dev, dst=0, force=force_dist, alloc_world=alloc_world) if do_gather else None     # step i's rows travel while step i+1 computes
+    gather_info = None
+    if gatherer is not None:
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        gather_info = {"depth": gatherer.depth, "buffers_sized_for_ranks": gatherer.alloc_world, "bytes_per_depth": AsyncRowGather.bytes_per_depth(B, m, gatherer.alloc_world, rank == 0),
+                       "hbm_free_GB_after_allocation": round(free_b / 1e9, 2), "hbm_total_GB": round(total_b / 1e9, 2)}
 
     def step(i):
         psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=1000 + i, first_index=first_index, stream=stream)
@@ -278,7 +286,7 @@ def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, s
         valid = bool(vt.item())
     return {"psf": psf, "scheme": scheme, "n": n, "q": q, "r": r, "s": s, "m": m, "gp": gp, "B": B, "u": u, "e": e, "stream": stream,
             "first_index": first_index, "kern_ms": kern_ms, "elapsed": elapsed, "valid": valid, "do_gather": do_gather, "trap_gen_s": t_trapgen,
-            "rank_elapsed": rank_elapsed, "ranks_seen": ranks_seen}
+            "rank_elapsed": rank_elapsed, "ranks_seen": ranks_seen, "gather_info": gather_info}
 
 
 def nearest_plane_form(psf):

@@ -56,16 +56,21 @@ class AsyncRowGather:
     checked on device), which halves the bytes on the links; two staging buffers alternate so that a buffer is only
     rewritten after the gather that reads it has completed."""
 
-    def __init__(self, rows, cols, device, dst=0, depth=2, force=False):
+    def __init__(self, rows, cols, device, dst=0, depth=2, force=False, alloc_world=0):
+        """alloc_world: size the buffers as rank `dst` of a job of that many ranks would (receive blocks beyond the real world size are allocated and never
+        written) -- the memory side of an 8-rank job rehearsed on the ranks there are (bench.py --emulate-world)."""
         self.enabled = dist.is_initialized() and (dist.get_world_size() > 1 or force)   # force: exercise the path on one rank
         self.rank = dist.get_rank() if self.enabled else 0
         self.world = dist.get_world_size() if self.enabled else 1
-        depth = self.fit_depth(rows, cols, device, depth, self.world, self.rank == dst) if self.enabled else depth
+        self.alloc_world = max(self.world, int(alloc_world or 0))
+        depth = self.fit_depth(rows, cols, device, depth, self.alloc_world, self.rank == dst) if self.enabled else depth
         self.dst, self.depth = dst, depth
         self.stage = [torch.empty((rows, cols), dtype=torch.int32, device=device) for _ in range(depth)] if self.enabled else []
         self.recv = None
+        self.spare = []
         if self.enabled and self.rank == dst:
             self.recv = [[torch.empty((rows, cols), dtype=torch.int32, device=device) for _ in range(self.world)] for _ in range(depth)]
+            self.spare = [torch.empty((rows, cols), dtype=torch.int32, device=device) for _ in range(depth * (self.alloc_world - self.world))]
         self.work = [None] * depth
         self.step = 0
         self.overflow = torch.zeros((), dtype=torch.int32, device=device) if self.enabled else None
