@@ -139,7 +139,7 @@ def test_full_size_preimages_have_the_right_variance_in_every_panel(c3):
 
 
 @pytest.mark.parametrize("n,q", [(8, 64), (20, 257), (40, 2**20)])
-def test_the_three_cholesky_forms_agree(monkeypatch, oracle, n, q):
+def test_the_three_cholesky_forms_agree(monkeypatch, exp_lib, oracle, n, q):
     """PSF_CHOL selects the factorisation: on the key's chunk stream (the default for large keys: no dense matrix), left-looking on a dense matrix with
     the LDS-staged GEMM (the default below 16 GB), right-looking (rounds 1-2).  Same key seed: A and R are bitwise equal, the factors agree with each
     other and with the oracle's unblocked recurrence within rounding, and each reproduces Sigma_2; m runs from one partial panel to several panels."""

@@ -153,7 +153,7 @@ def test_two_handles_in_two_threads_do_not_interfere():
             assert (together[k][i] == alone[k][i]).all()
 
 
-def test_host_pointer_path_slices_large_batches_without_changing_a_bit(monkeypatch):
+def test_host_pointer_path_slices_large_batches_without_changing_a_bit(monkeypatch, exp_lib):
     """psfp_samp_p cuts big batches into slices so that PCIe overlaps compute; PSF_HOST_SLICE forces slicing at a small size."""
     import numpy as np
     import tools_amd as T

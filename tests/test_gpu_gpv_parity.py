@@ -84,7 +84,7 @@ def test_samp_d_f_a_domain(T, oracle):
 
 
 @pytest.mark.parametrize("g", [1, 2, 4])
-def test_sampler_gives_the_same_bits_for_every_lane_split(T, oracle, monkeypatch, g):
+def test_sampler_gives_the_same_bits_for_every_lane_split(T, oracle, monkeypatch, exp_lib, g):
     """k_np_sample<G> evaluates the attempts of one draw on 64 / G lanes; the value of a draw is its first accepted attempt,
     so G = 1, 2, 4 must agree with each other and with the oracle (PSF_NP_G forces the variant)."""
     n, q, s = 10, 157, 30.0
@@ -123,7 +123,7 @@ def test_large_modulus(T, oracle, n, q, s):
 
 
 @pytest.mark.parametrize("force", [0, 1])
-def test_both_forms_of_the_walk_stay_reachable(T, oracle, monkeypatch, force):
+def test_both_forms_of_the_walk_stay_reachable(T, oracle, monkeypatch, exp_lib, force):
     """PSF_NP_TWO_PASS forces one form: two passes at a small modulus (the second projection runs over all d coordinates, K = d, several
     blocks) and one pass at a large one (the pre-round-3 behaviour, kept only as the comparison arm); bitwise against the oracle forced alike."""
     n, q, s = (40, 256, 300.0) if force else (3, 2**45, 60.0)
@@ -175,7 +175,7 @@ def test_recombination_in_64_bit_integers_when_the_digit_planes_do_not_fit(T, or
 
 
 @pytest.mark.parametrize("n,q,immediate", [(32, 256, 0), (64, 256, 1), (128, 2**15, 0), (128, 2**15, 1), (300, 2**15, 0)])
-def test_samp_p_parity_across_block_counts(T, oracle, monkeypatch, n, q, immediate):
+def test_samp_p_parity_across_block_counts(T, oracle, monkeypatch, exp_lib, n, q, immediate):
     """Lattice dimensions of 537 ... 9081 rows: 9 to 142 blocks of 64 with a short top block, the last one beyond the 8192 rows
     the register-resident walk of round 1 was limited to.  Key from the device, three preimages (the last wave is partly empty);
     s = 1000 makes |z| > 127 common, so the hi digit plane of z is exercised.  Both schedules of the updates below a block (the

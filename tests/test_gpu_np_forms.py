@@ -50,10 +50,8 @@ FORMS = [{}, {"PSF_NP_WALK": "0"}, {"PSF_NP_WALK": "3"}, {"PSF_NP_G": "2"}, {"PS
 
 
 def run(kind, B, **extra):
-    env = dict(os.environ, **extra)
-    for k in ("PSF_NP_WALK", "PSF_NP_G", "PSF_NP_IMMEDIATE", "PSF_NP_WALK_SPINS", "PSF_NP_COMBINE"):
-        if k not in extra:
-            env.pop(k, None)
+    from tests.conftest import exp_env
+    env = exp_env(**extra)                       # a switch = the experiments build of the library; no switch = the release library
     r = subprocess.run([sys.executable, "-c", SCRIPT, kind, str(B)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])

@@ -159,7 +159,8 @@ np.save(sys.argv[3], u)
         outs = []
         for mode in ("ntt", "matmul"):
             with tempfile.NamedTemporaryFile(suffix=".npy") as f:
-                env = dict(os.environ, PSF_RING_FA=mode)
+                from tests.conftest import exp_env
+                env = exp_env(PSF_RING_FA=mode) if mode == "matmul" else exp_env()      # "ntt" is the release library's default route; "matmul" the experiments build's switch
                 subprocess.check_call([sys.executable, "-c", code, str(n), str(q), f.name], env=env, timeout=900)
                 outs.append(np.load(f.name))
         assert (outs[0] == outs[1]).all(), (n, q)

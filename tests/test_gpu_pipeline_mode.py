@@ -33,7 +33,8 @@ print(h.hexdigest())
 
 
 def run(mode, **extra):
-    env = dict(os.environ, PSF_PIPELINE=mode, **extra)
+    from tests.conftest import exp_env
+    env = exp_env(PSF_PIPELINE=mode, **extra) if (mode != "0" or extra) else exp_env()      # the plain run is the release library, a switch the experiments build
     r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout.strip().splitlines()[-1]
@@ -43,7 +44,7 @@ def test_pipelined_mode_is_bit_identical():
     assert run("0") == run("1")
 
 
-def test_the_fp64_product_kernels_give_the_same_bits(monkeypatch):
+def test_the_fp64_product_kernels_give_the_same_bits(monkeypatch, exp_lib):
     """k_trmm_f64_big (one workgroup per CU, accumulators in AccVGPRs: the default), k_trmm_f64_reg (PSF_TRMM_VARIANT=1) and k_trmm_f64 (LDS-staged,
     PSF_TRMM_VARIANT=0) run the same ascending fma chains: x and everything downstream must agree bit for bit, here on keys of several row-blocks
     (m = 932: 8 blocks of 128 with a ragged top; structured: 484 rows = 4 blocks, and with n = 40 an ODD number of row-blocks, so the last 256-row
@@ -247,7 +248,7 @@ def test_overlapped_async_calls_return_the_rows_of_synchronous_ones(oracle):
 
 
 @pytest.mark.parametrize("mode", ["sdma", "runtime", "kernel:8"])
-def test_every_chunk_transport_of_the_host_path_returns_the_same_rows(oracle, monkeypatch, mode):
+def test_every_chunk_transport_of_the_host_path_returns_the_same_rows(oracle, monkeypatch, exp_lib, mode):
     """PSF_HOST_COPY picks how a chunk of narrowed rows crosses PCIe: the DMA engine through the HSA runtime (default, psf_sdma.hpp), the HIP runtime's copies,
     or a copy kernel storing into pinned memory.  Each must hand back the rows of the device-pointer path, with chunks smaller than a call (PSF_HOST_CHUNK_MB=1:
     several chunks per worker, both pinned buffers of a worker in use) and asynchronous calls cut into slices or not."""
@@ -281,7 +282,7 @@ def test_every_chunk_transport_of_the_host_path_returns_the_same_rows(oracle, mo
     psf.close()
 
 
-def test_small_host_calls_through_one_pinned_buffer_equal_the_straight_form(oracle, monkeypatch):
+def test_small_host_calls_through_one_pinned_buffer_equal_the_straight_form(oracle, monkeypatch, exp_lib):
     """A small host-pointer call (u + e <= 1 MiB) stages u, e and the flags through one pinned buffer with kernels in stream order and synchronises once;
     PSF_HOST_STRAIGHT=1 keeps the hipMemcpy form.  Same rows, same status, for the three PSF types, growing and shrinking batches."""
     import numpy as np
@@ -304,7 +305,7 @@ def test_small_host_calls_through_one_pinned_buffer_equal_the_straight_form(orac
         psf.close()
 
 
-def test_batch_host_calls_of_the_nearest_plane_types_equal_the_straight_form(oracle, monkeypatch):
+def test_batch_host_calls_of_the_nearest_plane_types_equal_the_straight_form(oracle, monkeypatch, exp_lib):
     """psfgpv_samp_p / psfring_samp_p above 1 MiB: cached device buffers, rows narrowed to int32, one pinned copy, threaded widening -- against the straight form
     (PSF_HOST_STRAIGHT=1: two allocations and two pageable copies per call) and the device-pointer call."""
     import numpy as np

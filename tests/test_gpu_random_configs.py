@@ -137,7 +137,7 @@ LEGACY = {"PSF_TRMM_STREAM_MAX": "0", "PSF_FUSED_MAX": "0", "PSF_GADGET_WAVE": "
 
 
 @pytest.mark.parametrize("case", range(0, 64, 3))
-def test_perturbation_random_configuration_on_the_batch_kernels(oracle, monkeypatch, case):
+def test_perturbation_random_configuration_on_the_batch_kernels(oracle, monkeypatch, exp_lib, case):
     """Since round 4 every batch of this file's menus (<= 300 preimages) takes the single-call kernels (k_samp_p_small, k_trmm_stream, k_gadget_wave*, the
     128-bit Z_q fold).  The same seeded draws with those switched off keep the batch kernels (k_trmm_f64_big, k_gadget_queue, the per-class fold, the
     chunk-stream normals) under the random shapes they were found correct on."""

@@ -29,6 +29,27 @@ def pair(request, T, oracle):
     psf.close()
 
 
+@pytest.fixture(scope="module", params=SHAPES, ids=lambda p: f"n{p[0]}")
+def exp_pair(request, T, oracle):
+    """the same pair with the handle created in the EXPERIMENTS build of the library (tests that flip PSF_* switches; a handle stays with the build that made it)"""
+    from tests.conftest import EXP_LIB
+    from tools_amd import _ffi
+    if not os.path.exists(EXP_LIB):
+        pytest.skip("the experiments build of the library is missing (make -C tools_amd/csrc exp)")
+    n, q, r, s = request.param
+    _ffi.lib()
+    old, _ffi._lib = _ffi._lib, _ffi.open_library(EXP_LIB)
+    try:
+        psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+        A, (R, Lp, _) = psf.trap_gen(21)
+    finally:
+        _ffi._lib = old
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s)
+    orc.load_key(A, R, Lp)
+    yield psf, orc, n, q
+    psf.close()
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65])
 def test_small_batch_stages_bitwise(pair, oracle, B):
     psf, orc, n, q = pair
@@ -47,9 +68,9 @@ def test_small_batch_stages_bitwise(pair, oracle, B):
 
 @pytest.mark.parametrize("shape,B", [("1,1", 16), ("1,1", 100), ("1,2", 100), ("1,4", 100), ("1,8", 100), ("2,1", 5), ("2,1", 100), ("2,2", 20), ("2,2", 100),
                                      ("2,4", 100), ("4,2", 100), ("1,4", 300), ("2,4", 257), ("4,2", 513)])
-def test_every_tile_shape_gives_the_batch_kernels_bits(pair, oracle, shape, B):
+def test_every_tile_shape_gives_the_batch_kernels_bits(exp_pair, exp_lib, oracle, shape, B):
     """PSF_TRMM_STREAM_SHAPE forces (row tiles, column fragments) per wave; PSF_TRMM_STREAM_MAX = 0 is the batch kernel (k_trmm_f64_big)."""
-    psf, orc, n, q = pair
+    psf, orc, n, q = exp_pair
     u = oracle.uniform_targets(4, B, n, q)
     old = {k: os.environ.get(k) for k in ("PSF_TRMM_STREAM_MAX", "PSF_TRMM_STREAM_SHAPE")}
     try:
@@ -111,7 +132,7 @@ FUSED = [  # (n, q, r, s): m <= 256, every kind of modulus / sampler word the st
 
 @pytest.mark.parametrize("n,q,r,s", FUSED)
 @pytest.mark.parametrize("B", [1, 5, 64])
-def test_fused_one_launch_call_gives_the_oracles_rows(T, oracle, monkeypatch, n, q, r, s, B):
+def test_fused_one_launch_call_gives_the_oracles_rows(T, oracle, monkeypatch, exp_lib, n, q, r, s, B):
     """k_samp_p_small: the whole samp_p of a preimage in one workgroup (small m, few preimages -- the reference's own benchmarks, benches/psf.rs:51-66).
     Same rows as the oracle and as the stage kernels (PSF_FUSED_MAX=0)."""
     psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
@@ -132,11 +153,11 @@ def test_fused_one_launch_call_gives_the_oracles_rows(T, oracle, monkeypatch, n,
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 4])
-def test_streaming_stage_kernels_of_a_handful_of_preimages_equal_the_matrix_core_ones(pair, oracle, B):
+def test_streaming_stage_kernels_of_a_handful_of_preimages_equal_the_matrix_core_ones(exp_pair, exp_lib, oracle, B):
     """Up to four preimages e = p + [R; I] z streams R once (k_recombine_small), one preimage also streams A for v = u - A p (k_syndrome_small), up to
     n B = 4096 the gadget walk runs one wave per problem: PSF_RECOMBINE_SMALL=0 / PSF_SYNDROME_SMALL=0 / PSF_GADGET_WAVE=0 are the matrix-core and queue forms.
     PSF_SYNDROME_SMALL=4 takes the streaming syndrome where it is not the default."""
-    psf, orc, n, q = pair
+    psf, orc, n, q = exp_pair
     u = oracle.uniform_targets(61 + B, B, n, q)
     names = ("PSF_RECOMBINE_SMALL", "PSF_SYNDROME_SMALL", "PSF_GADGET_WAVE")
     old = {k: os.environ.get(k) for k in names}

@@ -1,4 +1,4 @@
-"""Every environment switch of the PSFPerturbation path selects another kernel, stream arrangement or slicing for the SAME arithmetic: on seeded random shapes
+"""Every experiment switch of the PSFPerturbation path (alive in the experiments build only: tools_amd/csrc `make exp`; the release library reads none) selects another kernel, stream arrangement or slicing for the SAME arithmetic: on seeded random shapes
 (ragged batches on both sides of the 128 / 256 tile boundaries, key dimensions with partial row blocks, moduli of one to three limbs) each setting must
 reproduce the default's bytes.  One subprocess per setting (the switches are read at handle creation / first use); the key comes from the same seed every time,
 so key generation under PSF_CHOL's three forms is part of what is compared (A, R bitwise; the factors agree within rounding, checked elsewhere), and the
@@ -63,7 +63,8 @@ SETTINGS = [{}, {"PSF_PIPELINE": "1"}, {"PSF_HALVES": "1"}, {"PSF_HOST_SLICE": "
 
 
 def run(script, case, path, **extra):
-    env = dict(os.environ, **extra)
+    from tests.conftest import exp_env
+    env = exp_env(**extra)                       # a switch = the experiments build of the library; no switch = the release library
     r = subprocess.run([sys.executable, "-c", script, str(case), path], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""

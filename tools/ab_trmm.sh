@@ -1,5 +1,7 @@
 #!/bin/bash
 # library-level A/B of the FP64 product variants (PSF_TRMM_VARIANT), alternating to see the run-to-run spread
+# the PSF_* switches below are alive in the experiments build only (make -C tools_amd/csrc exp); the release library reads none of them
+export PSF_LIB="${PSF_LIB:-$(cd "$(dirname "$0")/.." && pwd)/tools_amd/lib/libpsf_mi355x_exp.so}"
 O=gpurun_out/ab; mkdir -p $O
 line() { tail -1 "$1" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$2', d['value'], d['ms_per_step'], d.get('kernels_ms')['k_trmm_f64'], d['roofline']['frac'])"; }
 PSF_TRMM_VARIANT=1 timeout 300 python3 -m pytest tests/test_gpu_psfp_parity.py tests/test_gpu_structured.py -q -m gpu -x 2>&1 | tail -2

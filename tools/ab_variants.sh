@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B pass for experimental switches (environment variables read by the library): parity tests under the switch, then the bench line.
 # usage: tools/ab_variants.sh  -> gpurun_out/ab/*.json
+# the PSF_* switches below are alive in the experiments build only (make -C tools_amd/csrc exp); the release library reads none of them
+export PSF_LIB="${PSF_LIB:-$(cd "$(dirname "$0")/.." && pwd)/tools_amd/lib/libpsf_mi355x_exp.so}"
 O=gpurun_out/ab; mkdir -p $O
 line() { tail -1 "$1" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$2', d['value'], d['ms_per_step'], d.get('kernels_ms'), d.get('roofline'))"; }
 # nearest plane: parity first

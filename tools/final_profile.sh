@@ -3,6 +3,8 @@
 # stats under rocprofv3, PMC traffic of the FP64 product, the probe harnesses.  Every step is bounded by `timeout` (the PMC passes of the nearest-plane
 # configurations are left out: FETCH_SIZE collection segfaults at C2 and did not finish in 45 minutes at C4).  Outputs under gpurun_out/final/; copy what
 # should be judged into profiles/.
+# the PSF_* switches below are alive in the experiments build only (make -C tools_amd/csrc exp); the release library reads none of them
+export PSF_LIB="${PSF_LIB:-$(cd "$(dirname "$0")/.." && pwd)/tools_amd/lib/libpsf_mi355x_exp.so}"
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 for cfg in c3 c2 c4; do

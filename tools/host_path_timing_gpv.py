@@ -1,4 +1,7 @@
 """Host-pointer against device-pointer samp_p for PSFGPV (C2: n=256, q=3329, s=1024, batch 1024) and PSFGPVRing (C4: batch 4096)."""
+# the PSF_* switches this script sets are alive in the experiments build only (make -C tools_amd/csrc exp); the release library reads none of them
+import os as _os
+_os.environ.setdefault("PSF_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools_amd", "lib", "libpsf_mi355x_exp.so"))
 import os, sys, time, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

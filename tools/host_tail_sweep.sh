@@ -1,3 +1,5 @@
+# the PSF_* switches below are alive in the experiments build only (make -C tools_amd/csrc exp); the release library reads none of them
+export PSF_LIB="${PSF_LIB:-$(cd "$(dirname "$0")/.." && pwd)/tools_amd/lib/libpsf_mi355x_exp.so}"
 cd /root/repo
 run() { echo "=== $*"; env "$@" timeout 300 python3 tools/host_path_timing.py 8 2>&1 | grep -E "synchronous|async|device-pointer|same rows|fresh" | tail -9; }
 run PSF_HOST_TAIL=256

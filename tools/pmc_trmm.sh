@@ -1,5 +1,7 @@
 #!/bin/bash
 # L2 hit rate and fetch traffic of k_trmm_f64 for several super-tile shapes (PSF_TRMM_GROUP = rows per group)
+# the PSF_* switches below are alive in the experiments build only (make -C tools_amd/csrc exp); the release library reads none of them
+export PSF_LIB="${PSF_LIB:-$(cd "$(dirname "$0")/.." && pwd)/tools_amd/lib/libpsf_mi355x_exp.so}"
 export TMPDIR=/tmp; R=$PWD
 for G in 8; do
   export PSF_TRMM_GROUP=$G

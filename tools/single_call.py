@@ -6,6 +6,9 @@
 (b) the reference's three criterion sets (GPV n=8, Perturbation n=8, n=64; one preimage per call) as GPU microseconds per call.
 Writes a JSON record (default profiles/r04_single_call.json).
 """
+# the PSF_* switches this script sets are alive in the experiments build only (make -C tools_amd/csrc exp); the release library reads none of them
+import os as _os
+_os.environ.setdefault("PSF_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools_amd", "lib", "libpsf_mi355x_exp.so"))
 import argparse
 import ctypes as C
 import json

@@ -3,6 +3,9 @@
 library's shape per batch size) and, from 256 on, the batch kernel (PSF_TRMM_STREAM_MAX=0).  Median HIP-event time of `reps` synchronised calls, the product kernel's
 own time, and a comparison of the rows of the two forms.  (Round 5 used the same harness for k_trmm_stream_lds -- the normals through LDS once per workgroup in
 lock-step rounds of eight k-steps -- which was correct and SLOWER at every size, 1.31 vs 1.28 ms at 64 preimages, 2.42 vs 1.87 ms at 128: profiles/r05_notes.md.)"""
+# the PSF_* switches this script sets are alive in the experiments build only (make -C tools_amd/csrc exp); the release library reads none of them
+import os as _os
+_os.environ.setdefault("PSF_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools_amd", "lib", "libpsf_mi355x_exp.so"))
 import json
 import os
 import sys

@@ -2,6 +2,9 @@
 """PSFGPVRing::f_a (gpv_ring.rs:243-247) at C4 (n = 256, q = 3329, 4096 preimages) on device buffers: the k+2 R_q products against the cached images of a
 (PSF_RING_FA unset / ntt) or the product with rot^-(iota(a)) on the int8 matrix cores (PSF_RING_FA=matmul).  Run once per setting; prints one JSON line
 with the HIP-event time per call and a checksum of u so that the two runs can be compared."""
+# the PSF_* switches this script sets are alive in the experiments build only (make -C tools_amd/csrc exp); the release library reads none of them
+import os as _os
+_os.environ.setdefault("PSF_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools_amd", "lib", "libpsf_mi355x_exp.so"))
 import json
 import math
 import os

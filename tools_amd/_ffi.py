@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PSF_LIB") or os.path.join(_HERE, "lib", "libpsf_mi355x.so")   # PSF_LIB: A/B builds of the same ABI
+LIB_PATH = os.environ.get("PSF_LIB") or os.path.join(_HERE, "lib", "libpsf_mi355x.so")   # PSF_LIB: another build of the same ABI (the experiments build, A/B builds)
+EXP_LIB_PATH = os.path.join(_HERE, "lib", "libpsf_mi355x_exp.so")                          # `make exp`: every PSF_* experiment switch alive (tests, tools/); never loaded by default
 
 OK, ERR_PARAM, ERR_NOT_PD, ERR_DOMAIN, ERR_MODULUS, ERR_NO_SOLUTION, ERR_NO_KEY, ERR_HIP, ERR_UNSUPPORTED, ERR_SAMPLER = range(10)
 
@@ -62,26 +63,31 @@ def _share_torch_hip_runtime():
         pass                                   # fall back to the system runtime the library was linked against
 
 
+def open_library(path):
+    """CDLL of one build of the library with the few non-default signatures set (the release library, or the experiments build the form-comparison tests load)."""
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). tools_amd has no CPU fallback.")
+    _share_torch_hip_runtime()
+    L = C.CDLL(path)
+    L.psf_status_string.restype = C.c_char_p
+    L.psf_status_string.argtypes = [C.c_int]
+    L.psfp_m.restype = C.c_size_t
+    L.psfp_m.argtypes = [C.c_void_p]
+    L.psfp_destroy.restype = None
+    L.psfp_destroy.argtypes = [C.c_void_p]
+    L.psfgpv_destroy.restype = None
+    L.psfgpv_destroy.argtypes = [C.c_void_p]
+    L.psfring_destroy.restype = None
+    L.psfring_destroy.argtypes = [C.c_void_p]
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950). tools_amd has no CPU fallback.")
-        _share_torch_hip_runtime()
-        L = C.CDLL(LIB_PATH)
-        L.psf_status_string.restype = C.c_char_p
-        L.psf_status_string.argtypes = [C.c_int]
-        L.psfp_m.restype = C.c_size_t
-        L.psfp_m.argtypes = [C.c_void_p]
-        L.psfp_destroy.restype = None
-        L.psfp_destroy.argtypes = [C.c_void_p]
-        L.psfgpv_destroy.restype = None
-        L.psfgpv_destroy.argtypes = [C.c_void_p]
-        L.psfring_destroy.restype = None
-        L.psfring_destroy.argtypes = [C.c_void_p]
-        _lib = L
+        _lib = open_library(LIB_PATH)
     return _lib
 
 

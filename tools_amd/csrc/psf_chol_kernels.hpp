@@ -17,6 +17,7 @@ constexpr int CH_NB = 128;
 
 
 // ---- diagonal block ---------------------------------------------------------------------------------------------
+#ifdef PSF_EXPERIMENTS   /* rounds 1-2: the right-looking Cholesky (PSF_CHOL=right), comparison arm of the experiments build */
 __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ A, size_t ld, size_t off, int nb, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double ch_smem[];   // nb x (CH_NB + 1)
   constexpr int LD = CH_NB + 1;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ A, size_
     if (c <= r) A[(off + r) * ld + off + c] = ch_smem[r * LD + c];
   }
 }
+#endif
 
 // ---- diagonal block + its inverse (left-looking form) ----------------------------------------------------------------------------------
 // 256 threads; the block lives in LDS as [128][129].  Step j: pivot, column j scaled by the threads i > j, then the rank-1 update of the rows
@@ -246,6 +248,7 @@ __global__ void k_chol_pack_panel(const double* __restrict__ Pbuf, int J, int nc
 }
 
 // ---- panel below the diagonal block: one row per thread ------------------------------------------------------------
+#ifdef PSF_EXPERIMENTS   /* rounds 1-2, as k_chol_diag */
 __global__ __launch_bounds__(64) void k_chol_trsm(double* __restrict__ A, size_t ld, size_t off, int nb, size_t m, const int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double ch_smem[];   // L11 packed lower (nb(nb+1)/2) | x[nb][64]
   if (*info != 0) return;
@@ -272,11 +275,13 @@ __global__ __launch_bounds__(64) void k_chol_trsm(double* __restrict__ A, size_t
   if (live)
     for (int j = 0; j < nb; ++j) A[row * ld + off + j] = sx[j * 64 + tid];
 }
+#endif
 
 // ---- trailing update on the matrix cores ---------------------------------------------------------------------------------
 // tile (ti, tj), tj <= ti, of the trailing matrix (tile size 128): C -= P_i P_j^t with P = the freshly solved panel (K = 128).
 // 4 waves (2 x 2), wave tile 64 x 64; K chunks of 16 staged by LDS-DMA as [row][16]; A and B fragments are read the same
 // way because both operands are row-major in k (an "NT" product).
+#ifdef PSF_EXPERIMENTS   /* rounds 1-2, as k_chol_diag */
 __global__ __launch_bounds__(256, 2) void k_chol_syrk(double* __restrict__ A, size_t ld, size_t off /*panel column offset*/, size_t m,
                                                       int ntiles_side, const int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double ch_smem[];   // 2 stages x (Pi chunk 2048 | Pj chunk 2048)
@@ -349,5 +354,6 @@ __global__ __launch_bounds__(256, 2) void k_chol_syrk(double* __restrict__ A, si
         if (rr < m && cc < m && cc <= rr) A[rr * ld + cc] -= acc[i][j][r];
       }
 }
+#endif
 
 }  // namespace psf

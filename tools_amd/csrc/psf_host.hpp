@@ -4,8 +4,22 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 #include "../../include/psf_mi355x.h"
+
+// Experiment switches.  The release library (libpsf_mi355x.so) reads NO environment variable for them: psf_exp_env() is a constant nullptr there, the
+// branches behind it fold away and the kernels that lost their A/B (k_trmm_f64, k_trmm_f64_reg, k_gadget, k_np_walk2, the per-pair k_np_combine8, the
+// copy-kernel transport) are not compiled.  `make exp` builds libpsf_mi355x_exp.so with -DPSF_EXPERIMENTS: the same sources with every PSF_* switch alive --
+// what the form-comparison tests and the A/B scripts under tools/ load through PSF_LIB.  A switch a USER needs is a field of the params structs or, for
+// the one host-side resource knob (PSF_HOST_WORKERS), read and validated in psfp.hip.
+#ifdef PSF_EXPERIMENTS
+inline const char* psf_exp_env(const char* name) { return std::getenv(name); }
+constexpr bool psf_experiments_build = true;
+#else
+constexpr const char* psf_exp_env(const char*) { return nullptr; }
+constexpr bool psf_experiments_build = false;
+#endif
 
 namespace psf {
 

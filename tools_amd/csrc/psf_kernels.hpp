@@ -271,6 +271,7 @@ __device__ unsigned long long* g_trmm_log;      /* optional: per workgroup {star
 #define TR_CLK_BEGIN
 #define TR_CLK_END
 #endif
+#ifdef PSF_EXPERIMENTS   /* round 1's LDS-staged product: lost to k_trmm_f64_big (-5 %), comparison arm of the experiments build */
 __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const double* __restrict__ Lt, const double* __restrict__ Dt,
                                                      double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx, int GR, int GC, size_t row_hi) {
   // LDS: 2 stages x (A chunk 2048 doubles | B chunk 2048 doubles); filled by LDS-DMA (global_load_lds_dwordx4), no
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256, PSF_TR_BK == 16 ? 2 : 3) void k_trmm_f64(const
       }
   TR_CLK_END
 }
+#endif
 
 // Same product, operands streamed from global memory straight into MFMA operand registers: the chunk streams are already in fragment order, so
 // k-step s of a wave is eight 512-byte loads (4 A fragments, 4 B fragments) at stream offset 512 s.  No LDS, no barrier: the four waves of a
@@ -363,6 +365,7 @@ constexpr int TR_PD = 6;
 // their waits are written out: loads return in order, hence "all but the newest 8 (TR_PD - 1) have landed".
 #define TR_LOAD8(dst, voff, base, imm) asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(voff), "s"(base) : "memory")
 #define TR_WAIT(n, A, Bv) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(Bv[0]), "+v"(Bv[1]), "+v"(Bv[2]), "+v"(Bv[3]))
+#ifdef PSF_EXPERIMENTS   /* round 2's register-streamed product: lost to k_trmm_f64_big, comparison arm of the experiments build */
 __global__ __launch_bounds__(256, 2) void k_trmm_f64_reg(const double* __restrict__ Lt, const double* __restrict__ Dt,
                                                          double* __restrict__ X, int nbi, int nbj, size_t nkb, size_t ldx, int GR, int GC, size_t row_hi) {
   int bi, bj;
@@ -425,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void k_trmm_f64_reg(const double* __restric
       }
   TR_CLK_END
 }
+#endif
 
 // The default since the end of round 2: ONE workgroup per CU, four waves, each alone on its SIMD with a 128 x 64 tile of X -- 256 AccVGPRs of
 // accumulators (the MFMAs are asm statements: hipcc keeps builtin accumulators in architectural VGPRs) and the operand ring in the 256

@@ -1196,6 +1196,7 @@ __global__ __launch_bounds__(512, 4) void k_np_walk_solo(NpSampleArgs a, size_t 
 // takes t = fma(-z_j, g[j][.], t), j ascending (one 16-step MFMA loop, operands straight from the fragment-ordered streams), the tiles of block J - 2 first -- they
 // are complete then and their owner raises the block's flag.  Before its sampler starts block J a helper finishes everything up to the z of block J + 2 (a sampler of
 // the group may be waiting for exactly those rows), so the chain of waits always ends at a workgroup that is still sampling.  Same chains, same bits.
+#ifdef PSF_EXPERIMENTS   /* measured slower than one launch per block (6.97 against 4.49 ms at C4, profiles/r05_notes.md): comparison arm of the experiments build */
 template <int G>
 struct NpWalk2Jobs {
   const double* Gp; double* T; const double* Zf;
@@ -1320,11 +1321,13 @@ __global__ __launch_bounds__(512, 4) void k_np_walk2(NpSampleArgs a, size_t dim,
   }
   if (lane == 0 && __hip_atomic_load(sy.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicOr(a.flags, 1);
 }
+#endif
 
 // E[b][j] (+)= scale * sum_i Z8[i][b] B8[j][i] on the int8 matrix cores (v_mfma_i32_16x16x64_i8): Z as the A operand (rows = preimages),
 // the basis plane as the B operand (columns = coordinates j), so 16 lanes hold 16 consecutive j of one preimage and the int64 stores
 // are 128-byte runs.  Workgroup tile 128 (b) x 128 (j), K = 128 per stage, two LDS stages filled by LDS-DMA.  int32 accumulation is
 // exact (at most 2^17 terms of |z b| <= 2^14).  `gate`: the pass is skipped unless *gate != 0 (hi plane of z, decided on device).
+#ifdef PSF_EXPERIMENTS   /* one launch per digit pair: replaced by k_np_combine8_fused (round 5), comparison arm of the experiments build */
 template <bool ACCUM>
 __global__ __launch_bounds__(256, 2) void k_np_combine8(const int8_t* __restrict__ B8, size_t ldb, size_t d, int nk128, const int8_t* __restrict__ Z8, size_t ld,
                                                         size_t B, long long scale, const int* __restrict__ gate, int64_t* __restrict__ E, size_t lde) {
@@ -1392,6 +1395,7 @@ __global__ __launch_bounds__(256, 2) void k_np_combine8(const int8_t* __restrict
         }
       }
 }
+#endif
 
 // ---- the recombination in ONE launch (round 5) ---------------------------------------------------------------------------------------------
 // Six digit-pair products (three z digits x two basis digits) used to be six launches, each a read-modify-write of the whole of E; measured at C2 five of

@@ -140,7 +140,7 @@ NttDev dev_args(const Plan* P, int e, int e_fa) {
   return a;
 }
 unsigned wave_grid(size_t count) {                                       // four products per workgroup at a time, at most 8 workgroups per CU
-  static const size_t cap = [] { const char* e = std::getenv("PSF_NTT_GRID"); const long v = e ? std::atol(e) : 0; return (size_t)(v > 0 ? v : 2048); }();
+  static const size_t cap = [] { const char* e = psf_exp_env("PSF_NTT_GRID"); const long v = e ? std::atol(e) : 0; return (size_t)(v > 0 ? v : 2048); }();
   const size_t g = (count + 3) / 4;
   return (unsigned)(g < 1 ? 1 : g > cap ? cap : g);
 }

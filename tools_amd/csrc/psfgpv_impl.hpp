@@ -272,6 +272,7 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
   // The sampler workgroups alone fill the chip (two per CU): the walk in one launch with the helper waves updating T in memory (k_np_walk2)
   // MEASURED SLOWER than one launch per block at C4 (6.9 against 4.4 ms, profiles/r05_notes.md: with two wave pairs per SIMD the vector pipe is the bound, and the
   // helpers' tiles re-read the block's z per 16 rows): a labelled opt-in (PSF_NP_WALK=3), kept bit-identical by tests/test_gpu_switch_matrix.py
+#ifdef PSF_EXPERIMENTS
   if (g->np_walk == 3 && g->cus > 0 && g->nblk >= 3 && nS <= 2u * (unsigned)g->cus) {
     const unsigned per = (unsigned)(NP_GW / (4 * G)), ngroups = (nS + per - 1) / per;
     NpWalkSync sy{g->dWalk, g->dWalk + (size_t)ngroups * g->nblk, g->dWalk + (size_t)2 * ngroups * g->nblk, (unsigned)g->nblk, g->walk_spins};
@@ -281,6 +282,7 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
     g->last_form = 3; g->last_G = G;
     return launch_np_recombination(g, st, B, d_e, pass);
   }
+#endif
   const size_t W = NP_PANEL;
   // small batches: a rank-64 update of every row below costs less than the sampler's 64 steps, and the T matrix stays in the Infinity Cache (measured
   // at C2, 1024 preimages: 4.57 vs 4.80 ms); large batches: the panel-deferred update moves T an eighth as often (C4, 4096 preimages: 5.06 vs 5.20 ms)
@@ -325,14 +327,16 @@ static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size
   const psfp_handle* b = g->base;
   const dim3 cgrid((unsigned)((B + 127) / 128), (unsigned)(g->dpad / 128));
   const int nk128 = (int)(g->dpad / 128);
-  const size_t plane = g->dpad * g->dpad;
   if (!g->basis_generic && g->np_combine != 0) {
     // z = z0 + 256 z1 + 65536 z2, b = b0 + 256 b1: every digit pair in one launch, over the tiles of the digit planes that hold anything
     hipLaunchKernelGGL(k_np_occ_z, dim3((unsigned)(cgrid.x * g->nrb), 2), dim3(256), 0, st, g->dZ8, g->zplane, ld, nk128, g->dZocc);
     hipLaunchKernelGGL(k_np_combine8_fused, cgrid, dim3(256), 65536 + 768, st, g->dB8, g->dpad, g->dim, nk128, g->basis_hi ? 2 : 1, g->dBocc, g->dZ8, g->zplane, ld, B, g->dZocc, d_e, g->dim);
     if (pass == 0) hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dSol, g->dPiv, g->n, B, ld, d_e, g->dim);
-  } else if (!g->basis_generic) {
+  }
+#ifdef PSF_EXPERIMENTS
+  else if (!g->basis_generic) {
     // the same sum as one pass per digit pair in use (the z digits beyond the first are gated on the device): PSF_NP_COMBINE=0, kept for the switch matrix
+    const size_t plane = g->dpad * g->dpad;
     const int8_t* zp[3] = {g->dZ8, g->dZ8 + g->zplane, g->dZ8 + 2 * g->zplane};
     const int* gate[3] = {nullptr, flags + 1, flags + 2};
     bool first = true;
@@ -345,6 +349,7 @@ static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size
       }
     if (pass == 0) hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dSol, g->dPiv, g->n, B, ld, d_e, g->dim);
   }
+#endif
   // integer fallback: always for a basis beyond two int8 digits, otherwise only if a z left the three-digit range (decided on the device)
   hipLaunchKernelGGL(k_np_combine_generic, dim3(grid_for(g->dim * B, 256, 256 * 64)), dim3(256), 0, st, g->dSt, g->dim, g->dZf, g->nkb, g->dSol, g->dPiv, pass == 0 ? g->n : (size_t)0, B, ld,
                      g->basis_generic ? (const int*)nullptr : (const int*)(flags + 3), d_e, g->dim);
@@ -418,30 +423,32 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipMemset(g->dFlags, 0, 12 * sizeof(int)));
   // large moduli: q sqrt(n) > 2^13 s (relative centre error of a single pass above 2^-40, see include/psf_mi355x.h "Precision of the centres"); PSF_NP_TWO_PASS=0/1 forces
   g->two_pass = (double)g->base->q * std::sqrt((double)g->n) > g->s * 8192.0;
-  { const char* ev = getenv("PSF_NP_TWO_PASS"); if (ev) g->two_pass = atoi(ev) != 0; }
+  { const char* ev = psf_exp_env("PSF_NP_TWO_PASS"); if (ev) g->two_pass = atoi(ev) != 0; }
   g->nkd = round_up(d, 16) / 16;
   if (g->two_pass) HIP_TRY(hipMalloc(&g->dBfull, g->nrb * g->nkd * TR_CHUNK * sizeof(double)));
-  { const char* ev = getenv("PSF_NP_G"); g->np_g = ev ? atoi(ev) : 0; }
-  { const char* ev = getenv("PSF_NP_IMMEDIATE"); g->np_immediate = ev ? (atoi(ev) != 0 ? 1 : 0) : -1; }
+  { const char* ev = psf_exp_env("PSF_NP_G"); g->np_g = ev ? atoi(ev) : 0; }
+  { const char* ev = psf_exp_env("PSF_NP_IMMEDIATE"); g->np_immediate = ev ? (atoi(ev) != 0 ? 1 : 0) : -1; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_project), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+#ifdef PSF_EXPERIMENTS
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+#endif
   { int cu = 0; HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, g->base->prm.device)); g->cus = cu; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk_solo<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk_solo<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   // workgroups of the one-launch walk a compute unit really holds (registers, LDS): the residency test of launch_nearest_plane multiplies by the CU count
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&g->walk_slots[1], reinterpret_cast<const void*>(k_np_walk<1>), 512, 65536));
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&g->walk_slots[2], reinterpret_cast<const void*>(k_np_walk<2>), 512, 65536));
-  if (const char* e = std::getenv("PSF_NP_WALK")) g->np_walk = std::atoi(e);
-  if (const char* e = std::getenv("PSF_NP_WALK_SPINS")) { const long v = std::atol(e); if (v >= 1) g->walk_spins = (unsigned)v; }
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  if (const char* e = psf_exp_env("PSF_NP_WALK")) g->np_walk = std::atoi(e);
+  if (const char* e = psf_exp_env("PSF_NP_WALK_SPINS")) { const long v = std::atol(e); if (v >= 1) g->walk_spins = (unsigned)v; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 768));
-  if (const char* e = std::getenv("PSF_NP_COMBINE")) g->np_combine = std::atoi(e);
+  if (const char* e = psf_exp_env("PSF_NP_COMBINE")) g->np_combine = std::atoi(e);
   for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
   return PSF_OK;
 }
@@ -579,7 +586,7 @@ psf_status psfgpv_samp_p(psfgpv_handle* g, uint64_t seed, uint64_t first_index, 
   if (!g->has_key) return PSF_ERR_NO_KEY;
   if (B == 0) return PSF_OK;
   HIP_TRY(hipSetDevice(g->base->prm.device));
-  if (B * (g->n + g->m) * 8 <= SIO_MAX_BYTES && !std::getenv("PSF_HOST_STRAIGHT")) {
+  if (B * (g->n + g->m) * 8 <= SIO_MAX_BYTES && !psf_exp_env("PSF_HOST_STRAIGHT")) {
     // a small call (the reference's call is one preimage): cached device buffers, u / e / flags through one pinned buffer, one synchronisation
     psfp_handle* h = g->base;
     if (B * g->n > h->sio_du_cap) { hipFree(h->sio_du); h->sio_du = nullptr; h->sio_du_cap = 0; HIP_TRY(hipMalloc(&h->sio_du, B * g->n * sizeof(uint64_t))); h->sio_du_cap = B * g->n; }
@@ -592,7 +599,7 @@ psf_status psfgpv_samp_p(psfgpv_handle* g, uint64_t seed, uint64_t first_index, 
     g->last_generic = g->basis_generic || fl[1 + (g->two_pass ? 7 : 3)] != 0;
     return (fl[1 + 0] || fl[1 + 4]) ? PSF_ERR_SAMPLER : PSF_OK;
   }
-  if (std::getenv("PSF_HOST_STRAIGHT")) {                      // the form of rounds 1-3 (comparison arm of the tests)
+  if (psf_exp_env("PSF_HOST_STRAIGHT")) {                      // the form of rounds 1-3 (comparison arm of the tests)
     uint64_t* du = nullptr; int64_t* de = nullptr;
     HIP_TRY(hipMalloc(&du, B * g->n * sizeof(uint64_t)));
     if (hipMalloc(&de, B * g->m * sizeof(int64_t)) != hipSuccess) { hipFree(du); return PSF_ERR_HIP; }
@@ -1059,7 +1066,7 @@ psf_status psfring_samp_p_dev(psfring_handle* h, uint64_t seed, uint64_t first_i
 // transforms, k+2 leaf products and one inverse transform per preimage (k_ring_fa); PSF_RING_FA=matmul keeps the product with rot^-(iota(a)) on
 // the int8 matrix cores (same residues; also the route of every (q, n) without a wave kernel).
 static bool ring_fa_by_ntt(const psfring_handle* h) {
-  static const int forced = [] { const char* e = std::getenv("PSF_RING_FA"); return !e ? 0 : (std::strcmp(e, "matmul") == 0 ? 1 : 2); }();
+  static const int forced = [] { const char* e = psf_exp_env("PSF_RING_FA"); return !e ? 0 : (std::strcmp(e, "matmul") == 0 ? 1 : 2); }();
   return h->fa_ntt && forced != 1;
 }
 psf_status psfring_f_a_dev(psfring_handle* h, size_t B, const int64_t* d_sigma, uint64_t* d_u, uint8_t* d_ok, void* stream) {

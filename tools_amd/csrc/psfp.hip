@@ -25,7 +25,7 @@
 // PSF_KEYGEN_TIMING=1: wall time of the phases of key generation on stderr (each mark drains the device first; off, a mark is one branch)
 struct KeygenClock {
   bool on; const char* what; std::chrono::steady_clock::time_point t0, last;
-  explicit KeygenClock(const char* w) : on(std::getenv("PSF_KEYGEN_TIMING") != nullptr), what(w) { if (on) { hipDeviceSynchronize(); t0 = last = std::chrono::steady_clock::now(); } }
+  explicit KeygenClock(const char* w) : on(psf_exp_env("PSF_KEYGEN_TIMING") != nullptr), what(w) { if (on) { hipDeviceSynchronize(); t0 = last = std::chrono::steady_clock::now(); } }
   void mark(const char* phase) {
     if (!on) return;
     hipDeviceSynchronize();
@@ -173,7 +173,7 @@ struct psfp_handle {
 // The compact copies follow the key without ever blocking a call: the first small call after a key change launches the two packers on its stream and goes on with
 // the full-size matrices; a later call finds their event complete and switches over.  PSF_SMALL_COMPACT=0: never.
 static void ensure_small_copies(psfp_handle* h, hipStream_t st) {
-  static const bool on = [] { const char* e = std::getenv("PSF_SMALL_COMPACT"); return !e || std::atoi(e) != 0; }();
+  static const bool on = [] { const char* e = psf_exp_env("PSF_SMALL_COMPACT"); return !e || std::atoi(e) != 0; }();
   if (!on || (h->prm.flags & PSFP_FLAG_NO_PERTURB) || h->small_state >= 2) return;
   if (h->small_state == 1) {
     if (hipEventQuery(h->evSmall) == hipSuccess) h->small_state = *h->hR2bad ? 3 : 2;
@@ -195,7 +195,7 @@ static void ensure_small_copies(psfp_handle* h, hipStream_t st) {
 
 // PSF_RECOMBINE_PACKED=0: k_recombine_mfma_big fetches its R tiles from the row-major matrix as in rounds 2-4 (comparison arm; same bits)
 static bool rcb_packed() {
-  static const bool on = [] { const char* e = std::getenv("PSF_RECOMBINE_PACKED"); return !e || std::atoi(e) != 0; }();
+  static const bool on = [] { const char* e = psf_exp_env("PSF_RECOMBINE_PACKED"); return !e || std::atoi(e) != 0; }();
   return on;
 }
 // the tile-packed copy of R, rebuilt on `st` when R has changed since
@@ -522,7 +522,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
     HIP_TRY(hipEventCreateWithFlags(&h->evP[i], hipEventDisableTiming));
   }
   HIP_TRY(hipEventCreateWithFlags(&h->evIn, hipEventDisableTiming));
-  if (const char* env = std::getenv("PSF_PIPELINE")) h->pipeline = std::atoi(env) != 0;
+  if (const char* env = psf_exp_env("PSF_PIPELINE")) h->pipeline = std::atoi(env) != 0;
   // gadget part of the trapdoor: (S, S~) of mp_perturbation.rs:233-234, block form
   h->hSk = short_basis_gadget_block(gp);
   std::vector<double> norm2;
@@ -553,9 +553,11 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipMemcpy(h->dNorm2, norm2.data(), h->k * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dSz, sz.data(), h->k * sizeof(SampleZParams), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->dGvec, gvec.data(), h->k * sizeof(uint64_t), hipMemcpyHostToDevice));
+#ifdef PSF_EXPERIMENTS
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, CH_NB * (CH_NB + 1) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (CH_NB * (CH_NB + 1) / 2 + CH_NB * 64) * 8));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_f64), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TR_CHUNK * sizeof(double)));
+#endif
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_mfma_big), hipFuncAttributeMaxDynamicSharedMemorySize, RCB_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -568,7 +570,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
-  if (const char* env = std::getenv("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
+  if (const char* env = psf_exp_env("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
   for (int64_t v : h->hSk) if (v > 32767 || v < -32768) h->gadget_queue = false;      // the queue kernel keeps S_k in int16
   return PSF_OK;
 }
@@ -580,7 +582,7 @@ static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_w
 // (PSF_HOST_PREWARM=0: on first use, as for small keys).
 static void hp_prewarm(psfp_handle* h) {
   if (h->m < 8192) return;
-  if (const char* env = std::getenv("PSF_HOST_PREWARM")) if (std::atoi(env) == 0) return;
+  if (const char* env = psf_exp_env("PSF_HOST_PREWARM")) if (std::atoi(env) == 0) return;
   if (h->hp_warm.joinable()) h->hp_warm.join();
   try {
     h->hp_warm = std::thread([h]() { if (hipSetDevice(h->prm.device) == hipSuccess) (void)hp_ensure(h, 0, 0, 0, true); });      // beside the factorisation, not behind it
@@ -745,7 +747,7 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     // dense form while the matrix stays below 16 GB (m < 46 341), the stream form above.  (The dense form factors the diagonal blocks beside the updates on a
     // second stream; beside k_chol_update_big that overlap returns nothing -- FP64 MFMAs and the vector work of the triangular kernel share
     // one pipe, profiles/r03_notes.md -- so the stream form runs them in line: 0.3 s of C5's total.)
-    const char* ce = std::getenv("PSF_CHOL");
+    const char* ce = psf_exp_env("PSF_CHOL");
     const bool stream = ce ? !std::strcmp(ce, "stream") : m * m * sizeof(double) > (16ull << 30);
     if (stream) return build_sqrt_sigma2_stream(h, nf_r2, s2, b2p1, d_sigma_packed);
   }
@@ -763,7 +765,8 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
   int*& dinfo = dg.dinfo;
   HIP_TRY(hipMalloc(&dinfo, sizeof(int)));
   HIP_TRY(hipMemset(dinfo, 0, sizeof(int)));
-  const char* chol_env = std::getenv("PSF_CHOL");
+#ifdef PSF_EXPERIMENTS
+  const char* chol_env = psf_exp_env("PSF_CHOL");
   if (chol_env && !std::strcmp(chol_env, "right")) {
     for (size_t off = 0; off < m; off += CH_NB) {
       const int nb = (int)(m - off < (size_t)CH_NB ? m - off : (size_t)CH_NB);
@@ -775,7 +778,9 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
       const size_t nt = (rest + 127) / 128;
       hipLaunchKernelGGL(k_chol_syrk, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 2 * 4096 * sizeof(double), 0, dS, m, off, m, (int)nt, dinfo);
     }
-  } else {
+  } else
+#endif
+  {
     if (gemm_prepare() != hipSuccess) return PSF_ERR_HIP;
     const size_t diag_lds = ((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double);
     GemmWorkspace w;
@@ -847,7 +852,7 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
   const size_t ld = h->ld;
   {  // a handful of preimages: A streamed once as 64-bit words (k_syndrome_small; PSF_SYNDROME_SMALL = largest batch it serves, 0: never)
     size_t small_max = 1;                                             // measured at C3: 39 vs 48 us at one preimage, 52 vs 50 at two, 81 vs 50 at four (64-bit multiply-adds)
-    if (const char* e = std::getenv("PSF_SYNDROME_SMALL")) small_max = (size_t)std::atol(e);
+    if (const char* e = psf_exp_env("PSF_SYNDROME_SMALL")) small_max = (size_t)std::atol(e);
     if (small_max > 4) small_max = 4;
     const int splits = (int)((h->m + SYN_KLEN - 1) / SYN_KLEN);
     if (mode == ZQ_SYNDROME && P == h->dP && ncols <= small_max && splits <= h->zq_split_cap && splits <= 64) {
@@ -870,17 +875,17 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
   if (col0 + cw > ld) cw = ld - col0;
   hipLaunchKernelGGL(k_split_P, dim3(grid_for(h->K_pad / 16 * cw, 256, 256 * 64)), dim3(256), 0, st, P, h->m, ld, h->K_pad / 16, P8, h->dFail, col0, cw);
   {  // PSF_ZQ_PLANES3=1: the third digit plane of p is multiplied whether or not it holds anything (comparison arm; same residues)
-    static const bool force3 = [] { const char* e = std::getenv("PSF_ZQ_PLANES3"); return e && std::atoi(e) != 0; }();
+    static const bool force3 = [] { const char* e = psf_exp_env("PSF_ZQ_PLANES3"); return e && std::atoi(e) != 0; }();
     if (force3) hipMemsetAsync(h->dFail + 2, 1, sizeof(int), st);
   }
   const int nks = (int)(h->K_pad / 64);
   const int splits = zq_plan(h, ncols, h->zq_split_cap), zq_ks = (nks + splits - 1) / splits;
   dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)(h->n_pad / 64), (unsigned)splits);
   int fold128 = zq_ks <= 32 ? 1 : 0;                                  // short splits (few preimages): one 128-bit fold per output; long ones: the per-class fold
-  if (const char* e = std::getenv("PSF_ZQ_FOLD128")) fold128 = std::atoi(e);
+  if (const char* e = psf_exp_env("PSF_ZQ_FOLD128")) fold128 = std::atoi(e);
   // a power-of-two modulus covered by the digits of A: the classes from NA on vanish mod q (pw[NA] = 0) and their digit pairs are skipped (PSF_ZQ_POW2=0: multiplied anyway)
   bool pow2 = (h->q & (h->q - 1)) == 0 && h->NA <= 8 && h->zc.pw[h->NA] == 0;
-  if (const char* e = std::getenv("PSF_ZQ_POW2")) pow2 = pow2 && std::atoi(e) != 0;
+  if (const char* e = psf_exp_env("PSF_ZQ_POW2")) pow2 = pow2 && std::atoi(e) != 0;
 #define ZQL(NA_, F_, P_) hipLaunchKernelGGL((k_zq_mfma<NA_, F_, P_>), grid, dim3(256), 2 * (NA_ + 3) * 4096, st, h->dA8, h->n_pad, h->K_pad, P8, ld, zq_ks, h->zc, (int)h->wide, h->dPart, col0, h->dFail)
 #define ZQM(NA_)                                                                                                        \
   case NA_:                                                                                                             \
@@ -1149,7 +1154,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   {  // small parameter sets, few preimages (the reference's own benchmarks: n = 8, one call; benches/psf.rs:51-66): the whole call in ONE launch, one
      // workgroup per preimage (k_samp_p_small).  PSF_FUSED_MAX = largest batch it serves (0: never).  Stage exports need the intermediates: not here.
     size_t fused_max = 64;
-    if (const char* e = std::getenv("PSF_FUSED_MAX")) fused_max = (size_t)std::atol(e);
+    if (const char* e = psf_exp_env("PSF_FUSED_MAX")) fused_max = (size_t)std::atol(e);
     if (!pipe && !h->structured && !h->no_slice && h->gadget_queue && m <= (size_t)FS_MAX_M && h->n <= 64 && B <= fused_max) {
       u_gate();
       if (gate_rc != PSF_OK) return gate_rc;
@@ -1168,20 +1173,20 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // the compact normals stream.  PSF_TRMM_STREAM_MAX = largest batch it serves (0 switches it off); PSF_TRMM_STREAM_SHAPE = "RT,NB" forces a tile
   // shape, PSF_COMPACT_D=0 the chunk-stream layout of the normals (experiments; same bits).
   size_t stream_max = 1024;      // measured at C3 (profiles/r04_notes.md): the streaming form wins up to ~1024 preimages, k_trmm_f64_big beyond
-  if (const char* e = std::getenv("PSF_TRMM_STREAM_MAX")) stream_max = (size_t)std::atol(e);
+  if (const char* e = psf_exp_env("PSF_TRMM_STREAM_MAX")) stream_max = (size_t)std::atol(e);
   if (stream_max > 2048) stream_max = 2048;      // 128 column fragments: beyond, the over-read of the compact normals stream would leave TS_SLACK_DOUBLES
   const bool stream = B <= stream_max;
   // tile shape per wave (RT 16-row tiles x NB fragments of 16 preimages) and workgroup form, from tools/probe_stream.hip at the C3 shape
   // (profiles/r04_probe_stream.log): <= 16 preimages the launch is bound by reading the factor, beyond that by the longest MFMA chain
   int RT = 2, NB = B <= 16 ? 1 : B <= 64 ? 2 : 4;
-  if (const char* e = std::getenv("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
+  if (const char* e = psf_exp_env("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
   if (!(NB == 1 || NB == 2 || NB == 4 || NB == 8)) NB = 1;
   const int ncg = (int)((B + 16 * (size_t)NB - 1) / (16 * (size_t)NB));
   bool compact = stream && !h->structured;
-  if (const char* e = std::getenv("PSF_COMPACT_D")) compact = compact && std::atoi(e) != 0;
+  if (const char* e = psf_exp_env("PSF_COMPACT_D")) compact = compact && std::atoi(e) != 0;
   // <= 16 preimages in one fragment: the dense stream of bc = 1, 2, 4, 8, 16 preimages (PSF_COMPACT_D=1 keeps the fragment stream)
   int bc = 0;
-  if (compact && NB == 1 && ncg == 1 && !(std::getenv("PSF_COMPACT_D") && std::atoi(std::getenv("PSF_COMPACT_D")) == 1)) { bc = 1; while ((size_t)bc < B) bc <<= 1; }
+  if (compact && NB == 1 && ncg == 1 && !(psf_exp_env("PSF_COMPACT_D") && std::atoi(psf_exp_env("PSF_COMPACT_D")) == 1)) { bc = 1; while ((size_t)bc < B) bc <<= 1; }
   const uint32_t ncf = bc ? 0x100u + (uint32_t)bc : compact ? (uint32_t)(ncg * NB) : 0u;      // layout code of the normals stream (k_normals_wave)
   h->normals_ncf = ncf;
   {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
@@ -1196,7 +1201,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     ScopedTimer t(h, st, "k_trmm_f64");
     // default: k_trmm_f64_big (one workgroup per CU, accumulators in AccVGPRs); PSF_TRMM_VARIANT=1: k_trmm_f64_reg (two 128 x 128 workgroups per CU,
     // operands streamed into registers), 0: k_trmm_f64 (LDS-staged, round 1).  Same bits from all three.
-    const char* venv = std::getenv("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
+    const char* venv = psf_exp_env("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
     const int variant = venv ? std::atoi(venv) : 2;
     const size_t row_hi = h->structured ? h->mb : h->M_pad;
     if (stream) {
@@ -1223,16 +1228,18 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       else TS_GO(1, 1, 8, 4)
 #undef TS_GO
     }
-    else if (variant == 2) {
+    else if (variant == 2 || !psf_experiments_build) {
       int GR = 8, GC = 4;                                     // super-tile of an XCD's 32 resident workgroups; PSF_TRMM_GR x PSF_TRMM_GC for experiments (product = 32)
-      if (const char* e1 = std::getenv("PSF_TRMM_GR")) if (const char* e2 = std::getenv("PSF_TRMM_GC")) { GR = std::atoi(e1); GC = std::atoi(e2); }
+      if (const char* e1 = psf_exp_env("PSF_TRMM_GR")) if (const char* e2 = psf_exp_env("PSF_TRMM_GC")) { GR = std::atoi(e1); GC = std::atoi(e2); }
       if (GR < 1 || GC < 1 || GR * GC != 32) { GR = 8; GC = 4; }
       hipLaunchKernelGGL(k_trmm_f64_big, dim3(tr_grid_size(((int)h->nbiL + 1) / 2, (int)nbj, GR, GC)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, GR, GC, row_hi);
     }
+#ifdef PSF_EXPERIMENTS
     else if (variant == 1)
       hipLaunchKernelGGL(k_trmm_f64_reg, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
     else
       hipLaunchKernelGGL(k_trmm_f64, dim3(tr_grid_size((int)h->nbiL, (int)nbj, 8, 8)), dim3(256), 4 * TR_CHUNK * sizeof(double), st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, 8, 8, row_hi);
+#endif
   }
   if (h->structured) {  // x_top -= g R d_2 (exact integer sum on the int8 matrix cores)
     ensure_R8(h, st);
@@ -1250,7 +1257,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   auto tail = [&](hipStream_t sx, size_t b0, size_t Bh) {
     {  // p_i <- D_{Z,r,x_i}
       ScopedTimer t(h, sx, "k_perturb_round");
-      const char* renv = std::getenv("PSF_ROUND");                 // "wave": the round-2 kernel (comparison arm; same bits)
+      const char* renv = psf_exp_env("PSF_ROUND");                 // "wave": the round-2 kernel (comparison arm; same bits)
       if (h->szR.sh == 16 && !(renv && !std::strcmp(renv, "wave"))) {
         const uint32_t seg = prl_segment(m * Bh);
         const size_t waves = (m * Bh + seg - 1) / seg;
@@ -1279,9 +1286,9 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
     {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
       ScopedTimer t(h, sx, "k_gadget");
-      const char* genv = std::getenv("PSF_GADGET_WAVE");            // max n B served by the one-wave-per-problem kernel (0: never)
+      const char* genv = psf_exp_env("PSF_GADGET_WAVE");            // max n B served by the one-wave-per-problem kernel (0: never)
       const size_t wave_max = genv ? (size_t)std::atol(genv) : 4096;    // measured at C3 (n = 512): 55 vs 98 us at 3-4 preimages, 90 vs 100 at 8, 162 vs 119 at 16
-      const char* genv16 = std::getenv("PSF_GADGET_WAVE16");        // max n B served by the sixteen-lanes-per-problem kernel (0: never)
+      const char* genv16 = psf_exp_env("PSF_GADGET_WAVE16");        // max n B served by the sixteen-lanes-per-problem kernel (0: never)
       const size_t wave16_max = genv16 ? (size_t)std::atol(genv16) : 49152;     // measured at C3: 0.33 vs 0.48 ms at 64 preimages, 0.65 vs 0.60 at 128
       if (h->gadget_queue && h->n * Bh <= wave_max) {               // a single call / a handful of preimages: the chain of k draws is the launch time
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
@@ -1311,7 +1318,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       ScopedTimer t(h, sx, "k_recombine");
       // a handful of preimages: R streamed once by one wave per row (PSF_RECOMBINE_SMALL = largest batch it serves, 0: never)
       size_t small_max = 4;
-      if (const char* e = std::getenv("PSF_RECOMBINE_SMALL")) small_max = (size_t)std::atol(e);
+      if (const char* e = psf_exp_env("PSF_RECOMBINE_SMALL")) small_max = (size_t)std::atol(e);
       if (small_max > 4) small_max = 4;
       const size_t small_lds = 32 * (h->ldr / 16) * Bh;
       if (Bh <= small_max && small_lds <= 150 * 1024) {
@@ -1357,7 +1364,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   };
   // PSF_HALVES=1: the batch's two halves run these stages on two streams, so that the int8 matrix-core kernels of one half (Z_q product, recombination)
   // can share the chip with the vector-bound samplers of the other (vector work hides behind int8 / bf16 MFMAs, unlike behind FP64 ones: profiles/r03_notes.md)
-  const char* henv = std::getenv("PSF_HALVES");
+  const char* henv = psf_exp_env("PSF_HALVES");
   const bool halves = !pipe && henv && std::atoi(henv) != 0 && B >= 512 && B % 256 == 0;
   if (!halves) {
     tail(s2, 0, B);
@@ -1535,15 +1542,15 @@ static psf_status hp_ensure(psfp_handle* h, int slot, size_t entries, size_t u_w
       int lo_prio = 0, hi_prio = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
       int pc = hi_prio, pk = (lo_prio + hi_prio) / 2;
-      if (const char* env = std::getenv("PSF_HOST_PRIO")) { if (std::atoi(env) == 0) pc = pk; else if (std::atoi(env) == 2) { pc = pk; pk = hi_prio; } }      // experiments: 0 = equal, 2 = compute high
+      if (const char* env = psf_exp_env("PSF_HOST_PRIO")) { if (std::atoi(env) == 0) pc = pk; else if (std::atoi(env) == 2) { pc = pk; pk = hi_prio; } }      // experiments: 0 = equal, 2 = compute high
       if (!hp.copy) HIP_TRY(hipStreamCreateWithPriority(&hp.copy, hipStreamNonBlocking, pc));
       if (!hp.compute) HIP_TRY(hipStreamCreateWithPriority(&hp.compute, hipStreamNonBlocking, pk));
     }
     if (!hp.dOvf) HIP_TRY(hipMalloc(&hp.dOvf, 2 * sizeof(int)));
     hp.chunk_entries = (size_t)2 << 20;                                  // 8 MiB of int32 per chunk
     if (const char* env = std::getenv("PSF_HOST_WORKERS")) { const int v = std::atoi(env); if (v >= 1 && v <= NW) hp.nw = v; }
-    if (const char* env = std::getenv("PSF_HOST_CHUNK_MB")) { const long v = std::atol(env); if (v >= 1 && v <= 256) hp.chunk_entries = (size_t)v << 18; }
-    if (const char* env = std::getenv("PSF_HOST_COPY")) {                 // sdma (default) | runtime | kernel[:workgroups]
+    if (const char* env = psf_exp_env("PSF_HOST_CHUNK_MB")) { const long v = std::atol(env); if (v >= 1 && v <= 256) hp.chunk_entries = (size_t)v << 18; }
+    if (const char* env = psf_exp_env("PSF_HOST_COPY")) {                 // sdma (default) | runtime | kernel[:workgroups]
       if (std::strncmp(env, "runtime", 7) == 0) hp.copy_mode = 0;
       else if (std::strncmp(env, "kernel", 6) == 0) { hp.copy_mode = 2; if (env[6] == ':') { const int g = std::atoi(env + 7); if (g >= 1 && g <= 4096) hp.copy_grid = g; } }
     }
@@ -1651,11 +1658,11 @@ static psf_status hp_async(psfp_handle* h, size_t B, const uint64_t* u, int64_t*
   int nsl = 1;
   // (two slices cost the product ~4 ms)
   size_t tail = 1024;
-  if (const char* env = std::getenv("PSF_HOST_TAIL")) { const long v = std::atol(env); if (v >= 128) tail = (size_t)v; }
+  if (const char* env = psf_exp_env("PSF_HOST_TAIL")) { const long v = std::atol(env); if (v >= 128) tail = (size_t)v; }
   bool cut = hp.slice_tail;                                 // the synchronous form only: behind an asynchronous call the next call's compute covers the transfer
-  if (const char* env = std::getenv("PSF_HOST_ASYNC_SLICE")) cut = cut || std::atoi(env) != 0;      // experiments: 1 = asynchronous calls cut the tail slice too
+  if (const char* env = psf_exp_env("PSF_HOST_ASYNC_SLICE")) cut = cut || std::atoi(env) != 0;      // experiments: 1 = asynchronous calls cut the tail slice too
   if (cut && allow_slices && !h->no_slice && !h->pipeline && B >= 2 * tail) { cuts[1] = B - tail; cuts[2] = B; nsl = 2; }
-  if (const char* env = std::getenv("PSF_HOST_SLICE")) {    // experiments: equal slices of this many rows (at most four)
+  if (const char* env = psf_exp_env("PSF_HOST_SLICE")) {    // experiments: equal slices of this many rows (at most four)
     const long v = std::atol(env);
     if (v >= 128 && allow_slices && !h->no_slice && !h->pipeline && (size_t)v < B) {
       nsl = 0;
@@ -1687,9 +1694,9 @@ static psf_status hp_async(psfp_handle* h, size_t B, const uint64_t* u, int64_t*
   for (int j = 0; j < nsl; ++j) { slice_end[j] = cuts[j + 1] * m; slice_ev[j] = hp.evSlice[slot][j]; }
   const int nw = hp.nw;
   int dbg = 0;
-  if (const char* env = std::getenv("PSF_HOST_DEBUG")) dbg = std::atoi(env);      // measurement only: 1 = no widening, 2 = no copies either (e is NOT filled)
+  if (const char* env = psf_exp_env("PSF_HOST_DEBUG")) dbg = std::atoi(env);      // measurement only: 1 = no widening, 2 = no copies either (e is NOT filled)
   const int copy_mode = hp.copy_mode, copy_grid = hp.copy_grid;
-  const bool plain_widen = std::getenv("PSF_HOST_PLAIN_WIDEN") != nullptr;      // measurement only: the scalar loop with ordinary stores
+  const bool plain_widen = psf_exp_env("PSF_HOST_PLAIN_WIDEN") != nullptr;      // measurement only: the scalar loop with ordinary stores
   auto worker = [&hp, slot, src, e, total, CE, nchunks, nsl, device, slice_end, slice_ev, nw, dbg, copy_mode, copy_grid, plain_widen](int w) {
     if (hipSetDevice(device) != hipSuccess) { hp.status[slot] = (int)PSF_ERR_HIP; return; }
     auto widen = [&](size_t c, int k) {
@@ -1757,7 +1764,7 @@ psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size
     if (rc != PSF_OK) return rc;
     rc = ensure_batch(h, B);
     if (rc != PSF_OK) return rc;
-    if (!h->no_slice && !h->pipeline && B * (h->n + h->m) * 8 <= SIO_MAX_BYTES && !std::getenv("PSF_HOST_STRAIGHT")) {
+    if (!h->no_slice && !h->pipeline && B * (h->n + h->m) * 8 <= SIO_MAX_BYTES && !psf_exp_env("PSF_HOST_STRAIGHT")) {
       if (h->timing) clear_slots(h);
       int fl[1] = {0};
       rc = sio_call(h, B * h->n, B * h->m, u, e, h->dU, h->dE, h->sets[0].dFail, h->sets[1].dFail, nullptr, 0, fl,
