@@ -47,6 +47,10 @@ struct psfgpv_handle {
   int walk_slots[3] = {0, 0, 0};      // [G]: workgroups of k_np_walk<G> a compute unit holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor)
   unsigned walk_spins = 1u << 22;      // NpWalkSync::spin_limit
   int last_form = 0, last_G = 0;      // what the last call launched for the walk: 1 = k_np_walk<G> (one launch), 0 = k_np_step<G> per block, 3 = k_np_walk2<G>
+  int last_parts = 1;                 // column ranges the last call walked side by side (np_split)
+  int np_split = -1;                  // -1: by shape (two halves when the batch does not fit the one-launch walk and is large), 0 / 1: never / whenever the shape allows (tests)
+  hipStream_t sh[2] = {nullptr, nullptr};                  // the two halves of a large batch walk side by side on these (equal priority, non-blocking)
+  hipEvent_t evFork = nullptr, evHalf[2] = {nullptr, nullptr};
   int np_g = 0;                       // PSF_NP_G: preimages per wave of the sampler (0 = by batch size)
   int np_immediate = -1;              // PSF_NP_IMMEDIATE: 1 = every block updates all the rows below it in the launch that follows, 0 = panel-deferred far update, -1 = by batch size
   bool has_key = false;
@@ -201,7 +205,7 @@ static psf_status ensure_np_batch(psfgpv_handle* g, size_t B) {
   return PSF_OK;
 }
 
-static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size_t B, int64_t* d_e, int pass);
+static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size_t B, int64_t* d_e, int pass, size_t col0 = 0);
 
 // One one-launch walk at a time per device and process: the constructor makes `st` wait for the walk launched before (any handle, any stream), the destructor
 // records the event the next one will wait for.  Held across the launch only; costs one hipStreamWaitEvent + one hipEventRecord per call.
@@ -222,31 +226,54 @@ struct WalkTurn {
   }
 };
 
-// MatZ::sample_d_precomputed_gso for the whole batch (gpv.rs:160): the launch sequence of psf_np_kernels.hpp, one stream
+// The per-batch buffers of the walk seen from preimage column `col0` (a multiple of 128) on: every one of them is laid out by columns or by 128-column blocks, so a
+// column range of the batch is the same launch sequence on offset pointers -- what lets two halves of a large batch walk side by side (gpv_samp_p_enqueue).
+struct NpCols {
+  double* Tm; double* Zf; int8_t* Z8; unsigned char* Zocc; double* C0p; double* C1; uint64_t* Sol; int64_t* E1;
+};
+static NpCols np_cols(const psfgpv_handle* g, size_t col0) {
+  const size_t cb = col0 / TR_BN;
+  return NpCols{g->dTm + col0, g->dZf + cb * g->nkb * TR_CHUNK, g->dZ8 + col0 * 16, g->dZocc + cb * g->nrb, g->dC0p + cb * g->nkc * TR_CHUNK,
+                g->dC1 ? g->dC1 + cb * g->nkd * TR_CHUNK : nullptr, g->dSol + col0, g->dE1 ? g->dE1 + col0 * g->dim : nullptr};
+}
+
+// does a batch of B preimages fit the one-launch walk?  (one sampler workgroup per CU at most beside the updaters that hold d/64 - 2 row blocks per column group)
+static bool np_walk_fits(const psfgpv_handle* g, size_t B, int* Gw_out, unsigned* nSw_out, unsigned* ngroups_out, unsigned* ug_out) {
+  if (g->np_walk == 0 || g->np_walk == 3 || g->cus <= 0 || g->nblk < 3) return false;      // (PSF_NP_WALK=3: k_np_walk2 for every batch, tests)
+  const int Gw = (g->np_g == 1 || g->np_g == 2) ? g->np_g : (B <= 4 * (size_t)g->cus ? 1 : 2);
+  const unsigned nSw = (unsigned)((B + 4 * (size_t)Gw - 1) / (4 * (size_t)Gw));
+  const unsigned per = (unsigned)(NP_GW / (4 * Gw)), ngroups = (nSw + per - 1) / per;
+  // residency: the device holds walk_slots workgroups of this kernel per CU (occupancy API: registers and LDS, not an assumption about the chip being ours alone --
+  // that part no API can promise, hence k_np_walk_solo); one sampler workgroup per CU at most, the updaters take what the samplers leave
+  const long slots = (long)g->cus * (long)g->walk_slots[Gw];
+  unsigned ug = 0;
+  if (ngroups && nSw <= (unsigned)g->cus && slots > (long)nSw) ug = (unsigned)std::min<long>((slots - (long)nSw) / (long)ngroups, (long)g->cus / (long)ngroups);
+  if (ug > g->nblk - 2) ug = (unsigned)(g->nblk - 2);
+  if (!(nSw <= (unsigned)g->cus && ug >= 1 && (size_t)2 * NP_WALK_SLOTS * ug >= g->nblk - 2)) return false;
+  if (Gw_out) { *Gw_out = Gw; *nSw_out = nSw; *ngroups_out = ngroups; *ug_out = ug; }
+  return true;
+}
+
+// MatZ::sample_d_precomputed_gso for B preimages (gpv.rs:160), the columns col0 ... of the batch buffers: the launch sequence of psf_np_kernels.hpp on one stream
 // pass 0: centre -sol on the pivot columns (K = n), e = sum z b + sol; pass 1 (two-pass mode): centre -e1 on every coordinate (K = d), e = sum z b + e1
-static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e, int pass = 0) {
+// first_index / d_e: of the range's first preimage
+static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_t seed, uint32_t tag, uint64_t first_index, size_t B, int64_t* d_e, int pass = 0, size_t col0 = 0,
+                                       bool may_walk = true) {
   const size_t ld = g->ld, nbj = round_up(B, TR_BN) / TR_BN;
   const size_t lds_gemm = 4 * TR_CHUNK * sizeof(double);
+  const NpCols v = np_cols(g, col0);
   // T = B~[:, pivots] C0[pivots]
   int* const flags = g->dFlags + 4 * pass;
-  if (pass == 0) hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, g->dC0p, g->nkc, (int)g->nkc, g->dTm, ld);
-  else hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBfull, g->nkd, g->dC1, g->nkd, (int)g->nkd, g->dTm, ld);
+  if (pass == 0) hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, v.C0p, g->nkc, (int)g->nkc, v.Tm, ld);
+  else hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBfull, g->nkd, v.C1, g->nkd, (int)g->nkd, v.Tm, ld);
   int G = g->np_g;
   if (G != 1 && G != 2) G = B <= 1536 ? 1 : 2;      // one or two wave pairs per SIMD of the chip (1024 SIMDs)
-  NpSampleArgs a{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, flags};
+  NpSampleArgs a{v.Tm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, v.Zf, g->nkb, v.Z8, g->zplane, ld, flags};
   // The whole walk in one launch (k_np_walk) where every workgroup can be resident at once: one sampler workgroup per CU at most (B <= 4 G CUs) beside one
   // updater workgroup per CU, and at most 2 * NP_WALK_SLOTS blocks of T per updater.  Otherwise one launch per block (k_np_step).
-  if (g->np_walk != 0 && g->np_walk != 3 && g->cus > 0 && g->nblk >= 3) {      // (PSF_NP_WALK=3: k_np_walk2 for every batch, tests)
-    const int Gw = (g->np_g == 1 || g->np_g == 2) ? g->np_g : (B <= 4 * (size_t)g->cus ? 1 : 2);
-    const unsigned nSw = (unsigned)((B + 4 * (size_t)Gw - 1) / (4 * (size_t)Gw));
-    const unsigned per = (unsigned)(NP_GW / (4 * Gw)), ngroups = (nSw + per - 1) / per;
-    // residency: the device holds walk_slots workgroups of this kernel per CU (occupancy API: registers and LDS, not an assumption about the chip being ours alone --
-    // that part no API can promise, hence k_np_walk_solo below); one sampler workgroup per CU at most, the updaters take what the samplers leave
-    const long slots = (long)g->cus * (long)g->walk_slots[Gw];
-    unsigned ug = 0;
-    if (ngroups && nSw <= (unsigned)g->cus && slots > (long)nSw) ug = (unsigned)std::min<long>((slots - (long)nSw) / (long)ngroups, (long)g->cus / (long)ngroups);
-    if (ug > g->nblk - 2) ug = (unsigned)(g->nblk - 2);
-    if (nSw <= (unsigned)g->cus && ug >= 1 && (size_t)2 * NP_WALK_SLOTS * ug >= g->nblk - 2) {
+  {
+    int Gw = 0; unsigned nSw = 0, ngroups = 0, ug = 0;
+    if (may_walk && col0 == 0 && np_walk_fits(g, B, &Gw, &nSw, &ngroups, &ug)) {
       NpWalkSync sy{g->dWalk, g->dWalk + (size_t)ngroups * g->nblk, g->dWalk + (size_t)2 * ngroups * g->nblk, (unsigned)g->nblk, g->walk_spins};
       NpSampleArgs aw{g->dTm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, g->dZf, g->nkb, g->dZ8, g->zplane, ld, flags};
       const unsigned ntot = nSw + ngroups * ug;
@@ -265,7 +292,7 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
       if (Gw == 1) hipLaunchKernelGGL((k_np_walk_solo<1>), dim3(nSw), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, g->dGp, g->dTm, (const unsigned*)sy.abort, reruns);
       else hipLaunchKernelGGL((k_np_walk_solo<2>), dim3(nSw), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, g->dGp, g->dTm, (const unsigned*)sy.abort, reruns);
       g->last_form = 1; g->last_G = Gw;
-      return launch_np_recombination(g, st, B, d_e, pass);
+      return launch_np_recombination(g, st, B, d_e, pass, col0);
     }
   }
   const unsigned nS = (unsigned)((B + 4 * (size_t)G - 1) / (4 * (size_t)G));
@@ -273,14 +300,14 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
   // MEASURED SLOWER than one launch per block at C4 (6.9 against 4.4 ms, profiles/r05_notes.md: with two wave pairs per SIMD the vector pipe is the bound, and the
   // helpers' tiles re-read the block's z per 16 rows): a labelled opt-in (PSF_NP_WALK=3), kept bit-identical by tests/test_gpu_switch_matrix.py
 #ifdef PSF_EXPERIMENTS
-  if (g->np_walk == 3 && g->cus > 0 && g->nblk >= 3 && nS <= 2u * (unsigned)g->cus) {
+  if (g->np_walk == 3 && col0 == 0 && g->cus > 0 && g->nblk >= 3 && nS <= 2u * (unsigned)g->cus) {
     const unsigned per = (unsigned)(NP_GW / (4 * G)), ngroups = (nS + per - 1) / per;
     NpWalkSync sy{g->dWalk, g->dWalk + (size_t)ngroups * g->nblk, g->dWalk + (size_t)2 * ngroups * g->nblk, (unsigned)g->nblk, g->walk_spins};
     hipMemsetAsync(g->dWalk, 0, g->walk_words * sizeof(unsigned), st);
     if (G == 1) hipLaunchKernelGGL((k_np_walk2<1>), dim3(nS), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, g->dGp, g->dTm, sy);
     else hipLaunchKernelGGL((k_np_walk2<2>), dim3(nS), dim3(512), 65536, st, a, g->dim, g->nblk, seed, tag, first_index, B, nS, g->dGp, g->dTm, sy);
     g->last_form = 3; g->last_G = G;
-    return launch_np_recombination(g, st, B, d_e, pass);
+    return launch_np_recombination(g, st, B, d_e, pass, col0);
   }
 #endif
   const size_t W = NP_PANEL;
@@ -313,31 +340,32 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
       if (i == 0) set_job(2, top, nsub, 0, near_lo / 128, 0, near_lo);
     }
     const unsigned ntot = nS + jobs.ntiles[0] + jobs.ntiles[1] + jobs.ntiles[2];
-    if (G == 1) hipLaunchKernelGGL((k_np_step<1>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, g->dTm);
-    else hipLaunchKernelGGL((k_np_step<2>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, g->dTm);
+    if (G == 1) hipLaunchKernelGGL((k_np_step<1>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, v.Tm);
+    else hipLaunchKernelGGL((k_np_step<2>), dim3(ntot), dim3(512), 65536, st, a, g->dim, J, seed, tag, first_index, B, nS, jobs, (int)nbj, g->dGp, v.Tm);
   }
   g->last_form = 0; g->last_G = G;
-  return launch_np_recombination(g, st, B, d_e, pass);
+  return launch_np_recombination(g, st, B, d_e, pass, col0);
 }
 
 // e = sum_i z_i b_i + sol (pass 1 of the two-pass walk: + e1)
-static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size_t B, int64_t* d_e, int pass) {
+static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size_t B, int64_t* d_e, int pass, size_t col0) {
   const size_t ld = g->ld;
+  const NpCols v = np_cols(g, col0);
   int* const flags = g->dFlags + 4 * pass;
   const psfp_handle* b = g->base;
   const dim3 cgrid((unsigned)((B + 127) / 128), (unsigned)(g->dpad / 128));
   const int nk128 = (int)(g->dpad / 128);
   if (!g->basis_generic && g->np_combine != 0) {
     // z = z0 + 256 z1 + 65536 z2, b = b0 + 256 b1: every digit pair in one launch, over the tiles of the digit planes that hold anything
-    hipLaunchKernelGGL(k_np_occ_z, dim3((unsigned)(cgrid.x * g->nrb), 2), dim3(256), 0, st, g->dZ8, g->zplane, ld, nk128, g->dZocc);
-    hipLaunchKernelGGL(k_np_combine8_fused, cgrid, dim3(256), 65536 + 768, st, g->dB8, g->dpad, g->dim, nk128, g->basis_hi ? 2 : 1, g->dBocc, g->dZ8, g->zplane, ld, B, g->dZocc, d_e, g->dim);
-    if (pass == 0) hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dSol, g->dPiv, g->n, B, ld, d_e, g->dim);
+    hipLaunchKernelGGL(k_np_occ_z, dim3((unsigned)(cgrid.x * g->nrb), 2), dim3(256), 0, st, v.Z8, g->zplane, ld, nk128, v.Zocc);
+    hipLaunchKernelGGL(k_np_combine8_fused, cgrid, dim3(256), 65536 + 768, st, g->dB8, g->dpad, g->dim, nk128, g->basis_hi ? 2 : 1, g->dBocc, v.Z8, g->zplane, ld, B, v.Zocc, d_e, g->dim);
+    if (pass == 0) hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, v.Sol, g->dPiv, g->n, B, ld, d_e, g->dim);
   }
 #ifdef PSF_EXPERIMENTS
   else if (!g->basis_generic) {
     // the same sum as one pass per digit pair in use (the z digits beyond the first are gated on the device): PSF_NP_COMBINE=0, kept for the switch matrix
     const size_t plane = g->dpad * g->dpad;
-    const int8_t* zp[3] = {g->dZ8, g->dZ8 + g->zplane, g->dZ8 + 2 * g->zplane};
+    const int8_t* zp[3] = {v.Z8, v.Z8 + g->zplane, v.Z8 + 2 * g->zplane};
     const int* gate[3] = {nullptr, flags + 1, flags + 2};
     bool first = true;
     for (int zi = 0; zi < 3; ++zi)
@@ -347,13 +375,13 @@ static psf_status launch_np_recombination(psfgpv_handle* g, hipStream_t st, size
         else hipLaunchKernelGGL((k_np_combine8<true>), cgrid, dim3(256), 65536, st, g->dB8 + bi * plane, g->dpad, g->dim, nk128, zp[zi], ld, B, scale, gate[zi], d_e, g->dim);
         first = false;
       }
-    if (pass == 0) hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, g->dSol, g->dPiv, g->n, B, ld, d_e, g->dim);
+    if (pass == 0) hipLaunchKernelGGL(k_np_add_sol, dim3(grid_for(g->n * B)), dim3(256), 0, st, v.Sol, g->dPiv, g->n, B, ld, d_e, g->dim);
   }
 #endif
   // integer fallback: always for a basis beyond two int8 digits, otherwise only if a z left the three-digit range (decided on the device)
-  hipLaunchKernelGGL(k_np_combine_generic, dim3(grid_for(g->dim * B, 256, 256 * 64)), dim3(256), 0, st, g->dSt, g->dim, g->dZf, g->nkb, g->dSol, g->dPiv, pass == 0 ? g->n : (size_t)0, B, ld,
+  hipLaunchKernelGGL(k_np_combine_generic, dim3(grid_for(g->dim * B, 256, 256 * 64)), dim3(256), 0, st, g->dSt, g->dim, v.Zf, g->nkb, v.Sol, g->dPiv, pass == 0 ? g->n : (size_t)0, B, ld,
                      g->basis_generic ? (const int*)nullptr : (const int*)(flags + 3), d_e, g->dim);
-  if (pass == 1) hipLaunchKernelGGL(k_np_add_e1, dim3(grid_for(g->dim * B, 256, 256 * 64)), dim3(256), 0, st, g->dE1, g->dim * B, d_e);
+  if (pass == 1) hipLaunchKernelGGL(k_np_add_e1, dim3(grid_for(g->dim * B, 256, 256 * 64)), dim3(256), 0, st, v.E1, g->dim * B, d_e);
   (void)b;
   return PSF_OK;
 }
@@ -450,6 +478,10 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 768));
   if (const char* e = psf_exp_env("PSF_NP_COMBINE")) g->np_combine = std::atoi(e);
   for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
+  for (auto& sx : g->sh) HIP_TRY(hipStreamCreateWithFlags(&sx, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
+  for (auto& e : g->evHalf) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (const char* e = psf_exp_env("PSF_NP_SPLIT")) g->np_split = std::atoi(e);
   return PSF_OK;
 }
 
@@ -460,6 +492,9 @@ void psfgpv_destroy(psfgpv_handle* g) {
   hipFree(g->dSt); hipFree(g->dGt); hipFree(g->dNorm2); hipFree(g->dSz); hipFree(g->dT); hipFree(g->dPiv);
   hipFree(g->dGp); hipFree(g->dGin); hipFree(g->dGnx); hipFree(g->dRows); hipFree(g->dBpiv); hipFree(g->dB8); hipFree(g->dBocc); hipFree(g->dFlags); hipFree(g->dBfull);
   for (auto& e : g->ev) if (e) hipEventDestroy(e);
+  for (auto& sx : g->sh) if (sx) hipStreamDestroy(sx);
+  if (g->evFork) hipEventDestroy(g->evFork);
+  for (auto& e : g->evHalf) if (e) hipEventDestroy(e);
   psfp_destroy(g->base);
   delete g;
 }
@@ -557,8 +592,34 @@ static psf_status gpv_samp_p_enqueue(psfgpv_handle* g, uint64_t seed, uint64_t f
   if (g->timing) hipEventRecord(g->ev[1], st);
   // :160  sol + sample_d_precomputed_gso(basis, gso, centre, s)
   psf_status rc;
-  if (!g->two_pass) rc = launch_nearest_plane(g, st, seed, TAG_GPV, first_index, B, d_e);
+  // Two halves side by side.  A batch that does not fit the one-launch walk runs one launch per 64-row block, and in every such launch the FP64-MFMA update tiles
+  // wait for the sampler workgroups to leave their slots (both slots of every CU: 59 us of vector work, then 12 us of matrix work on an otherwise idle chip at C4,
+  // profiles/r05_notes.md).  Cut into two column ranges on two streams, the launches of the halves drift apart and the update tiles of one half run beside the
+  // samplers of the other: C4 4.44 -> 4.05 ms (tools/c4_split_probe.py, profiles/r06_notes.md).  Preimages are independent (row b draws from the streams of global
+  // index first_index + b), so the rows are the rows of the undivided call bit for bit.  Only where neither the batch nor its halves fit the one-launch walk
+  // (two walks at once would take turns, WalkTurn) and the batch is large enough for the halves to fill the chip.
+  size_t half0 = 0;
+  if (!g->two_pass && g->np_split != 0 && g->sh[0] && B >= 256) {
+    const size_t h0 = round_up((B + 1) / 2, TR_BN);
+    const bool shape_ok = h0 < B && !np_walk_fits(g, B, nullptr, nullptr, nullptr, nullptr) && !np_walk_fits(g, h0, nullptr, nullptr, nullptr, nullptr) &&
+                          !np_walk_fits(g, B - h0, nullptr, nullptr, nullptr, nullptr);
+    if (shape_ok && (g->np_split == 1 || B >= 3072)) half0 = h0;
+  }
+  if (half0) {
+    HIP_TRY(hipEventRecord(g->evFork, st));                                    // sol and the centres of the whole batch are on `st`
+    const size_t cnt[2] = {half0, B - half0}, off[2] = {0, half0};
+    rc = PSF_OK;
+    for (int i = 0; i < 2 && rc == PSF_OK; ++i) {
+      HIP_TRY(hipStreamWaitEvent(g->sh[i], g->evFork, 0));
+      rc = launch_nearest_plane(g, g->sh[i], seed, TAG_GPV, first_index + off[i], cnt[i], d_e + off[i] * g->dim, 0, off[i], false);
+      HIP_TRY(hipEventRecord(g->evHalf[i], g->sh[i]));
+    }
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(st, g->evHalf[i], 0));      // the caller's stream continues behind both halves
+    g->last_parts = 2;
+  }
+  else if (!g->two_pass) { rc = launch_nearest_plane(g, st, seed, TAG_GPV, first_index, B, d_e); g->last_parts = 1; }
   else {
+    g->last_parts = 1;
     rc = launch_nearest_plane(g, st, seed, TAG_GPV, first_index, B, g->dE1, 0);          // a short representative e1 of the coset (A e1 = u)
     hipLaunchKernelGGL(k_np_center_from_e, dim3(grid_for(g->nkd * 16 * g->ld, 256, 256 * 64)), dim3(256), 0, st, g->dE1, g->dim, B, g->ld, g->nkd, g->dC1, g->dFlags);
     if (rc == PSF_OK) rc = launch_nearest_plane(g, st, seed, TAG_GPV2, first_index, B, d_e, 1);   // v ~ D_{Lambda, s, -e1}; e = e1 + v
@@ -763,6 +824,14 @@ psf_status psfgpv_debug_set_walk(psfgpv_handle* g, int form, unsigned spins) {
   if (spins) g->walk_spins = spins;
   return PSF_OK;
 }
+// tests: the two-halves form of large launch-per-block batches: -1 = by shape and size, 0 = never, 1 = whenever the shape allows (from 256 preimages on)
+psf_status psfgpv_debug_set_split(psfgpv_handle* g, int split) {
+  if (!g || split < -1 || split > 1) return PSF_ERR_PARAM;
+  g->np_split = split;
+  return PSF_OK;
+}
+// column ranges the last call walked side by side (1 or 2)
+int psfgpv_debug_last_parts(const psfgpv_handle* g) { return g ? g->last_parts : 0; }
 
 psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle* g, size_t* blocks, size_t* generic_recombination) {
   if (!g) return PSF_ERR_PARAM;
@@ -1117,5 +1186,7 @@ psf_status psfring_get_nearest_plane_form(psfring_handle* h, int* form, int* pre
   return h ? psfgpv_get_nearest_plane_form(h->g, form, preimages_per_wave, blocks, reruns) : PSF_ERR_PARAM;
 }
 psf_status psfring_debug_set_walk(psfring_handle* h, int form, unsigned spins) { return h ? psfgpv_debug_set_walk(h->g, form, spins) : PSF_ERR_PARAM; }
+psf_status psfring_debug_set_split(psfring_handle* h, int split) { return h ? psfgpv_debug_set_split(h->g, split) : PSF_ERR_PARAM; }
+int psfring_debug_last_parts(const psfring_handle* h) { return h ? psfgpv_debug_last_parts(h->g) : 0; }
 
 }  // extern "C"

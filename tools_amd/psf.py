@@ -424,6 +424,13 @@ class PSFGPV:
         """tests: force the walk's launch form (-1 by batch size, 0 per block, 1 one launch where it fits) / the poll limit of its waits (1: every wait gives up)"""
         check(lib().psfgpv_debug_set_walk(self._h, C.c_int(form), C.c_uint(spins)), "debug_set_walk")
 
+    def _debug_set_split(self, split=-1):
+        """tests: the two-halves form of large launch-per-block batches (-1 by shape and size, 0 never, 1 whenever the shape allows)"""
+        check(lib().psfgpv_debug_set_split(self._h, C.c_int(split)), "debug_set_split")
+
+    def _debug_last_parts(self):
+        return int(lib().psfgpv_debug_last_parts(self._h))
+
 
 class PSFGPVRing:
     """gpv_ring.rs:62-67 / impl PSF :69-284 on one MI355X.  Polynomials are coefficient rows (constant term first):
@@ -568,3 +575,10 @@ class PSFGPVRing:
     def _debug_set_walk(self, form=-1, spins=0):
         """tests: force the walk's launch form (-1 by batch size, 0 per block, 1 one launch where it fits) / the poll limit of its waits (1: every wait gives up)"""
         check(lib().psfring_debug_set_walk(self._h, C.c_int(form), C.c_uint(spins)), "debug_set_walk")
+
+    def _debug_set_split(self, split=-1):
+        """tests: the two-halves form of large launch-per-block batches (-1 by shape and size, 0 never, 1 whenever the shape allows)"""
+        check(lib().psfring_debug_set_split(self._h, C.c_int(split)), "debug_set_split")
+
+    def _debug_last_parts(self):
+        return int(lib().psfring_debug_last_parts(self._h))
