@@ -123,7 +123,7 @@ def rank_main(args):
     value = total / elapsed
     out = None
     if rank == 0:
-        roof = roofline(scheme, psf, m, B, kern_ms, args.config, args.structured)
+        roof = roofline(scheme, psf, m, B, kern_ms, args.config, args.structured, run["np_form"])
         out = {
             "metric": "preimages/sec (whole node) + HBM-BW% for samp_p, n=512 q~2^30 batch=4096",
             "value": round(value, 2), "unit": "preimages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -265,6 +265,7 @@ def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, s
         kern_ms[nm] = ms
     psf.enable_timing(False)
     status = psf.last_status()
+    np_form = nearest_plane_form(psf) if hasattr(psf, "nearest_plane_form") else None      # of the timed steps (the latency legs launch other forms)
     rank_elapsed, ranks_seen = [own], 1
     if multi:
         ranks_seen = dist.get_world_size()
@@ -286,7 +287,7 @@ def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, s
         valid = bool(vt.item())
     return {"psf": psf, "scheme": scheme, "n": n, "q": q, "r": r, "s": s, "m": m, "gp": gp, "B": B, "u": u, "e": e, "stream": stream,
             "first_index": first_index, "kern_ms": kern_ms, "elapsed": elapsed, "valid": valid, "do_gather": do_gather, "trap_gen_s": t_trapgen,
-            "rank_elapsed": rank_elapsed, "ranks_seen": ranks_seen, "gather_info": gather_info}
+            "rank_elapsed": rank_elapsed, "ranks_seen": ranks_seen, "gather_info": gather_info, "np_form": np_form}
 
 
 def nearest_plane_form(psf):
@@ -295,12 +296,13 @@ def nearest_plane_form(psf):
         form, G, blocks, fallbacks = psf.nearest_plane_form()
     except Exception:
         return "nearest plane", {}
-    walk = {1: f"k_np_walk<{G}> (one launch: sampler + updater workgroups)", 0: f"{blocks} x k_np_step<{G}> (one launch per 64-row block)"}.get(form, f"form {form}")
-    return f"nearest plane: k_np_project + {walk} + k_np_combine8_fused", {"form": "one launch" if form == 1 else "launch per block", "G": G, "blocks": blocks,
-                                                                           "calls_rerun_per_block": fallbacks}
+    walk = {1: f"k_np_walk<{G}> (one launch: sampler + updater workgroups)", 0: f"{blocks} x k_np_step<{G}> (one launch per 64-row block)",
+            2: f"2 x {blocks} x k_np_step<{G}> (two column ranges side by side on two streams, one launch per 64-row block each)"}.get(form, f"form {form}")
+    return f"nearest plane: k_np_project + {walk} + k_np_combine8_fused", {"form": {1: "one launch", 0: "launch per block", 2: "launch per block, two halves side by side"}.get(form, str(form)),
+                                                                           "G": G, "blocks": blocks, "walks_rerun_without_waits": fallbacks}
 
 
-def roofline(scheme, psf, m, B, kern_ms, cfg, structured=False):
+def roofline(scheme, psf, m, B, kern_ms, cfg, structured=False, np_form=None):
     trmm = kern_ms.get("k_trmm_f64")
     mL = psf.m_bar if (scheme == "PSFPerturbation" and structured) else m
     flops_per_launch = float(mL) * (mL + 1) * B          # mL(mL+1)/2 fma per preimage (m^2 flop; structured: the m_bar x m_bar block)
@@ -322,7 +324,7 @@ def roofline(scheme, psf, m, B, kern_ms, cfg, structured=False):
         # preimage, so the phase is latency bound, not MFMA bound.
         flops = 2.0 * float(m) * float(m) * B
         ach = flops / (npl * 1e-3) / 1e12
-        kname, form = nearest_plane_form(psf)
+        kname, form = np_form or nearest_plane_form(psf)
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 3),
                 "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F64_MFMA_TFLOPS, 4),
                 "traffic": load_traffic(cfg, B, "np_traffic.json", ("psf_np_kernels.hpp",)),
@@ -346,7 +348,7 @@ def other_configs(local_rank, dev, steps=5, warmup=1):
             res[cfg] = {"workload": f"{scheme} n={run['n']} q={run['q']} m={run['m']} s={run['s']} batch={B}",
                         "ms_per_step": round(run["elapsed"] / steps * 1e3, 3), "value": round(B * steps / run["elapsed"], 2), "unit": "preimages/s",
                         "steps": steps, "warmup": warmup, "valid": run["valid"], "kernels_ms": {k: round(v, 3) for k, v in run["kern_ms"].items()},
-                        "trap_gen_s": round(run["trap_gen_s"], 2), "roofline": roofline(scheme, run["psf"], run["m"], B, run["kern_ms"], cfg)}
+                        "trap_gen_s": round(run["trap_gen_s"], 2), "roofline": roofline(scheme, run["psf"], run["m"], B, run["kern_ms"], cfg, np_form=run["np_form"])}
             run["psf"].close()
             run.clear()
         except Exception as exc:                    # a failed side leg is reported in the line, it does not take the headline with it

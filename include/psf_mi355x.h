@@ -335,7 +335,9 @@ psf_status psfgpv_get_timing(psfgpv_handle*, double* solve_ms, double* nearest_p
 psf_status psfgpv_get_nearest_plane_stats(psfgpv_handle*, size_t* blocks, size_t* generic_recombination);
 /* The walk of gpv.rs:160 has two launch forms with identical results: ONE launch (k_np_walk<G>: sampler workgroups and updater workgroups that hand blocks to each
  * other through device memory; chosen when the device's occupancy figures say every workgroup is resident at once) and one launch per 64-row block (k_np_step<G>).
- * form: 1 / 0 as launched by the last call; preimages_per_wave: G; reruns: walks of this handle since its creation in which a workgroup of the one-launch form gave
+ * A large batch of the second form walks as two column ranges side by side on two streams of the handle (the matrix-core update tiles of one range run beside the
+ * samplers of the other), joined on the caller's stream before the call's last kernel: form 2.
+ * form: 1 / 0 / 2 as launched by the last call; preimages_per_wave: G; reruns: walks of this handle since its creation in which a workgroup of the one-launch form gave
  * up waiting for another (a GPU shared with other work) and the call was walked again, inside the same call, by a form without waits between workgroups
  * (k_np_walk_solo).  Contention costs time, never the call: PSF_ERR_SAMPLER is reserved for SampleZ itself.  One-launch walks of one process take turns per device. */
 psf_status psfgpv_get_nearest_plane_form(psfgpv_handle*, int* form, int* preimages_per_wave, size_t* blocks, uint64_t* reruns);

@@ -161,8 +161,8 @@ __global__ void k_np_pack_basis8(const int32_t* __restrict__ St, size_t d, size_
 //   Sol[r][b]           the residues, added back to the pivot columns of e at the end (gpv.rs:160: sol + sample)
 //   C0p chunk (bj, kc)  (double)(-sol): the centre c0 = -sol (gpv.rs:158) as the B operand of the initial projection
 __global__ void k_np_solve(const uint64_t* __restrict__ Tt, size_t n, size_t nk16, uint64_t q, uint64_t two64, const uint64_t* __restrict__ U,
-                           size_t B, size_t ld, uint64_t* __restrict__ Sol, double* __restrict__ C0p) {
-  const size_t total = nk16 * ld;      // (every column of the padded width: the padding columns of the operand are rewritten as zeros)
+                           size_t B, size_t ld, uint64_t* __restrict__ Sol, double* __restrict__ C0p, size_t cols) {
+  const size_t total = nk16 * cols;    // cols: B rounded up to whole 128-column blocks at least (the padding columns of the operand are rewritten as zeros)
   const size_t nkc = nk16 / 16;
   for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const size_t r = g % nk16, b = g / nk16;

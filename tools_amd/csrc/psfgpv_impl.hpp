@@ -587,11 +587,6 @@ static psf_status gpv_samp_p_enqueue(psfgpv_handle* g, uint64_t seed, uint64_t f
   HIP_TRY(hipMemsetAsync(b->dFail, 0, 2 * sizeof(int), st));
   HIP_TRY(hipMemsetAsync(g->dFlags, 0, 8 * sizeof(int), st));
   if (g->timing) hipEventRecord(g->ev[0], st);
-  // :153-158  sol = A.solve(u), centre = -sol
-  hipLaunchKernelGGL(k_np_solve, dim3(grid_for(g->nkc * 16 * g->ld)), dim3(256), 0, st, g->dT, g->n, g->nkc * 16, b->q, b->two64, d_u, B, g->ld, g->dSol, g->dC0p);
-  if (g->timing) hipEventRecord(g->ev[1], st);
-  // :160  sol + sample_d_precomputed_gso(basis, gso, centre, s)
-  psf_status rc;
   // Two halves side by side.  A batch that does not fit the one-launch walk runs one launch per 64-row block, and in every such launch the FP64-MFMA update tiles
   // wait for the sampler workgroups to leave their slots (both slots of every CU: 59 us of vector work, then 12 us of matrix work on an otherwise idle chip at C4,
   // profiles/r05_notes.md).  Cut into two column ranges on two streams, the launches of the halves drift apart and the update tiles of one half run beside the
@@ -605,12 +600,23 @@ static psf_status gpv_samp_p_enqueue(psfgpv_handle* g, uint64_t seed, uint64_t f
                           !np_walk_fits(g, B - h0, nullptr, nullptr, nullptr, nullptr);
     if (shape_ok && (g->np_split == 1 || B >= 3072)) half0 = h0;
   }
+  // :153-158  sol = A.solve(u), centre = -sol  (the halves solve for their own columns on their own streams)
+  auto solve = [&](hipStream_t sx, size_t col0, size_t cnt) {
+    const NpCols v = np_cols(g, col0);
+    const size_t cols = col0 + cnt == B ? g->ld - col0 : round_up(cnt, TR_BN);      // the last range also rewrites the padding columns of the batch buffers
+    hipLaunchKernelGGL(k_np_solve, dim3(grid_for(g->nkc * 16 * cols)), dim3(256), 0, sx, g->dT, g->n, g->nkc * 16, b->q, b->two64, d_u + col0 * g->n, cnt, g->ld, v.Sol, v.C0p, cols);
+  };
+  if (!half0) solve(st, 0, B);
+  if (g->timing) hipEventRecord(g->ev[1], st);
+  // :160  sol + sample_d_precomputed_gso(basis, gso, centre, s)
+  psf_status rc;
   if (half0) {
-    HIP_TRY(hipEventRecord(g->evFork, st));                                    // sol and the centres of the whole batch are on `st`
+    HIP_TRY(hipEventRecord(g->evFork, st));                                    // what the caller enqueued before the call (u) is complete
     const size_t cnt[2] = {half0, B - half0}, off[2] = {0, half0};
     rc = PSF_OK;
     for (int i = 0; i < 2 && rc == PSF_OK; ++i) {
       HIP_TRY(hipStreamWaitEvent(g->sh[i], g->evFork, 0));
+      solve(g->sh[i], off[i], cnt[i]);
       rc = launch_nearest_plane(g, g->sh[i], seed, TAG_GPV, first_index + off[i], cnt[i], d_e + off[i] * g->dim, 0, off[i], false);
       HIP_TRY(hipEventRecord(g->evHalf[i], g->sh[i]));
     }
@@ -810,7 +816,7 @@ psf_status psfgpv_get_nearest_plane_form(psfgpv_handle* g, int* form, int* preim
   HIP_TRY(hipStreamSynchronize(g->last_stream));
   unsigned long long r = 0;
   HIP_TRY(hipMemcpy(&r, g->dFlags + 8, sizeof(r), hipMemcpyDeviceToHost));
-  if (form) *form = g->last_form;
+  if (form) *form = (g->last_form == 0 && g->last_parts == 2) ? 2 : g->last_form;
   if (preimages_per_wave) *preimages_per_wave = g->last_G;
   if (blocks) *blocks = g->nblk;
   if (reruns) *reruns = (uint64_t)r;
