@@ -1547,6 +1547,13 @@ __global__ __launch_bounds__(256, 2) void k_np_combine8_fused(const int8_t* __re
       }
 }
 
+// holds its stream for `ticks` of the 100 MHz wall clock (one wave): the second half of a two-halves call starts half a block time behind the first, so that the
+// update tiles at the end of one half's launches fall into the middle of the other half's sampling instead of colliding with its own phase twin
+__global__ void k_np_delay(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 // e[b][piv[r]] += sol[r][b]  (gpv.rs:160: sol + sample; e = -(c0 - sum z b) with c0 = -sol)
 __global__ void k_np_add_sol(const uint64_t* __restrict__ Sol, const uint32_t* __restrict__ piv, size_t n, size_t B, size_t ld, int64_t* __restrict__ E, size_t lde) {
   const size_t total = n * B;

@@ -48,7 +48,8 @@ struct psfgpv_handle {
   unsigned walk_spins = 1u << 22;      // NpWalkSync::spin_limit
   int last_form = 0, last_G = 0;      // what the last call launched for the walk: 1 = k_np_walk<G> (one launch), 0 = k_np_step<G> per block, 3 = k_np_walk2<G>
   int last_parts = 1;                 // column ranges the last call walked side by side (np_split)
-  int np_split = -1;                  // -1: by shape (two halves when the batch does not fit the one-launch walk and is large), 0 / 1: never / whenever the shape allows (tests)
+  int split_delay_us = 0;             // the second half starts this much behind the first
+  int np_split = 0;                   // experiments build: 0 never, 1 whenever the shape allows, 2 for large batches (>= 3072) only
   hipStream_t sh[2] = {nullptr, nullptr};                  // the two halves of a large batch walk side by side on these (equal priority, non-blocking)
   hipEvent_t evFork = nullptr, evHalf[2] = {nullptr, nullptr};
   int np_g = 0;                       // PSF_NP_G: preimages per wave of the sampler (0 = by batch size)
@@ -481,7 +482,8 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   for (auto& sx : g->sh) HIP_TRY(hipStreamCreateWithFlags(&sx, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
   for (auto& e : g->evHalf) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  if (const char* e = psf_exp_env("PSF_NP_SPLIT")) g->np_split = std::atoi(e);
+  if (const char* e = psf_exp_env("PSF_NP_SPLIT")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) g->np_split = v; }
+  if (const char* e = psf_exp_env("PSF_NP_SPLIT_DELAY")) { const int v = std::atoi(e); if (v >= 0 && v <= 1000) g->split_delay_us = v; }
   return PSF_OK;
 }
 
@@ -587,19 +589,22 @@ static psf_status gpv_samp_p_enqueue(psfgpv_handle* g, uint64_t seed, uint64_t f
   HIP_TRY(hipMemsetAsync(b->dFail, 0, 2 * sizeof(int), st));
   HIP_TRY(hipMemsetAsync(g->dFlags, 0, 8 * sizeof(int), st));
   if (g->timing) hipEventRecord(g->ev[0], st);
-  // Two halves side by side.  A batch that does not fit the one-launch walk runs one launch per 64-row block, and in every such launch the FP64-MFMA update tiles
-  // wait for the sampler workgroups to leave their slots (both slots of every CU: 59 us of vector work, then 12 us of matrix work on an otherwise idle chip at C4,
-  // profiles/r05_notes.md).  Cut into two column ranges on two streams, the launches of the halves drift apart and the update tiles of one half run beside the
-  // samplers of the other: C4 4.44 -> 4.05 ms (tools/c4_split_probe.py, profiles/r06_notes.md).  Preimages are independent (row b draws from the streams of global
-  // index first_index + b), so the rows are the rows of the undivided call bit for bit.  Only where neither the batch nor its halves fit the one-launch walk
-  // (two walks at once would take turns, WalkTurn) and the batch is large enough for the halves to fill the chip.
+  // Two halves side by side (EXPERIMENTS build only: measured and not kept).  A batch that does not fit the one-launch walk runs one launch per 64-row block, and in
+  // every such launch the FP64-MFMA update tiles wait for the sampler workgroups to leave their slots (59 us of vector work, then 12 us of matrix work at C4).  Cut into
+  // two column ranges on two streams the halves could overlap those phases -- they do not: inside one call the halves run in lockstep and an FP64 MFMA holds its SIMD
+  // against the other half's samplers; C4 4.416 -> 4.396 ms per call (3 x 60 steps each, tools/c4_split_ab.sh; a phase offset of 10 ... 100 us between the halves
+  // changes nothing, tools/c4_delay_sweep.sh).  Two INDEPENDENT handles on two streams do reach 4.05 ms per 4096 preimages (tools/c4_split_probe.py): what
+  // overlaps there is one call's solve / projection / recombination (0.4 ms) with the other call's walk, across calls -- not available inside one call, whose
+  // result the caller's stream waits for.  profiles/r06_notes.md, "C4".  Rows are those of the undivided call bit for bit (tests/test_gpu_np_forms.py).
   size_t half0 = 0;
-  if (!g->two_pass && g->np_split != 0 && g->sh[0] && B >= 256) {
+#ifdef PSF_EXPERIMENTS
+  if (!g->two_pass && g->np_split > 0 && g->sh[0] && B >= 256) {
     const size_t h0 = round_up((B + 1) / 2, TR_BN);
     const bool shape_ok = h0 < B && !np_walk_fits(g, B, nullptr, nullptr, nullptr, nullptr) && !np_walk_fits(g, h0, nullptr, nullptr, nullptr, nullptr) &&
                           !np_walk_fits(g, B - h0, nullptr, nullptr, nullptr, nullptr);
     if (shape_ok && (g->np_split == 1 || B >= 3072)) half0 = h0;
   }
+#endif
   // :153-158  sol = A.solve(u), centre = -sol  (the halves solve for their own columns on their own streams)
   auto solve = [&](hipStream_t sx, size_t col0, size_t cnt) {
     const NpCols v = np_cols(g, col0);
@@ -617,6 +622,7 @@ static psf_status gpv_samp_p_enqueue(psfgpv_handle* g, uint64_t seed, uint64_t f
     for (int i = 0; i < 2 && rc == PSF_OK; ++i) {
       HIP_TRY(hipStreamWaitEvent(g->sh[i], g->evFork, 0));
       solve(g->sh[i], off[i], cnt[i]);
+      if (i == 1 && g->split_delay_us > 0) hipLaunchKernelGGL(k_np_delay, dim3(1), dim3(64), 0, g->sh[i], (unsigned long long)g->split_delay_us * 100ull);
       rc = launch_nearest_plane(g, g->sh[i], seed, TAG_GPV, first_index + off[i], cnt[i], d_e + off[i] * g->dim, 0, off[i], false);
       HIP_TRY(hipEventRecord(g->evHalf[i], g->sh[i]));
     }
@@ -830,9 +836,10 @@ psf_status psfgpv_debug_set_walk(psfgpv_handle* g, int form, unsigned spins) {
   if (spins) g->walk_spins = spins;
   return PSF_OK;
 }
-// tests: the two-halves form of large launch-per-block batches: -1 = by shape and size, 0 = never, 1 = whenever the shape allows (from 256 preimages on)
+// tests (experiments build): the two-halves form of launch-per-block batches: 0 = never, 1 = whenever the shape allows (from 256 preimages on), 2 = from 3072 preimages on
 psf_status psfgpv_debug_set_split(psfgpv_handle* g, int split) {
-  if (!g || split < -1 || split > 1) return PSF_ERR_PARAM;
+  if (!g || split < 0 || split > 2) return PSF_ERR_PARAM;
+  if (!psf_experiments_build) return split == 0 ? PSF_OK : PSF_ERR_UNSUPPORTED;
   g->np_split = split;
   return PSF_OK;
 }
