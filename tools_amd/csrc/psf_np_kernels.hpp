@@ -208,6 +208,71 @@ __global__ void k_np_solve(const uint64_t* __restrict__ Tt, size_t n, size_t nk1
   }
 }
 
+// The same for q < 2^24 (C2 / C4: q = 3329) as a register-tiled integer product: a 64 (pivot rows) x 64 (preimages) tile per workgroup, 4 x 4 outputs per thread, K in
+// chunks of 32 through LDS.  k_np_solve above walks n terms per OUTPUT with two dependent loads per term: 227 us for C4's 256 x 256 operator and 4096 targets
+// (2.7 x 10^8 multiply-adds: the whole chip for a quarter of a millisecond); this form takes the loads off the multiply-add chain.  ACC32: n (q - 1)^2 < 2^32 -- the
+// sum of a row fits 32 bits and a term is ONE full-rate v_mad_u32_u24; otherwise 64-bit sums (products below 2^48, n <= 65536 terms).  Same residues.
+template <bool ACC32>
+__global__ __launch_bounds__(256) void k_np_solve_tiled(const uint64_t* __restrict__ Tt, size_t n, size_t nk16, uint64_t q, const uint64_t* __restrict__ U, size_t B, size_t ld,
+                                                        uint64_t* __restrict__ Sol, double* __restrict__ C0p, size_t cols) {
+  __shared__ uint32_t sT[32][64 + 1];
+  __shared__ uint32_t sU[32][64 + 1];
+  const size_t b0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 64;
+  const int tid = threadIdx.x, tb = tid & 15, tr = tid >> 4;
+  const size_t nkc = nk16 / 16;
+  typedef typename std::conditional<ACC32, uint32_t, uint64_t>::type acc_t;
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+  const uint32_t q32 = (uint32_t)q;
+  for (size_t t0 = 0; t0 < n; t0 += 32) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = e * 256 + tid;
+      {  // operator: Tt[t][r], consecutive r
+        const int tt = idx >> 6, rr = idx & 63;
+        const size_t t = t0 + tt, r = r0 + rr;
+        sT[tt][rr] = (t < n && r < n) ? (uint32_t)Tt[t * n + r] : 0u;
+      }
+      {  // targets: U[b][t], consecutive t
+        const int bb = idx >> 5, tt = idx & 31;
+        const size_t t = t0 + tt, b = b0 + bb;
+        uint64_t u = (t < n && b < B) ? U[b * n + t] : 0;
+        if (u >= q) u %= q;
+        sU[tt][bb] = (uint32_t)u;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int tt = 0; tt < 32; ++tt) {
+      uint32_t a[4], u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = sT[tt][tr + 16 * i]; u[i] = sU[tt][tb + 16 * i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ACC32) acc[i][j] = (acc_t)__umul24(a[i], u[j]) + acc[i][j];
+          else acc[i][j] += (acc_t)((uint64_t)a[i] * u[j]);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t r = r0 + tr + 16 * i, b = b0 + tb + 16 * j;
+      if (r >= nk16 || b >= cols) continue;
+      const uint64_t v = ACC32 ? (uint64_t)((uint32_t)acc[i][j] % q32) : (uint64_t)acc[i][j] % q;
+      if (r < n && b < B) Sol[r * ld + b] = v;
+      const size_t chunk = (b / TR_BN) * nkc + r / 16;
+      C0p[chunk * TR_CHUNK + tr_chunk_pos((int)(b % TR_BN), (int)(r % 16))] = -(double)((r < n && b < B) ? v : 0ull);
+    }
+}
+
 // Initial projection T = A B on the FP64 matrix cores: 128 x 128 tile per workgroup, wave tile 64 x 64, K chunks of 16 staged by
 // LDS-DMA exactly as in k_trmm_f64 (both operands are fragment-ordered chunk streams).  The per-block updates of the walk are
 // np_update_tile below.

@@ -609,7 +609,13 @@ static psf_status gpv_samp_p_enqueue(psfgpv_handle* g, uint64_t seed, uint64_t f
   auto solve = [&](hipStream_t sx, size_t col0, size_t cnt) {
     const NpCols v = np_cols(g, col0);
     const size_t cols = col0 + cnt == B ? g->ld - col0 : round_up(cnt, TR_BN);      // the last range also rewrites the padding columns of the batch buffers
-    hipLaunchKernelGGL(k_np_solve, dim3(grid_for(g->nkc * 16 * cols)), dim3(256), 0, sx, g->dT, g->n, g->nkc * 16, b->q, b->two64, d_u + col0 * g->n, cnt, g->ld, v.Sol, v.C0p, cols);
+    const size_t nk16 = g->nkc * 16;
+    const dim3 tgrid((unsigned)((cols + 63) / 64), (unsigned)((nk16 + 63) / 64));
+    const bool tiled = b->q < (1ull << 24) && g->n <= 65536 && !psf_exp_env("PSF_NP_SOLVE_PLAIN");
+    const bool acc32 = tiled && (double)g->n * (double)(b->q - 1) * (double)(b->q - 1) < 4294967296.0;
+    if (acc32) hipLaunchKernelGGL((k_np_solve_tiled<true>), tgrid, dim3(256), 0, sx, g->dT, g->n, nk16, b->q, d_u + col0 * g->n, cnt, g->ld, v.Sol, v.C0p, cols);
+    else if (tiled) hipLaunchKernelGGL((k_np_solve_tiled<false>), tgrid, dim3(256), 0, sx, g->dT, g->n, nk16, b->q, d_u + col0 * g->n, cnt, g->ld, v.Sol, v.C0p, cols);
+    else hipLaunchKernelGGL(k_np_solve, dim3(grid_for(nk16 * cols)), dim3(256), 0, sx, g->dT, g->n, nk16, b->q, b->two64, d_u + col0 * g->n, cnt, g->ld, v.Sol, v.C0p, cols);
   };
   if (!half0) solve(st, 0, B);
   if (g->timing) hipEventRecord(g->ev[1], st);
