@@ -147,16 +147,20 @@ def test_the_three_cholesky_forms_agree(monkeypatch, exp_lib, oracle, n, q):
     r, s = 4.0, 120.0
     gp = T.GadgetParameters.init_default(n, q)
     got = {}
-    for form in ("stream", "gemm", "right"):
-        monkeypatch.setenv("PSF_CHOL", form)
+    for form in ("stream", "gemm", "right", "hybrid"):                 # "hybrid" = no switch: the default below 16 GB (Sigma_2 dense at once, factorisation on the chunk stream)
+        if form == "hybrid":
+            monkeypatch.delenv("PSF_CHOL", raising=False)
+        else:
+            monkeypatch.setenv("PSF_CHOL", form)
         psf = T.PSFPerturbation(gp, r, s)
         A, (R, Lp, _) = psf.trap_gen(6)
         got[form] = (A, R, Lp)
         psf.close()
     A, R, L0 = got["stream"]
-    for form in ("gemm", "right"):
+    for form in ("gemm", "right", "hybrid"):
         assert (got[form][0] == A).all() and (got[form][1] == R).all()
         np.testing.assert_allclose(got[form][2], L0, rtol=0, atol=1e-10 * np.abs(L0).max())
+    assert (got["hybrid"][2] == L0).all()                             # the hybrid copies its panels out of the same integers: the stream form's factor bit for bit
     orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s)
     rc, Lref = orc.compute_sqrt_sigma_2(R, s)
     assert rc == 0

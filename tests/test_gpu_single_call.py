@@ -226,3 +226,34 @@ def test_compact_key_copies_of_small_calls_give_the_same_rows(T, oracle, ternary
             torch.cuda.synchronize()
             assert (got == want).all(), (B, rep, ternary)
     psf.close()
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_fused_tail_of_one_or_two_preimages_matches_the_oracle_in_every_stage(pair, oracle, B):
+    """k_trmm_stream_fused (round 6): with one or two preimages every wave of the streaming product rounds its own 32 rows of x (four lanes per sample) and adds its
+    share A[:, rows] p[rows] of the syndrome from the transposed compact copy of A; the separate rounding and syndrome launches disappear.  The compact copies are
+    built beside the first small calls after a key change, so the first call runs the separate kernels and a later one the fused launch: both must give the
+    oracle's d, x, p, v, z, e, and the timing slots say which form ran."""
+    import time
+    psf, orc, n, q = pair
+    u = oracle.uniform_targets(700 + B, B, n, q)
+    trace = [orc.samp_p_trace(44, 9 + b, u[b]) for b in range(B)]
+    fused_seen = False
+    for attempt in range(6):
+        psf.enable_timing(True)
+        st = psf.samp_p_stages(u, seed=44, first_index=9)
+        names = set(dict(psf.get_timing()))
+        psf.enable_timing(False)
+        fused = "k_perturb_round" not in names and "k_trmm_f64" in names
+        fused_seen = fused_seen or fused
+        assert (st["e"] == orc.samp_p(44, u, first_index=9)).all(), (attempt, fused)
+        for b in range(B):
+            assert (st["x"][b].view(np.uint64) == trace[b]["x"].view(np.uint64)).all(), (attempt, fused)
+            for key in ("p", "v", "z"):
+                assert (st[key][b] == trace[b][key]).all(), (key, attempt, fused)
+        assert psf.check_domain(st["e"]).all() and (psf.f_a(st["e"]) == u).all()
+        if fused:
+            break
+        time.sleep(0.05)                              # the packers of the compact copies finish in the background
+    if q <= 2**32 and n % 8 == 0:
+        assert fused_seen, "the fused launch never ran"

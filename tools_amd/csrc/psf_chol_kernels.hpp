@@ -230,6 +230,16 @@ __global__ void k_chol_panel_reduce(double* __restrict__ Pbuf, const double* __r
 
 // the finished panel J (dense, leading dimension 256, rows = matrix rows 256 J ..) -> chunks (bi, 16 J + kc) of the stream, kc < 8 `ncb`; above the
 // diagonal and beyond m: zero
+// panel J of a dense, lower-stored Sigma_2 (leading dimension lds) into the panel buffer of the stream factorisation: P[i][j] = Sigma_2[off + i][off + j] for the rows
+// off ... m-1 and the panel's `cols` columns; the part of the diagonal blocks above the diagonal is taken from its mirror image
+__global__ void k_chol_copy_panel(const double* __restrict__ S, size_t lds, size_t m, size_t off, size_t cols, double* __restrict__ P, size_t pw) {
+  const size_t rows = m - off, total = rows * cols;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g / cols, j = g % cols;
+    P[i * pw + j] = j <= i ? S[(off + i) * lds + off + j] : S[(off + j) * lds + off + i];
+  }
+}
+
 __global__ void k_chol_pack_panel(const double* __restrict__ Pbuf, int J, int ncb, int nbi, size_t m, double* __restrict__ Lt) {
   const size_t per_rb = (size_t)ncb * 8 * TR_CHUNK;
   const size_t total = (size_t)(nbi - 2 * J) * per_rb;

@@ -42,10 +42,32 @@ struct StreamGeom {
   int bc;           // CD == 2: preimages the dense normals stream stores per k-step (1, 2, 4, 8 or 16)
 };
 
+// ---- the fused tail of ONE or TWO preimages (round 6) -----------------------------------------------------------------------------------------------
+// A call of one preimage spent 61 us behind the product in two launches that only exist because x is complete: p <- D_{Z,r,x} (25 us for 30 801 draws) and
+// v = u - A p (36 us for one pass over A).  Neither needs ALL of x at once: a wave of k_trmm_stream owns 32 rows of x from k = 0 to the diagonal, so it rounds its
+// own rows as soon as its chain ends and adds its share  A[:, rows] p[rows]  of the syndrome -- the short tasks do so long before the launch ends, only the
+// epilogue of the tasks that finish last is exposed (~8 us), and A is read beside the factor (63 MB next to 3.8 GB).
+//   rounding: 4 lanes per sample, lane s of a quad evaluates the attempt groups s, s + 4, ... of the sample's own Philox stream (sz_group4 / sz_group4_narrow: the
+//             expressions of k_perturb_round_lean), the lowest accepting group of a round wins -- the first accepted attempt of the stream, i.e. the value every
+//             other sampler of the library returns.  16 samples per pass.
+//   syndrome: lane l owns the rows 8 l ... 8 l + 7 of A (n <= 512 per 64 lanes, more in further rounds), read from the TRANSPOSED compact copy A32T[coordinate][row]
+//             (32 bytes per lane and coordinate), products with p in 64 bits (|a p| < 2^31 2^23), one residue per (row, preimage) into part[task][row][b];
+//             k_zq_combine_wave sums the tasks and subtracts from u, as it does for the K splits of the other forms.  Exact integers: any order, same v.
+struct StreamFuse {
+  uint64_t seed, first_index;
+  size_t m;                       // coordinates (rows of x that exist)
+  SampleZParams sp;               // D_{Z, r, .}
+  int32_t* P; size_t ldp;         // p as [coordinate][preimage]
+  const uint32_t* A32T; size_t n; // A transposed, [coordinate][row], n rows
+  uint64_t q;
+  uint64_t* part;                 // [task][row][bc]
+  int* fail;
+};
+
 // task (descending length) -> (tile group, column group); column groups of one tile group are neighbours in the order
-template <int RT, int NB, int PD, int HALF = 4, int CD = 0>
-__global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
-                                                        StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
+template <int RT, int NB, int PD, int HALF, int CD, bool FUSE>
+__device__ __forceinline__ void trmm_stream_body(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
+                                                 const StreamGeom& g, size_t nkb, size_t ldx, size_t row_hi, const StreamFuse* fz) {
   static_assert((PD - 1) * (RT + NB) <= 63, "vmcnt is a 6-bit counter");
   static_assert(CD != 2 || NB == 1, "the dense normals stream holds one fragment");
   static_assert(8 % RT == 0 && 8 % NB == 0, "a tile group stays inside one row block, a column group inside one column block");
@@ -143,6 +165,120 @@ __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(cons
         const size_t row = (size_t)(t0 + i) * 16 + (lane >> 4) + 4 * r;
         if (row < row_hi) X[row * ldx + (size_t)(cf0 + j) * 16 + (lane & 15)] = acc[i][j][r];
       }
+  if constexpr (FUSE) {
+    static_assert(CD == 2 && NB == 1, "the fused tail serves the dense stream of one or two preimages");
+    __shared__ double s_x[2 * HALF][RT * 16 * 2];
+    __shared__ int32_t s_p[2 * HALF][RT * 16 * 2];
+    const StreamFuse& F = *fz;
+    double* sx = s_x[wave];
+    int32_t* spv = s_p[wave];
+    const int nrow = RT * 16, npos = nrow * bc;                       // samples of this wave: (local row rr, preimage b) at rr * bc + b
+    if ((lane & 15) < bc) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sx[(i * 16 + (lane >> 4) + 4 * r) * bc + (lane & 15)] = acc[i][0][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int f = 0;
+    const int sub = lane & 3, quad0 = lane & ~3;
+    const float inv_s_f = (float)F.sp.inv_s;
+    for (int p0 = 0; p0 < npos; p0 += 16) {
+      const int pos = p0 + (lane >> 2);
+      const int rr = pos / bc, b = pos - rr * bc;
+      const uint32_t coord = (uint32_t)(t0 * 16 + rr);
+      const bool live = pos < npos && (size_t)coord < F.m;
+      const double c = live ? sx[pos] : 0.0;
+      const uint64_t index = F.first_index + (uint64_t)b;
+      const uint32_t idx_lo = (uint32_t)index, tw = tag_word(TAG_PERTURB, index);
+      const SzRange rg = sz_range(c, F.sp);
+      const float c_rel = (float)((double)rg.lo - c);
+      const bool generic = !(fabs(c) < 0x1.0p40);
+      bool found = !live;
+      long long x = 0;
+      for (uint32_t t = (uint32_t)sub; ; t += 4) {
+        if (!__builtin_amdgcn_ballot_w64(!found)) break;
+        bool acc1 = false;
+        long long xl = 0;
+        if (!found) {
+          if (t >= kMaxAttempts / 4) { acc1 = true; f = 1; xl = (long long)floor(c + 0.5); }      // (every lane of the quad gets here in the same round: the lowest takes it)
+          else acc1 = generic ? sz_group4(F.seed, coord, idx_lo, tw, t, rg, c, F.sp.inv_s, &xl)
+                              : sz_group4_narrow(F.seed, coord, idx_lo, tw, t, rg, c, F.sp.inv_s, c_rel, inv_s_f, &xl);
+        }
+        const uint32_t qm = (uint32_t)(__builtin_amdgcn_ballot_w64(acc1) >> quad0) & 0xfu;
+        const int src = qm ? quad0 + __builtin_ctz(qm) : lane;
+        const long long xs = __shfl(xl, src);
+        if (!found && qm) { x = xs; found = true; }
+      }
+      if (live && sub == 0) {
+        if (x > kDigitRangeP || x < -kDigitRangeP) f = 1;             // the syndrome product needs |p| < 2^23
+        F.P[(size_t)coord * F.ldp + (size_t)b] = (int32_t)x;
+      }
+      if (pos < npos && sub == 0) spv[pos] = live ? (int32_t)x : 0;
+    }
+    if (f) atomicOr(F.fail, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // this task's share of A p: rows 8 lane ... of A (rounds of 512 rows), coordinates t0 * 16 ... + nrow - 1
+    const size_t c0 = (size_t)t0 * 16;
+    const int ncoord = (int)(c0 + nrow <= F.m ? (size_t)nrow : (F.m > c0 ? F.m - c0 : 0));
+    uint64_t* mypart = F.part + (size_t)tg * F.n * (size_t)bc;
+    const bool pow2 = (F.q & (F.q - 1)) == 0;
+    for (size_t j0 = 0; j0 < F.n; j0 += 512) {
+      const size_t j = j0 + (size_t)lane * 8;
+      long long sum[2][8];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum[b][u] = 0;
+      if (j < F.n) {                                                  // (n is a multiple of 8 here: the host checks)
+        for (int ci = 0; ci < ncoord; ++ci) {
+          const uint4* src = reinterpret_cast<const uint4*>(F.A32T + (c0 + (size_t)ci) * F.n + j);
+          const uint4 a0 = src[0], a1 = src[1];
+          const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const long long pa = (long long)spv[ci * bc];
+          const long long pb = bc > 1 ? (long long)spv[ci * bc + 1] : 0ll;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            sum[0][u] += (long long)av[u] * pa;
+            if (bc > 1) sum[1][u] += (long long)av[u] * pb;
+          }
+        }
+        for (int b = 0; b < bc && b < 2; ++b)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            long long r;
+            if (pow2) r = (long long)((uint64_t)sum[b][u] & (F.q - 1));
+            else { r = sum[b][u] % (long long)F.q; if (r < 0) r += (long long)F.q; }
+            mypart[(j + (size_t)u) * (size_t)bc + (size_t)b] = (uint64_t)r;
+          }
+      }
+    }
+  }
+}
+
+template <int RT, int NB, int PD, int HALF = 4, int CD = 0>
+__global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
+                                                        StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
+  trmm_stream_body<RT, NB, PD, HALF, CD, false>(Lt, Dt, X, g, nkb, ldx, row_hi, nullptr);
+}
+// the same launch with the fused tail (one or two preimages, dense normals stream)
+template <int RT, int PD, int HALF>
+__global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream_fused(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
+                                                              StreamGeom g, size_t nkb, size_t ldx, size_t row_hi, StreamFuse fz) {
+  trmm_stream_body<RT, 1, PD, HALF, 2, true>(Lt, Dt, X, g, nkb, ldx, row_hi, &fz);
+}
+// A32T[coordinate][row] = A[row][coordinate] (the compact copy the fused tail reads): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void k_transpose_A32(const uint64_t* __restrict__ A, size_t n, size_t m, uint32_t* __restrict__ A32T) {
+  __shared__ uint32_t tile[32][33];
+  const size_t i0 = (size_t)blockIdx.y * 32, j0 = (size_t)blockIdx.x * 32;      // rows of A, coordinates
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = (i0 + r < n && j0 + tx < m) ? (uint32_t)A[(i0 + r) * m + j0 + tx] : 0u;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) if (j0 + r < m && i0 + tx < n) A32T[(j0 + r) * n + i0 + tx] = tile[tx][r];
 }
 
 // ---- gadget nearest plane for a SINGLE CALL (mp_perturbation.rs:173-191; gadget_classical.rs:169-229 for the digits) ------------------------------

@@ -86,6 +86,8 @@ struct psfp_handle {
   // compact copies of the key for calls with a handful of preimages, where reading A and R once IS the time of their stages (psf_stream_kernels.hpp):
   // R as two bits per entry (k_recombine_small2; only a {-1, 0, 1} trapdoor has one), A as 32-bit words (k_syndrome_small32; q <= 2^32)
   uint32_t* dR2 = nullptr; uint32_t* dA32 = nullptr; int* dR2bad = nullptr; int* hR2bad = nullptr; hipEvent_t evSmall = nullptr;
+  uint32_t* dA32T = nullptr;   // A transposed, [coordinate][row], 32-bit: the fused tail of k_trmm_stream_fused (q <= 2^32, n a multiple of 8)
+  uint64_t* dPartF = nullptr; size_t partF_cap = 0;      // its partial residues, [task][row][preimage]
   int small_state = 0;         // 0: stale (the key changed); 1: being built (evSmall); 2: usable; 3: usable, R is not ternary (A32 only)
   double g_const = 0, h_const = 0;
   // gadget tables
@@ -184,10 +186,12 @@ static void ensure_small_copies(psfp_handle* h, hipStream_t st) {
     if (hipMalloc(&h->dR2, h->mb * ng * sizeof(uint32_t)) != hipSuccess || hipMalloc(&h->dR2bad, sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->hR2bad, sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&h->evSmall, hipEventDisableTiming) != hipSuccess) { h->small_state = 4; return; }
     if (h->q <= (1ull << 32) && hipMalloc(&h->dA32, h->n * h->m * sizeof(uint32_t)) != hipSuccess) { h->small_state = 4; return; }
+    if (h->q <= (1ull << 32) && h->n % 8 == 0 && hipMalloc(&h->dA32T, h->n * h->m * sizeof(uint32_t)) != hipSuccess) { h->dA32T = nullptr; (void)hipGetLastError(); }
   }
   hipMemsetAsync(h->dR2bad, 0, sizeof(int), st);
   hipLaunchKernelGGL(k_pack_R2, dim3(grid_for(h->mb * ng, 256, 256 * 32)), dim3(256), 0, st, h->dR, h->ldr, h->mb, h->dR2, h->dR2bad);
   if (h->dA32) hipLaunchKernelGGL(k_narrow_A32, dim3(grid_for(h->n * h->m, 256, 256 * 32)), dim3(256), 0, st, h->dA, h->n * h->m, h->dA32);
+  if (h->dA32T) hipLaunchKernelGGL(k_transpose_A32, dim3((unsigned)((h->m + 31) / 32), (unsigned)((h->n + 31) / 32)), dim3(256), 0, st, h->dA, h->n, h->m, h->dA32T);
   hipMemcpyAsync(h->hR2bad, h->dR2bad, sizeof(int), hipMemcpyDeviceToHost, st);
   hipEventRecord(h->evSmall, st);
   h->small_state = 1;
@@ -598,7 +602,7 @@ void psfp_destroy(psfp_handle* h) {
   free_batch(h);
   clear_slots(h);
   if (h->aux) hipStreamDestroy(h->aux);
-  hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dR8); hipFree(h->dR2); hipFree(h->dA32); hipFree(h->dR2bad);
+  hipFree(h->dA); hipFree(h->dR); hipFree(h->dLt); hipFree(h->dR8); hipFree(h->dR2); hipFree(h->dA32); hipFree(h->dR2bad); hipFree(h->dA32T); hipFree(h->dPartF);
   if (h->hR2bad) hipHostFree(h->hR2bad);
   if (h->evSmall) hipEventDestroy(h->evSmall);
   if (h->evR8) hipEventDestroy(h->evR8);
@@ -619,7 +623,9 @@ size_t psfp_m(const psfp_handle* h) { return h ? h->m : 0; }
 // beta = alpha - kappa) as B B^t with B = [[L_1 / sqrt c, -kappa R / sqrt beta], [0, sqrt beta I]] sqrt c, where L_1 is the Cholesky factor of
 // c (alpha I - kappa (alpha / beta) R R^t): only that m_bar x m_bar block is assembled, factored and stored.
 // Cholesky of Sigma_2 directly on the key's chunk stream (psf_chol_kernels.hpp, "Cholesky directly on the key's chunk stream"): no dense m x m matrix.
-static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double s2, double b2p1, const double* d_sig) {
+// dS_dense: nullptr, or Sigma_2 already assembled as a dense m x m matrix (lower triangle; the hybrid of build_sqrt_sigma2): the panels are then copied out of it
+// instead of being assembled one by one -- R R^t on the int8 matrix cores takes 5.5 ms for the whole of C3's Sigma_2 at once and 76 ms in 121 panel-sized pieces.
+static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double s2, double b2p1, const double* d_sig, const double* dS_dense = nullptr) {
   const size_t m = h->mL;
   const int nbi = (int)h->nbiL;
   const int nP = (nbi + 1) / 2;                                       // panels of two column blocks (256 columns)
@@ -673,8 +679,12 @@ static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double 
     const size_t off = (size_t)J * PW;
     const size_t cols = m - off < PW ? m - off : PW;
     const dim3 sg((unsigned)((cols + 63) / 64), (unsigned)((m - off + 63) / 64));
-    hipLaunchKernelGGL(k_sigma2_rrt, sg, dim3(256), 3 * 2 * 4096, ss, h->dR, h->ldr, h->mb, m, nf_r2, s2, b2p1, d_sig, dPn[J & 1], PW, off, off);
-    hipLaunchKernelGGL(k_sigma2, sg, dim3(256), 0, ss, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sig, dPn[J & 1], PW, off, off, 1);
+    if (dS_dense) {
+      hipLaunchKernelGGL(k_chol_copy_panel, dim3(grid_for((m - off) * cols, 256, 4096)), dim3(256), 0, ss, dS_dense, m, m, off, cols, dPn[J & 1], PW);
+    } else {
+      hipLaunchKernelGGL(k_sigma2_rrt, sg, dim3(256), 3 * 2 * 4096, ss, h->dR, h->ldr, h->mb, m, nf_r2, s2, b2p1, d_sig, dPn[J & 1], PW, off, off);
+      hipLaunchKernelGGL(k_sigma2, sg, dim3(256), 0, ss, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sig, dPn[J & 1], PW, off, off, 1);
+    }
     hipEventRecord(evSig[J & 1], ss);
   };
   sigma_panel(0);
@@ -760,6 +770,12 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
   hipLaunchKernelGGL(k_sigma2_rrt, dim3(tiles, tiles), dim3(256), 3 * 2 * 4096, 0, h->dR, h->ldr, h->mb, m, nf_r2, s2, b2p1, d_sigma_packed, dS, m, (size_t)0, (size_t)0);
   hipLaunchKernelGGL(k_sigma2, dim3(tiles, tiles), dim3(256), 0, 0, h->dR, h->ldr, h->mb, h->w, m, nf_r2, s2, b2p1, d_sigma_packed, dS, m, (size_t)0, (size_t)0, 1);
   HIP_TRY(hipGetLastError());
+  {
+    // The hybrid (round 6, the default below 16 GB): Sigma_2 dense AT ONCE (above), the factorisation on the key's chunk stream (k_chol_update_big: 64 TFLOP/s against
+    // the 44 of the LDS-staged GEMM of the dense left-looking form), panels copied out of the dense matrix.  PSF_CHOL=gemm (experiments build): the dense form.
+    const char* ce2 = psf_exp_env("PSF_CHOL");
+    if (!(ce2 && (!std::strcmp(ce2, "gemm") || !std::strcmp(ce2, "right")))) return build_sqrt_sigma2_stream(h, nf_r2, s2, b2p1, d_sigma_packed, dS);
+  }
   // blocked Cholesky of the lower triangle, panel width 128 (psf_chol_kernels.hpp): left-looking on the FP64 GEMM; PSF_CHOL=right: the right-looking
   // kernels of rounds 1-2 (comparison arm)
   int*& dinfo = dg.dinfo;
@@ -1197,8 +1213,25 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     const NormalsFixed fx = h->structured ? NormalsFixed{h->mb, h->dD8, h->ldr * ld, ld, h->dX, h->h_const} : NormalsFixed{0, nullptr, 0, 0, nullptr, 0.0};
     hipLaunchKernelGGL(k_normals_wave, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail, fx, ncf, nseg);
   }
+  // One or two preimages: the rounding and this call's share of the syndrome ride in the product's launch (k_trmm_stream_fused, psf_stream_kernels.hpp) once the
+  // transposed compact copy of A is there (built beside the first small calls after a key change, as the other compact copies)
+  bool fused_tail = false;
+  int fused_ntask = 0;
+  if (stream && bc && B <= 2 && RT == 2 && NB == 1 && !h->structured && !pipe && h->szR.sh == 16 && !(h->prm.flags & PSFP_FLAG_NO_PERTURB)) {
+    ensure_small_copies(h, st);
+    const char* fe = psf_exp_env("PSF_FUSED_TAIL");
+    if (h->dA32T && (h->small_state == 2 || h->small_state == 3) && !(fe && std::atoi(fe) == 0)) {
+      fused_ntask = ((int)((h->mL + 15) / 16) + 1) / 2;
+      const size_t need = (size_t)fused_ntask * h->n * 2;
+      if (need > h->partF_cap) {
+        hipFree(h->dPartF); h->dPartF = nullptr; h->partF_cap = 0;
+        if (hipMalloc(&h->dPartF, need * sizeof(uint64_t)) == hipSuccess) h->partF_cap = need; else (void)hipGetLastError();
+      }
+      fused_tail = h->dPartF != nullptr;
+    }
+  }
   {  // x = sqrt(Sigma_2) d   (structured: the m_bar x m_bar block L_1 d_1; rows from m_bar on already hold x_bot = h d_2)
-    ScopedTimer t(h, st, "k_trmm_f64");
+    ScopedTimer t(h, st, "k_trmm_f64");      // (with the fused tail the slot covers x, p and the shares of A p; "k_perturb_round" is then absent from the timing)
     // default: k_trmm_f64_big (one workgroup per CU, accumulators in AccVGPRs); PSF_TRMM_VARIANT=1: k_trmm_f64_reg (two 128 x 128 workgroups per CU,
     // operands streamed into registers), 0: k_trmm_f64 (LDS-staged, round 1).  Same bits from all three.
     const char* venv = psf_exp_env("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
@@ -1215,7 +1248,13 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         hipLaunchKernelGGL(kern, dim3((unsigned)((g.ntask + 2 * half - 1) / (2 * half))), dim3(128 * half), 0, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
       };
 #define TS_GO(rt, nb, pd, half) { if (compact) go(k_trmm_stream<rt, nb, pd, half, 1>, rt, half); else go(k_trmm_stream<rt, nb, pd, half, 0>, rt, half); }
-      if (bc && RT == 2 && NB == 1) go(k_trmm_stream<2, 1, 12, 2, 2>, 2, 2);
+      if (fused_tail) {
+        StreamGeom g;
+        g.ntile = (ntile16 + 1) / 2; g.ncg = 1; g.ntask = g.ntile; g.bc = bc;
+        const StreamFuse fz{seed, first_index, m, h->szR, h->dP, ld, h->dA32T, h->n, h->q, h->dPartF, h->dFail};
+        hipLaunchKernelGGL((k_trmm_stream_fused<2, 12, 2>), dim3((unsigned)((g.ntask + 3) / 4)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi, fz);
+      }
+      else if (bc && RT == 2 && NB == 1) go(k_trmm_stream<2, 1, 12, 2, 2>, 2, 2);
       else if (bc && NB == 1) go(k_trmm_stream<1, 1, 8, 4, 2>, 1, 4);
       else if (RT == 2 && NB == 1) TS_GO(2, 1, 12, 2)
       else if (RT == 2 && NB == 2 && B <= 32) TS_GO(2, 2, 8, 2)
@@ -1255,7 +1294,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // The stages behind the product, for the columns [b0, b0 + Bh) of the batch on stream sx.  Column offsets: [coord][b] matrices move by b0 elements,
   // digit planes ([group][b][16]) by 16 b0 bytes, row-major API matrices by b0 rows; the Z_q product takes its window as (col0, ncols).
   auto tail = [&](hipStream_t sx, size_t b0, size_t Bh) {
-    {  // p_i <- D_{Z,r,x_i}
+    if (!fused_tail) {  // p_i <- D_{Z,r,x_i}
       ScopedTimer t(h, sx, "k_perturb_round");
       const char* renv = psf_exp_env("PSF_ROUND");                 // "wave": the round-2 kernel (comparison arm; same bits)
       if (h->szR.sh == 16 && !(renv && !std::strcmp(renv, "wave"))) {
@@ -1282,7 +1321,9 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     u_gate();                                                      // (host path: u reaches the device now)
     {  // mp_perturbation.rs:318 -- v = u - A p
       ScopedTimer t(h, sx, "k_zq_matmul(syndrome)");
-      launch_zq_mfma(h, sx, ZQ_SYNDROME, h->dP, h->dP8, Bh, d_u, h->dV, ld, b0);
+      if (fused_tail)      // the tasks of the product left their shares of A p in dPartF: summed and taken from u, one wave per output
+        hipLaunchKernelGGL(k_zq_combine_wave, dim3((unsigned)((h->n * Bh + 3) / 4)), dim3(256), 0, sx, ZQ_SYNDROME, h->dPartF, fused_ntask, h->n, h->n, (size_t)bc, Bh, h->q, d_u, h->dV, ld, (size_t)0);
+      else launch_zq_mfma(h, sx, ZQ_SYNDROME, h->dP, h->dP8, Bh, d_u, h->dV, ld, b0);
     }
     {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
       ScopedTimer t(h, sx, "k_gadget");
