@@ -1225,6 +1225,8 @@ __global__ void k_zq_combine(int mode, const uint64_t* __restrict__ part, int sp
 
 // the same for a single call (few outputs, up to 64 splits): one WAVE per output, lane z holds split z's residue, a butterfly of modular additions
 // (exact in any order) instead of a thread walking 64 dependent loads -- 18 -> 4 us at one preimage
+// SPLIT_MINOR: part[(row * ld + column) * splits + split] -- the residues of one output side by side (the fused tail of k_trmm_stream_fused leaves ~1000 of them per output)
+template <bool SPLIT_MINOR = false>
 __global__ __launch_bounds__(256) void k_zq_combine_wave(int mode, const uint64_t* __restrict__ part, int splits, size_t n, size_t n_pad, size_t ld, size_t ncols, uint64_t q,
                                                          const uint64_t* __restrict__ U, uint64_t* __restrict__ out, size_t ldo, size_t col0) {
   const size_t g0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1233,7 +1235,7 @@ __global__ __launch_bounds__(256) void k_zq_combine_wave(int mode, const uint64_
   const size_t i = g0 / ncols, cc = col0 + g0 % ncols;
   const size_t g = i * ld + cc;
   uint64_t s = 0;
-  for (int z = lane; z < splits; z += 64) { s += part[(size_t)z * n_pad * ld + g]; if (s >= q) s -= q; }
+  for (int z = lane; z < splits; z += 64) { s += SPLIT_MINOR ? part[g * (size_t)splits + (size_t)z] : part[(size_t)z * n_pad * ld + g]; if (s >= q) s -= q; }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     s += (uint64_t)__shfl_xor((unsigned long long)s, off);

@@ -60,7 +60,7 @@ struct StreamFuse {
   int32_t* P; size_t ldp;         // p as [coordinate][preimage]
   const uint32_t* A32T; size_t n; // A transposed, [coordinate][row], n rows
   uint64_t q;
-  uint64_t* part;                 // [task][row][bc]
+  uint64_t* part;                 // [row][bc][task]
   int* fail;
 };
 
@@ -225,7 +225,7 @@ __device__ __forceinline__ void trmm_stream_body(const double* __restrict__ Lt, 
     // this task's share of A p: rows 8 lane ... of A (rounds of 512 rows), coordinates t0 * 16 ... + nrow - 1
     const size_t c0 = (size_t)t0 * 16;
     const int ncoord = (int)(c0 + nrow <= F.m ? (size_t)nrow : (F.m > c0 ? F.m - c0 : 0));
-    uint64_t* mypart = F.part + (size_t)tg * F.n * (size_t)bc;
+    uint64_t* mypart = F.part + (size_t)tg;                           // part[(row * bc + b) * ntask + task]: the tasks of one output side by side for the combine
     const bool pow2 = (F.q & (F.q - 1)) == 0;
     for (size_t j0 = 0; j0 < F.n; j0 += 512) {
       const size_t j = j0 + (size_t)lane * 8;
@@ -235,16 +235,28 @@ __device__ __forceinline__ void trmm_stream_body(const double* __restrict__ Lt, 
 #pragma unroll
         for (int u = 0; u < 8; ++u) sum[b][u] = 0;
       if (j < F.n) {                                                  // (n is a multiple of 8 here: the host checks)
-        for (int ci = 0; ci < ncoord; ++ci) {
-          const uint4* src = reinterpret_cast<const uint4*>(F.A32T + (c0 + (size_t)ci) * F.n + j);
-          const uint4 a0 = src[0], a1 = src[1];
-          const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-          const long long pa = (long long)spv[ci * bc];
-          const long long pb = bc > 1 ? (long long)spv[ci * bc + 1] : 0ll;
+        // sixteen coordinates' loads in flight at once: under the product's own stream a dependent round trip to memory costs microseconds, so a loop that waited for
+        // one coordinate at a time made this epilogue 110 us long (measured); two batches make it two round trips
+        constexpr int CB = 16;
+        for (int cb = 0; cb < nrow; cb += CB) {
+          uint4 a0[CB], a1[CB];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            sum[0][u] += (long long)av[u] * pa;
-            if (bc > 1) sum[1][u] += (long long)av[u] * pb;
+          for (int u = 0; u < CB; ++u) {
+            const int ci = cb + u < ncoord ? cb + u : (ncoord > 0 ? ncoord - 1 : 0);      // (clamped: a row past the end is multiplied by p = 0 below)
+            const uint4* src = reinterpret_cast<const uint4*>(F.A32T + (c0 + (size_t)ci) * F.n + j);
+            a0[u] = src[0]; a1[u] = src[1];
+          }
+#pragma unroll
+          for (int u = 0; u < CB; ++u) {
+            const bool in = cb + u < ncoord;
+            const long long pa = in ? (long long)spv[(cb + u) * bc] : 0ll;
+            const long long pb = (in && bc > 1) ? (long long)spv[(cb + u) * bc + 1] : 0ll;
+            const uint32_t av[8] = {a0[u].x, a0[u].y, a0[u].z, a0[u].w, a1[u].x, a1[u].y, a1[u].z, a1[u].w};
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) {
+              sum[0][w8] += (long long)av[w8] * pa;
+              if (bc > 1) sum[1][w8] += (long long)av[w8] * pb;
+            }
           }
         }
         for (int b = 0; b < bc && b < 2; ++b)
@@ -253,7 +265,7 @@ __device__ __forceinline__ void trmm_stream_body(const double* __restrict__ Lt, 
             long long r;
             if (pow2) r = (long long)((uint64_t)sum[b][u] & (F.q - 1));
             else { r = sum[b][u] % (long long)F.q; if (r < 0) r += (long long)F.q; }
-            mypart[(j + (size_t)u) * (size_t)bc + (size_t)b] = (uint64_t)r;
+            mypart[((j + (size_t)u) * (size_t)bc + (size_t)b) * (size_t)g.ntask] = (uint64_t)r;
           }
       }
     }

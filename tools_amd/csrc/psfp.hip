@@ -883,7 +883,7 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
       if (ncols == 1) hipLaunchKernelGGL(k_syndrome_small<1>, grid, dim3(512), 0, st, h->dA, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
       else if (ncols == 2) hipLaunchKernelGGL(k_syndrome_small<2>, grid, dim3(512), 0, st, h->dA, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
       else hipLaunchKernelGGL(k_syndrome_small<4>, grid, dim3(512), 0, st, h->dA, h->n, h->m, P, ld, ncols, h->q, rows_per_wg, h->dPart, h->n_pad, col0);
-      hipLaunchKernelGGL(k_zq_combine_wave, dim3((unsigned)((h->n * ncols + 3) / 4)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols, h->q, U, out, ldo, col0);
+      hipLaunchKernelGGL((k_zq_combine_wave<false>), dim3((unsigned)((h->n * ncols + 3) / 4)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols, h->q, U, out, ldo, col0);
       return;
     }
   }
@@ -910,7 +910,7 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
     break;
   switch (h->NA) { ZQM(1) ZQM(2) ZQM(3) ZQM(4) ZQM(5) ZQM(6) ZQM(7) ZQM(8) default: break; }
   if (splits >= 16 && h->n * ncols <= 16384)      // a single call: few outputs, many splits -- one wave per output
-    hipLaunchKernelGGL(k_zq_combine_wave, dim3((unsigned)((h->n * ncols + 3) / 4)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols,
+    hipLaunchKernelGGL((k_zq_combine_wave<false>), dim3((unsigned)((h->n * ncols + 3) / 4)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols,
                        h->q, U, out, ldo, col0);
   else
     hipLaunchKernelGGL(k_zq_combine, dim3(grid_for(h->n * ncols, 256, 256 * 32)), dim3(256), 0, st, mode, h->dPart, splits, h->n, h->n_pad, ld, ncols,
@@ -1322,7 +1322,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     {  // mp_perturbation.rs:318 -- v = u - A p
       ScopedTimer t(h, sx, "k_zq_matmul(syndrome)");
       if (fused_tail)      // the tasks of the product left their shares of A p in dPartF: summed and taken from u, one wave per output
-        hipLaunchKernelGGL(k_zq_combine_wave, dim3((unsigned)((h->n * Bh + 3) / 4)), dim3(256), 0, sx, ZQ_SYNDROME, h->dPartF, fused_ntask, h->n, h->n, (size_t)bc, Bh, h->q, d_u, h->dV, ld, (size_t)0);
+        hipLaunchKernelGGL((k_zq_combine_wave<true>), dim3((unsigned)((h->n * Bh + 3) / 4)), dim3(256), 0, sx, ZQ_SYNDROME, h->dPartF, fused_ntask, h->n, h->n, (size_t)bc, Bh, h->q, d_u, h->dV, ld, (size_t)0);
       else launch_zq_mfma(h, sx, ZQ_SYNDROME, h->dP, h->dP8, Bh, d_u, h->dV, ld, b0);
     }
     {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
