@@ -52,12 +52,190 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ A, size_
 }
 #endif
 
+// ---- diagonal block + its inverse, BLOCKED (round 6) ---------------------------------------------------------------------------------------
+// The step-by-step form below (rounds 3-5) walks 128 dependent columns with three workgroup barriers each, then 128 more for the inverse: 0.19 ms alone and 0.36 ms
+// in line with the stream factorisation, 241 times per C3 key = 86 of trap_gen's 289 ms (profiles/r06_keygen_timeline_c3.txt).  Here the 128 x 128 block is cut into
+// four 32 x 32 leaves: a leaf is factored AND inverted by ONE wave (LDS traffic ordered inside the wave: no workgroup barrier in the 32 + 31 dependent steps), the
+// rows below take  L = A X_leaf^t  (8 threads per row, the row held in registers), the trailing block its rank-32 update in 4 x 4 register tiles -- 3 barriers per
+// leaf instead of 96 -- and the inverse of the whole block follows from the leaf inverses by block substitution, level by level (X_ij = -X_ii sum_t L_it X_tj).
+// The inverse lives in the unused upper triangle of the LDS tile, transposed (X[i][j] at [j][i]), its diagonal in a vector.  Same algorithm, another summation order:
+// the factor agrees with the step form to rounding (the tests compare against the oracle's unblocked recurrence within 1e-10 of the largest entry).
+constexpr int CH_LEAF = 32;
+constexpr size_t CH_DIAG_LDS = ((size_t)CH_NB * (CH_NB + 1) + CH_NB + 3 * CH_LEAF * (CH_LEAF + 1) + 2) * sizeof(double);      // tile | 1 / diagonal | three 32 x 32 temporaries | flag
+
+__device__ __forceinline__ void ch_wave_sync() {      // LDS writes of this wave before, LDS reads of this wave after (one wave works alone: no workgroup barrier)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Cholesky of a 128 x 128 block held lower-triangular in sG (stride 129) by 256 threads, and its inverse: on return sG[r][c], c <= r, is L; sG[c][r], c < r, is
+// (L^-1)[r][c]; sDinv[r] = 1 / L[r][r].  Returns 0, or 1 + the index of the first non-positive pivot.
+__device__ inline int chol128_blocked(double* __restrict__ sG, double* __restrict__ sDinv, double* __restrict__ sTmp, int* __restrict__ sBad, int tid) {
+  constexpr int LD = CH_NB + 1, NL = CH_LEAF, TL = CH_LEAF + 1;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) *sBad = 0;
+  __syncthreads();
+  for (int b = 0; b < CH_NB; b += NL) {
+    if (wave == 0) {
+      const int i = lane & 31, h = lane >> 5;
+      double* __restrict__ row = sG + (size_t)(b + i) * LD + b;
+      int bad = 0;
+      for (int j = 0; j < NL; ++j) {                                   // the leaf's factor: column j, then the rank-1 update of the columns behind it (two lanes per row)
+        const double d = sG[(size_t)(b + j) * LD + b + j];
+        if (!(d > 0.0)) { bad = b + j + 1; break; }                   // (every lane reads the same word)
+        const double sd = sqrt(d), rs = 1.0 / sd;
+        if (h == 0 && i >= j) {
+          row[j] = (i == j) ? sd : row[j] * rs;
+          if (i == j) sDinv[b + j] = rs;
+        }
+        ch_wave_sync();
+        if (i > j) {
+          const double nl = -row[j];
+          for (int c = j + 1 + h; c <= i; c += 2) row[c] = fma(nl, sG[(size_t)(b + c) * LD + b + j], row[c]);
+        }
+        ch_wave_sync();
+      }
+      if (bad) { if (lane == 0) *sBad = bad; }
+      else {
+        // the leaf's inverse, row by row: X[i][j] = -(1 / L[i][i]) sum_{j <= t < i} L[i][t] X[t][j] for every column j < i at once (lane = column, the two halves share the sum)
+        const int jj = lane & 31;
+        double* __restrict__ xcol = sG + (size_t)(b + jj) * LD + b;   // X[t][jj] at xcol[t] (t > jj)
+        for (int r = 1; r < NL; ++r) {
+          double acc = 0.0;
+          if (jj < r) {
+            const double* __restrict__ lrow = sG + (size_t)(b + r) * LD + b;
+            for (int t = jj + h; t < r; t += 2) acc = fma(lrow[t], t == jj ? sDinv[b + jj] : xcol[t], acc);
+          }
+          acc += __shfl_xor(acc, 32);
+          if (h == 0 && jj < r) xcol[r] = -acc * sDinv[b + r];
+          ch_wave_sync();
+        }
+      }
+    }
+    __syncthreads();
+    if (*sBad) return *sBad;
+    const int below = CH_NB - (b + NL);                                // rows under the leaf
+    if (below > 0) {
+      // L[r][b + c] = sum_{t <= c} A[r][b + t] X[c][t]: 8 threads per row (columns c = c0, c0 + 8, ...), the row in registers before anything is written
+      for (int base = 0; base < below; base += 32) {
+        const int r = b + NL + base + (tid >> 3), c0 = tid & 7;
+        double a[NL];
+        double* __restrict__ row = sG + (size_t)r * LD + b;
+#pragma unroll
+        for (int t = 0; t < NL; ++t) a[t] = row[t];
+        ch_wave_sync();                                                // (the eight threads of a row sit in one wave: its loads are done before its stores)
+        double o[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < NL; ++t) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = c0 + 8 * u;
+            if (t <= c) o[u] = fma(a[t], t == c ? sDinv[b + c] : sG[(size_t)(b + t) * LD + b + c], o[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row[c0 + 8 * u] = o[u];
+      }
+      __syncthreads();
+      // trailing block -= panel panel^t, the lower triangle in 4 x 4 tiles
+      const int nt = below / 4, ntiles = nt * (nt + 1) / 2;
+      for (int idx = tid; idx < ntiles; idx += 256) {
+        int tr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+        while (tr * (tr + 1) / 2 > idx) --tr;
+        while ((tr + 1) * (tr + 2) / 2 <= idx) ++tr;
+        const int tc = idx - tr * (tr + 1) / 2;
+        const int r0 = b + NL + 4 * tr, c0 = b + NL + 4 * tc;
+        double acc[4][4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+#pragma unroll 8
+        for (int t = 0; t < NL; ++t) {
+          double pr[4], pc[4];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) { pr[x] = sG[(size_t)(r0 + x) * LD + b + t]; pc[x] = sG[(size_t)(c0 + x) * LD + b + t]; }
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) acc[x][y] = fma(pr[x], pc[y], acc[x][y]);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y)
+            if (c0 + y <= r0 + x) sG[(size_t)(r0 + x) * LD + c0 + y] -= acc[x][y];
+      }
+      __syncthreads();
+    }
+  }
+  // the blocks of the inverse under the diagonal, by distance from it: X_ij = -X_ii (sum_{j <= t < i} L_it X_tj)
+  constexpr int NBL = CH_NB / NL;
+  for (int dist = 1; dist < NBL; ++dist) {
+    const int nblk = NBL - dist;
+    for (int o = tid; o < nblk * NL * NL; o += 256) {                  // S = sum_t L_it X_tj
+      const int blk = o / (NL * NL), r = (o / NL) % NL, c = o % NL;
+      const int bj = blk, bi = blk + dist;
+      const double* __restrict__ lrow = sG + (size_t)(NL * bi + r) * LD;
+      const double* __restrict__ xcol = sG + (size_t)(NL * bj + c) * LD;     // X[.][NL bj + c] at xcol[.]
+      double acc = 0.0;
+      for (int kk = c; kk < NL; ++kk) acc = fma(lrow[NL * bj + kk], kk == c ? sDinv[NL * bj + c] : xcol[NL * bj + kk], acc);      // t = j: the leaf's own (triangular) inverse
+      for (int t = bj + 1; t < bi; ++t)
+#pragma unroll 8
+        for (int kk = 0; kk < NL; ++kk) acc = fma(lrow[NL * t + kk], xcol[NL * t + kk], acc);
+      sTmp[(size_t)blk * NL * TL + r * TL + c] = acc;
+    }
+    __syncthreads();
+    for (int o = tid; o < nblk * NL * NL; o += 256) {                  // X_ij = -X_ii S (X_ii lower triangular)
+      const int blk = o / (NL * NL), r = (o / NL) % NL, c = o % NL;
+      const int bj = blk, bi = blk + dist;
+      const double* __restrict__ S = sTmp + (size_t)blk * NL * TL;
+      double acc = 0.0;
+      for (int kk = 0; kk <= r; ++kk) acc = fma(kk == r ? sDinv[NL * bi + r] : sG[(size_t)(NL * bi + kk) * LD + NL * bi + r], S[kk * TL + c], acc);
+      sG[(size_t)(NL * bj + c) * LD + NL * bi + r] = -acc;
+    }
+    __syncthreads();
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, size_t ld, size_t off, int nb, double* __restrict__ Linv, int* __restrict__ info, size_t report_base) {
+  extern __shared__ __attribute__((aligned(16))) double ch_smem[];
+  constexpr int LD = CH_NB + 1;
+  double* __restrict__ sG = ch_smem;
+  double* __restrict__ sDinv = ch_smem + CH_NB * LD;
+  double* __restrict__ sTmp = sDinv + CH_NB;
+  int* __restrict__ sBad = reinterpret_cast<int*>(sTmp + 3 * CH_LEAF * (CH_LEAF + 1));
+  const int tid = threadIdx.x;
+  if (*info != 0) return;
+#ifndef CHOL_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(3);      // a short dependent chain beside whatever shares its CU
+#endif
+  for (int e = tid; e < CH_NB * CH_NB; e += 256) {                     // a ragged last block is completed by the identity: its factor and inverse are the block's own, bordered by I
+    const int r = e >> 7, c = e & 127;
+    if (c <= r) sG[r * LD + c] = (r < nb && c < nb) ? A[(off + r) * ld + off + c] : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int bad = chol128_blocked(sG, sDinv, sTmp, sBad, tid);
+  if (bad) {                                                           // not positive definite (mp_perturbation.rs:109-110)
+    if (tid == 0) atomicCAS(info, 0, (int)(report_base + (size_t)bad));
+    return;
+  }
+  for (int e = tid; e < nb * CH_NB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    if (c <= r && c < nb) A[(off + r) * ld + off + c] = sG[r * LD + c];
+    if (r < nb && c < nb) Linv[(size_t)r * CH_NB + c] = c < r ? sG[c * LD + r] : (c == r ? sDinv[r] : 0.0);
+  }
+}
+
+#ifdef PSF_EXPERIMENTS   /* rounds 3-5: the step-by-step form (PSF_CHOL_DIAG=steps), comparison arm of the experiments build */
 // ---- diagonal block + its inverse (left-looking form) ----------------------------------------------------------------------------------
 // 256 threads; the block lives in LDS as [128][129].  Step j: pivot, column j scaled by the threads i > j, then the rank-1 update of the rows
 // below -- thread (i = t % 128, h = t / 128) takes the columns j < c <= i with c = j + 1 + h (mod 2): lanes walk rows (stride 129: no bank
 // conflict), the pivot column is a broadcast.  L11 goes back to A; the inverse (lower triangular, written to Linv row-major, zeros above the
 // diagonal) is formed in place from the last column to the first: X[i][j] = -(sum_{j < t <= i} X[i][t] L[t][j]) / L[j][j].
-__global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, size_t ld, size_t off, int nb, double* __restrict__ Linv, int* __restrict__ info, size_t report_base) {
+__global__ __launch_bounds__(256) void k_chol_diag_inv_steps(double* __restrict__ A, size_t ld, size_t off, int nb, double* __restrict__ Linv, int* __restrict__ info, size_t report_base) {
   extern __shared__ __attribute__((aligned(16))) double ch_smem[];   // nb x (CH_NB + 1) | one column
   constexpr int LD = CH_NB + 1;
   double* __restrict__ sG = ch_smem;
@@ -118,6 +296,7 @@ __global__ __launch_bounds__(256) void k_chol_diag_inv(double* __restrict__ A, s
     if (r < nb && c < nb) Linv[(size_t)r * CH_NB + c] = (c <= r) ? sG[r * LD + c] : 0.0;
   }
 }
+#endif
 
 // ---- Cholesky directly on the key's chunk stream (round 3, the default) ---------------------------------------------------------------------
 // sqrt(Sigma_2) is stored as the fragment-ordered chunk stream k_trmm_f64_big reads (psf_kernels.hpp: chunk (bi, c) = 128 rows x 16 columns).  A row block

@@ -623,6 +623,25 @@ size_t psfp_m(const psfp_handle* h) { return h ? h->m : 0; }
 // beta = alpha - kappa) as B B^t with B = [[L_1 / sqrt c, -kappa R / sqrt beta], [0, sqrt beta I]] sqrt c, where L_1 is the Cholesky factor of
 // c (alpha I - kappa (alpha / beta) R R^t): only that m_bar x m_bar block is assembled, factored and stored.
 // Cholesky of Sigma_2 directly on the key's chunk stream (psf_chol_kernels.hpp, "Cholesky directly on the key's chunk stream"): no dense m x m matrix.
+// factor + invert one 128 x 128 diagonal block: the blocked kernel (round 6); PSF_CHOL_DIAG=steps (experiments build): the step-by-step kernel of rounds 3-5
+static void launch_chol_diag(hipStream_t st, double* P, size_t ld, size_t off, int nb, double* dLi, int* dinfo, size_t report_base) {
+#ifdef PSF_EXPERIMENTS
+  static const bool steps = [] { const char* e = psf_exp_env("PSF_CHOL_DIAG"); return e && !std::strcmp(e, "steps"); }();
+  if (steps) {
+    hipLaunchKernelGGL(k_chol_diag_inv_steps, dim3(1), dim3(256), ((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double), st, P, ld, off, nb, dLi, dinfo, report_base);
+    return;
+  }
+#endif
+  hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), CH_DIAG_LDS, st, P, ld, off, nb, dLi, dinfo, report_base);
+}
+static bool prepare_chol_diag() {
+  bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_DIAG_LDS) == hipSuccess;
+#ifdef PSF_EXPERIMENTS
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv_steps), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double))) == hipSuccess;
+#endif
+  return ok;
+}
+
 // dS_dense: nullptr, or Sigma_2 already assembled as a dense m x m matrix (lower triangle; the hybrid of build_sqrt_sigma2): the panels are then copied out of it
 // instead of being assembled one by one -- R R^t on the int8 matrix cores takes 5.5 ms for the whole of C3's Sigma_2 at once and 76 ms in 121 panel-sized pieces.
 static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double s2, double b2p1, const double* d_sig, const double* dS_dense = nullptr) {
@@ -654,23 +673,23 @@ static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double 
     if (b > ws_doubles) ws_doubles = b;
   }
   double *dPn[2] = {nullptr, nullptr}, *dLi = nullptr, *dWs = nullptr; int* dinfo = nullptr;
-  hipStream_t sm = nullptr, ss = nullptr;                             // factorisation / Sigma_2 panels (one panel ahead)
-  hipEvent_t evSig[2] = {nullptr, nullptr}, evPack[2] = {nullptr, nullptr};
-  GemmWorkspace w;                                                    // the in-panel products have K = 128: never cut
+  hipStream_t sm = nullptr, ss = nullptr, sd = nullptr;               // factorisation / Sigma_2 panels (one panel ahead) / the diagonal blocks' chain (look-ahead)
+  hipEvent_t evSig[2] = {nullptr, nullptr}, evPack[2] = {nullptr, nullptr}, evHead = nullptr, evDiag = nullptr;
+  GemmWorkspace w, w2;                                                // the in-panel products have K = 128: never cut
+  bool lookahead = true;
+  if (const char* e = psf_exp_env("PSF_CHOL_LOOKAHEAD")) lookahead = std::atoi(e) != 0;
   auto cleanup = [&]() {
-    for (hipStream_t st : {sm, ss}) if (st) hipStreamDestroy(st);
-    for (hipEvent_t ev : {evSig[0], evSig[1], evPack[0], evPack[1]}) if (ev) hipEventDestroy(ev);
+    for (hipStream_t st : {sm, ss, sd}) if (st) hipStreamDestroy(st);
+    for (hipEvent_t ev : {evSig[0], evSig[1], evPack[0], evPack[1], evHead, evDiag}) if (ev) hipEventDestroy(ev);
     hipFree(dPn[0]); hipFree(dPn[1]); hipFree(dLi); hipFree(dWs); hipFree(dinfo);
   };
-  const size_t diag_lds = ((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double);
-  bool ok = gemm_prepare() == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds) == hipSuccess &&
+  bool ok = gemm_prepare() == hipSuccess && prepare_chol_diag() &&
             hipMalloc(&dPn[0], prow * PW * sizeof(double)) == hipSuccess && hipMalloc(&dPn[1], prow * PW * sizeof(double)) == hipSuccess &&
-            hipMalloc(&dLi, CH_NB * CH_NB * sizeof(double)) == hipSuccess && (!ws_doubles || hipMalloc(&dWs, ws_doubles * sizeof(double)) == hipSuccess) &&
+            hipMalloc(&dLi, 2 * CH_NB * CH_NB * sizeof(double)) == hipSuccess && (!ws_doubles || hipMalloc(&dWs, ws_doubles * sizeof(double)) == hipSuccess) &&
             hipMalloc(&dinfo, sizeof(int)) == hipSuccess && hipMemset(dinfo, 0, sizeof(int)) == hipSuccess &&
             hipMemset(dPn[0], 0, prow * PW * sizeof(double)) == hipSuccess && hipMemset(dPn[1], 0, prow * PW * sizeof(double)) == hipSuccess;
-  for (hipStream_t* st : {&sm, &ss}) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
-  for (hipEvent_t* ev : {&evSig[0], &evSig[1], &evPack[0], &evPack[1]}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+  for (hipStream_t* st : {&sm, &ss, &sd}) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t* ev : {&evSig[0], &evSig[1], &evPack[0], &evPack[1], &evHead, &evDiag}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
   if (!ok) { cleanup(); return PSF_ERR_HIP; }
   if (hipDeviceSynchronize() != hipSuccess) { cleanup(); return PSF_ERR_HIP; }      // R (and k_pack_R8) were produced on the default stream
   // Sigma_2 restricted to panel J (rows off.., columns off..off+255), dense with leading dimension 256; it does not depend on the factorisation, so it
@@ -702,33 +721,59 @@ static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double 
       sigma_panel(J + 1);
     }
     hipStreamWaitEvent(sm, evSig[J & 1], 0);
-    if (J > 0) {                                                      // P -= L[rows of the panel, columns < off] L[panel's row blocks, columns < off]^t
-      auto update = [&](int rb0, int count) {
-        const int sp = splits_for(count, 8 * J);
-        const size_t stride = (size_t)count * TR_BM * PW;             // doubles per split in the workspace
-        const size_t first = (size_t)rb0 * TR_BM * PW;
-        hipLaunchKernelGGL(k_chol_update_big, dim3((unsigned)count, (unsigned)sp), dim3(256), 0, sm, h->dLt, J, nbi, rb0, 8 * J, dWs - first, stride);
-        hipLaunchKernelGGL(k_chol_panel_reduce, dim3(grid_for(stride, 256, 2048)), dim3(256), 0, sm, P + first, dWs, stride, sp, (size_t)0, stride);
-      };
+    auto update = [&](int rb0, int count) {                            // P -= L[rows of the panel, columns < off] L[panel's row blocks, columns < off]^t
+      const int sp = splits_for(count, 8 * J);
+      const size_t stride = (size_t)count * TR_BM * PW;               // doubles per split in the workspace
+      const size_t first = (size_t)rb0 * TR_BM * PW;
+      hipLaunchKernelGGL(k_chol_update_big, dim3((unsigned)count, (unsigned)sp), dim3(256), 0, sm, h->dLt, J, nbi, rb0, 8 * J, dWs - first, stride);
+      hipLaunchKernelGGL(k_chol_panel_reduce, dim3(grid_for(stride, 256, 2048)), dim3(256), 0, sm, P + first, dWs, stride, sp, (size_t)0, stride);
+    };
+    if (J > 0) {
       const int head = nrb < 2 ? nrb : 2;
       update(0, head);                                                // the two row blocks that hold the diagonal blocks (cut finely along K), then the rest
-      if (nrb > 2) update(2, nrb - 2);
-    }
+      if (lookahead) hipEventRecord(evHead, sm);
+      else if (nrb > 2) update(2, nrb - 2);
+    } else if (lookahead) hipEventRecord(evHead, sm);
+    double* const Li0 = dLi;
+    double* const Li1 = lookahead ? dLi + (size_t)CH_NB * CH_NB : dLi;
+    if (lookahead) {
+      // Round 6: the two diagonal blocks of the panel need only the HEAD of the update.  Their chain -- factor + invert block (0,0), L10 = P10 L00^-t, P11 -= L10 L10^t,
+      // factor + invert block (1,1): two single-workgroup kernels and two 128^3 products, 0.6 ms of pure latency per panel -- runs on a second stream while the rest
+      // of the update (the rows below, ~1 ms of matrix work per panel in the middle of the factorisation) occupies the chip; the panel's triangular solves wait for both.
+      hipStreamWaitEvent(sd, evHead, 0);
+      launch_chol_diag(sd, P, PW, (size_t)0, (int)nb0, Li0, dinfo, off);
+      if (ncb == 2) {
+        launch_gemm<true>(sd, GemmArgs{P + TR_BM * PW, PW, Li0, (size_t)CH_NB, P + TR_BM * PW, PW, nb1, nb0, nb0, 1.0, 0.0, nullptr, nullptr, 0}, w2);
+        launch_gemm<true>(sd, GemmArgs{P + TR_BM * PW, PW, P + TR_BM * PW, PW, P + TR_BM * PW + TR_BM, PW, nb1, nb1, (size_t)TR_BM, -1.0, 1.0, nullptr, nullptr, 0}, w2);
+        launch_chol_diag(sd, P, PW, (size_t)TR_BM, (int)nb1, Li1, dinfo, off + TR_BM);
+      }
+      hipEventRecord(evDiag, sd);
+      if (J > 0 && nrb > 2) update(2, nrb - 2);
+      hipStreamWaitEvent(sm, evDiag, 0);
+      if (below1) {                                                   // the rows under both diagonal blocks: solve, take column block 0 out of column block 1, solve
+        double* const Pr = P + 2 * TR_BM * PW;
+        launch_gemm<true>(sm, GemmArgs{Pr, PW, Li0, (size_t)CH_NB, Pr, PW, below1, nb0, nb0, 1.0, 0.0, nullptr, nullptr, 0}, w);
+        launch_gemm<true>(sm, GemmArgs{Pr, PW, P + TR_BM * PW, PW, Pr + TR_BM, PW, below1, nb1, (size_t)TR_BM, -1.0, 1.0, nullptr, nullptr, 0}, w);
+        launch_gemm<true>(sm, GemmArgs{Pr + TR_BM, PW, Li1, (size_t)CH_NB, Pr + TR_BM, PW, below1, nb1, nb1, 1.0, 0.0, nullptr, nullptr, 0}, w);
+      }
+    } else {
     // inside the panel: factor + invert the first diagonal block, solve its rows below, take its contribution out of the second column block, the same again
-    hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sm, P, PW, (size_t)0, (int)nb0, dLi, dinfo, off);
+    launch_chol_diag(sm, P, PW, (size_t)0, (int)nb0, dLi, dinfo, off);
     if (below0)
       launch_gemm<true>(sm, GemmArgs{P + TR_BM * PW, PW, dLi, (size_t)CH_NB, P + TR_BM * PW, PW, below0, nb0, nb0, 1.0, 0.0, nullptr, nullptr, 0}, w);
     if (ncb == 2) {
       launch_gemm<true>(sm, GemmArgs{P + TR_BM * PW, PW, P + TR_BM * PW, PW, P + TR_BM * PW + TR_BM, PW, below0, nb1, (size_t)TR_BM, -1.0, 1.0, nullptr, nullptr, 0}, w);
-      hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sm, P, PW, (size_t)TR_BM, (int)nb1, dLi, dinfo, off + TR_BM);
+      launch_chol_diag(sm, P, PW, (size_t)TR_BM, (int)nb1, dLi, dinfo, off + TR_BM);
       if (below1)
         launch_gemm<true>(sm, GemmArgs{P + 2 * TR_BM * PW + TR_BM, PW, dLi, (size_t)CH_NB, P + 2 * TR_BM * PW + TR_BM, PW, below1, nb1, nb1, 1.0, 0.0, nullptr, nullptr, 0}, w);
+    }
     }
     hipLaunchKernelGGL(k_chol_pack_panel, dim3(grid_for((size_t)nrb * ncb * 8 * TR_CHUNK, 256, 4096)), dim3(256), 0, sm, P, J, ncb, nbi, m, h->dLt);
     hipEventRecord(evPack[J & 1], sm);
   }
   hipError_t ce = hipStreamSynchronize(sm);
   if (ce == hipSuccess) ce = hipStreamSynchronize(ss);
+  if (ce == hipSuccess) ce = hipStreamSynchronize(sd);
   if (ce == hipSuccess) ce = hipGetLastError();
   int info = -1;
   if (ce == hipSuccess) ce = hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost);
@@ -798,7 +843,6 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
 #endif
   {
     if (gemm_prepare() != hipSuccess) return PSF_ERR_HIP;
-    const size_t diag_lds = ((size_t)CH_NB * (CH_NB + 1) + 2 * CH_NB) * sizeof(double);
     GemmWorkspace w;
     w.bytes = (size_t)900 * GM_T * GM_T * sizeof(double);              // < 384 + 512 (tile, split) pairs per launch, see launch_gemm
     double* dLi = nullptr;
@@ -808,7 +852,7 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
     if (hipMalloc(&w.ws, w.bytes) != hipSuccess || hipMalloc(&dLi, CH_NB * CH_NB * sizeof(double)) != hipSuccess ||
         hipStreamCreateWithFlags(&sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&evTile, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evDiag, hipEventDisableTiming) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds) != hipSuccess ||
+        !prepare_chol_diag() ||
         hipDeviceSynchronize() != hipSuccess) {                        // (k_sigma2 ran on the default stream)
       cleanup(); return PSF_ERR_HIP;
     }
@@ -826,7 +870,7 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
         if (rest) launch_gemm<true>(sm, GemmArgs{dS + (off + nb) * m, m, dS + off * m, m, P2, m, rest, nb, off, -1.0, 1.0, nullptr, nullptr, 0}, w);
         hipStreamWaitEvent(sd, evTile, 0);
       }
-      hipLaunchKernelGGL(k_chol_diag_inv, dim3(1), dim3(256), diag_lds, sd, dS, m, off, (int)nb, dLi, dinfo, off);
+      launch_chol_diag(sd, dS, m, off, (int)nb, dLi, dinfo, off);
       hipEventRecord(evDiag, sd);
       hipStreamWaitEvent(sm, evDiag, 0);
       if (rest == 0) break;
