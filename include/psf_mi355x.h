@@ -229,6 +229,13 @@ psf_status psfp_samp_p(psfp_handle*, uint64_t seed, uint64_t first_index, size_t
  * thread at a time. */
 psf_status psfp_samp_p_async(psfp_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
 psf_status psfp_wait(psfp_handle*);
+/* Per-call status for a caller that keeps several batches (the shim's PendingBatch).  Every asynchronous call of a handle carries a ticket 0, 1, 2, ...:
+ * psfp_async_next_ticket says which one the NEXT call will get; psfp_wait_ticket waits for that call (and the older one in flight, nothing newer) and returns ITS
+ * status, however many other waits have joined it in the meantime (psfp_wait reports the first failure of everything outstanding and so consumes statuses of
+ * calls the caller may not be asking about).  PSF_ERR_PARAM for a ticket never issued or older than the handle's last 8 joined calls.  (The synchronous
+ * psfp_samp_p of a large batch is an asynchronous call + wait inside the library and takes a ticket too.) */
+uint64_t   psfp_async_next_ticket(const psfp_handle*);
+psf_status psfp_wait_ticket(psfp_handle*, uint64_t ticket);
 /* PSF::f_a (mp_perturbation.rs:366-369): u[b] = A e[b] mod q; PSF_ERR_DOMAIN (u still written) if any
  * row fails check_domain */
 psf_status psfp_f_a(psfp_handle*, size_t B, const int64_t* e, uint64_t* u);
@@ -320,6 +327,8 @@ psf_status psfgpv_samp_p_dev(psfgpv_handle*, uint64_t seed, uint64_t first_index
  * PSF_ERR_SAMPLER as psfgpv_samp_p would; PSF_ERR_UNSUPPORTED if a row entry did not fit 32 bits (the synchronous call copies 64-bit rows in that case). */
 psf_status psfgpv_samp_p_async(psfgpv_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e);
 psf_status psfgpv_wait(psfgpv_handle*);
+uint64_t   psfgpv_async_next_ticket(const psfgpv_handle*);                    /* as psfp_async_next_ticket / psfp_wait_ticket */
+psf_status psfgpv_wait_ticket(psfgpv_handle*, uint64_t ticket);
 psf_status psfgpv_f_a(psfgpv_handle*, size_t B, const int64_t* e, uint64_t* u);                               /* gpv.rs:190-193 */
 psf_status psfgpv_f_a_dev(psfgpv_handle*, size_t B, const int64_t* d_e, uint64_t* d_u, uint8_t* d_ok, void* stream);
 psf_status psfgpv_check_domain(psfgpv_handle*, size_t B, const int64_t* e, size_t len, uint8_t* ok);         /* gpv.rs:219-224 */
@@ -379,6 +388,8 @@ psf_status psfring_samp_p_dev(psfring_handle*, uint64_t seed, uint64_t first_ind
 /* gpv_ring.rs:160-212 without waiting: as psfgpv_samp_p_async / psfgpv_wait */
 psf_status psfring_samp_p_async(psfring_handle*, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* sigma);
 psf_status psfring_wait(psfring_handle*);
+uint64_t   psfring_async_next_ticket(const psfring_handle*);
+psf_status psfring_wait_ticket(psfring_handle*, uint64_t ticket);
 psf_status psfring_f_a(psfring_handle*, size_t B, const int64_t* sigma, uint64_t* u);                                  /* :243-247 */
 psf_status psfring_f_a_dev(psfring_handle*, size_t B, const int64_t* d_sigma, uint64_t* d_u, uint8_t* d_ok, void* stream);
 psf_status psfring_check_domain(psfring_handle*, size_t B, const int64_t* sigma, size_t len, uint8_t* ok);            /* :274-283 */

@@ -393,6 +393,8 @@ impl GpuPSFPerturbation {
 /// pending batch waits as well, so the buffers are never freed under the workers.
 pub struct PendingBatch<'a> {
     owner: Owner<'a>,
+    /// the call's ticket (`psfp_async_next_ticket` read right before the call): `into_matz` asks for THIS call's status, whoever joined it in the meantime
+    ticket: u64,
     rows: i64,
     cols: i64,
     _u: Vec<u64>,
@@ -407,18 +409,26 @@ enum Owner<'a> {
 }
 
 impl<'a> Owner<'a> {
-    fn wait(&self) -> std::os::raw::c_int {
+    /// the ticket the next asynchronous call of the handle will carry
+    fn next_ticket(&self) -> u64 {
         match self {
-            Owner::Perturbation(p) => unsafe { ffi::psfp_wait(p.handle) },
-            Owner::Gpv(g) => unsafe { ffi::psfgpv_wait(g.handle) },
+            Owner::Perturbation(p) => unsafe { ffi::psfp_async_next_ticket(p.handle) },
+            Owner::Gpv(g) => unsafe { ffi::psfgpv_async_next_ticket(g.handle) },
+        }
+    }
+    /// waits for the call with this ticket (and the older one in flight) and returns ITS status: dropping or reading another batch first cannot consume it
+    fn wait_ticket(&self, ticket: u64) -> std::os::raw::c_int {
+        match self {
+            Owner::Perturbation(p) => unsafe { ffi::psfp_wait_ticket(p.handle, ticket) },
+            Owner::Gpv(g) => unsafe { ffi::psfgpv_wait_ticket(g.handle, ticket) },
         }
     }
 }
 
 impl<'a> PendingBatch<'a> {
-    /// the preimages, one per row; waits for the handle's outstanding batches first and panics with the first failure (oldest batch first)
+    /// the preimages, one per row; waits for this batch (and the older one in flight) and panics if THIS batch failed
     pub fn into_matz(self) -> MatZ {
-        check(self.owner.wait(), "wait");
+        check(self.owner.wait_ticket(self.ticket), "wait_ticket");
         self.waited.set(true);
         matz_from_rows(self.rows, self.cols, &self.e)
     }
@@ -427,8 +437,8 @@ impl<'a> PendingBatch<'a> {
 impl<'a> Drop for PendingBatch<'a> {
     fn drop(&mut self) {
         if !self.waited.get() {
-            // nothing may write into `e` once it is freed; the status of an abandoned batch is discarded
-            let _ = self.owner.wait();
+            // nothing may write into `e` once it is freed; the status of an abandoned batch is discarded -- and only its own: the other batches keep theirs
+            let _ = self.owner.wait_ticket(self.ticket);
         }
     }
 }
@@ -444,8 +454,10 @@ impl GpuPSFPerturbation {
         let u = matzq_to_rows(targets);
         let mut e = vec![0i64; (b * m) as usize];
         let seed = next_seed(&self.seed, &self.calls);
+        let owner = Owner::Perturbation(self);
+        let ticket = owner.next_ticket();
         check(unsafe { ffi::psfp_samp_p_async(self.handle, seed, 0, b as usize, u.as_ptr(), e.as_mut_ptr()) }, "psfp_samp_p_async");
-        PendingBatch { owner: Owner::Perturbation(self), rows: b, cols: m, _u: u, e, waited: Cell::new(false) }
+        PendingBatch { owner, ticket, rows: b, cols: m, _u: u, e, waited: Cell::new(false) }
     }
 
     /// every asynchronous batch of this handle has completed (`psfp_wait`); panics with the first failure, oldest batch first
@@ -619,8 +631,10 @@ impl GpuPSFGPV {
         assert_eq!(targets.get_num_columns(), n);
         let u = matzq_to_rows(targets);
         let mut e = vec![0i64; (b * m) as usize];
+        let owner = Owner::Gpv(self);
+        let ticket = owner.next_ticket();
         check(unsafe { ffi::psfgpv_samp_p_async(self.handle, next_seed(&self.seed, &self.calls), 0, b as usize, u.as_ptr(), e.as_mut_ptr()) }, "psfgpv_samp_p_async");
-        PendingBatch { owner: Owner::Gpv(self), rows: b, cols: m, _u: u, e, waited: Cell::new(false) }
+        PendingBatch { owner, ticket, rows: b, cols: m, _u: u, e, waited: Cell::new(false) }
     }
 
     /// every asynchronous batch of this handle has completed (`psfgpv_wait`)

@@ -116,3 +116,17 @@ def test_c3_single_calls_match_the_oracle_in_every_stage(oracle):
             fx = orc.samp_p_from_x(42, first + b, uh[b], st["x"][b])
             assert (fx["p"] == st["p"][b]).all() and (fx["v"] == st["v"][b]).all() and (fx["z"] == st["z"][b]).all() and (fx["e"] == st["e"][b]).all()
     psf.close()
+
+
+@pytest.mark.timeout(900)
+def test_c5_rank_zero_of_eight_fits_beside_the_key():
+    """BASELINE.json configs[4] as RANK 0 of its eight ranks sees it (the part of the 8-GPU job that can be rehearsed on one GPU): the 60.6 GB key, the batch
+    buffers of 8192 preimages and the gather ring sized for eight ranks (`--emulate-world 8`: 36.3 GB per level on the receiving rank, tools_amd/shard.py) all
+    resident, through bench.py's own launcher and a one-rank RCCL group.  The ring must get at least one level (AsyncRowGather.fit_depth), nothing may run out
+    of memory, every row must pass A e = u and check_domain."""
+    d = run_bench("--config", "c5", "--force-dist", "--emulate-world", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-latency", timeout=850)
+    assert d["valid"] is True and d["ranks_seen"] == 1 and "self-spawned" in d["launcher"]
+    g = d["gather"]
+    assert g["buffers_sized_for_ranks"] == 8 and g["depth"] >= 1
+    assert g["bytes_per_depth"] == 8192 * 122980 * 4 * 9                 # its own staging block + one receive block per rank
+    assert g["hbm_free_GB_after_allocation"] > 10.0

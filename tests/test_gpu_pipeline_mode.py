@@ -370,3 +370,69 @@ def test_overlapped_async_calls_of_the_nearest_plane_types(oracle):
         assert (outr[i] == syncr[i]).all(), i
     assert (ring.f_a(outr[0]) == ur[0]).all()
     ring.close()
+
+
+@pytest.mark.gpu
+def test_asynchronous_calls_keep_their_own_status_by_ticket(oracle):
+    """psfp_async_next_ticket / psfp_wait_ticket (the shim's PendingBatch): psfp_wait reports the FIRST failure of everything outstanding and thereby
+    consumes the status of calls the caller did not ask about; a ticket keeps each call's own status.  A key whose factor is scaled up makes |p| >= 2^23 (a sampler
+    failure, PSF_ERR_SAMPLER) a matter of the seed: one failing and one passing seed are found with synchronous calls, then issued as two overlapped asynchronous
+    calls -- whoever is asked first, each ticket answers for its own call, also after psfp_wait has joined both."""
+    import numpy as np
+    import tools_amd as T
+    n, q, r, s, B = 24, 2**10, 4.0, 80.0, 2200                 # m = 505: 2200 rows take the asynchronous transport also in the synchronous entry point
+    psf = T.PSFPerturbation(T.GadgetParameters.init_default(n, q), r, s)
+    A, (R, Lp, _) = psf.trap_gen(5)
+    u = oracle.uniform_targets(3, B, n, q)
+    t0 = psf.next_ticket()
+    out = np.zeros((B, psf.m), dtype=np.int64)
+    psf.samp_p_async(u, out, seed=1)
+    assert psf.next_ticket() == t0 + 1
+    psf.wait_ticket(t0)                                        # fine, and again after a general wait
+    psf.wait()
+    psf.wait_ticket(t0)
+    with pytest.raises(T.PsfError):
+        psf.wait_ticket(t0 + 5)                                # never issued
+    good = bad = None
+    scale = 2.0**23 / (6.0 * np.abs(Lp).max() * np.sqrt(psf.m))
+    for attempt in range(12):                                  # a scale at which failure depends on the seed
+        psf.load_key(A, R, Lp * scale)
+        res = {}
+        for seed in range(8):
+            try:
+                psf.samp_p(u, seed=seed)
+                res[seed] = 0
+            except T.PsfError as ex:
+                assert ex.status == 9
+                res[seed] = 9
+        if 0 in res.values() and 9 in res.values():
+            good = [k for k, v in res.items() if v == 0][0]
+            bad = [k for k, v in res.items() if v == 9][0]
+            break
+        scale *= 0.7 if all(v == 9 for v in res.values()) else 1.4
+    if good is None:
+        pytest.skip("no scale with seed-dependent failures found")
+    outs = [np.zeros((B, psf.m), dtype=np.int64) for _ in range(2)]
+    for order in ((bad, good), (good, bad)):
+        ta = psf.next_ticket()
+        psf.samp_p_async(u, outs[0], seed=order[0])
+        psf.samp_p_async(u, outs[1], seed=order[1])
+        want = {ta: 9 if order[0] == bad else 0, ta + 1: 9 if order[1] == bad else 0}
+        for t in (ta + 1, ta):                                 # the NEWER call first: joining it joins the older one as well, whose status must survive
+            if want[t]:
+                with pytest.raises(T.PsfError) as ei:
+                    psf.wait_ticket(t)
+                assert ei.value.status == 9
+            else:
+                psf.wait_ticket(t)
+        try:
+            psf.wait()                                          # nothing outstanding: OK, and the tickets still answer
+        except T.PsfError:
+            pytest.fail("psfp_wait reported a call that had already been joined")
+        for t in (ta, ta + 1):
+            if want[t]:
+                with pytest.raises(T.PsfError):
+                    psf.wait_ticket(t)
+            else:
+                psf.wait_ticket(t)
+    psf.close()

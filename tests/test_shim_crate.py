@@ -97,4 +97,6 @@ def test_one_state_for_what_the_handle_holds():
     assert "unwrap_or(0)" not in lib
     pend = lib[lib.index("pub struct PendingBatch<'a>"):lib.index("impl Drop for GpuPSFPerturbation")]
     assert "owner: Owner<'a>" in pend and "Perturbation(&'a GpuPSFPerturbation)" in pend and "impl<'a> Drop for PendingBatch<'a>" in pend
-    assert pend[pend.index("pub fn into_matz(self)"):].index("self.owner.wait()") < pend[pend.index("pub fn into_matz(self)"):].index("matz_from_rows")
+    # a batch asks for ITS OWN status by ticket (psfp_wait_ticket) -- dropping or reading another batch first cannot consume it
+    assert pend[pend.index("pub fn into_matz(self)"):].index("self.owner.wait_ticket(self.ticket)") < pend[pend.index("pub fn into_matz(self)"):].index("matz_from_rows")
+    assert "ticket: u64" in pend and "let ticket = owner.next_ticket();" in lib and "self.owner.wait()" not in pend

@@ -774,6 +774,8 @@ psf_status psfgpv_wait(psfgpv_handle* g) {
   if (!g) return PSF_ERR_PARAM;
   return psfp_wait(g->base);
 }
+uint64_t psfgpv_async_next_ticket(const psfgpv_handle* g) { return g ? psfp_async_next_ticket(g->base) : 0; }
+psf_status psfgpv_wait_ticket(psfgpv_handle* g, uint64_t ticket) { return g ? psfp_wait_ticket(g->base, ticket) : PSF_ERR_PARAM; }
 
 psf_status psfgpv_samp_d(psfgpv_handle* g, uint64_t seed, uint64_t first_index, size_t B, int64_t* e) {
   return g ? psfp_samp_d(g->base, seed, first_index, B, e) : PSF_ERR_PARAM;
@@ -1147,6 +1149,8 @@ psf_status psfring_samp_p_async(psfring_handle* h, uint64_t seed, uint64_t first
   return h ? psfgpv_samp_p_async(h->g, seed, first_index, B, u, sigma) : PSF_ERR_PARAM;
 }
 psf_status psfring_wait(psfring_handle* h) { return h ? psfgpv_wait(h->g) : PSF_ERR_PARAM; }
+uint64_t psfring_async_next_ticket(const psfring_handle* h) { return h ? psfgpv_async_next_ticket(h->g) : 0; }
+psf_status psfring_wait_ticket(psfring_handle* h, uint64_t ticket) { return h ? psfgpv_wait_ticket(h->g, ticket) : PSF_ERR_PARAM; }
 psf_status psfring_samp_p_dev(psfring_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* d_u, int64_t* d_sigma, void* stream) {
   return h ? psfgpv_samp_p_dev(h->g, seed, first_index, B, d_u, d_sigma, stream) : PSF_ERR_PARAM;
 }

@@ -140,6 +140,9 @@ struct psfp_handle {
     bool busy[2] = {false, false};
     std::atomic<int> status[2] = {{0}, {0}};     // psf_status of the call in each slot (written by its workers)
     size_t next = 0;                            // slot of the next asynchronous call
+    uint64_t seq = 0;                           // ticket of the next asynchronous call (0, 1, 2, ... since the handle was created)
+    uint64_t slot_seq[2] = {0, 0};              // ticket of the call in each slot
+    struct Done { uint64_t seq; int status; bool used; } done[8] = {};      // the last joined calls and their statuses (psfp_wait_ticket)
     bool slice_tail = false;                    // set by psfp_samp_p around its own asynchronous call: cut a short last slice (single-call latency)
     int copy_mode = 1;                          // how a chunk crosses PCIe: 1 = SDMA engine through the HSA runtime (psf_sdma.hpp), 0 = hipMemcpyAsync, 2 = a copy kernel (PSF_HOST_COPY)
     int copy_grid = 32;                         // workgroups of the copy kernel (mode 2)
@@ -1582,6 +1585,7 @@ static psf_status hp_join(psfp_handle* h, int slot) {
   // an entry beyond 32 bits: impossible for PSFPerturbation (every entry is checked on the device: a sampler failure); a PSFGPV / PSFGPVRing row of that size
   // needs the synchronous call, which copies 64-bit rows then
   if (rc == PSF_OK && hp.hFlags[slot][2]) rc = hp.hFlags[slot][3] ? PSF_ERR_UNSUPPORTED : PSF_ERR_SAMPLER;
+  hp.done[hp.slot_seq[slot] & 7] = psfp_handle::HostPipe::Done{hp.slot_seq[slot], (int)rc, true};      // whoever joins consumes the status: the ticket keeps it
   return rc;
 }
 
@@ -1717,6 +1721,7 @@ static psf_status hp_async(psfp_handle* h, size_t B, const uint64_t* u, int64_t*
   rc = hp_ensure(h, slot, total, B * h->n);
   if (rc != PSF_OK) return rc;
   ++hp.next;
+  hp.slot_seq[slot] = hp.seq++;
   hipStream_t cs = hp.compute;
   // targets: pageable -> pinned (this thread) -> this call's device copy -- deferred until the syndrome stage of the first slice is about to be enqueued
   // (h->before_u, run_samp_p): by then the product is executing, and neither the staging copy nor the upload delays the call
@@ -1836,6 +1841,23 @@ psf_status psfp_wait(psfp_handle* h) {
     if (first == PSF_OK) first = rc;
   }
   return first;
+}
+
+// the ticket the next asynchronous call of this handle will carry, and the status of ONE asynchronous call by its ticket (waits for it and for the older call
+// in flight, nothing newer): psfp_wait returns the first failure of everything outstanding and thereby consumes the statuses of calls the caller may not be
+// asking about -- a caller that keeps several batches (the shim's PendingBatch) asks per ticket.  PSF_ERR_PARAM: a ticket never issued or older than the last 8 joined calls.
+uint64_t psfp_async_next_ticket(const psfp_handle* h) { return h ? h->hp.seq : 0; }
+psf_status psfp_wait_ticket(psfp_handle* h, uint64_t ticket) {
+  if (!h) return PSF_ERR_PARAM;
+  HIP_TRY(hipSetDevice(h->prm.device));
+  auto& hp = h->hp;
+  if (ticket >= hp.seq) return PSF_ERR_PARAM;
+  for (int i = 0; i < 2; ++i) {                                         // oldest first, up to the ticket's own call
+    const int slot = (int)((hp.next + (size_t)i) & 1);
+    if (hp.busy[slot] && hp.slot_seq[slot] <= ticket) hp_join(h, slot);
+  }
+  const auto& d = hp.done[ticket & 7];
+  return (d.used && d.seq == ticket) ? (psf_status)d.status : PSF_ERR_PARAM;
 }
 
 psf_status psfp_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index, size_t B, const uint64_t* u, int64_t* e) {

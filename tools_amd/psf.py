@@ -122,6 +122,16 @@ class PSFPerturbation:
         finally:
             self._inflight = []
 
+    def next_ticket(self):
+        """the ticket the next asynchronous call of this handle will carry (psfp_async_next_ticket)"""
+        f = lib().psfp_async_next_ticket
+        f.restype = C.c_uint64
+        return int(f(self._h))
+
+    def wait_ticket(self, ticket):
+        """waits for the asynchronous call with this ticket (and the older one in flight) and raises if THAT call failed (psfp_wait_ticket)"""
+        check(lib().psfp_wait_ticket(self._h, C.c_uint64(ticket)), "wait_ticket")
+
     def f_a(self, sigma):
         """mp_perturbation.rs:366-369; raises PsfError(ERR_DOMAIN) where the reference's assert! panics."""
         sigma = np.ascontiguousarray(sigma, dtype=np.int64)
@@ -378,6 +388,16 @@ class PSFGPV:
         finally:
             self._inflight = []
 
+    def next_ticket(self):
+        """the ticket the next asynchronous call of this handle will carry (psfgpv_async_next_ticket)"""
+        f = lib().psfgpv_async_next_ticket
+        f.restype = C.c_uint64
+        return int(f(self._h))
+
+    def wait_ticket(self, ticket):
+        """waits for the asynchronous call with this ticket (and the older one in flight) and raises if THAT call failed (psfgpv_wait_ticket)"""
+        check(lib().psfgpv_wait_ticket(self._h, C.c_uint64(ticket)), "wait_ticket")
+
     # device-resident API
     def samp_p_dev(self, d_u_ptr, d_e_ptr, B, seed=0, first_index=0, stream=None):
         check(lib().psfgpv_samp_p_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), C.c_void_p(d_u_ptr),
@@ -541,6 +561,16 @@ class PSFGPVRing:
             check(lib().psfring_wait(self._h), "wait")
         finally:
             self._inflight = []
+
+    def next_ticket(self):
+        """the ticket the next asynchronous call of this handle will carry (psfring_async_next_ticket)"""
+        f = lib().psfring_async_next_ticket
+        f.restype = C.c_uint64
+        return int(f(self._h))
+
+    def wait_ticket(self, ticket):
+        """waits for the asynchronous call with this ticket (and the older one in flight) and raises if THAT call failed (psfring_wait_ticket)"""
+        check(lib().psfring_wait_ticket(self._h, C.c_uint64(ticket)), "wait_ticket")
 
     def samp_p_dev(self, d_u_ptr, d_sigma_ptr, B, seed=0, first_index=0, stream=None):
         check(lib().psfring_samp_p_dev(self._h, C.c_uint64(seed), C.c_uint64(first_index), C.c_size_t(B), C.c_void_p(d_u_ptr),
