@@ -694,7 +694,7 @@ static psf_status build_sqrt_sigma2_stream(psfp_handle* h, double nf_r2, double 
   for (hipStream_t* st : {&sm, &ss, &sd}) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
   for (hipEvent_t* ev : {&evSig[0], &evSig[1], &evPack[0], &evPack[1], &evHead, &evDiag}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
   if (!ok) { cleanup(); return PSF_ERR_HIP; }
-  if (hipDeviceSynchronize() != hipSuccess) { cleanup(); return PSF_ERR_HIP; }      // R (and k_pack_R8) were produced on the default stream
+  if (hipStreamSynchronize(nullptr) != hipSuccess) { cleanup(); return PSF_ERR_HIP; }      // R, the dense Sigma_2 (and k_pack_R8) were produced on the default stream (not a device-wide wait: psfp_trap_gen computes A on a side stream meanwhile)
   // Sigma_2 restricted to panel J (rows off.., columns off..off+255), dense with leading dimension 256; it does not depend on the factorisation, so it
   // is assembled one panel ahead on its own stream into the other of two panel buffers
   auto sigma_panel = [&](int J) {
@@ -896,18 +896,18 @@ static psf_status build_sqrt_sigma2(psfp_handle* h, double s_cov, const double* 
 }
 
 // A[:, m_bar:] = G - A_bar R  (gadget_classical.rs:66): the one product still on the limb kernel (setup path, R in int8)
-static void launch_zq_trapdoor(psfp_handle* h, const uint64_t* d_tag = nullptr) {
+static void launch_zq_trapdoor(psfp_handle* h, const uint64_t* d_tag = nullptr, hipStream_t st = nullptr) {
   dim3 grid((unsigned)((h->w + 63) / 64), (unsigned)((h->n + 63) / 64));
   if (h->wide)
-    hipLaunchKernelGGL((k_zq_matmul<int8_t, true>), grid, dim3(256), 0, 0, (int)ZQ_TRAPDOOR, h->dA, h->m, (size_t)0, h->n, h->mb, h->dR, h->ldr, h->w,
+    hipLaunchKernelGGL((k_zq_matmul<int8_t, true>), grid, dim3(256), 0, st, (int)ZQ_TRAPDOOR, h->dA, h->m, (size_t)0, h->n, h->mb, h->dR, h->ldr, h->w,
                        h->q, h->two64, h->two31, (const uint64_t*)nullptr, h->dA, h->m, h->mb, h->dGvec, (uint64_t)h->k, d_tag);
   else
-    hipLaunchKernelGGL((k_zq_matmul<int8_t, false>), grid, dim3(256), 0, 0, (int)ZQ_TRAPDOOR, h->dA, h->m, (size_t)0, h->n, h->mb, h->dR, h->ldr, h->w,
+    hipLaunchKernelGGL((k_zq_matmul<int8_t, false>), grid, dim3(256), 0, st, (int)ZQ_TRAPDOOR, h->dA, h->m, (size_t)0, h->n, h->mb, h->dR, h->ldr, h->w,
                        h->q, h->two64, h->two31, (const uint64_t*)nullptr, h->dA, h->m, h->mb, h->dGvec, (uint64_t)h->k, d_tag);
 }
 
-static void split_A(psfp_handle* h) {
-  hipLaunchKernelGGL(k_split_A, dim3(grid_for(h->n_pad * h->K_pad)), dim3(256), 0, 0, h->dA, h->m, h->n, h->m, h->n_pad, h->K_pad, h->NA, h->dA8);
+static void split_A(psfp_handle* h, hipStream_t st = nullptr) {
+  hipLaunchKernelGGL(k_split_A, dim3(grid_for(h->n_pad * h->K_pad)), dim3(256), 0, st, h->dA, h->m, h->n, h->m, h->n_pad, h->K_pad, h->NA, h->dA8);
 }
 
 // out = (mode syndrome) U - A P  or  (mode f_a) A P for the columns [col0, col0 + ncols), with P (K x ld int32) first cut into digit planes
@@ -967,16 +967,22 @@ static void launch_zq_mfma(psfp_handle* h, hipStream_t st, int mode, const int32
 }
 
 // A_bar <- U(Z_q^{n x m_bar}), R <- PlusMinusOneZero, A = [A_bar | G - A_bar R] (gen_trapdoor, gadget_classical.rs:56-68, tag = I)
-static psf_status gen_A_R(psfp_handle* h, uint64_t seed) {
+// side: nullptr, or a non-blocking stream on which A = [A_bar | G - A_bar R] and its digit planes are computed while the caller goes on with R alone (the
+// factorisation of Sigma_2 needs R, not A: psfp_trap_gen); the caller synchronises `side` before anything reads A
+static psf_status gen_A_R(psfp_handle* h, uint64_t seed, hipStream_t side = nullptr) {
   if (gadget_too_short(h->prm.gp.base, h->k, h->q)) return PSF_ERR_MODULUS;
   // mp_perturbation.rs:222 / gpv.rs:84 ; gadget_classical.rs:62-64
   hipLaunchKernelGGL(k_sample_abar, dim3(grid_for(h->n * h->mb)), dim3(256), 0, 0, seed, h->n, h->mb, h->m, h->q, h->dA);
   h->r8_valid = false; h->small_state = 0;
   hipLaunchKernelGGL(k_sample_R, dim3(grid_for(h->mb * h->ldr)), dim3(256), 0, 0, seed, h->mb, h->w, h->ldr, h->dR);
+  if (side) {
+    HIP_TRY(hipEventRecord(h->evIn, nullptr));
+    HIP_TRY(hipStreamWaitEvent(side, h->evIn, 0));
+  }
   // gadget_classical.rs:66
-  launch_zq_trapdoor(h);
+  launch_zq_trapdoor(h, nullptr, side);
   HIP_TRY(hipGetLastError());
-  split_A(h);
+  split_A(h, side);
   return PSF_OK;
 }
 
@@ -1043,11 +1049,13 @@ psf_status psfp_trap_gen(psfp_handle* h, uint64_t seed) {
   HIP_TRY(hipSetDevice(h->prm.device));
   PSFP_QUIESCE(h);
   KeygenClock kc("psfp");
-  const psf_status rcg = gen_A_R(h, seed);
+  // A = [A_bar | G - A_bar R] (13 ms at C3) on the handle's low-priority stream beside the factorisation of Sigma_2, which needs R alone
+  const psf_status rcg = gen_A_R(h, seed, h->aux);
   if (rcg != PSF_OK) return rcg;
-  kc.mark("A, R");
+  kc.mark("A_bar, R (A on the side stream)");
   h->has_pub = h->has_R = true;
   const psf_status rc = build_sqrt_sigma2(h, h->prm.s);            // mp_perturbation.rs:227-231
+  HIP_TRY(hipStreamSynchronize(h->aux));
   if (rc != PSF_OK) { h->has_key = false; return rc; }
   kc.mark("sqrt(Sigma_2)");
   h->has_key = true;
