@@ -52,6 +52,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency legs (batch 1 / 16 / 64)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short c2 / c4 / c3prime legs the default invocation appends (\"other_configs\")")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (launcher, process group, barriers, gather, reductions) on a one-rank RCCL group")
+    ap.add_argument("--oversubscribe", action="store_true", help="REHEARSAL of the N>1 path on a box with fewer GPUs: rank r uses device r %% (GPUs there are), the process group is gloo with a host-staged gather; "
+                    "exercises launcher, sharding by global index, barriers, reductions and the gather with real kernels -- labelled in the line, never a scaling number")
+    ap.add_argument("--verify-gather", action="store_true", help="rank 0 recomputes every rank's last step itself (same key, the rank's first_index) and compares with the gathered rows")
     ap.add_argument("--emulate-world", type=int, default=0, help="with --force-dist: size the gather's buffers as rank 0 of a job of this many ranks would (C5 readiness: 8)")
     ap.add_argument("--multi-handle", action="store_true", help="torch-free scaling mode: ONE process drives --gpus devices through psfp_samp_p_multi (host buffers, one worker thread per handle)")
     ap.add_argument("--launch-timeout", type=float, default=0.0, help="seconds after which the self-launcher stops every rank (0 = none)")
@@ -74,6 +77,8 @@ def launcher_main(args):
     non-zero if any rank does.  `python -m torch.distributed.run ... bench.py --gpus N` keeps working: WORLD_SIZE is then set and this is skipped."""
     from tools_amd import launch
     have = launch.visible_gpu_count()
+    if args.oversubscribe and have >= 1:
+        have = args.gpus                             # ranks share the devices there are (rehearsal mode)
     if have < args.gpus:
         print(f"[bench] --gpus {args.gpus} but this host shows {have} GPU(s) (KFD topology / *_VISIBLE_DEVICES): not starting any rank", file=sys.stderr)
         sys.exit(2)
@@ -98,16 +103,19 @@ def rank_main(args):
     if not torch.cuda.is_available():
         print("[bench] no GPU: tools_amd has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.oversubscribe:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # RCCL refuses two ranks on one device; the rehearsal mode therefore runs its collectives over gloo (host tensors)
+        dist.init_process_group(backend="gloo" if args.oversubscribe else "nccl", rank=rank, world_size=world)
 
     run = run_config(args.config, args.batch, args.steps, args.warmup, local_rank, rank, world, multi, dev, structured=args.structured,
-                     gather=multi and not args.no_gather, force_dist=args.force_dist, alloc_world=args.emulate_world)
+                     gather=multi and not args.no_gather, force_dist=args.force_dist, alloc_world=args.emulate_world, verify_gather=args.verify_gather)
     psf, scheme, n, q, r, s, m, B, u, e = (run[k] for k in ("psf", "scheme", "n", "q", "r", "s", "m", "B", "u", "e"))
     stream, first_index, kern_ms, elapsed, valid, do_gather = (run[k] for k in ("stream", "first_index", "kern_ms", "elapsed", "valid", "do_gather"))
 
@@ -142,6 +150,11 @@ def rank_main(args):
             out["launcher"] = "bench.py (self-spawned ranks, tools_amd/launch.py)" if os.environ.get("PSF_LAUNCHED_BY") else "external (torch.distributed.run or equivalent)"
             if run["gather_info"]:
                 out["gather"] = run["gather_info"]
+            if args.oversubscribe:
+                out["oversubscribed"] = f"{world} ranks on {torch.cuda.device_count()} GPU(s), gloo process group with a host-staged gather: a rehearsal of the N>1 code path, not a scaling measurement"
+                out["config"]["parallelism"] = out["config"]["parallelism"].replace("RCCL gather", "gloo gather (host-staged)")
+            if run.get("gather_verified") is not None:
+                out["gather_verified"] = run["gather_verified"]
         if latency:
             out["latency"] = latency
         if args.config != "c3" or args.structured:
@@ -188,7 +201,7 @@ def rank_main(args):
         sys.exit(4)
 
 
-def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, structured=False, gather=False, force_dist=False, key_seed=3, alloc_world=0):
+def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, structured=False, gather=False, force_dist=False, key_seed=3, alloc_world=0, verify_gather=False):
     """Key generation (outside the timed region, benches/psf.rs:36,61,88), `warmup` untimed steps, then exactly `steps` samp_p passes over one batch of
     uniform syndromes between two fences (device synchronise + barrier + device synchronise), and the correctness gate on the last step's rows."""
     import torch
@@ -255,8 +268,9 @@ def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, s
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
+    gathered = None
     if do_gather:
-        gatherer.finish()                  # every step's rows have reached rank 0 inside the timed region
+        gathered = gatherer.finish()       # every step's rows have reached rank 0 inside the timed region
     fence()
     own = elapsed = time.perf_counter() - t0
     # per-kernel HIP-event times of the last step (events were recorded on the launch stream, no host sync in the loop)
@@ -267,13 +281,26 @@ def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, s
     status = psf.last_status()
     np_form = nearest_plane_form(psf) if hasattr(psf, "nearest_plane_form") else None      # of the timed steps (the latency legs launch other forms)
     rank_elapsed, ranks_seen = [own], 1
+    cdev = torch.device("cpu") if (multi and dist.get_backend() == "gloo") else dev      # the small reductions of a gloo group run on host tensors
     if multi:
         ranks_seen = dist.get_world_size()
-        mine = torch.tensor([own], dtype=torch.float64, device=dev)
+        mine = torch.tensor([own], dtype=torch.float64, device=cdev)
         every = [torch.zeros_like(mine) for _ in range(ranks_seen)]
         dist.all_gather(every, mine)
         rank_elapsed = [float(t.item()) for t in every]
         elapsed = max(rank_elapsed)                  # MAX over ranks
+    gather_verified = None
+    if verify_gather and gathered is not None and rank == 0 and steps > 0:
+        # rank 0 holds the same key: it recomputes every rank's last step from that rank's global indices and compares with what the gather delivered
+        gather_verified = True
+        u_r = torch.empty_like(u)
+        e_r = torch.empty_like(e)
+        for rr in range(world):
+            fi = shard_range(rr, world, B)[0]
+            psf.uniform_targets_dev(u_r.data_ptr(), B, seed=7, first_index=fi, stream=stream)
+            psf.samp_p_dev(u_r.data_ptr(), e_r.data_ptr(), B, seed=1000 + warmup + steps - 1, first_index=fi, stream=stream)
+            torch.cuda.synchronize()
+            gather_verified = gather_verified and bool((gathered[rr].to(torch.int64).cpu() == e_r.cpu()).all().item())
 
     # correctness gate on the last step's output: A e == u and check_domain for every row
     u2 = torch.empty_like(u)
@@ -281,13 +308,15 @@ def run_config(cfg, batch, steps, warmup, local_rank, rank, world, multi, dev, s
     psf.f_a_dev(e.data_ptr(), u2.data_ptr(), ok.data_ptr(), B, stream=stream)
     torch.cuda.synchronize()
     valid = bool((u2 == u).all().item()) and bool(ok.all().item()) and status == 0
+    if gather_verified is False:
+        valid = False
     if multi:                                       # every rank's rows must pass, not only rank 0's
-        vt = torch.tensor([1 if valid else 0], dtype=torch.int32, device=dev)
+        vt = torch.tensor([1 if valid else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(vt, op=dist.ReduceOp.MIN)
         valid = bool(vt.item())
     return {"psf": psf, "scheme": scheme, "n": n, "q": q, "r": r, "s": s, "m": m, "gp": gp, "B": B, "u": u, "e": e, "stream": stream,
             "first_index": first_index, "kern_ms": kern_ms, "elapsed": elapsed, "valid": valid, "do_gather": do_gather, "trap_gen_s": t_trapgen,
-            "rank_elapsed": rank_elapsed, "ranks_seen": ranks_seen, "gather_info": gather_info, "np_form": np_form}
+            "rank_elapsed": rank_elapsed, "ranks_seen": ranks_seen, "gather_info": gather_info, "np_form": np_form, "gather_verified": gather_verified}
 
 
 def nearest_plane_form(psf):

@@ -436,3 +436,26 @@ def test_asynchronous_calls_keep_their_own_status_by_ticket(oracle):
             else:
                 psf.wait_ticket(t)
     psf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["bench64", "c2"])
+def test_two_ranks_rehearse_the_multi_gpu_path_on_the_gpus_there_are(config):
+    """`bench.py --gpus 2 --oversubscribe`: bench.py's own launcher starts two ranks that share this box's GPU (RCCL refuses two ranks on one device, so the
+    process group is gloo and the gather is staged through pinned host memory): everything of the N > 1 path except the RCCL transport runs with real kernels --
+    rank environment, the same key on both ranks, targets and Philox streams by GLOBAL preimage index, barriers, the all-gather of the ranks' clocks, the MIN
+    reduction of the validity bit, the overlapped gather.  `--verify-gather`: rank 0 recomputes each rank's last step itself and compares with the gathered rows."""
+    import json
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--verify-gather", "--config", config, "--no-cpu-baseline",
+                            "--no-latency", "--steps", "3", "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=420,
+                           env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    except subprocess.TimeoutExpired:
+        pytest.fail("the two-rank rehearsal did not finish within 420 s")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["valid"] is True and d["gather_verified"] is True
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["ms_per_step_ranks"]["all"]) == 2
+    assert "self-spawned" in d["launcher"] and "oversubscribed" in d and "gloo gather" in d["config"]["parallelism"]
+    per = {"bench64": 4096, "c2": 1024}[config]
+    assert d["config"]["global_batch"] == 2 * per

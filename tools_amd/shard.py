@@ -74,6 +74,13 @@ class AsyncRowGather:
         self.work = [None] * depth
         self.step = 0
         self.overflow = torch.zeros((), dtype=torch.int32, device=device) if self.enabled else None
+        # A gloo group with device rows (bench.py --oversubscribe: several ranks rehearsing the N > 1 path on the GPUs there are): the collective runs on pinned host
+        # copies of the staging blocks -- gloo has no device gather -- and the received blocks are host tensors.  RCCL groups gather device to device, as before.
+        self.host_staged = bool(self.enabled and dist.get_backend() == "gloo" and isinstance(device, torch.device) and device.type == "cuda")
+        if self.host_staged:
+            self.stage_host = [torch.empty((rows, cols), dtype=torch.int32).pin_memory() for _ in range(depth)]
+            if self.rank == dst:
+                self.recv = [[torch.empty((rows, cols), dtype=torch.int32) for _ in range(self.world)] for _ in range(depth)]
 
     @staticmethod
     def bytes_per_depth(rows, cols, world, is_dst):
@@ -97,7 +104,12 @@ class AsyncRowGather:
         if self.work[i] is not None:
             self.work[i].wait()                      # the previous user of this staging buffer has been delivered
         narrow_rows(e_int64, self.stage[i], self.overflow)       # int64 -> int32 on the current stream
-        self.work[i] = dist.gather(self.stage[i], self.recv[i] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        if self.host_staged:
+            self.stage_host[i].copy_(self.stage[i], non_blocking=True)
+            torch.cuda.current_stream(self.stage[i].device).synchronize()
+            self.work[i] = dist.gather(self.stage_host[i], self.recv[i] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        else:
+            self.work[i] = dist.gather(self.stage[i], self.recv[i] if self.rank == self.dst else None, dst=self.dst, async_op=True)
         self.step += 1
 
     def finish(self):
