@@ -479,9 +479,11 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 768));
   if (const char* e = psf_exp_env("PSF_NP_COMBINE")) g->np_combine = std::atoi(e);
   for (auto& e : g->ev) HIP_TRY(hipEventCreate(&e));
+#ifdef PSF_EXPERIMENTS      /* the two-halves walk (measured neutral: not in the release library) */
   for (auto& sx : g->sh) HIP_TRY(hipStreamCreateWithFlags(&sx, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
   for (auto& e : g->evHalf) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+#endif
   if (const char* e = psf_exp_env("PSF_NP_SPLIT")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) g->np_split = v; }
   if (const char* e = psf_exp_env("PSF_NP_SPLIT_DELAY")) { const int v = std::atoi(e); if (v >= 0 && v <= 1000) g->split_delay_us = v; }
   return PSF_OK;
