@@ -230,8 +230,8 @@ def test_compact_key_copies_of_small_calls_give_the_same_rows(T, oracle, ternary
 
 @pytest.mark.parametrize("B", [1, 2])
 def test_fused_tail_of_one_or_two_preimages_matches_the_oracle_in_every_stage(pair, oracle, B):
-    """k_trmm_stream_fused (round 6): with one or two preimages every wave of the streaming product rounds its own 32 rows of x (four lanes per sample) and adds its
-    share A[:, rows] p[rows] of the syndrome from the transposed compact copy of A; the separate rounding and syndrome launches disappear.  The compact copies are
+    """k_round_syndrome_small (round 6): with one or two preimages ONE launch behind the product rounds x (four lanes per sample) and adds every tile's share
+    A[:, rows] p[rows] of the syndrome from the transposed compact copy of A; the separate rounding and syndrome launches disappear.  The compact copies are
     built beside the first small calls after a key change, so the first call runs the separate kernels and a later one the fused launch: both must give the
     oracle's d, x, p, v, z, e, and the timing slots say which form ran."""
     import time

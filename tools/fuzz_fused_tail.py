@@ -1,4 +1,4 @@
-"""Seeded random configurations through the FUSED tail of a single call (k_trmm_stream_fused: one or two preimages, q <= 2^32, n a multiple of 8): several calls per
+"""Seeded random configurations through the fused rounding + syndrome launch of a single call (k_round_syndrome_small: one or two preimages, q <= 2^32, n a multiple of 8): several calls per
 key -- the first builds the compact copies and runs the separate kernels, the later ones the fused launch -- every call against the CPU oracle, bit for bit.
    python3 tools/fuzz_fused_tail.py <first case> <count>"""
 import math, os, sys, time

@@ -42,17 +42,19 @@ struct StreamGeom {
   int bc;           // CD == 2: preimages the dense normals stream stores per k-step (1, 2, 4, 8 or 16)
 };
 
-// ---- the fused tail of ONE or TWO preimages (round 6) -----------------------------------------------------------------------------------------------
-// A call of one preimage spent 61 us behind the product in two launches that only exist because x is complete: p <- D_{Z,r,x} (25 us for 30 801 draws) and
-// v = u - A p (36 us for one pass over A).  Neither needs ALL of x at once: a wave of k_trmm_stream owns 32 rows of x from k = 0 to the diagonal, so it rounds its
-// own rows as soon as its chain ends and adds its share  A[:, rows] p[rows]  of the syndrome -- the short tasks do so long before the launch ends, only the
-// epilogue of the tasks that finish last is exposed (~8 us), and A is read beside the factor (63 MB next to 3.8 GB).
+// ---- rounding and the syndrome of ONE or TWO preimages in one launch (round 6) -----------------------------------------------------------------------------
+// A call of one preimage spent 61 us behind the product in two launches: p <- D_{Z,r,x} (25 us for 30 801 draws) and v = u - A p (36 us for one pass over A).
+// k_round_syndrome_small does both: a wave owns RT 16-row tiles of x, rounds them and adds its share A[:, rows] p[rows] of the syndrome, so p never travels and one
+// launch disappears (26 + 10 us for the pair; the call 0.825-0.848 -> 0.828-0.833 ms median, 0.814-0.819 -> 0.789-0.791 fastest, same box: tools/fused_skip_sweep2.sh).
 //   rounding: 4 lanes per sample, lane s of a quad evaluates the attempt groups s, s + 4, ... of the sample's own Philox stream (sz_group4 / sz_group4_narrow: the
 //             expressions of k_perturb_round_lean), the lowest accepting group of a round wins -- the first accepted attempt of the stream, i.e. the value every
 //             other sampler of the library returns.  16 samples per pass.
 //   syndrome: lane l owns the rows 8 l ... 8 l + 7 of A (n <= 512 per 64 lanes, more in further rounds), read from the TRANSPOSED compact copy A32T[coordinate][row]
-//             (32 bytes per lane and coordinate), products with p in 64 bits (|a p| < 2^31 2^23), one residue per (row, preimage) into part[task][row][b];
-//             k_zq_combine_wave sums the tasks and subtracts from u, as it does for the K splits of the other forms.  Exact integers: any order, same v.
+//             (32 bytes per lane and coordinate, sixteen coordinates in flight), products with p in 64 bits (|a p| < 2^32 2^23), one residue per (row, preimage)
+//             into part[row][b][task]; k_zq_combine_wave<true> sums the tasks and subtracts from u, as it does for the K splits of the other forms.  Exact
+//             integers: any order, same v.
+// MEASURED AND NOT KEPT: the same epilogue INSIDE the streaming product (every wave rounding its own rows as its chain ends).  It made the product 60-70 us slower
+// (0.67 -> 0.73-0.74 ms) whether or not the longest tasks were excused from it: the epilogues of the short tasks disturb the stream they run beside (profiles/r06_notes.md).
 struct StreamFuse {
   uint64_t seed, first_index;
   size_t m;                       // coordinates (rows of x that exist)
@@ -64,10 +66,106 @@ struct StreamFuse {
   int* fail;
 };
 
+// the epilogue of one task of the fused tail: sx holds the task's RT * 16 rows of x for its bc preimages ((local row) * bc + b); rounding, then the share of A p
+template <int RT>
+__device__ __forceinline__ void fused_tail_epilogue(const StreamFuse& F, int ntask, int bc, int t0, int tg, double* sx, int32_t* spv, int lane) {
+    const int nrow = RT * 16, npos = nrow * bc;                       // samples of this wave: (local row rr, preimage b) at rr * bc + b
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int f = 0;
+    const int sub = lane & 3, quad0 = lane & ~3;
+    const float inv_s_f = (float)F.sp.inv_s;
+    for (int p0 = 0; p0 < npos; p0 += 16) {
+      const int pos = p0 + (lane >> 2);
+      const int rr = pos / bc, b = pos - rr * bc;
+      const uint32_t coord = (uint32_t)(t0 * 16 + rr);
+      const bool live = pos < npos && (size_t)coord < F.m;
+      const double c = live ? sx[pos] : 0.0;
+      const uint64_t index = F.first_index + (uint64_t)b;
+      const uint32_t idx_lo = (uint32_t)index, tw = tag_word(TAG_PERTURB, index);
+      const SzRange rg = sz_range(c, F.sp);
+      const float c_rel = (float)((double)rg.lo - c);
+      const bool generic = !(fabs(c) < 0x1.0p40);
+      bool found = !live;
+      long long x = 0;
+      for (uint32_t t = (uint32_t)sub; ; t += 4) {
+        if (!__builtin_amdgcn_ballot_w64(!found)) break;
+        bool acc1 = false;
+        long long xl = 0;
+        if (!found) {
+          if (t >= kMaxAttempts / 4) { acc1 = true; f = 1; xl = (long long)floor(c + 0.5); }      // (every lane of the quad gets here in the same round: the lowest takes it)
+          else acc1 = generic ? sz_group4(F.seed, coord, idx_lo, tw, t, rg, c, F.sp.inv_s, &xl)
+                              : sz_group4_narrow(F.seed, coord, idx_lo, tw, t, rg, c, F.sp.inv_s, c_rel, inv_s_f, &xl);
+        }
+        const uint32_t qm = (uint32_t)(__builtin_amdgcn_ballot_w64(acc1) >> quad0) & 0xfu;
+        const int src = qm ? quad0 + __builtin_ctz(qm) : lane;
+        const long long xs = __shfl(xl, src);
+        if (!found && qm) { x = xs; found = true; }
+      }
+      if (live && sub == 0) {
+        if (x > kDigitRangeP || x < -kDigitRangeP) f = 1;             // the syndrome product needs |p| < 2^23
+        F.P[(size_t)coord * F.ldp + (size_t)b] = (int32_t)x;
+      }
+      if (pos < npos && sub == 0) spv[pos] = live ? (int32_t)x : 0;
+    }
+    if (f) atomicOr(F.fail, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // this task's share of A p: rows 8 lane ... of A (rounds of 512 rows), coordinates t0 * 16 ... + nrow - 1
+    const size_t c0 = (size_t)t0 * 16;
+    const int ncoord = (int)(c0 + nrow <= F.m ? (size_t)nrow : (F.m > c0 ? F.m - c0 : 0));
+    uint64_t* mypart = F.part + (size_t)tg;                           // part[(row * bc + b) * ntask + task]: the tasks of one output side by side for the combine
+    const bool pow2 = (F.q & (F.q - 1)) == 0;
+    for (size_t j0 = 0; j0 < F.n; j0 += 512) {
+      const size_t j = j0 + (size_t)lane * 8;
+      long long sum[2][8];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum[b][u] = 0;
+      if (j < F.n) {                                                  // (n is a multiple of 8 here: the host checks)
+        // sixteen coordinates' loads in flight at once: under the product's own stream a dependent round trip to memory costs microseconds, so a loop that waited for
+        // one coordinate at a time made this epilogue 110 us long (measured); two batches make it two round trips
+        constexpr int CB = 16;
+        for (int cb = 0; cb < nrow; cb += CB) {
+          uint4 a0[CB], a1[CB];
+#pragma unroll
+          for (int u = 0; u < CB; ++u) {
+            const int ci = cb + u < ncoord ? cb + u : (ncoord > 0 ? ncoord - 1 : 0);      // (clamped: a row past the end is multiplied by p = 0 below)
+            const uint4* src = reinterpret_cast<const uint4*>(F.A32T + (c0 + (size_t)ci) * F.n + j);
+            a0[u] = src[0]; a1[u] = src[1];
+          }
+#pragma unroll
+          for (int u = 0; u < CB; ++u) {
+            const bool in = cb + u < ncoord;
+            const long long pa = in ? (long long)spv[(cb + u) * bc] : 0ll;
+            const long long pb = (in && bc > 1) ? (long long)spv[(cb + u) * bc + 1] : 0ll;
+            const uint32_t av[8] = {a0[u].x, a0[u].y, a0[u].z, a0[u].w, a1[u].x, a1[u].y, a1[u].z, a1[u].w};
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) {
+              sum[0][w8] += (long long)av[w8] * pa;
+              if (bc > 1) sum[1][w8] += (long long)av[w8] * pb;
+            }
+          }
+        }
+        for (int b = 0; b < bc && b < 2; ++b)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            long long r;
+            if (pow2) r = (long long)((uint64_t)sum[b][u] & (F.q - 1));
+            else { r = sum[b][u] % (long long)F.q; if (r < 0) r += (long long)F.q; }
+            mypart[((j + (size_t)u) * (size_t)bc + (size_t)b) * (size_t)ntask] = (uint64_t)r;
+          }
+      }
+    }
+}
+
 // task (descending length) -> (tile group, column group); column groups of one tile group are neighbours in the order
-template <int RT, int NB, int PD, int HALF, int CD, bool FUSE>
+template <int RT, int NB, int PD, int HALF, int CD>
 __device__ __forceinline__ void trmm_stream_body(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
-                                                 const StreamGeom& g, size_t nkb, size_t ldx, size_t row_hi, const StreamFuse* fz) {
+                                                 const StreamGeom& g, size_t nkb, size_t ldx, size_t row_hi) {
   static_assert((PD - 1) * (RT + NB) <= 63, "vmcnt is a 6-bit counter");
   static_assert(CD != 2 || NB == 1, "the dense normals stream holds one fragment");
   static_assert(8 % RT == 0 && 8 % NB == 0, "a tile group stays inside one row block, a column group inside one column block");
@@ -165,123 +263,28 @@ __device__ __forceinline__ void trmm_stream_body(const double* __restrict__ Lt, 
         const size_t row = (size_t)(t0 + i) * 16 + (lane >> 4) + 4 * r;
         if (row < row_hi) X[row * ldx + (size_t)(cf0 + j) * 16 + (lane & 15)] = acc[i][j][r];
       }
-  if constexpr (FUSE) {
-    static_assert(CD == 2 && NB == 1, "the fused tail serves the dense stream of one or two preimages");
-    __shared__ double s_x[2 * HALF][RT * 16 * 2];
-    __shared__ int32_t s_p[2 * HALF][RT * 16 * 2];
-    const StreamFuse& F = *fz;
-    double* sx = s_x[wave];
-    int32_t* spv = s_p[wave];
-    const int nrow = RT * 16, npos = nrow * bc;                       // samples of this wave: (local row rr, preimage b) at rr * bc + b
-    if ((lane & 15) < bc) {
-#pragma unroll
-      for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sx[(i * 16 + (lane >> 4) + 4 * r) * bc + (lane & 15)] = acc[i][0][r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    int f = 0;
-    const int sub = lane & 3, quad0 = lane & ~3;
-    const float inv_s_f = (float)F.sp.inv_s;
-    for (int p0 = 0; p0 < npos; p0 += 16) {
-      const int pos = p0 + (lane >> 2);
-      const int rr = pos / bc, b = pos - rr * bc;
-      const uint32_t coord = (uint32_t)(t0 * 16 + rr);
-      const bool live = pos < npos && (size_t)coord < F.m;
-      const double c = live ? sx[pos] : 0.0;
-      const uint64_t index = F.first_index + (uint64_t)b;
-      const uint32_t idx_lo = (uint32_t)index, tw = tag_word(TAG_PERTURB, index);
-      const SzRange rg = sz_range(c, F.sp);
-      const float c_rel = (float)((double)rg.lo - c);
-      const bool generic = !(fabs(c) < 0x1.0p40);
-      bool found = !live;
-      long long x = 0;
-      for (uint32_t t = (uint32_t)sub; ; t += 4) {
-        if (!__builtin_amdgcn_ballot_w64(!found)) break;
-        bool acc1 = false;
-        long long xl = 0;
-        if (!found) {
-          if (t >= kMaxAttempts / 4) { acc1 = true; f = 1; xl = (long long)floor(c + 0.5); }      // (every lane of the quad gets here in the same round: the lowest takes it)
-          else acc1 = generic ? sz_group4(F.seed, coord, idx_lo, tw, t, rg, c, F.sp.inv_s, &xl)
-                              : sz_group4_narrow(F.seed, coord, idx_lo, tw, t, rg, c, F.sp.inv_s, c_rel, inv_s_f, &xl);
-        }
-        const uint32_t qm = (uint32_t)(__builtin_amdgcn_ballot_w64(acc1) >> quad0) & 0xfu;
-        const int src = qm ? quad0 + __builtin_ctz(qm) : lane;
-        const long long xs = __shfl(xl, src);
-        if (!found && qm) { x = xs; found = true; }
-      }
-      if (live && sub == 0) {
-        if (x > kDigitRangeP || x < -kDigitRangeP) f = 1;             // the syndrome product needs |p| < 2^23
-        F.P[(size_t)coord * F.ldp + (size_t)b] = (int32_t)x;
-      }
-      if (pos < npos && sub == 0) spv[pos] = live ? (int32_t)x : 0;
-    }
-    if (f) atomicOr(F.fail, 1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // this task's share of A p: rows 8 lane ... of A (rounds of 512 rows), coordinates t0 * 16 ... + nrow - 1
-    const size_t c0 = (size_t)t0 * 16;
-    const int ncoord = (int)(c0 + nrow <= F.m ? (size_t)nrow : (F.m > c0 ? F.m - c0 : 0));
-    uint64_t* mypart = F.part + (size_t)tg;                           // part[(row * bc + b) * ntask + task]: the tasks of one output side by side for the combine
-    const bool pow2 = (F.q & (F.q - 1)) == 0;
-    for (size_t j0 = 0; j0 < F.n; j0 += 512) {
-      const size_t j = j0 + (size_t)lane * 8;
-      long long sum[2][8];
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sum[b][u] = 0;
-      if (j < F.n) {                                                  // (n is a multiple of 8 here: the host checks)
-        // sixteen coordinates' loads in flight at once: under the product's own stream a dependent round trip to memory costs microseconds, so a loop that waited for
-        // one coordinate at a time made this epilogue 110 us long (measured); two batches make it two round trips
-        constexpr int CB = 16;
-        for (int cb = 0; cb < nrow; cb += CB) {
-          uint4 a0[CB], a1[CB];
-#pragma unroll
-          for (int u = 0; u < CB; ++u) {
-            const int ci = cb + u < ncoord ? cb + u : (ncoord > 0 ? ncoord - 1 : 0);      // (clamped: a row past the end is multiplied by p = 0 below)
-            const uint4* src = reinterpret_cast<const uint4*>(F.A32T + (c0 + (size_t)ci) * F.n + j);
-            a0[u] = src[0]; a1[u] = src[1];
-          }
-#pragma unroll
-          for (int u = 0; u < CB; ++u) {
-            const bool in = cb + u < ncoord;
-            const long long pa = in ? (long long)spv[(cb + u) * bc] : 0ll;
-            const long long pb = (in && bc > 1) ? (long long)spv[(cb + u) * bc + 1] : 0ll;
-            const uint32_t av[8] = {a0[u].x, a0[u].y, a0[u].z, a0[u].w, a1[u].x, a1[u].y, a1[u].z, a1[u].w};
-#pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) {
-              sum[0][w8] += (long long)av[w8] * pa;
-              if (bc > 1) sum[1][w8] += (long long)av[w8] * pb;
-            }
-          }
-        }
-        for (int b = 0; b < bc && b < 2; ++b)
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            long long r;
-            if (pow2) r = (long long)((uint64_t)sum[b][u] & (F.q - 1));
-            else { r = sum[b][u] % (long long)F.q; if (r < 0) r += (long long)F.q; }
-            mypart[((j + (size_t)u) * (size_t)bc + (size_t)b) * (size_t)g.ntask] = (uint64_t)r;
-          }
-      }
-    }
-  }
 }
 
 template <int RT, int NB, int PD, int HALF = 4, int CD = 0>
 __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
                                                         StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
-  trmm_stream_body<RT, NB, PD, HALF, CD, false>(Lt, Dt, X, g, nkb, ldx, row_hi, nullptr);
+  trmm_stream_body<RT, NB, PD, HALF, CD>(Lt, Dt, X, g, nkb, ldx, row_hi);
 }
-// the same launch with the fused tail (one or two preimages, dense normals stream)
-template <int RT, int PD, int HALF>
-__global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream_fused(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
-                                                              StreamGeom g, size_t nkb, size_t ldx, size_t row_hi, StreamFuse fz) {
-  trmm_stream_body<RT, 1, PD, HALF, 2, true>(Lt, Dt, X, g, nkb, ldx, row_hi, &fz);
+// rounding + syndrome shares of one or two preimages in ONE launch behind the product: one wave per RT 16-row tiles of x
+template <int RT>
+__global__ __launch_bounds__(256) void k_round_syndrome_small(const double* __restrict__ X, size_t ldx, size_t row_hi, StreamGeom g, StreamFuse fz) {
+  __shared__ double s_x[4][RT * 16 * 2];
+  __shared__ int32_t s_p[4][RT * 16 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int task = (int)blockIdx.x * 4 + wave;
+  if (task >= g.ntask) return;                                       // (wave-uniform; no barrier in here)
+  const int tg = task, t0 = tg * RT, bc = g.bc;
+  double* sx = s_x[wave];
+  for (int e = lane; e < RT * 16 * bc; e += 64) {
+    const size_t row = (size_t)t0 * 16 + (size_t)(e / bc);
+    sx[e] = row < row_hi ? X[row * ldx + (size_t)(e % bc)] : 0.0;
+  }
+  fused_tail_epilogue<RT>(fz, g.ntask, bc, t0, tg, sx, s_p[wave], lane);
 }
 // A32T[coordinate][row] = A[row][coordinate] (the compact copy the fused tail reads): 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void k_transpose_A32(const uint64_t* __restrict__ A, size_t n, size_t m, uint32_t* __restrict__ A32T) {

@@ -1268,15 +1268,16 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     const NormalsFixed fx = h->structured ? NormalsFixed{h->mb, h->dD8, h->ldr * ld, ld, h->dX, h->h_const} : NormalsFixed{0, nullptr, 0, 0, nullptr, 0.0};
     hipLaunchKernelGGL(k_normals_wave, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail, fx, ncf, nseg);
   }
-  // One or two preimages: the rounding and this call's share of the syndrome ride in the product's launch (k_trmm_stream_fused, psf_stream_kernels.hpp) once the
-  // transposed compact copy of A is there (built beside the first small calls after a key change, as the other compact copies)
+  // One or two preimages: rounding and syndrome in ONE launch behind the product (k_round_syndrome_small, psf_stream_kernels.hpp) once the transposed compact copy
+  // of A is there (built beside the first small calls after a key change, as the other compact copies)
   bool fused_tail = false;
-  int fused_ntask = 0;
+  int fused_ntask = 0, fused_rt = 2;      // two 16-row tiles per wave: 27 + 10 us against 34 + 14 with one (tools/fused_tail_ab.sh)
   if (stream && bc && B <= 2 && RT == 2 && NB == 1 && !h->structured && !pipe && h->szR.sh == 16 && !(h->prm.flags & PSFP_FLAG_NO_PERTURB)) {
     ensure_small_copies(h, st);
     const char* fe = psf_exp_env("PSF_FUSED_TAIL");
     if (h->dA32T && (h->small_state == 2 || h->small_state == 3) && !(fe && std::atoi(fe) == 0)) {
-      fused_ntask = ((int)((h->mL + 15) / 16) + 1) / 2;
+      if (const char* e = psf_exp_env("PSF_FUSED_RT")) fused_rt = std::atoi(e) == 1 ? 1 : 2;
+      fused_ntask = ((int)((h->mL + 15) / 16) + fused_rt - 1) / fused_rt;      // one wave per fused_rt 16-row tiles of x
       const size_t need = (size_t)fused_ntask * h->n * 2;
       if (need > h->partF_cap) {
         hipFree(h->dPartF); h->dPartF = nullptr; h->partF_cap = 0;
@@ -1286,7 +1287,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
   }
   {  // x = sqrt(Sigma_2) d   (structured: the m_bar x m_bar block L_1 d_1; rows from m_bar on already hold x_bot = h d_2)
-    ScopedTimer t(h, st, "k_trmm_f64");      // (with the fused tail the slot covers x, p and the shares of A p; "k_perturb_round" is then absent from the timing)
+    ScopedTimer t(h, st, "k_trmm_f64");
     // default: k_trmm_f64_big (one workgroup per CU, accumulators in AccVGPRs); PSF_TRMM_VARIANT=1: k_trmm_f64_reg (two 128 x 128 workgroups per CU,
     // operands streamed into registers), 0: k_trmm_f64 (LDS-staged, round 1).  Same bits from all three.
     const char* venv = psf_exp_env("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
@@ -1303,13 +1304,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         hipLaunchKernelGGL(kern, dim3((unsigned)((g.ntask + 2 * half - 1) / (2 * half))), dim3(128 * half), 0, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
       };
 #define TS_GO(rt, nb, pd, half) { if (compact) go(k_trmm_stream<rt, nb, pd, half, 1>, rt, half); else go(k_trmm_stream<rt, nb, pd, half, 0>, rt, half); }
-      if (fused_tail) {
-        StreamGeom g;
-        g.ntile = (ntile16 + 1) / 2; g.ncg = 1; g.ntask = g.ntile; g.bc = bc;
-        const StreamFuse fz{seed, first_index, m, h->szR, h->dP, ld, h->dA32T, h->n, h->q, h->dPartF, h->dFail};
-        hipLaunchKernelGGL((k_trmm_stream_fused<2, 12, 2>), dim3((unsigned)((g.ntask + 3) / 4)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi, fz);
-      }
-      else if (bc && RT == 2 && NB == 1) go(k_trmm_stream<2, 1, 12, 2, 2>, 2, 2);
+      if (bc && RT == 2 && NB == 1) go(k_trmm_stream<2, 1, 12, 2, 2>, 2, 2);
       else if (bc && NB == 1) go(k_trmm_stream<1, 1, 8, 4, 2>, 1, 4);
       else if (RT == 2 && NB == 1) TS_GO(2, 1, 12, 2)
       else if (RT == 2 && NB == 2 && B <= 32) TS_GO(2, 2, 8, 2)
@@ -1349,6 +1344,15 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // The stages behind the product, for the columns [b0, b0 + Bh) of the batch on stream sx.  Column offsets: [coord][b] matrices move by b0 elements,
   // digit planes ([group][b][16]) by 16 b0 bytes, row-major API matrices by b0 rows; the Z_q product takes its window as (col0, ncols).
   auto tail = [&](hipStream_t sx, size_t b0, size_t Bh) {
+    if (fused_tail) {   // p_i <- D_{Z,r,x_i} and every 16-row tile's share of A p, one launch (k_round_syndrome_small)
+      ScopedTimer t(h, sx, "k_round+A p");
+      StreamGeom g;
+      g.ntile = fused_ntask; g.ncg = 1; g.ntask = fused_ntask; g.bc = bc;
+      const StreamFuse fz{seed, first_index, m, h->szR, h->dP, ld, h->dA32T, h->n, h->q, h->dPartF, h->dFail};
+      const size_t row_hi2 = h->structured ? h->mb : h->M_pad;
+      if (fused_rt == 1) hipLaunchKernelGGL((k_round_syndrome_small<1>), dim3((unsigned)((g.ntask + 3) / 4)), dim3(256), 0, sx, h->dX, ld, row_hi2, g, fz);
+      else hipLaunchKernelGGL((k_round_syndrome_small<2>), dim3((unsigned)((g.ntask + 3) / 4)), dim3(256), 0, sx, h->dX, ld, row_hi2, g, fz);
+    }
     if (!fused_tail) {  // p_i <- D_{Z,r,x_i}
       ScopedTimer t(h, sx, "k_perturb_round");
       const char* renv = psf_exp_env("PSF_ROUND");                 // "wave": the round-2 kernel (comparison arm; same bits)
