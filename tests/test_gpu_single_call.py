@@ -257,3 +257,90 @@ def test_fused_tail_of_one_or_two_preimages_matches_the_oracle_in_every_stage(pa
         time.sleep(0.05)                              # the packers of the compact copies finish in the background
     if q <= 2**32 and n % 8 == 0:
         assert fused_seen, "the fused launch never ran"
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("B", [17, 33, 48, 64, 65, 100, 128, 129, 300, 1000])
+def test_shared_operand_tiles_give_the_batch_kernels_bits(exp_pair, exp_lib, oracle, B):
+    """k_trmm_stream_wg (64 x 64 tiles, operands shared through LDS; the default at 33 ... 64 preimages) at every batch size the experiments build lets it serve
+    (PSF_STREAM_WG = smallest batch, PSF_STREAM_WG_MAX = largest): the bits of k_trmm_f64_big (PSF_TRMM_STREAM_MAX = 0).  The shapes have 31 / 59 / 83 sixteen-row
+    tiles: the last tile group is ragged, the task count odd or even, and the ring runs 16 k-steps past the diagonal."""
+    psf, orc, n, q = exp_pair
+    u = oracle.uniform_targets(6, B, n, q)
+    ref = _with_env({"PSF_TRMM_STREAM_MAX": "0", "PSF_STREAM_WG": None, "PSF_STREAM_WG_MAX": None}, lambda: psf.samp_p_stages(u, seed=19, first_index=7))
+    got = _with_env({"PSF_TRMM_STREAM_MAX": "4096", "PSF_STREAM_WG": "17", "PSF_STREAM_WG_MAX": "1024"}, lambda: psf.samp_p_stages(u, seed=19, first_index=7))
+    one = _with_env({"PSF_TRMM_STREAM_MAX": "4096", "PSF_STREAM_WG": "0"}, lambda: psf.samp_p_stages(u, seed=19, first_index=7))
+    assert (got["x"].view(np.uint64) == ref["x"].view(np.uint64)).all(), "the shared-operand tiles differ from k_trmm_f64_big"
+    assert (one["x"].view(np.uint64) == ref["x"].view(np.uint64)).all(), "the one-wave tasks differ from k_trmm_f64_big"
+    assert (got["e"] == ref["e"]).all()
+    if B <= 129:
+        assert (got["e"] == orc.samp_p(19, u, first_index=7)).all()
+
+
+@pytest.mark.parametrize("B", [40, 64])
+def test_shared_operand_tiles_with_the_structured_factor(T, oracle, B):
+    """the chunk-stream layout of the normals (structured handles keep it): k_trmm_stream_wg<.., 0> is what 33 ... 64 preimages take there"""
+    n, q, r, s = 32, 256, 5.0, 120.0
+    gp = T.GadgetParameters.init_default(n, q)
+    psf = T.PSFPerturbation(gp, r, s, structured=True)
+    A, (R, L1, _) = psf.trap_gen(11)
+    orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s, with_L=False)
+    orc.load_key(A, R)
+    u = oracle.uniform_targets(3, B, n, q)
+    st = psf.samp_p_stages(u, seed=77, first_index=1000)
+    for b in (0, 15, 16, 33, B - 1):
+        tr = orc.samp_p_structured_trace(L1, s, 77, 1000 + b, u[b])
+        assert (st["x"][b].view(np.uint64) == tr["x"].view(np.uint64)).all(), "centres differ"
+        assert (st["e"][b] == tr["e"]).all()
+    psf.close()
+
+
+@pytest.mark.parametrize("B", [1, 3, 16, 17, 64, 65, 100, 257])
+def test_gadget_walk_with_a_quad_per_problem_equals_the_other_forms(exp_pair, exp_lib, oracle, B):
+    """k_gadget_quad (four lanes per problem; the default between 4 097 and 98 304 problems) forced at every size against the default choice of the same batch and
+    the queue kernel: the same z, hence the same rows"""
+    psf, orc, n, q = exp_pair
+    u = oracle.uniform_targets(12, B, n, q)
+    ref = _with_env({"PSF_GADGET_QUAD": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))
+    quad = _with_env({"PSF_GADGET_QUAD": "100000000", "PSF_GADGET_WAVE": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))
+    queue = _with_env({"PSF_GADGET_QUAD": "0", "PSF_GADGET_WAVE": "0", "PSF_GADGET_WAVE16": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))
+    assert (quad["z"] == ref["z"]).all() and (queue["z"] == ref["z"]).all()
+    assert (quad["e"] == ref["e"]).all()
+    assert (quad["e"] == orc.samp_p(23, u, first_index=99)).all()
+
+
+@pytest.mark.parametrize("n,q,base,k,m_bar,r,s,B", [(70, 625, 5, 4, 70 * 4 + 4, 2.0, 600.0, 64), (80, 538, 5, 4, 80 * 4 + 4, 2.0, 600.0, 100), (24, 2**40, 2, 40, 24 * 40 + 8, 3.0, 600.0, 200),
+                                                    (9, 2**61 - 1, 2, 61, 9 * 61 + 5, 2.0, 400.0, 500)])
+def test_gadget_quad_kernel_general_base_and_long_chains(oracle, n, q, base, k, m_bar, r, s, B):
+    """more than 4 096 problems by default parameters: base 5 with q = base^k and with a digit column, and chains of 40 and 61 draws (k_gadget_quad<16>), against the oracle"""
+    import tools_amd as T
+    gp = T.GadgetParameters(n, k, m_bar, base, q)
+    psf = T.PSFPerturbation(gp, r, s)
+    A, (R, Lp, _) = psf.trap_gen(2)
+    orc = oracle.PSFPerturbation(oracle.GadgetParams(n, k, m_bar, base, q), r, s)
+    orc.load_key(A, R, Lp)
+    assert 4096 < n * B <= 98304
+    u = oracle.uniform_targets(4, B, n, q)
+    e = psf.samp_p(u, seed=5, first_index=17)
+    assert psf.last_status() == 0
+    sub = [0, 1, B // 2, B - 1]
+    for b in sub:
+        assert (e[b] == orc.samp_p(5, u[b:b + 1], first_index=17 + b)[0]).all()
+    assert (psf.f_a(e) == u).all() and psf.check_domain(e).all()
+    psf.close()

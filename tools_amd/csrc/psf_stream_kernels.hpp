@@ -270,6 +270,134 @@ __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(cons
                                                         StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
   trmm_stream_body<RT, NB, PD, HALF, CD>(Lt, Dt, X, g, nkb, ldx, row_hi);
 }
+// ---- 33 ... 1024 preimages: the operands SHARED by the four waves of a 64 x 64 tile through LDS (round 6) ---------------------------------------------------
+// k_trmm_stream at 64 and at 128 preimages runs at the same ~19.5 bytes per clock and CU of operand fetches (one 512-byte fragment per MFMA at 64 preimages: 1.28 ms
+// where the matrix pipe needs 0.77; 0.75 fragments per MFMA at 128: 1.87 against 1.54): what bounds it is neither HBM nor the matrix pipe but what a CU can pull
+// through its L1.  Here four waves (2 x 2, each 2 x 2 MFMA tiles) own 64 rows x 64 preimages and fetch every fragment of the factor and of the normals ONCE per
+// workgroup half, by LDS-DMA: 4 KiB per k-step for 16 MFMAs = a quarter of the fetches.  Every accumulator is still one ascending-k chain from +0 (same bits); a
+// tile group runs to the diagonal of its LAST 16-row tile, the shorter tiles add the stream's explicit zeros behind their diagonals (exact).
+//   ring: NBUF buffers of H k-steps per half; round r: wait for the own pieces of round r (vmcnt), ONE barrier (everybody's pieces of round r have landed, and
+//   everybody is done reading round r - 1), refill the buffer of round r - 1 with round r + NBUF - 1, consume.  Loads run NBUF - 1 rounds ahead of the MFMAs and,
+//   as in k_trmm_stream, up to that far past the diagonal (bytes that exist and are never consumed).
+//   balance: waves 0-3 take the long task `slot`, waves 4-7 its mirror (the two lengths add up to the same for every slot), wave w and w + 4 share a SIMD; the
+//   short half leaves when it is done (s_barrier counts the surviving waves only).
+constexpr int TSW_H = 4, TSW_NBUF = 4;                                // k-steps per round, rounds in the ring
+constexpr size_t TSW_LDS = (size_t)2 * TSW_NBUF * TSW_H * 4096;       // 128 KiB: one workgroup per CU
+// one piece (64 lanes x 16 bytes) of a k-step from global memory into LDS at `lds` + lane * 16: wave-uniform base, a per-lane 32-bit offset -- no vector
+// arithmetic per load (an FP64 MFMA holds the SIMD's vector pipe; scalar and memory instructions issue beside it)
+__device__ __forceinline__ void tsw_dma(uint32_t lds, uint32_t voff, const void* base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds), "v"(voff), "s"(base) : "memory");      // (M0 is reserved: the compiler sets it before every use of its own and has none in these kernels)
+}
+template <int H, int NBUF, int CD>
+__global__ __launch_bounds__(512, 1) void k_trmm_stream_wg(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
+                                                           StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
+  static_assert(H == 4 && NBUF == 4, "the loop below is written out for rounds of four k-steps in a ring of four");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int KS_D = 512;                                          // doubles per k-step of a half: 4 fragments of the factor | 4 of the normals
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = wave >> 2, w4 = wave & 3;
+  const int slot = (int)blockIdx.x, mirror = g.ntask - 1 - slot;
+  if (half ? mirror <= slot : slot > mirror) return;                 // the middle of an odd count belongs to the long half
+  const int task = half ? mirror : slot;
+  const int tg = g.ntile - 1 - task / g.ncg, cg = task % g.ncg;      // g.ntile: groups of four 16-row tiles, g.ncg: groups of four column fragments
+  const int t0 = tg * 4;
+  const int nround = t0 + 4;                                         // 4 (t0 + 4) k-steps to the diagonal of the group's last tile, four per round; a multiple of 4
+  const int bi = t0 >> 3, tl = t0 & 7;
+  const int cf0 = cg * 4;
+  const size_t strideB = CD ? (size_t)g.ncg * 4 * 64 : 512;          // doubles per k-step of the normals stream (compact: [k-step][fragment][lane] over the fragments in use)
+  // piece w4 of a k-step: 0, 1 = the factor's four fragments (2 KiB, contiguous in the chunk stream), 2, 3 = the normals' four fragments (2 KiB, contiguous)
+  const double* src = w4 < 2 ? Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK + (size_t)tl * 64 + (size_t)w4 * 128
+                             : (CD ? Dt + (size_t)cf0 * 64 : Dt + (size_t)(cf0 >> 3) * nkb * TR_CHUNK + (size_t)(cf0 & 7) * 64) + (size_t)(w4 - 2) * 128;
+  const size_t sstride = w4 < 2 ? (size_t)512 : strideB;
+  uint32_t voff[H];
+#pragma unroll
+  for (int u = 0; u < H; ++u) voff[u] = (uint32_t)lane * 16u + (uint32_t)u * (uint32_t)sstride * 8u;
+  double* ring = smem + (size_t)half * (NBUF * H * KS_D);
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void_ptr)ring + (uint32_t)w4 * 1024u;      // this wave's piece of k-step 0 of buffer 0
+  const char* sbase = reinterpret_cast<const char*>(src);            // the wave's piece of the round the next fill brings
+  const size_t round_bytes = (size_t)H * sstride * 8;
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  const int wr = w4 >> 1, wc = w4 & 1;
+  const double* rdA = ring + (wr * 2) * 64 + lane;                   // fragment wr * 2 of the factor, this lane's element; the next fragment 64 doubles on
+  const double* rdB = ring + 256 + (wc * 2) * 64 + lane;
+#pragma unroll
+  for (int r = 0; r < NBUF; ++r) {
+#pragma unroll
+    for (int u = 0; u < H; ++u) tsw_dma(lds0 + (uint32_t)(r * H + u) * 4096u, voff[u], sbase);
+    sbase += round_bytes;
+  }
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NBUF - 1) * H) : "memory");      // round 0 is there
+  double a0[2][2], b0[2][2], a1[2][2], b1[2][2];                     // k-steps 0, 1 and 2, 3 of a round: [k-step][fragment]
+  auto rd = [&](double (&a)[2][2], double (&b)[2][2], int off) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      a[u][0] = rdA[off + u * KS_D]; a[u][1] = rdA[off + u * KS_D + 64];
+      b[u][0] = rdB[off + u * KS_D]; b[u][1] = rdB[off + u * KS_D + 64];
+    }
+  };
+  auto mm = [&](double x, double y, int i, int j) { acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[i][j], 0, 0, 0); };
+  rd(a0, b0, 0);
+  // One round: [a0 / b0 hold k-steps 0, 1]; k-steps 2, 3 are read while the first eight MFMAs run; behind them ONE barrier says that round r + 1 has landed for
+  // everybody and that nobody reads buffer r any more; the refills of buffer r (round r + NBUF) and the reads of round r + 1 issue between the last eight MFMAs.
+  auto round = [&](auto BUFC) {
+    constexpr int BUF = decltype(BUFC)::value;
+    constexpr int cur = BUF * H * KS_D, nxt = ((BUF + 1) % NBUF) * H * KS_D;
+    rd(a1, b1, cur + 2 * KS_D);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a0[0][0], b0[0][0], 0, 0); mm(a0[0][0], b0[0][1], 0, 1); mm(a0[0][1], b0[0][0], 1, 0); mm(a0[0][1], b0[0][1], 1, 1);
+    mm(a0[1][0], b0[1][0], 0, 0); mm(a0[1][0], b0[1][1], 0, 1); mm(a0[1][1], b0[1][0], 1, 0); mm(a0[1][1], b0[1][1], 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((NBUF - 2) * H) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a1[0][0], b1[0][0], 0, 0);
+    tsw_dma(lds0 + (uint32_t)(BUF * H + 0) * 4096u, voff[0], sbase);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a1[0][0], b1[0][1], 0, 1);
+    tsw_dma(lds0 + (uint32_t)(BUF * H + 1) * 4096u, voff[1], sbase);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a1[0][1], b1[0][0], 1, 0);
+    tsw_dma(lds0 + (uint32_t)(BUF * H + 2) * 4096u, voff[2], sbase);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a1[0][1], b1[0][1], 1, 1);
+    tsw_dma(lds0 + (uint32_t)(BUF * H + 3) * 4096u, voff[3], sbase);
+    sbase += round_bytes;
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a1[1][0], b1[1][0], 0, 0);
+    a0[0][0] = rdA[nxt]; a0[0][1] = rdA[nxt + 64];
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a1[1][0], b1[1][1], 0, 1);
+    b0[0][0] = rdB[nxt]; b0[0][1] = rdB[nxt + 64];
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a1[1][1], b1[1][0], 1, 0);
+    a0[1][0] = rdA[nxt + KS_D]; a0[1][1] = rdA[nxt + KS_D + 64];
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a1[1][1], b1[1][1], 1, 1);
+    b0[1][0] = rdB[nxt + KS_D]; b0[1][1] = rdB[nxt + KS_D + 64];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int r = 0; r < nround; r += NBUF) {
+    round(std::integral_constant<int, 0>{});
+    round(std::integral_constant<int, 1>{});
+    round(std::integral_constant<int, 2>{});
+    round(std::integral_constant<int, 3>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the over-read pieces land before the workgroup's LDS is released
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = (size_t)(t0 + wr * 2 + i) * 16 + (lane >> 4) + 4 * r;
+        if (row < row_hi) X[row * ldx + (size_t)(cf0 + wc * 2 + j) * 16 + (lane & 15)] = acc[i][j][r];
+      }
+}
+
 // rounding + syndrome shares of one or two preimages in ONE launch behind the product: one wave per RT 16-row tiles of x
 template <int RT>
 __global__ __launch_bounds__(256) void k_round_syndrome_small(const double* __restrict__ X, size_t ldx, size_t row_hi, StreamGeom g, StreamFuse fz) {
@@ -501,6 +629,130 @@ __global__ __launch_bounds__(256) void k_gadget_wave16(uint64_t seed, uint64_t f
       const int r = sl * 16 + ln;
       if (r >= (int)k) continue;
       const int32_t zz = -c[sl];
+      const int32_t zl = (int32_t)(int8_t)(zz & 0xff);
+      const int32_t zh = (zz - zl) >> 8;
+      const size_t cc = (size_t)j * k + (size_t)r;
+      const size_t addr = ((cc >> 4) * ld + b) * 16 + (cc & 15);
+      Zlo[addr] = (int8_t)zl;
+      Zhi[addr] = (int8_t)zh;
+      if (zh) anyhi = 1;
+    }
+  }
+  if (f) atomicOr(fail, 1);
+  if (anyhi) atomicOr(fail + 1, 1);
+}
+
+// ---- the same walk with FOUR lanes per problem (sixteen problems per wave): tens to a few hundred preimages (round 6) ---------------------------------------------
+// k_gadget_wave16 spends 2 600 issue cycles per step on four problems (sixteen exact attempts per problem and round, the centre chain repeated by sixteen lanes):
+// from ~8 k problems on the instruction stream bounds it (0.32 ms at 64 preimages of C3), and the queue kernel, whose lanes never wait, has a floor of 0.23 ms however
+// few the problems (a step is three trips through its LDS queues and a projection with dependent LDS reads).  Here a QUAD owns a problem: lane s of the quad holds
+// c_r for r = s, s + 4, ...; it evaluates the attempt groups s, s + 4, ... of the current draw (sz_group4_narrow: one Philox block and four fp32 screens for four
+// attempts, the exact decision only inside the 0.1 % band), sixteen attempts per problem and round as before, the lowest accepting group wins = the first accepted
+// attempt of the draw's own Philox stream.  The centre chain takes its terms by v_mov_dpp quad_perm, the coefficients by v_readlane (lane L <-> row L), unrolled
+// behind wave-uniform guards on the support of b~_i.  Same checks, same values as the other three kernels.  KT = ceil(k / 4) rounded up to 8 or 16.
+template <int S> __device__ __forceinline__ int ts_quad_share(int v) { return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xf, 0xf, false); }
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q, uint64_t base, size_t B, size_t ld,
+                                                     const uint64_t* __restrict__ V, GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
+                                                     int* __restrict__ fail) {
+  const int lane = threadIdx.x & 63, quad0 = lane & ~3, sub = lane & 3;
+  const size_t total = (size_t)n * B;
+  const size_t pid0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  if (pid0 >= total) return;                                    // wave-uniform; no barrier in this kernel
+  const size_t pid = pid0 + (size_t)(lane >> 2);
+  const bool active = pid < total;
+  const uint32_t j = active ? (uint32_t)(pid / B) : 0;
+  const size_t b = active ? pid % B : 0;
+  int f = 0;
+  int c[KT];
+  {  // digits of v_j: row r = 4 t + sub
+    const uint64_t v0 = V[(size_t)j * ld + b] % q;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int r = 4 * t + sub;
+      uint64_t v = v0, d = 0;
+      if (base == 2) d = (v >> r) & 1;
+      else for (int u = 0; u <= r && u < (int)k; ++u) { d = v % base; v = (v - d) / base; }
+      c[t] = r < (int)k ? -(int)d : 0;
+    }
+  }
+  const uint64_t index = first_index + b;
+  const uint32_t tw = tag_word(TAG_GADGET, index), idx_lo = (uint32_t)index;
+  // per-step scalars and the coefficient column: held wave-wide, lane L <-> step / row L (k <= 64), read by v_readlane
+  const int li = lane < (int)k ? lane : 0;
+  const double my_norm2 = tb.norm2[li];
+  const SampleZParams my_sz = tb.sz[li];
+  const int my_glo = tb.rng[li], my_ghi = tb.rng[k + li];
+  auto bcast_d = [&](double x, int src) -> double {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(__double2loint(x), src), hi = (uint32_t)__builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double((int)hi, (int)lo);
+  };
+  auto bcast_ll = [&](long long x, int src) -> long long {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), src);
+    return (long long)(((uint64_t)hi << 32) | lo);
+  };
+  double gcol = tb.gso[(size_t)li * k + (k - 1)];
+  int skc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) { const int r = 4 * t + sub; skc[t] = r < (int)k ? tb.Sk[(size_t)r * k + (k - 1)] : 0; }
+  for (int i = (int)k - 1; i >= 0; --i) {
+    const double g_now = gcol;
+    int sk_now[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) sk_now[t] = skc[t];
+    if (i > 0) {                                                 // in flight during this step
+      gcol = tb.gso[(size_t)li * k + (i - 1)];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) { const int r = 4 * t + sub; skc[t] = r < (int)k ? tb.Sk[(size_t)r * k + (i - 1)] : 0; }
+    }
+    // centre <c, b~_i> / ||b~_i||^2: ONE ascending fma chain over the support of b~_i (zeros outside: skipped, exact), per quad its own c
+    double dot = 0.0;
+    const int glo = __builtin_amdgcn_readlane(my_glo, i), ghi = __builtin_amdgcn_readlane(my_ghi, i);
+    ts_for<0, 4 * KT>([&](auto R) {
+      constexpr int r = decltype(R)::value;
+      if (r >= glo && r <= ghi) dot = fma((double)ts_quad_share<r % 4>(c[r / 4]), bcast_d(g_now, r), dot);      // (wave-uniform guard)
+    });
+    const double cen = dot / bcast_d(my_norm2, i);
+    SampleZParams sp;
+    sp.inv_s = bcast_d(my_sz.inv_s, i); sp.c6 = bcast_ll(my_sz.c6, i); sp.f6 = bcast_ll(my_sz.f6, i);
+    sp.n_int = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.n_int, i); sp.thr_int = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.thr_int, i);
+    sp.thr_frac = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.thr_frac, i); sp.sh = (uint32_t)__builtin_amdgcn_readlane((int)my_sz.sh, i);
+    const SzRange rg = sz_range(cen, sp);
+    const bool narrow = sp.sh == 16 && fabs(cen) < 0x1.0p30;
+    const float c_rel = (float)((double)rg.lo - cen), inv_s_f = (float)sp.inv_s;
+    const uint32_t coord = j * k + (uint32_t)i;
+    long long x = 0;
+    bool found = !active;
+    for (uint32_t t = (uint32_t)sub; ; t += 4) {                 // a round: the groups 4 R .. 4 R + 3 of every quad's draw; a quad that has found its draw idles
+      if (!__builtin_amdgcn_ballot_w64(!found)) break;
+      bool acc1 = false;
+      long long xl = 0;
+      if (!found) {
+        if (t >= kMaxAttempts / 4) { acc1 = true; f = 1; xl = (long long)floor(cen + 0.5); }      // (every lane of the quad gets here in the same round: the lowest takes it)
+        else acc1 = narrow ? sz_group4_narrow(seed, coord, idx_lo, tw, t, rg, cen, sp.inv_s, c_rel, inv_s_f, &xl)
+                           : sz_group4(seed, coord, idx_lo, tw, t, rg, cen, sp.inv_s, &xl);
+      }
+      const uint32_t qm = (uint32_t)(__builtin_amdgcn_ballot_w64(acc1) >> quad0) & 0xfu;
+      const int src = qm ? quad0 + __builtin_ctz(qm) : lane;
+      const long long xs = __shfl(xl, src);
+      if (!found && qm) { x = xs; found = true; }
+    }
+    if (active && (x > 16000 || x < -16000)) f = 1;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int nv = c[t] - (int)x * sk_now[t];
+      if (active && 4 * t + sub < (int)k && (nv > 32767 || nv < -32768)) f = 1;
+      c[t] = nv;
+    }
+  }
+  int anyhi = 0;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int r = 4 * t + sub;
+      if (r >= (int)k) continue;
+      const int32_t zz = -c[t];
       const int32_t zl = (int32_t)(int8_t)(zz & 0xff);
       const int32_t zh = (zz - zl) >> 8;
       const size_t cc = (size_t)j * k + (size_t)r;

@@ -575,6 +575,8 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rd2_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (1 + kFixPlanes) * 4096));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   if (const char* env = psf_exp_env("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
@@ -1250,6 +1252,15 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // tile shape per wave (RT 16-row tiles x NB fragments of 16 preimages) and workgroup form, from tools/probe_stream.hip at the C3 shape
   // (profiles/r04_probe_stream.log): <= 16 preimages the launch is bound by reading the factor, beyond that by the longest MFMA chain
   int RT = 2, NB = B <= 16 ? 1 : B <= 64 ? 2 : 4;
+  // more than wg_min preimages: 64 x 64 tiles whose four waves share the operands through LDS (k_trmm_stream_wg); PSF_STREAM_WG=0 keeps the one-wave tasks,
+  // PSF_STREAM_WG=<B> moves the threshold (experiments build; same bits)
+  size_t wg_min = 33;
+  if (const char* e = psf_exp_env("PSF_STREAM_WG")) wg_min = std::atol(e) > 0 ? (size_t)std::atol(e) : (size_t)-1;
+  size_t wg_max = 64;            // measured at C3 (tools/stream_wg_ab.py): 0.91-0.96 against 1.26 ms at 33 ... 64 preimages; two column groups (65 ... 128) make 482 workgroups of
+                                 // 128 KiB LDS for 256 CUs: 2.13 against 1.89 ms; PSF_STREAM_WG_MAX moves the upper end (<= 1024: the over-read of the normals stream)
+  if (const char* e = psf_exp_env("PSF_STREAM_WG_MAX")) wg_max = std::min<size_t>((size_t)std::atol(e), 1024);
+  const bool wg = stream && B >= wg_min && B <= wg_max && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
+  if (wg) { RT = 2; NB = 4; }
   if (const char* e = psf_exp_env("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
   if (!(NB == 1 || NB == 2 || NB == 4 || NB == 8)) NB = 1;
   const int ncg = (int)((B + 16 * (size_t)NB - 1) / (16 * (size_t)NB));
@@ -1293,7 +1304,17 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     const char* venv = psf_exp_env("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
     const int variant = venv ? std::atoi(venv) : 2;
     const size_t row_hi = h->structured ? h->mb : h->M_pad;
-    if (stream) {
+    if (stream && wg) {
+      StreamGeom g;
+      g.ntile = ((int)((h->mL + 15) / 16) + 3) / 4;
+      g.ncg = ncg;
+      g.ntask = g.ntile * g.ncg;
+      g.bc = 0;
+      const unsigned grid = (unsigned)((g.ntask + 1) / 2);
+      if (compact) hipLaunchKernelGGL((k_trmm_stream_wg<TSW_H, TSW_NBUF, 1>), dim3(grid), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      else hipLaunchKernelGGL((k_trmm_stream_wg<TSW_H, TSW_NBUF, 0>), dim3(grid), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+    }
+    else if (stream) {
       const int ntile16 = (int)((h->mL + 15) / 16);
       auto go = [&](auto kern, int rt, int half) {
         StreamGeom g;
@@ -1390,17 +1411,29 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       const size_t wave_max = genv ? (size_t)std::atol(genv) : 4096;    // measured at C3 (n = 512): 55 vs 98 us at 3-4 preimages, 90 vs 100 at 8, 162 vs 119 at 16
       const char* genv16 = psf_exp_env("PSF_GADGET_WAVE16");        // max n B served by the sixteen-lanes-per-problem kernel (0: never)
       const size_t wave16_max = genv16 ? (size_t)std::atol(genv16) : 49152;     // measured at C3: 0.33 vs 0.48 ms at 64 preimages, 0.65 vs 0.60 at 128
+      const char* genvq = psf_exp_env("PSF_GADGET_QUAD");          // max n B served by the four-lanes-per-problem kernel (0: never)
+      const size_t quad_max = genvq ? (size_t)std::atol(genvq) : 98304;      // measured at C3 (tools/gadget_mid_ab.py): 0.092 / 0.092 / 0.12 / 0.24 ms at 16 / 32 / 64 / 128 preimages against
+                                                                                // 0.12 / 0.18 / 0.33 / 0.35; 0.39 against 0.33 (queue kernel) at 256
       if (h->gadget_queue && h->n * Bh <= wave_max) {               // a single call / a handful of preimages: the chain of k draws is the launch time
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         hipLaunchKernelGGL(k_gadget_wave, dim3((unsigned)((h->n * Bh + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
                            h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+      } else if (h->gadget_queue && h->n * Bh <= quad_max && h->k <= 64) {      // tens to a few hundred preimages: a quad per problem
+        GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
+        if (h->k <= 32)
+          hipLaunchKernelGGL(k_gadget_quad<8>, dim3((unsigned)((h->n * Bh + 63) / 64)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
+                             h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+        else
+          hipLaunchKernelGGL(k_gadget_quad<16>, dim3((unsigned)((h->n * Bh + 63) / 64)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
+                             h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
       } else if (h->gadget_queue && h->n * Bh <= wave16_max) {      // up to a few hundred preimages: four problems per wave
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         hipLaunchKernelGGL(k_gadget_wave16, dim3((unsigned)((h->n * Bh + 15) / 16)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
                            h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
       } else if (h->gadget_queue) {
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
-        const int P = gq_problems_for((uint32_t)h->k, h->n * Bh);
+        int P = gq_problems_for((uint32_t)h->k, h->n * Bh);
+        if (const char* e = psf_exp_env("PSF_GQ_P")) { const int v = std::atoi(e); if (v >= 1 && v <= 128 && (v & (v - 1)) == 0) P = v; }      // problems per wave (experiments)
         const size_t per_wg = (size_t)GQ_WAVES * P;
         if (P == 128)
           hipLaunchKernelGGL(k_gadget_queue<true>, dim3((unsigned)((h->n * Bh + per_wg - 1) / per_wg)), dim3(256), gadget_queue_lds_bytes(h->k, P), sx, seed,
