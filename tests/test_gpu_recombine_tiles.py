@@ -13,6 +13,15 @@ CASES = [  # (n, k, m_bar, base, q, r, s, B, expect_hi)
     (8, 10, 700, 2, 1024, 3.0, 450.0, 384, False),      # batch not a multiple of 256: the 128 x 128 kernel
     (8, 2, 512, 32, 1024, 6.0, 12000.0, 256, True),      # big tiles are launched, see the second plane and leave the call to the 128 x 128 kernel
     (8, 10, 300, 2, 1024, 3.0, 300.0, 256, False),      # m_bar below the big-tile threshold
+    # 5 ... 64 preimages: k_recombine_wg (64 x 64 tiles over all of K through an LDS-DMA ring; K a multiple of 128), one to four fragments of 16 preimages
+    (8, 10, 512, 2, 1024, 3.0, 400.0, 5, False),
+    (8, 10, 700, 2, 1024, 3.0, 450.0, 16, False),        # m_bar = 10 tiles of 64 + 60 rows
+    (8, 10, 700, 2, 1024, 3.0, 450.0, 40, False),        # three fragments on eight waves
+    (8, 10, 300, 2, 1024, 3.0, 300.0, 64, False),
+    (24, 16, 1000, 2, 65536, 3.0, 700.0, 33, False),     # K = 384: three slots, fewer than the ring holds
+    (64, 2, 512, 32, 1024, 6.0, 12000.0, 48, True),      # the second plane: a second pass over the ring
+    (64, 2, 512, 32, 1024, 6.0, 12000.0, 9, True),
+    (8, 2, 512, 32, 1024, 6.0, 12000.0, 16, True),       # K = 64 is not a multiple of 128: the 128 x 128 kernel with K splits
 ]
 
 

@@ -766,6 +766,87 @@ __global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t fir
   if (anyhi) atomicOr(fail + 1, 1);
 }
 
+// ---- e_top = p_top + R z for 5 ... 64 preimages (round 6) ---------------------------------------------------------------------------------------------------------
+// k_recombine_mfma serves these sizes with its 128 x 128 (preimages x coordinates) tile cut along K over blockIdx.z: half or more of every tile is padding, p comes
+// through an LDS transposition in every split and the K ranges meet in 64-bit atomics: 79 us at 16 and 145 us at 64 preimages of C3 (R is 237 MB: 40 us of HBM).
+// MEASURED AND NOT KEPT: one wave per 64 coordinates x K range with its operands in a register ring (the form of k_trmm_stream): ~2 000 waves are needed to keep
+// enough bytes in flight from registers, i.e. K ranges whose sums meet in atomics again -- and the atomics are what it then costs (4 ps each: 0.11 ms with 4 ranges,
+// 0.17 with 16, at 64 preimages).
+// k_recombine_wg: a workgroup owns 64 coordinates x 64 preimages over ALL of K; a ring of RW_NBUF slots of K = 128 (R tile 2 x 4 KiB in the bank-rotated layout of
+// k_recombine_mfma, z planes 2 x 4 KiB) is filled by LDS-DMA three slots ahead of the MFMAs, so 48 KiB per CU are in flight without a register; Z is the A operand
+// (rows = preimages), R the B operand (columns = coordinates: 16 lanes hold 16 consecutive coordinates of one preimage); e = p + sum leaves with plain stores
+// (k_recombine_bottom does not have to zero anything); the hi plane of z (some |z| > 127: flags[1], decided by the gadget kernel) is a second pass over the ring.
+constexpr size_t RS_SLACK_SLOTS = 4;      // ring slots (K = 128 each) the host allocates behind the digit planes of z
+constexpr int RW_NBUF = 4;
+constexpr size_t RW_LDS = (size_t)RW_NBUF * 16384;
+// NW = 4 waves (one per 16 coordinates, every fragment of preimages) or 8 (33 ... 64 preimages: waves 4-7 take the upper half of the fragments from the same R tiles,
+// so that the chain of a slot -- barrier, reads, MFMAs -- is half as long and two waves share a SIMD)
+template <int NBF, int NW>
+__global__ __launch_bounds__(64 * NW) void k_recombine_wg(const int8_t* __restrict__ R, size_t ldr, size_t mbar, int nk2 /* K / 128 */, const int8_t* __restrict__ Zlo,
+                                                          const int8_t* __restrict__ Zhi, size_t ld, const int* __restrict__ flags, const int32_t* __restrict__ P,
+                                                          size_t B, int64_t* __restrict__ E, size_t m) {
+  static_assert(NW == 4 || NW == 8, "four or eight waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char rw_smem[];
+  constexpr int FPW = NW == 8 ? (NBF + 1) / 2 : NBF;                 // fragments per wave
+  constexpr int DPW = 16 / NW;                                       // DMA pieces per wave and slot
+  const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wq = wave & 3, f0 = (wave >> 2) * FPW;                   // coordinates 16 wq ..., fragments f0 ... f0 + FPW - 1 (those below NBF)
+  const size_t i0 = (size_t)blockIdx.x * 64;
+  const bool use_hi = flags[1] != 0;
+  // DMA sources per slot: piece wq of the 4 KiB tiles (R half 0, R half 1, z half 0, z half 1); with eight waves, waves 0-3 bring the first halves, 4-7 the second
+  const int pp = wq * 64 + lane;                                     // 16-byte position inside a 4 KiB tile
+  const int8_t* srcR = R + (i0 + (size_t)(pp >> 2)) * ldr + (size_t)(((pp & 3) - (pp >> 4)) & 3) * 16;      // LDS slot (row, position) takes k group (position - row / 4) mod 4
+  const size_t zoff = ((size_t)wq * ld + (size_t)lane) * 16;         // k group wq of the half, preimage `lane`
+  const int h0 = NW == 8 ? wave >> 2 : 0;                            // first half this wave brings
+  v4i alo[FPW], ahi[FPW];
+#pragma unroll
+  for (int f = 0; f < FPW; ++f) { alo[f] = v4i{0, 0, 0, 0}; ahi[f] = v4i{0, 0, 0, 0}; }
+  for (int plane = 0; plane < (use_hi ? 2 : 1); ++plane) {
+    const int8_t* srcZ = (plane ? Zhi : Zlo) + zoff;
+    auto fill = [&](int s) {
+      unsigned char* base = rw_smem + (size_t)(s % RW_NBUF) * 16384 + wq * 1024;
+#pragma unroll
+      for (int d = 0; d < DPW / 2; ++d) {
+        const int hh = h0 + d;
+        __builtin_amdgcn_global_load_lds(srcR + (size_t)s * 128 + hh * 64, (lds_void_ptr)(base + hh * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srcZ + ((size_t)s * 8 + hh * 4) * ld * 16, (lds_void_ptr)(base + 8192 + hh * 4096), 16, 0, 0);
+      }
+    };
+    // (fills past the last slot read the next columns of R / the planes' slack and are never consumed)
+#pragma unroll
+    for (int s = 0; s < RW_NBUF - 1; ++s) fill(s);
+    for (int s = 0; s < nk2; ++s) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((RW_NBUF - 2) * DPW) : "memory");
+      fill(s + RW_NBUF - 1);
+      const unsigned char* sb = rw_smem + (size_t)(s % RW_NBUF) * 16384;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int row = wq * 16 + r16;
+        const v4i fr = *reinterpret_cast<const v4i*>(sb + hh * 4096 + (row * 64 + i8_slot(row, g) * 16));
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+          if (f0 + f >= NBF) continue;                               // (wave-uniform: the odd fragment of three)
+          const v4i fl = *reinterpret_cast<const v4i*>(sb + 8192 + hh * 4096 + ((g * 64 + (f0 + f) * 16 + r16) * 16));
+          if (plane) ahi[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fl, fr, ahi[f], 0, 0, 0);
+          else alo[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fl, fr, alo[f], 0, 0, 0);
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // the ring is quiet before the next plane (or the end) reuses it
+  }
+  // C map: column (coordinate) = lane & 15, rows (preimages) = 4 (lane >> 4) + reg
+  const size_t ii = i0 + (size_t)wq * 16 + (size_t)r16;
+#pragma unroll
+  for (int f = 0; f < FPW; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t bb = (size_t)(f0 + f) * 16 + (size_t)g * 4 + (size_t)r;
+      if (f0 + f < NBF && ii < mbar && bb < B) E[bb * m + ii] = (int64_t)P[ii * ld + bb] + (int64_t)alo[f][r] + 256 * (int64_t)ahi[f][r];
+    }
+}
+
 // ---- the whole samp_p of ONE preimage in ONE workgroup, for small parameter sets (mp_perturbation.rs:304-336) ------------------------------------
 // The reference's own benchmarks call samp_p once at n = 8 (m = 121; benches/psf.rs:51-66): nine dependent launches cost more than the arithmetic.
 // Here workgroup b does everything for preimage b with LDS between the stages: normals (thread = coordinate), x = sqrt(Sigma_2) d (thread = row, one

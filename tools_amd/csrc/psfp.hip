@@ -274,8 +274,8 @@ static psf_status ensure_batch(psfp_handle* h, size_t B) {
       HIP_TRY(hipMalloc(&t.dP, h->M_pad * ld * sizeof(int32_t)));
       HIP_TRY(hipMalloc(&t.dP8, 3 * h->K_pad * ld));
       HIP_TRY(hipMalloc(&t.dV, h->n * ld * sizeof(uint64_t)));
-      HIP_TRY(hipMalloc(&t.dZlo, h->ldr * ld));      // [ldr/16][ld][16]
-      HIP_TRY(hipMalloc(&t.dZhi, h->ldr * ld));
+      HIP_TRY(hipMalloc(&t.dZlo, h->ldr * ld + RS_SLACK_SLOTS * 128 * ld));      // [ldr/16][ld][16] (+ the slots k_recombine_wg's ring reads past the last K group)
+      HIP_TRY(hipMalloc(&t.dZhi, h->ldr * ld + RS_SLACK_SLOTS * 128 * ld));
       HIP_TRY(hipMemset(t.dZlo, 0, h->ldr * ld));
       HIP_TRY(hipMemset(t.dZhi, 0, h->ldr * ld));
       HIP_TRY(hipMemset(t.dP, 0, h->M_pad * ld * sizeof(int32_t)));
@@ -509,7 +509,7 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   }
   h->szSR = make_sample_z_params(prm->s * prm->r);                    // mp_perturbation.rs:266
   HIP_TRY(hipMalloc(&h->dA, h->n * h->m * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc(&h->dR, h->mb_pad * h->ldr));
+  HIP_TRY(hipMalloc(&h->dR, h->mb_pad * h->ldr + 4096));      // (+ what k_recombine_wg's ring reads past the last row)
   HIP_TRY(hipMemset(h->dR, 0, h->mb_pad * h->ldr));
   if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dLt, (tr_total_chunks(h->nbiL) * TR_CHUNK + TS_SLACK_DOUBLES) * sizeof(double)));
   if (!(prm->flags & PSFP_FLAG_NO_PERTURB)) HIP_TRY(hipMalloc(&h->dR8, h->mb_pad * h->ldr));      // tile-packed copy of R: k_recombine_mfma_big, k_rd2_mfma
@@ -575,6 +575,10 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_small2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rd2_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (1 + kFixPlanes) * 4096));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_lds_bytes(h->k)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_wg<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_wg<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_wg<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_wg<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
@@ -1274,7 +1278,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   {  // mp_perturbation.rs:315 -- d <- N(0,1)^m
     ScopedTimer t(h, st, "k_normals");
     const size_t npos = bc ? h->nkb * 4 * 4 * (size_t)bc : ncf ? h->nkb * 4 * (size_t)ncf * 64 : nbj * h->nkb * TR_CHUNK;
-    const uint32_t nseg = nr_segment(npos);
+    uint32_t nseg = nr_segment(npos);
+    if (const char* e = psf_exp_env("PSF_NR_SEG")) { const long v = std::atol(e); if (v >= 64 && v <= NR_SEG && v % 64 == 0) nseg = (uint32_t)v; }      // positions per wave (experiments)
     const size_t nwaves = (npos + nseg - 1) / nseg;
     const NormalsFixed fx = h->structured ? NormalsFixed{h->mb, h->dD8, h->ldr * ld, ld, h->dX, h->h_const} : NormalsFixed{0, nullptr, 0, 0, nullptr, 0.0};
     hipLaunchKernelGGL(k_normals_wave, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, seed, first_index, m, B, h->nkb, nbj, h->dDt, h->dFail, fx, ncf, nseg);
@@ -1378,7 +1383,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       ScopedTimer t(h, sx, "k_perturb_round");
       const char* renv = psf_exp_env("PSF_ROUND");                 // "wave": the round-2 kernel (comparison arm; same bits)
       if (h->szR.sh == 16 && !(renv && !std::strcmp(renv, "wave"))) {
-        const uint32_t seg = prl_segment(m * Bh);
+        uint32_t seg = prl_segment(m * Bh);
+        if (const char* e = psf_exp_env("PSF_PRL_SEG")) { const long v = std::atol(e); if (v >= 64 && v <= PRL_SEG && v % 64 == 0) seg = (uint32_t)v; }      // samples per wave (experiments)
         const size_t waves = (m * Bh + seg - 1) / seg;
         if (h->szF && !(renv && !std::strcmp(renv, "lean"))) {     // the table screen ("lean": the fp32 screen of rounds 3-4, comparison arm; same bits)
           // a segment that is one row of the [coordinate][preimage] matrix never wraps: the sample's position is its offset (no division per sample)
@@ -1466,6 +1472,21 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         if (Bh == 1) hipLaunchKernelGGL(k_recombine_small<1>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
         else if (Bh == 2) hipLaunchKernelGGL(k_recombine_small<2>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
         else hipLaunchKernelGGL(k_recombine_small<4>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
+        return;
+      }
+      // 5 ... 64 preimages: 64 x 64 tiles over all of K, operands through an LDS-DMA ring, no atomics (k_recombine_wg); PSF_RECOMBINE_STREAM=0: the tiled kernel below
+      // (experiments build; same rows): 0.067 against 0.091 ms at 16, 0.081 against 0.155 at 64 preimages of C3 (tools/tail_ab.py)
+      size_t rs_max = 64;
+      if (const char* e = psf_exp_env("PSF_RECOMBINE_STREAM")) rs_max = (size_t)std::min<long>(std::atol(e), 64);
+      if (Bh <= rs_max && h->ldr % 128 == 0 && h->mb >= 64) {
+        const int nbf = (int)((Bh + 15) / 16), nk2 = (int)(h->ldr / 128);
+        hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bh + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, sx, h->mb, h->w,
+                           h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m, 0);
+        const unsigned grid = (unsigned)((h->mb + 63) / 64);
+#define RW_GO(nb, nw) hipLaunchKernelGGL((k_recombine_wg<nb, nw>), dim3(grid), dim3(64 * nw), RW_LDS, sx, h->dR, h->ldr, h->mb, nk2, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, \
+                                         h->dFail, h->dP + b0, Bh, d_e + b0 * m, m)
+        if (nbf == 1) RW_GO(1, 4); else if (nbf == 2) RW_GO(2, 8); else if (nbf == 3) RW_GO(3, 8); else RW_GO(4, 8);      // (four waves at 33 ... 64 preimages: 0.147 against 0.081 ms)
+#undef RW_GO
         return;
       }
       // one digit plane (decided on the device by the gadget kernel): 256 x 256 tiles; otherwise, or for shapes the big tile does not fit, the 128 x 128 kernel
