@@ -283,30 +283,44 @@ __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(cons
 //   short half leaves when it is done (s_barrier counts the surviving waves only).
 constexpr int TSW_H = 4, TSW_NBUF = 4;                                // k-steps per round, rounds in the ring
 constexpr size_t TSW_LDS = (size_t)2 * TSW_NBUF * TSW_H * 4096;       // 128 KiB: one workgroup per CU
+constexpr size_t TSW128_LDS = (size_t)2 * TSW_NBUF * 2 * 6144;            // 96 KiB (halves of eight waves: 6 KiB per k-step, rounds of two k-steps)
+constexpr size_t TSW32_LDS = (size_t)2 * TSW_NBUF * TSW_H * 3072;     // 96 KiB (k_trmm_stream_wg32: 3 KiB per k-step)
 // one piece (64 lanes x 16 bytes) of a k-step from global memory into LDS at `lds` + lane * 16: wave-uniform base, a per-lane 32-bit offset -- no vector
 // arithmetic per load (an FP64 MFMA holds the SIMD's vector pipe; scalar and memory instructions issue beside it)
 __device__ __forceinline__ void tsw_dma(uint32_t lds, uint32_t voff, const void* base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds), "v"(voff), "s"(base) : "memory");      // (M0 is reserved: the compiler sets it before every use of its own and has none in these kernels)
 }
-template <int H, int NBUF, int CD>
-__global__ __launch_bounds__(512, 1) void k_trmm_stream_wg(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
+// WCN = 2: halves of four waves, 64 rows x 64 preimages (33 ... 64 preimages); WCN = 4: halves of EIGHT waves (2 x 4), 64 rows x 128 preimages: 6 KiB per k-step for 32
+// MFMAs -- 12 bytes per clock and CU at the matrix peak instead of 16, which is what the four-wave tiles needed beside a fetch ceiling of ~19.5 (65 ... 1024 preimages;
+// 1024 threads, the waves 6 and 7 of a half bring nothing)
+template <int H, int NBUF, int CD, int WCN = 2>
+__global__ __launch_bounds__(256 * WCN, 1) void k_trmm_stream_wg(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
                                                            StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
-  static_assert(H == 4 && NBUF == 4, "the loop below is written out for rounds of four k-steps in a ring of four");
+  static_assert((H == 4 || H == 2) && NBUF == 4, "rounds of four or two k-steps in a ring of four");
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int KS_D = 512;                                          // doubles per k-step of a half: 4 fragments of the factor | 4 of the normals
+  constexpr int NP = 2 + WCN;                                        // 1 KiB pieces per k-step of a half: 2 of the factor (4 fragments) | WCN of the normals (2 WCN fragments)
+  constexpr int KS_D = NP * 128;                                     // doubles per k-step of a half
+  constexpr int NWH = 2 * WCN;                                       // waves per half
+  constexpr int G = H / 2;                                           // k-steps per register group
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int half = wave >> 2, w4 = wave & 3;
-  const int slot = (int)blockIdx.x, mirror = g.ntask - 1 - slot;
+  const int half = wave / NWH, w4 = wave % NWH;
+  const bool brings = w4 < NP;                                       // wave-uniform
+  // workgroup -> slot: the column groups of one tile group (consecutive slots) stay on one XCD, so that the factor's fragments they all read cross that XCD's L2 once:
+  // workgroups are dealt to the XCDs round-robin, XCD x takes the slots [x per, (x + 1) per)
+  const int nwg = (g.ntask + 1) / 2, per = (nwg + 7) / 8;
+  const int slot = g.ncg > 1 ? (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (slot >= nwg || (g.ncg > 1 && (int)(blockIdx.x >> 3) >= per)) return;
+  const int mirror = g.ntask - 1 - slot;
   if (half ? mirror <= slot : slot > mirror) return;                 // the middle of an odd count belongs to the long half
   const int task = half ? mirror : slot;
   const int tg = g.ntile - 1 - task / g.ncg, cg = task % g.ncg;      // g.ntile: groups of four 16-row tiles, g.ncg: groups of four column fragments
   const int t0 = tg * 4;
-  const int nround = t0 + 4;                                         // 4 (t0 + 4) k-steps to the diagonal of the group's last tile, four per round; a multiple of 4
+  const int nround = (t0 + 4) * 4 / H;                               // 4 (t0 + 4) k-steps to the diagonal of the group's last tile; a multiple of NBUF
   const int bi = t0 >> 3, tl = t0 & 7;
-  const int cf0 = cg * 4;
-  const size_t strideB = CD ? (size_t)g.ncg * 4 * 64 : 512;          // doubles per k-step of the normals stream (compact: [k-step][fragment][lane] over the fragments in use)
-  // piece w4 of a k-step: 0, 1 = the factor's four fragments (2 KiB, contiguous in the chunk stream), 2, 3 = the normals' four fragments (2 KiB, contiguous)
+  const int cf0 = cg * 2 * WCN;
+  const size_t strideB = CD ? (size_t)g.ncg * 2 * WCN * 64 : 512;    // doubles per k-step of the normals stream (compact: [k-step][fragment][lane] over the fragments in use)
+  // piece w4 of a k-step: 0, 1 = the factor's four fragments (2 KiB, contiguous in the chunk stream), 2 ... = the normals' 2 WCN fragments (contiguous)
   const double* src = w4 < 2 ? Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK + (size_t)tl * 64 + (size_t)w4 * 128
                              : (CD ? Dt + (size_t)cf0 * 64 : Dt + (size_t)(cf0 >> 3) * nkb * TR_CHUNK + (size_t)(cf0 & 7) * 64) + (size_t)(w4 - 2) * 128;
   const size_t sstride = w4 < 2 ? (size_t)512 : strideB;
@@ -322,63 +336,51 @@ __global__ __launch_bounds__(512, 1) void k_trmm_stream_wg(const double* __restr
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-  const int wr = w4 >> 1, wc = w4 & 1;
+  const int wr = w4 / WCN, wc = w4 % WCN;
   const double* rdA = ring + (wr * 2) * 64 + lane;                   // fragment wr * 2 of the factor, this lane's element; the next fragment 64 doubles on
   const double* rdB = ring + 256 + (wc * 2) * 64 + lane;
 #pragma unroll
   for (int r = 0; r < NBUF; ++r) {
 #pragma unroll
-    for (int u = 0; u < H; ++u) tsw_dma(lds0 + (uint32_t)(r * H + u) * 4096u, voff[u], sbase);
+    for (int u = 0; u < H; ++u) if (brings) tsw_dma(lds0 + (uint32_t)((r * H + u) * KS_D * 8), voff[u], sbase);
     sbase += round_bytes;
   }
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NBUF - 1) * H) : "memory");      // round 0 is there
-  double a0[2][2], b0[2][2], a1[2][2], b1[2][2];                     // k-steps 0, 1 and 2, 3 of a round: [k-step][fragment]
-  auto rd = [&](double (&a)[2][2], double (&b)[2][2], int off) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      a[u][0] = rdA[off + u * KS_D]; a[u][1] = rdA[off + u * KS_D + 64];
-      b[u][0] = rdB[off + u * KS_D]; b[u][1] = rdB[off + u * KS_D + 64];
-    }
-  };
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NBUF - 1) * H) : "memory");      // round 0 is there (a wave that brings nothing passes the wait at once)
+  double a0[G][2], b0[G][2], a1[G][2], b1[G][2];                     // the first and the second G k-steps of a round: [k-step][fragment]
   auto mm = [&](double x, double y, int i, int j) { acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[i][j], 0, 0, 0); };
-  rd(a0, b0, 0);
-  // One round: [a0 / b0 hold k-steps 0, 1]; k-steps 2, 3 are read while the first eight MFMAs run; behind them ONE barrier says that round r + 1 has landed for
-  // everybody and that nobody reads buffer r any more; the refills of buffer r (round r + NBUF) and the reads of round r + 1 issue between the last eight MFMAs.
+#pragma unroll
+  for (int u = 0; u < G; ++u) { a0[u][0] = rdA[u * KS_D]; a0[u][1] = rdA[u * KS_D + 64]; b0[u][0] = rdB[u * KS_D]; b0[u][1] = rdB[u * KS_D + 64]; }
+  // One round: [a0 / b0 hold the first G k-steps]; the second G are read while the first 4 G MFMAs run; behind them ONE barrier says that round r + 1 has landed for
+  // everybody and that nobody reads buffer r any more; the refills of buffer r (round r + NBUF) and the reads of round r + 1 issue between the last 4 G MFMAs
+  // (MFMA e of those: the refill of k-step e for e < H, the (e - 2 G)-th read pair of the next round from e = 2 G on).
   auto round = [&](auto BUFC) {
     constexpr int BUF = decltype(BUFC)::value;
     constexpr int cur = BUF * H * KS_D, nxt = ((BUF + 1) % NBUF) * H * KS_D;
-    rd(a1, b1, cur + 2 * KS_D);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      a1[u][0] = rdA[cur + (G + u) * KS_D]; a1[u][1] = rdA[cur + (G + u) * KS_D + 64];
+      b1[u][0] = rdB[cur + (G + u) * KS_D]; b1[u][1] = rdB[cur + (G + u) * KS_D + 64];
+    }
     __builtin_amdgcn_sched_barrier(0);
-    mm(a0[0][0], b0[0][0], 0, 0); mm(a0[0][0], b0[0][1], 0, 1); mm(a0[0][1], b0[0][0], 1, 0); mm(a0[0][1], b0[0][1], 1, 1);
-    mm(a0[1][0], b0[1][0], 0, 0); mm(a0[1][0], b0[1][1], 0, 1); mm(a0[1][1], b0[1][0], 1, 0); mm(a0[1][1], b0[1][1], 1, 1);
+#pragma unroll
+    for (int u = 0; u < G; ++u) { mm(a0[u][0], b0[u][0], 0, 0); mm(a0[u][0], b0[u][1], 0, 1); mm(a0[u][1], b0[u][0], 1, 0); mm(a0[u][1], b0[u][1], 1, 1); }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((NBUF - 2) * H) : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    mm(a1[0][0], b1[0][0], 0, 0);
-    tsw_dma(lds0 + (uint32_t)(BUF * H + 0) * 4096u, voff[0], sbase);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(a1[0][0], b1[0][1], 0, 1);
-    tsw_dma(lds0 + (uint32_t)(BUF * H + 1) * 4096u, voff[1], sbase);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(a1[0][1], b1[0][0], 1, 0);
-    tsw_dma(lds0 + (uint32_t)(BUF * H + 2) * 4096u, voff[2], sbase);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(a1[0][1], b1[0][1], 1, 1);
-    tsw_dma(lds0 + (uint32_t)(BUF * H + 3) * 4096u, voff[3], sbase);
-    sbase += round_bytes;
-    __builtin_amdgcn_sched_barrier(0);
-    mm(a1[1][0], b1[1][0], 0, 0);
-    a0[0][0] = rdA[nxt]; a0[0][1] = rdA[nxt + 64];
-    __builtin_amdgcn_sched_barrier(0);
-    mm(a1[1][0], b1[1][1], 0, 1);
-    b0[0][0] = rdB[nxt]; b0[0][1] = rdB[nxt + 64];
-    __builtin_amdgcn_sched_barrier(0);
-    mm(a1[1][1], b1[1][0], 1, 0);
-    a0[1][0] = rdA[nxt + KS_D]; a0[1][1] = rdA[nxt + KS_D + 64];
-    __builtin_amdgcn_sched_barrier(0);
-    mm(a1[1][1], b1[1][1], 1, 1);
-    b0[1][0] = rdB[nxt + KS_D]; b0[1][1] = rdB[nxt + KS_D + 64];
-    __builtin_amdgcn_sched_barrier(0);
+    ts_for<0, 4 * G>([&](auto EC) {
+      constexpr int e = decltype(EC)::value, u = e / 4, i = (e % 4) / 2, j = e % 2;
+      mm(a1[u][i], b1[u][j], i, j);
+      if constexpr (e < H) {
+        if (brings) tsw_dma(lds0 + (uint32_t)((BUF * H + e) * KS_D * 8), voff[e], sbase);
+        if constexpr (e == H - 1) sbase += round_bytes;
+      }
+      if constexpr (e >= 2 * G) {
+        constexpr int rp = e - 2 * G, ru = rp / 2;                   // read pair rp: the factor's (even) or the normals' (odd) two fragments of k-step ru
+        if constexpr (rp % 2 == 0) { a0[ru][0] = rdA[nxt + ru * KS_D]; a0[ru][1] = rdA[nxt + ru * KS_D + 64]; }
+        else { b0[ru][0] = rdB[nxt + ru * KS_D]; b0[ru][1] = rdB[nxt + ru * KS_D + 64]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
   for (int r = 0; r < nround; r += NBUF) {
     round(std::integral_constant<int, 0>{});
@@ -396,6 +398,75 @@ __global__ __launch_bounds__(512, 1) void k_trmm_stream_wg(const double* __restr
         const size_t row = (size_t)(t0 + wr * 2 + i) * 16 + (lane >> 4) + 4 * r;
         if (row < row_hi) X[row * ldx + (size_t)(cf0 + wc * 2 + j) * 16 + (lane & 15)] = acc[i][j][r];
       }
+}
+
+// 17 ... 32 preimages: the same ring for tiles of 64 rows x 32 preimages -- wave w of a half owns the 16-row tile w and both column fragments (two MFMAs per
+// k-step), a k-step is 2 KiB of the factor (pieces 0, 1: waves 0, 1) and 1 KiB of the normals (piece 2: wave 2; wave 3 brings nothing).  Here the launch is bound by
+// reading the factor once (0.85 ms with the one-wave tasks, whose operand fetches are three fragments per two MFMAs), so the round is the plain one: wait, barrier,
+// refill, read, multiply.
+template <int H, int NBUF, int CD>
+__global__ __launch_bounds__(512, 1) void k_trmm_stream_wg32(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
+                                                             StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
+  static_assert((NBUF - 2) * H <= 63 && NBUF >= 3, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int KS_D = 384;                                          // doubles per k-step of a half: 4 fragments of the factor | 2 of the normals
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = wave >> 2, w4 = wave & 3;
+  const int slot = (int)blockIdx.x, mirror = g.ntask - 1 - slot;
+  if (half ? mirror <= slot : slot > mirror) return;                 // the middle of an odd count belongs to the long half
+  const int task = half ? mirror : slot;
+  const int tg = g.ntile - 1 - task / g.ncg, cg = task % g.ncg;      // g.ntile: groups of four 16-row tiles, g.ncg: groups of TWO column fragments
+  const int t0 = tg * 4;
+  const int nround = (t0 + 4) * 4 / H;
+  const int bi = t0 >> 3, tl = t0 & 7;
+  const int cf0 = cg * 2;
+  const size_t strideB = CD ? (size_t)g.ncg * 2 * 64 : 512;
+  const double* src = w4 < 2 ? Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK + (size_t)tl * 64 + (size_t)w4 * 128
+                             : (CD ? Dt + (size_t)cf0 * 64 : Dt + (size_t)(cf0 >> 3) * nkb * TR_CHUNK + (size_t)(cf0 & 7) * 64);
+  const size_t sstride = w4 < 2 ? (size_t)512 : strideB;
+  uint32_t voff[H];
+#pragma unroll
+  for (int u = 0; u < H; ++u) voff[u] = (uint32_t)lane * 16u + (uint32_t)u * (uint32_t)sstride * 8u;
+  double* ring = smem + (size_t)half * (NBUF * H * KS_D);
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void_ptr)ring + (uint32_t)w4 * 1024u;
+  const char* sbase = reinterpret_cast<const char*>(src);
+  const size_t round_bytes = (size_t)H * sstride * 8;
+  const bool brings = w4 < 3;                                        // wave-uniform
+  auto fill = [&](int r) {
+    if (brings) {
+#pragma unroll
+      for (int u = 0; u < H; ++u) tsw_dma(lds0 + (uint32_t)(((r % NBUF) * H + u) * KS_D * 8), voff[u], sbase);
+    }
+    sbase += round_bytes;
+  };
+  d4 acc[2];
+  acc[0] = d4{0.0, 0.0, 0.0, 0.0}; acc[1] = d4{0.0, 0.0, 0.0, 0.0};
+  const double* rdA = ring + w4 * 64 + lane;
+  const double* rdB = ring + 256 + lane;
+#pragma unroll
+  for (int r = 0; r < NBUF - 1; ++r) fill(r);
+  for (int r = 0; r < nround; ++r) {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NBUF - 2) * H) : "memory");      // (a wave without loads passes the wait at once)
+    fill(r + NBUF - 1);
+    const int off = (r % NBUF) * (H * KS_D);
+    double a[H], b[H][2];
+#pragma unroll
+    for (int u = 0; u < H; ++u) { a[u] = rdA[off + u * KS_D]; b[u][0] = rdB[off + u * KS_D]; b[u][1] = rdB[off + u * KS_D + 64]; }
+#pragma unroll
+    for (int u = 0; u < H; ++u)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][j], acc[j], 0, 0, 0);
+    asm volatile("" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = (size_t)(t0 + w4) * 16 + (lane >> 4) + 4 * r;
+      if (row < row_hi) X[row * ldx + (size_t)(cf0 + j) * 16 + (lane & 15)] = acc[j][r];
+    }
 }
 
 // rounding + syndrome shares of one or two preimages in ONE launch behind the product: one wave per RT 16-row tiles of x

@@ -579,8 +579,14 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_wg<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_wg<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recombine_wg<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg32<TSW_H, TSW_NBUF, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW32_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg32<TSW_H, TSW_NBUF, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW32_LDS));
+#ifdef PSF_EXPERIMENTS
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<2, TSW_NBUF, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW128_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<2, TSW_NBUF, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW128_LDS));
+#endif
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   if (const char* env = psf_exp_env("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
@@ -1260,11 +1266,15 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // PSF_STREAM_WG=<B> moves the threshold (experiments build; same bits)
   size_t wg_min = 33;
   if (const char* e = psf_exp_env("PSF_STREAM_WG")) wg_min = std::atol(e) > 0 ? (size_t)std::atol(e) : (size_t)-1;
-  size_t wg_max = 64;            // measured at C3 (tools/stream_wg_ab.py): 0.91-0.96 against 1.26 ms at 33 ... 64 preimages; two column groups (65 ... 128) make 482 workgroups of
-                                 // 128 KiB LDS for 256 CUs: 2.13 against 1.89 ms; PSF_STREAM_WG_MAX moves the upper end (<= 1024: the over-read of the normals stream)
-  if (const char* e = psf_exp_env("PSF_STREAM_WG_MAX")) wg_max = std::min<size_t>((size_t)std::atol(e), 1024);
+  size_t wg_max = 64;            // measured at C3 (tools/stream_wg_ab.py): 0.91-0.96 against 1.26 ms at 33 ... 64 preimages; 241 workgroups on 256 CUs, each as long as its pair of
+                                 // chains: 0.87 ms would be the matrix pipe's time on 241 CUs.  Beyond 64 preimages the forms tried (column groups of 64 with one or two
+                                 // workgroups per CU, column groups of 128 on halves of eight waves) end within 5 % of the one-wave tasks: PSF_STREAM_WG_MAX (<= 1024)
+  if (const char* e = psf_exp_env("PSF_STREAM_WG_MAX")) wg_max = std::min<size_t>((size_t)std::atol(e), 1024);      // (beyond 64: the experiments build's halves of eight waves)
   const bool wg = stream && B >= wg_min && B <= wg_max && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
-  if (wg) { RT = 2; NB = 4; }
+  // 17 ... 32 preimages: 64 x 32 tiles of the same ring (k_trmm_stream_wg32); PSF_STREAM_WG32=0 keeps the one-wave tasks (experiments build; same bits)
+  const bool wg32 = stream && !wg && B >= 17 && B <= 32 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE") && !(psf_exp_env("PSF_STREAM_WG32") && std::atoi(psf_exp_env("PSF_STREAM_WG32")) == 0);
+  if (wg) { RT = 2; NB = B <= 64 ? 4 : 8; }      // column groups of 64 (halves of four waves) or 128 preimages (halves of eight waves)
+  if (wg32) { RT = 2; NB = 2; }
   if (const char* e = psf_exp_env("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
   if (!(NB == 1 || NB == 2 || NB == 4 || NB == 8)) NB = 1;
   const int ncg = (int)((B + 16 * (size_t)NB - 1) / (16 * (size_t)NB));
@@ -1309,15 +1319,35 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     const char* venv = psf_exp_env("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
     const int variant = venv ? std::atoi(venv) : 2;
     const size_t row_hi = h->structured ? h->mb : h->M_pad;
-    if (stream && wg) {
+    if (stream && wg32) {
       StreamGeom g;
       g.ntile = ((int)((h->mL + 15) / 16) + 3) / 4;
       g.ncg = ncg;
       g.ntask = g.ntile * g.ncg;
       g.bc = 0;
       const unsigned grid = (unsigned)((g.ntask + 1) / 2);
-      if (compact) hipLaunchKernelGGL((k_trmm_stream_wg<TSW_H, TSW_NBUF, 1>), dim3(grid), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
-      else hipLaunchKernelGGL((k_trmm_stream_wg<TSW_H, TSW_NBUF, 0>), dim3(grid), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      if (compact) hipLaunchKernelGGL((k_trmm_stream_wg32<TSW_H, TSW_NBUF, 1>), dim3(grid), dim3(512), TSW32_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      else hipLaunchKernelGGL((k_trmm_stream_wg32<TSW_H, TSW_NBUF, 0>), dim3(grid), dim3(512), TSW32_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+    }
+    else if (stream && wg) {
+      StreamGeom g;
+      g.ntile = ((int)((h->mL + 15) / 16) + 3) / 4;
+      g.ncg = ncg;
+      g.ntask = g.ntile * g.ncg;
+      g.bc = 0;
+      const unsigned nwg = (unsigned)((g.ntask + 1) / 2);
+      if (NB == 4) {         // <= 64 preimages: one workgroup of 2 x 4 waves per CU, rounds of four k-steps
+        if (compact) hipLaunchKernelGGL((k_trmm_stream_wg<TSW_H, TSW_NBUF, 1, 2>), dim3(nwg), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+        else hipLaunchKernelGGL((k_trmm_stream_wg<TSW_H, TSW_NBUF, 0, 2>), dim3(nwg), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      }
+#ifdef PSF_EXPERIMENTS
+      else {                 // column groups of 128 preimages: 2 x 8 waves, rounds of two k-steps (96 KiB); the column groups of a tile group on one XCD.  Measured against the
+                             // one-wave tasks (tools/stream_wg_ab.py): 1.93 / 1.91 ms at 128, 3.55 / 3.72 at 256, 7.16 / 7.58 at 512, 14.25 / 14.33 at 1024 preimages -- not kept
+        const unsigned grid = ncg > 1 ? 8 * ((nwg + 7) / 8) : nwg;
+        if (compact) hipLaunchKernelGGL((k_trmm_stream_wg<2, TSW_NBUF, 1, 4>), dim3(grid), dim3(1024), TSW128_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+        else hipLaunchKernelGGL((k_trmm_stream_wg<2, TSW_NBUF, 0, 4>), dim3(grid), dim3(1024), TSW128_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      }
+#endif
     }
     else if (stream) {
       const int ntile16 = (int)((h->mL + 15) / 16);
