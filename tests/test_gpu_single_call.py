@@ -316,29 +316,32 @@ def test_shared_operand_tiles_with_the_structured_factor(T, oracle, B):
 
 @pytest.mark.parametrize("B", [1, 3, 16, 17, 64, 65, 100, 257])
 def test_gadget_walk_with_a_quad_per_problem_equals_the_other_forms(exp_pair, exp_lib, oracle, B):
-    """k_gadget_quad (four lanes per problem; the default between 4 097 and 98 304 problems) forced at every size against the default choice of the same batch and
-    the queue kernel: the same z, hence the same rows"""
+    """k_gadget_quad with four lanes per problem (the default between 12 289 and 98 304 problems) and with sixteen (2 049 ... 12 288) forced at every size against
+    the round-5 choice of the same batch, the queue kernel and the one-wave-per-problem kernel: the same z, hence the same rows"""
     psf, orc, n, q = exp_pair
     u = oracle.uniform_targets(12, B, n, q)
-    ref = _with_env({"PSF_GADGET_QUAD": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))
-    quad = _with_env({"PSF_GADGET_QUAD": "100000000", "PSF_GADGET_WAVE": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))
-    queue = _with_env({"PSF_GADGET_QUAD": "0", "PSF_GADGET_WAVE": "0", "PSF_GADGET_WAVE16": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))
-    assert (quad["z"] == ref["z"]).all() and (queue["z"] == ref["z"]).all()
+    ref = _with_env({"PSF_GADGET_QUAD": "0", "PSF_GADGET_ROW": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))
+    quad = _with_env({"PSF_GADGET_QUAD": "100000000", "PSF_GADGET_ROW": "0", "PSF_GADGET_WAVE": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))
+    queue = _with_env({"PSF_GADGET_QUAD": "0", "PSF_GADGET_ROW": "0", "PSF_GADGET_WAVE": "0", "PSF_GADGET_WAVE16": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))
+    row = _with_env({"PSF_GADGET_ROW": "100000000", "PSF_GADGET_WAVE": "0"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))      # sixteen lanes per problem
+    wave = _with_env({"PSF_GADGET_WAVE": "100000000"}, lambda: psf.samp_p_stages(u, seed=23, first_index=99))                             # one wave per problem
+    assert (quad["z"] == ref["z"]).all() and (queue["z"] == ref["z"]).all() and (row["z"] == ref["z"]).all() and (wave["z"] == ref["z"]).all()
     assert (quad["e"] == ref["e"]).all()
     assert (quad["e"] == orc.samp_p(23, u, first_index=99)).all()
 
 
-@pytest.mark.parametrize("n,q,base,k,m_bar,r,s,B", [(70, 625, 5, 4, 70 * 4 + 4, 2.0, 600.0, 64), (80, 538, 5, 4, 80 * 4 + 4, 2.0, 600.0, 100), (24, 2**40, 2, 40, 24 * 40 + 8, 3.0, 600.0, 200),
+@pytest.mark.parametrize("n,q,base,k,m_bar,r,s,B", [(70, 625, 5, 4, 70 * 4 + 4, 2.0, 600.0, 64), (70, 625, 5, 4, 70 * 4 + 4, 2.0, 600.0, 200), (24, 2**40, 2, 40, 24 * 40 + 8, 3.0, 600.0, 700), (80, 538, 5, 4, 80 * 4 + 4, 2.0, 600.0, 100), (24, 2**40, 2, 40, 24 * 40 + 8, 3.0, 600.0, 200),
                                                     (9, 2**61 - 1, 2, 61, 9 * 61 + 5, 2.0, 400.0, 500)])
 def test_gadget_quad_kernel_general_base_and_long_chains(oracle, n, q, base, k, m_bar, r, s, B):
-    """more than 4 096 problems by default parameters: base 5 with q = base^k and with a digit column, and chains of 40 and 61 draws (k_gadget_quad<16>), against the oracle"""
+    """2 049 ... 98 304 problems by default parameters (sixteen lanes per problem up to 12 288, a quad beyond): base 5 with q = base^k and with a digit column, and chains
+    of 40 and 61 draws (k_gadget_quad<16, 4>, <4, 16>), against the oracle"""
     import tools_amd as T
     gp = T.GadgetParameters(n, k, m_bar, base, q)
     psf = T.PSFPerturbation(gp, r, s)
     A, (R, Lp, _) = psf.trap_gen(2)
     orc = oracle.PSFPerturbation(oracle.GadgetParams(n, k, m_bar, base, q), r, s)
     orc.load_key(A, R, Lp)
-    assert 4096 < n * B <= 98304
+    assert 2048 < n * B <= 98304
     u = oracle.uniform_targets(4, B, n, q)
     e = psf.samp_p(u, seed=5, first_index=17)
     assert psf.last_status() == 0

@@ -591,6 +591,7 @@ __global__ __launch_bounds__(256) void k_gadget_wave(uint64_t seed, uint64_t fir
   if (anyhi) atomicOr(fail + 1, 1);
 }
 
+#ifdef PSF_EXPERIMENTS   /* round 4's sixteen-lane kernel with exact attempts: replaced by k_gadget_quad<., 16> (round 6); comparison arm of the experiments build */
 // ---- the same walk with SIXTEEN lanes per problem (four problems per wave): a handful to a few hundred preimages ------------------------------------
 // k_gadget_wave spends a whole wave's instruction stream on one problem; from ~1 k problems on that stream is what bounds the launch.  Here a DPP row
 // (16 lanes) owns a problem: lane n of the row holds c_r for r = n, n + 16, n + 32, n + 48; the 16 lanes evaluate attempts t0 .. t0 + 15 of the row's
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(256) void k_gadget_wave16(uint64_t seed, uint64_t f
   if (f) atomicOr(fail, 1);
   if (anyhi) atomicOr(fail + 1, 1);
 }
+#endif
 
 // ---- the same walk with FOUR lanes per problem (sixteen problems per wave): tens to a few hundred preimages (round 6) ---------------------------------------------
 // k_gadget_wave16 spends 2 600 issue cycles per step on four problems (sixteen exact attempts per problem and round, the centre chain repeated by sixteen lanes):
@@ -721,17 +723,23 @@ __global__ __launch_bounds__(256) void k_gadget_wave16(uint64_t seed, uint64_t f
 // attempts, the exact decision only inside the 0.1 % band), sixteen attempts per problem and round as before, the lowest accepting group wins = the first accepted
 // attempt of the draw's own Philox stream.  The centre chain takes its terms by v_mov_dpp quad_perm, the coefficients by v_readlane (lane L <-> row L), unrolled
 // behind wave-uniform guards on the support of b~_i.  Same checks, same values as the other three kernels.  KT = ceil(k / 4) rounded up to 8 or 16.
-template <int S> __device__ __forceinline__ int ts_quad_share(int v) { return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xf, 0xf, false); }
+// LPP = 4 (a quad per problem; 16 attempts per problem and round) or 16 (a DPP row per problem, 64 attempts per round: one round per draw, for the few thousand problems
+// of 8 ... 16 preimages, where the launch is one chain long and a round of a quad serves sixteen problems of which the slowest decides)
+template <int LPP, int S> __device__ __forceinline__ int ts_group_share(int v) {
+  if constexpr (LPP == 4) return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xf, 0xf, false);      // quad_perm: [S, S, S, S]
+  else return __builtin_amdgcn_update_dpp(0, v, 0x150 + S, 0xf, 0xf, false);                        // row_share: S
+}
 
-template <int KT>
+template <int KT, int LPP = 4>
 __global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t first_index, uint32_t n, uint32_t k, uint64_t q, uint64_t base, size_t B, size_t ld,
                                                      const uint64_t* __restrict__ V, GadgetTablesQ tb, int8_t* __restrict__ Zlo, int8_t* __restrict__ Zhi,
                                                      int* __restrict__ fail) {
-  const int lane = threadIdx.x & 63, quad0 = lane & ~3, sub = lane & 3;
+  constexpr int PPW = 64 / LPP;                                    // problems per wave
+  const int lane = threadIdx.x & 63, quad0 = lane & ~(LPP - 1), sub = lane & (LPP - 1);
   const size_t total = (size_t)n * B;
-  const size_t pid0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  const size_t pid0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW;
   if (pid0 >= total) return;                                    // wave-uniform; no barrier in this kernel
-  const size_t pid = pid0 + (size_t)(lane >> 2);
+  const size_t pid = pid0 + (size_t)(lane / LPP);
   const bool active = pid < total;
   const uint32_t j = active ? (uint32_t)(pid / B) : 0;
   const size_t b = active ? pid % B : 0;
@@ -741,7 +749,7 @@ __global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t fir
     const uint64_t v0 = V[(size_t)j * ld + b] % q;
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-      const int r = 4 * t + sub;
+      const int r = LPP * t + sub;
       uint64_t v = v0, d = 0;
       if (base == 2) d = (v >> r) & 1;
       else for (int u = 0; u <= r && u < (int)k; ++u) { d = v % base; v = (v - d) / base; }
@@ -766,7 +774,7 @@ __global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t fir
   double gcol = tb.gso[(size_t)li * k + (k - 1)];
   int skc[KT];
 #pragma unroll
-  for (int t = 0; t < KT; ++t) { const int r = 4 * t + sub; skc[t] = r < (int)k ? tb.Sk[(size_t)r * k + (k - 1)] : 0; }
+  for (int t = 0; t < KT; ++t) { const int r = LPP * t + sub; skc[t] = r < (int)k ? tb.Sk[(size_t)r * k + (k - 1)] : 0; }
   for (int i = (int)k - 1; i >= 0; --i) {
     const double g_now = gcol;
     int sk_now[KT];
@@ -775,14 +783,14 @@ __global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t fir
     if (i > 0) {                                                 // in flight during this step
       gcol = tb.gso[(size_t)li * k + (i - 1)];
 #pragma unroll
-      for (int t = 0; t < KT; ++t) { const int r = 4 * t + sub; skc[t] = r < (int)k ? tb.Sk[(size_t)r * k + (i - 1)] : 0; }
+      for (int t = 0; t < KT; ++t) { const int r = LPP * t + sub; skc[t] = r < (int)k ? tb.Sk[(size_t)r * k + (i - 1)] : 0; }
     }
     // centre <c, b~_i> / ||b~_i||^2: ONE ascending fma chain over the support of b~_i (zeros outside: skipped, exact), per quad its own c
     double dot = 0.0;
     const int glo = __builtin_amdgcn_readlane(my_glo, i), ghi = __builtin_amdgcn_readlane(my_ghi, i);
-    ts_for<0, 4 * KT>([&](auto R) {
+    ts_for<0, LPP * KT>([&](auto R) {
       constexpr int r = decltype(R)::value;
-      if (r >= glo && r <= ghi) dot = fma((double)ts_quad_share<r % 4>(c[r / 4]), bcast_d(g_now, r), dot);      // (wave-uniform guard)
+      if (r >= glo && r <= ghi) dot = fma((double)ts_group_share<LPP, r % LPP>(c[r / LPP]), bcast_d(g_now, r), dot);      // (wave-uniform guard)
     });
     const double cen = dot / bcast_d(my_norm2, i);
     SampleZParams sp;
@@ -795,7 +803,7 @@ __global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t fir
     const uint32_t coord = j * k + (uint32_t)i;
     long long x = 0;
     bool found = !active;
-    for (uint32_t t = (uint32_t)sub; ; t += 4) {                 // a round: the groups 4 R .. 4 R + 3 of every quad's draw; a quad that has found its draw idles
+    for (uint32_t t = (uint32_t)sub; ; t += LPP) {                 // a round: the groups 4 R .. 4 R + 3 of every quad's draw; a quad that has found its draw idles
       if (!__builtin_amdgcn_ballot_w64(!found)) break;
       bool acc1 = false;
       long long xl = 0;
@@ -804,7 +812,7 @@ __global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t fir
         else acc1 = narrow ? sz_group4_narrow(seed, coord, idx_lo, tw, t, rg, cen, sp.inv_s, c_rel, inv_s_f, &xl)
                            : sz_group4(seed, coord, idx_lo, tw, t, rg, cen, sp.inv_s, &xl);
       }
-      const uint32_t qm = (uint32_t)(__builtin_amdgcn_ballot_w64(acc1) >> quad0) & 0xfu;
+      const uint32_t qm = (uint32_t)(__builtin_amdgcn_ballot_w64(acc1) >> quad0) & ((1u << LPP) - 1u);
       const int src = qm ? quad0 + __builtin_ctz(qm) : lane;
       const long long xs = __shfl(xl, src);
       if (!found && qm) { x = xs; found = true; }
@@ -813,7 +821,7 @@ __global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t fir
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       const int nv = c[t] - (int)x * sk_now[t];
-      if (active && 4 * t + sub < (int)k && (nv > 32767 || nv < -32768)) f = 1;
+      if (active && LPP * t + sub < (int)k && (nv > 32767 || nv < -32768)) f = 1;
       c[t] = nv;
     }
   }
@@ -821,7 +829,7 @@ __global__ __launch_bounds__(256) void k_gadget_quad(uint64_t seed, uint64_t fir
   if (active) {
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-      const int r = 4 * t + sub;
+      const int r = LPP * t + sub;
       if (r >= (int)k) continue;
       const int32_t zz = -c[t];
       const int32_t zl = (int32_t)(int8_t)(zz & 0xff);

@@ -1444,16 +1444,29 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     {  // mp_perturbation.rs:321-326 -- z <- D_{Lambda_v(G), r sqrt(b^2+1)}
       ScopedTimer t(h, sx, "k_gadget");
       const char* genv = psf_exp_env("PSF_GADGET_WAVE");            // max n B served by the one-wave-per-problem kernel (0: never)
-      const size_t wave_max = genv ? (size_t)std::atol(genv) : 4096;    // measured at C3 (n = 512): 55 vs 98 us at 3-4 preimages, 90 vs 100 at 8, 162 vs 119 at 16
+      const size_t wave_max = genv ? (size_t)std::atol(genv) : 2048;    // measured at C3 (n = 512): 45 / 44 / 55 us at 1 / 2 / 4 preimages (a row per problem: 58); 91 against 58 at 8
+#ifdef PSF_EXPERIMENTS
       const char* genv16 = psf_exp_env("PSF_GADGET_WAVE16");        // max n B served by the sixteen-lanes-per-problem kernel (0: never)
       const size_t wave16_max = genv16 ? (size_t)std::atol(genv16) : 49152;     // measured at C3: 0.33 vs 0.48 ms at 64 preimages, 0.65 vs 0.60 at 128
+#endif
       const char* genvq = psf_exp_env("PSF_GADGET_QUAD");          // max n B served by the four-lanes-per-problem kernel (0: never)
       const size_t quad_max = genvq ? (size_t)std::atol(genvq) : 98304;      // measured at C3 (tools/gadget_mid_ab.py): 0.092 / 0.092 / 0.12 / 0.24 ms at 16 / 32 / 64 / 128 preimages against
                                                                                 // 0.12 / 0.18 / 0.33 / 0.35; 0.39 against 0.33 (queue kernel) at 256
+      const char* genvr = psf_exp_env("PSF_GADGET_ROW");           // max n B served by the sixteen-lanes-per-problem form of k_gadget_quad (0: never)
+      const size_t row_max = genvr ? (size_t)std::atol(genvr) : 12288;      // measured at C3 (tools/tail_ab.py k_gadget): 0.058 / 0.071 / 0.088 ms at 8 / 16 / 24 preimages against 0.091 (one
+                                                                              // wave per problem at 8, a quad per problem at 16 and 24); 0.107 against 0.091 at 32
       if (h->gadget_queue && h->n * Bh <= wave_max) {               // a single call / a handful of preimages: the chain of k draws is the launch time
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         hipLaunchKernelGGL(k_gadget_wave, dim3((unsigned)((h->n * Bh + 3) / 4)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
                            h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+      } else if (h->gadget_queue && h->n * Bh <= row_max && h->k <= 64) {       // a few thousand problems: a DPP row per problem, one round per draw
+        GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
+        if (h->k <= 32)
+          hipLaunchKernelGGL((k_gadget_quad<2, 16>), dim3((unsigned)((h->n * Bh + 15) / 16)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
+                             h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+        else
+          hipLaunchKernelGGL((k_gadget_quad<4, 16>), dim3((unsigned)((h->n * Bh + 15) / 16)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
+                             h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
       } else if (h->gadget_queue && h->n * Bh <= quad_max && h->k <= 64) {      // tens to a few hundred preimages: a quad per problem
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         if (h->k <= 32)
@@ -1462,10 +1475,12 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         else
           hipLaunchKernelGGL(k_gadget_quad<16>, dim3((unsigned)((h->n * Bh + 63) / 64)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
                              h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+#ifdef PSF_EXPERIMENTS
       } else if (h->gadget_queue && h->n * Bh <= wave16_max) {      // up to a few hundred preimages: four problems per wave
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         hipLaunchKernelGGL(k_gadget_wave16, dim3((unsigned)((h->n * Bh + 15) / 16)), dim3(256), 0, sx, seed, first_index + b0, (uint32_t)h->n, (uint32_t)h->k, h->q,
                            h->prm.gp.base, Bh, ld, h->dV + b0, tq, h->dZlo + 16 * b0, h->dZhi + 16 * b0, h->dFail);
+#endif
       } else if (h->gadget_queue) {
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
         int P = gq_problems_for((uint32_t)h->k, h->n * Bh);
