@@ -1,4 +1,4 @@
-"""Seeded random PSFPerturbation configurations at the batch sizes the mid-size kernels of round 6 serve -- 5 ... 200 preimages with 4 097 ... 98 304 gadget problems:
+"""Seeded random PSFPerturbation configurations at the batch sizes the mid-size kernels of round 6 serve -- 5 ... 200 preimages with 2 049 ... 98 304 gadget problems:
 k_trmm_stream_wg (33 ... 64 preimages), k_gadget_quad (<8> and <16>), k_recombine_wg (5 ... 64 preimages, K a multiple of 128, one or two digit planes) -- against the
 oracle: sampled rows bit for bit, A e = u and check_domain on every row.  The suite's own random configurations keep n <= 12, where none of the three is chosen.
    python3 tools/fuzz_midsize.py <first case> <count>"""
@@ -30,7 +30,7 @@ def one(case):
         if k > 64:
             continue
         B = int(rng.choice([100, 130, 200])) if long_chain else int(rng.choice([5, 9, 16, 17, 31, 33, 40, 48, 63, 64, 65, 100, 130, 200]))
-        n_lo, n_hi = 4097 // B + 1, min(98304 // B, 160)
+        n_lo, n_hi = 2049 // B + 1, min(98304 // B, 160)
         if n_lo > n_hi:
             continue
         n = int(rng.integers(n_lo, n_hi + 1))
