@@ -1564,7 +1564,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // PSF_HALVES=1: the batch's two halves run these stages on two streams, so that the int8 matrix-core kernels of one half (Z_q product, recombination)
   // can share the chip with the vector-bound samplers of the other (vector work hides behind int8 / bf16 MFMAs, unlike behind FP64 ones: profiles/r03_notes.md)
   const char* henv = psf_exp_env("PSF_HALVES");
-  const bool halves = !pipe && henv && ((std::atoi(henv) == 1 && B >= 512 && B % 256 == 0) || (std::atoi(henv) == 2 && B >= 32 && B % 32 == 0));      // (2: small batches too)
+  const bool halves = !pipe && henv && std::atoi(henv) != 0 && B >= 512 && B % 256 == 0;      // (at 32 / 64 preimages the two halves last as long as the whole: profiles/r06_notes.md)
   if (!halves) {
     tail(s2, 0, B);
   } else {
