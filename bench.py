@@ -473,7 +473,7 @@ def nearest_plane_call_latency(psf, u, m, first_index, stream, cfg, reps=15):
 
 
 def single_call_latency(psf, u, e, m, first_index, stream, cfg="c3", reps=30):
-    """One samp_p call at batch 1 / 16 / 64 through the device-pointer entry point: median of `reps` HIP-event times, each call synchronised on both
+    """One samp_p call at batch 1 / 16 / 32 / 64 through the device-pointer entry point: median of `reps` HIP-event times, each call synchronised on both
     sides (a latency, not a throughput), plus the per-kernel HIP-event times of one call.  The product of these calls is k_trmm_stream, bound by
     reading the factor (m(m+1)/2 doubles) from HBM once: `product_frac_b1` = those bytes / its launch time / 8 TB/s, `call_frac_b1` the same for the whole call."""
     import torch
@@ -481,7 +481,7 @@ def single_call_latency(psf, u, e, m, first_index, stream, cfg="c3", reps=30):
     out = {"bound": "hbm", "bytes": key_bytes, "peak_GBps": PEAK_HBM_GBS, "entry_point": "psfp_samp_p_dev (device pointers)", "reps": reps}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e = torch.empty((min(64, u.shape[0]), m), dtype=torch.int64, device=u.device)      # its own rows: the step's output is still to be checked against the oracle
-    for B in (1, 16, 64):
+    for B in (1, 16, 32, 64):      # 1-16: k_trmm_stream (bound by reading the factor); 32: k_trmm_stream_wg32; 64: k_trmm_stream_wg (LDS-shared tiles, bound by the matrix pipe)
         if B > u.shape[0]:
             continue
         call = lambda: psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=77, first_index=first_index, stream=stream)

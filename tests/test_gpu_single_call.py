@@ -316,7 +316,7 @@ def test_shared_operand_tiles_with_the_structured_factor(T, oracle, B):
 
 @pytest.mark.parametrize("B", [1, 3, 16, 17, 64, 65, 100, 257])
 def test_gadget_walk_with_a_quad_per_problem_equals_the_other_forms(exp_pair, exp_lib, oracle, B):
-    """k_gadget_quad with four lanes per problem (the default between 12 289 and 98 304 problems) and with sixteen (2 049 ... 12 288) forced at every size against
+    """k_gadget_quad with four lanes per problem (the default between 10 241 and 98 304 problems) and with sixteen (2 049 ... 10 240) forced at every size against
     the round-5 choice of the same batch, the queue kernel and the one-wave-per-problem kernel: the same z, hence the same rows"""
     psf, orc, n, q = exp_pair
     u = oracle.uniform_targets(12, B, n, q)
@@ -333,7 +333,7 @@ def test_gadget_walk_with_a_quad_per_problem_equals_the_other_forms(exp_pair, ex
 @pytest.mark.parametrize("n,q,base,k,m_bar,r,s,B", [(70, 625, 5, 4, 70 * 4 + 4, 2.0, 600.0, 64), (70, 625, 5, 4, 70 * 4 + 4, 2.0, 600.0, 200), (24, 2**40, 2, 40, 24 * 40 + 8, 3.0, 600.0, 700), (80, 538, 5, 4, 80 * 4 + 4, 2.0, 600.0, 100), (24, 2**40, 2, 40, 24 * 40 + 8, 3.0, 600.0, 200),
                                                     (9, 2**61 - 1, 2, 61, 9 * 61 + 5, 2.0, 400.0, 500)])
 def test_gadget_quad_kernel_general_base_and_long_chains(oracle, n, q, base, k, m_bar, r, s, B):
-    """2 049 ... 98 304 problems by default parameters (sixteen lanes per problem up to 12 288, a quad beyond): base 5 with q = base^k and with a digit column, and chains
+    """2 049 ... 98 304 problems by default parameters (sixteen lanes per problem up to 10 240, a quad beyond): base 5 with q = base^k and with a digit column, and chains
     of 40 and 61 draws (k_gadget_quad<16, 4>, <4, 16>), against the oracle"""
     import tools_amd as T
     gp = T.GadgetParameters(n, k, m_bar, base, q)

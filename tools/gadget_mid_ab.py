@@ -1,5 +1,6 @@
-"""The gadget walk at small and mid-size batches (C3): the default choice (one wave / sixteen lanes per problem / the queue kernel), four lanes per problem
-(k_gadget_quad), sixteen lanes, the queue kernel with 32 problems per wave (PSF_GQ_P) and with its own choice; experiments build; rows compared bit for bit.
+"""The gadget walk at small and mid-size batches (C3): the default choice of the batch size, then every form forced -- one wave per problem (k_gadget_wave), sixteen
+lanes (k_gadget_quad<., 16>), four lanes (k_gadget_quad<., 4>), round 4's sixteen-lane kernel with exact attempts (k_gadget_wave16), the queue kernel with 32 problems per
+wave (PSF_GQ_P) and with its own choice; experiments build; rows compared bit for bit.
    python tools/gadget_mid_ab.py [sizes ...]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,9 +23,10 @@ def main():
     for B in sizes:
         ref = None
         row = {"B": B}
-        for name, env in [("default", {}), ("quad", {"PSF_GADGET_QUAD": "100000000", "PSF_GADGET_WAVE": "0"}), ("wave16", {"PSF_GADGET_WAVE": "0", "PSF_GADGET_WAVE16": "100000000"}),
-                          ("q32", {"PSF_GADGET_WAVE": "0", "PSF_GADGET_WAVE16": "0", "PSF_GQ_P": "32"}), ("qauto", {"PSF_GADGET_WAVE": "0", "PSF_GADGET_WAVE16": "0"})]:
-            for k in ("PSF_GADGET_WAVE16", "PSF_GQ_P", "PSF_GADGET_QUAD", "PSF_GADGET_WAVE"):
+        OFF = {"PSF_GADGET_WAVE": "0", "PSF_GADGET_ROW": "0", "PSF_GADGET_QUAD": "0", "PSF_GADGET_WAVE16": "0"}
+        for name, env in [("default", {}), ("wave", dict(OFF, PSF_GADGET_WAVE="100000000")), ("row", dict(OFF, PSF_GADGET_ROW="100000000")), ("quad", dict(OFF, PSF_GADGET_QUAD="100000000")),
+                          ("wave16", dict(OFF, PSF_GADGET_WAVE16="100000000")), ("q32", dict(OFF, PSF_GADGET_QP="32", PSF_GQ_P="32")), ("qauto", dict(OFF))]:
+            for k in ("PSF_GADGET_WAVE16", "PSF_GQ_P", "PSF_GADGET_QUAD", "PSF_GADGET_WAVE", "PSF_GADGET_ROW", "PSF_GADGET_QP"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             e = torch.zeros((B, m), dtype=torch.int64, device=dev)

@@ -32,9 +32,9 @@ def main():
         res = {}
         for form in ("wave", "wg"):
             if form == "wave":
-                os.environ["PSF_STREAM_WG"] = "0"
+                os.environ["PSF_STREAM_WG"] = "0"; os.environ["PSF_STREAM_WG32"] = "0"
             else:
-                os.environ["PSF_STREAM_WG"] = "17"; os.environ["PSF_STREAM_WG_MAX"] = "1024"
+                os.environ.pop("PSF_STREAM_WG32", None); os.environ["PSF_STREAM_WG"] = "33"; os.environ["PSF_STREAM_WG_MAX"] = "1024"
             e = torch.zeros((B, m), dtype=torch.int64, device=dev)
             call = lambda: psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=9, first_index=1000, stream=stream)
             call(); call()

@@ -1453,7 +1453,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       const size_t quad_max = genvq ? (size_t)std::atol(genvq) : 98304;      // measured at C3 (tools/gadget_mid_ab.py): 0.092 / 0.092 / 0.12 / 0.24 ms at 16 / 32 / 64 / 128 preimages against
                                                                                 // 0.12 / 0.18 / 0.33 / 0.35; 0.39 against 0.33 (queue kernel) at 256
       const char* genvr = psf_exp_env("PSF_GADGET_ROW");           // max n B served by the sixteen-lanes-per-problem form of k_gadget_quad (0: never)
-      const size_t row_max = genvr ? (size_t)std::atol(genvr) : 12288;      // measured at C3 (tools/tail_ab.py k_gadget): 0.058 / 0.071 / 0.088 ms at 8 / 16 / 24 preimages against 0.091 (one
+      const size_t row_max = genvr ? (size_t)std::atol(genvr) : 10240;      // measured at C3 (tools/tail_ab.py k_gadget): 0.058 / 0.071 / 0.088 ms at 8 / 16 / 24 preimages against 0.091 (one
                                                                               // wave per problem at 8, a quad per problem at 16 and 24); 0.107 against 0.091 at 32
       if (h->gadget_queue && h->n * Bh <= wave_max) {               // a single call / a handful of preimages: the chain of k draws is the launch time
         GadgetTablesQ tq{h->dSk, h->dGso, h->dNorm2, h->dSz, h->dRng};
