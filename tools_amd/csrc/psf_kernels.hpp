@@ -86,6 +86,15 @@ __host__ inline uint32_t nr_segment(size_t total) {
   return (uint32_t)(seg > (size_t)NR_SEG ? (size_t)NR_SEG : seg);
 }
 __device__ inline int lane_rank(uint64_t mask);
+// o / d and o % d for o d < 2^32 by one high multiply: M = ceil(2^32 / d) (d >= 2; M = 0 stands for d = 1).  o M / 2^32 = o / d + o e / (d 2^32) with e < d, so the
+// floor is that of o / d as long as o e < 2^32.  (The kernels below locate a sample (coordinate, preimage) from its offset in a segment: o < 2^15, d < 2^13; a 32-bit
+// division is ~40 vector instructions, twice per sample.)
+__host__ __device__ inline uint32_t udiv_magic_of(uint32_t d) { return d < 2 ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); }
+__device__ inline void udivmod_magic(uint32_t o, uint32_t d, uint32_t M, uint32_t* q, uint32_t* r) {
+  const uint32_t qq = M ? __umulhi(o, M) : o;
+  *q = qq;
+  *r = o - qq * d;
+}
 
 // Structured sqrt(Sigma_2) (opt-in, struct NormalsFixed): the coordinates from `split` on (the gadget half, d_2) are taken in FIXED POINT,
 // d = q 2^-32 with q = floor(n 2^32 + 1/2) for the drawn normal n -- so that R d_2 is an exact integer sum on the int8 matrix cores.
@@ -110,18 +119,23 @@ __global__ __launch_bounds__(256) void k_normals_wave(uint64_t seed, uint64_t fi
   size_t cbj[NCH], cbk[NCH];                       // (column block, K block) of the chunks this wave touches
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { cbj[i] = (chunk0 + i) / nkb; cbk[i] = (chunk0 + i) % nkb; }
+  // (the small-batch layouts: positions below 2^32, bc a power of two, ncf <= 128 -- shifts and one high multiply instead of 64-bit divisions, which were two per position)
+  const uint32_t lbc = ncf >= 0x100u ? (uint32_t)__builtin_ctz(ncf - 0x100u) : 0u;
+  const uint32_t ncf_magic = ncf && ncf < 0x100u ? udiv_magic_of(ncf) : 0u;
   auto locate = [&](size_t g, size_t* coord, size_t* b) {
-    if (ncf >= 0x100u) {                                       // dense stream of <= 16 preimages: [k-step][preimage < bc][k % 4], bc = ncf - 0x100
-      const uint32_t bc = ncf - 0x100u;
-      *coord = (g / (4 * bc)) * 4 + (g & 3);
-      *b = (g >> 2) % bc;
+    if (ncf >= 0x100u) {                                       // dense stream of <= 16 preimages: [k-step][preimage < bc][k % 4], bc = ncf - 0x100 = 2^lbc
+      const uint32_t g32 = (uint32_t)g;
+      *coord = (size_t)((g32 >> (2 + lbc)) * 4 + (g32 & 3));
+      *b = (size_t)((g32 >> 2) & ((1u << lbc) - 1u));
       return;
     }
     if (ncf) {
       const uint32_t ln = (uint32_t)(g & 63);
-      const size_t fr = g >> 6;                                // fragment index = k-step * ncf + column fragment
-      *coord = (fr / ncf) * 4 + (ln >> 4);
-      *b = (fr % ncf) * 16 + (ln & 15);
+      const uint32_t fr = (uint32_t)(g >> 6);                  // fragment index = k-step * ncf + column fragment (< 2^21)
+      uint32_t ks, cf;
+      udivmod_magic(fr, ncf, ncf_magic, &ks, &cf);
+      *coord = (size_t)(ks * 4 + (ln >> 4));
+      *b = (size_t)(cf * 16 + (ln & 15));
       return;
     }
     const int ci = (int)(g / TR_CHUNK - chunk0);
@@ -656,7 +670,13 @@ constexpr int PRL_WIN = 256;
 // `seg` = samples per wave (a multiple of 64, at most PRL_SEG): PRL_SEG for full batches; a single call (one preimage, psf.rs:48-80) has only m
 // samples in all, and the launch lasts as long as its longest wave, so the host cuts them into short segments (prl_segment).
 __host__ inline uint32_t prl_segment(size_t total) {
-  size_t seg = (total / 2048 + 63) / 64 * 64;                  // ~2048 waves = two per SIMD
+  // ~2048 waves (two per SIMD) for a handful of preimages, up to ~8192 as the batch grows: a wave's last samples run with most lanes idle (~12 iterations), so few
+  // long waves waste least, but below ~500 samples per wave-slot more waves hide each other's latencies better (round 6, tools/segment_sweep.py at C3: 64 preimages
+  // 0.080 -> 0.068 ms, 256 preimages 0.237 -> 0.205)
+  size_t waves = total / 512;
+  if (waves < 2048) waves = 2048;
+  if (waves > 8192) waves = 8192;
+  size_t seg = (total / waves + 63) / 64 * 64;
   if (seg < 64) seg = 64;
   return (uint32_t)(seg > (size_t)PRL_SEG ? (size_t)PRL_SEG : seg);
 }
@@ -672,10 +692,11 @@ __global__ __launch_bounds__(256) void k_perturb_round_lean(uint64_t seed, uint6
   const uint32_t nseg = (uint32_t)(total - seg0 < (size_t)seg ? total - seg0 : (size_t)seg);
   const uint32_t coord0 = (uint32_t)(seg0 / B), b00 = (uint32_t)(seg0 % B), B32 = (uint32_t)B;
   const bool few_wraps = B32 >= seg;                           // then an offset wraps at most once
+  const uint32_t Bmagic = udiv_magic_of(B32);                  // (o < seg + B <= 2^14, B < seg <= 2^13 where it is used)
   auto locate = [&](uint32_t off, uint32_t* coord, uint32_t* bb) {
     const uint32_t o = b00 + off;
     if (few_wraps) { const bool wrap = o >= B32; *coord = coord0 + (wrap ? 1u : 0u); *bb = wrap ? o - B32 : o; }
-    else { *coord = coord0 + o / B32; *bb = o % B32; }
+    else { uint32_t qd; udivmod_magic(o, B32, Bmagic, &qd, bb); *coord = coord0 + qd; }
   };
   auto gload = [&](uint32_t off) -> double {
     if (off >= nseg) return 0.0;
@@ -756,13 +777,14 @@ __global__ __launch_bounds__(256) void k_perturb_round_tab(uint64_t seed, uint64
   const uint32_t nseg = (uint32_t)(total - seg0 < (size_t)seg ? total - seg0 : (size_t)seg);
   const uint32_t coord0 = (uint32_t)(seg0 / B), b00 = (uint32_t)(seg0 % B), B32 = (uint32_t)B;
   const bool few_wraps = B32 >= seg;                           // then an offset wraps at most once
+  const uint32_t Bmagic = udiv_magic_of(B32);                  // (o < seg + B <= 2^14, B < seg <= 2^13 where it is used)
   const double* __restrict__ Xrow = X + (size_t)coord0 * ld;
   int32_t* __restrict__ Prow = P + (size_t)coord0 * ld;
   auto locate = [&](uint32_t off, uint32_t* coord, uint32_t* bb) {
     if constexpr (ROW) { *coord = coord0; *bb = off; return; }
     const uint32_t o = b00 + off;
     if (few_wraps) { const bool wrap = o >= B32; *coord = coord0 + (wrap ? 1u : 0u); *bb = wrap ? o - B32 : o; }
-    else { *coord = coord0 + o / B32; *bb = o % B32; }
+    else { uint32_t qd; udivmod_magic(o, B32, Bmagic, &qd, bb); *coord = coord0 + qd; }
   };
   auto gload = [&](uint32_t off) -> double {
     if (off >= nseg) return 0.0;
