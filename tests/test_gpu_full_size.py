@@ -89,7 +89,8 @@ def test_c5_per_gpu_shape_is_valid_and_matches_the_oracle_on_a_sample(oracle):
 
 @pytest.mark.timeout(1200)
 def test_c3_single_calls_match_the_oracle_in_every_stage(oracle):
-    """The streaming product of a SINGLE call (k_trmm_stream: 1 and 16 preimages, psf.rs:48-80 -- one reference call is one preimage) at the C3 shape
+    """The streaming product of a SINGLE call (k_trmm_stream: 1 and 16 preimages, psf.rs:48-80 -- one reference call is one preimage; round 6: 24 and 40 preimages on
+    the LDS-shared tiles, with the recombination of k_recombine_wg) at the C3 shape
     (n = 512, q = 2^30, m = 30 801): every stage bit for bit against the oracle, the centres through the oracle's ascending fma chain over the factor streamed
     back in row blocks.  (The batch kernels at this shape are covered by the bench runs above, the single call at the C5 shape by the test above.)"""
     import numpy as np
@@ -101,7 +102,7 @@ def test_c3_single_calls_match_the_oracle_in_every_stage(oracle):
     A, R = psf.export_A_R()
     orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s, with_L=False)
     orc.load_key(A, R)
-    for S, first in ((1, 123456), (16, 7)):
+    for S, first in ((1, 123456), (16, 7), (24, 900), (40, 2**33 + 5)):      # k_trmm_stream (dense normals stream), k_trmm_stream_wg32, k_trmm_stream_wg; k_gadget_wave / quad<., 16> / quad<., 4>
         uh = oracle.uniform_targets(5, S, n, q)
         st = psf.samp_p_stages(uh, seed=42, first_index=first)
         assert (psf.samp_p(uh, seed=42, first_index=first) == st["e"]).all()
