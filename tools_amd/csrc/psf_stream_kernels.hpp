@@ -31,15 +31,15 @@ __device__ inline void ts_touch(double& x) { asm volatile("" : "+v"(x)); }
 template <int OFF> __device__ inline void ts_load(double& dst, uint32_t voff, const double* base) {
   asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(OFF) : "memory");
 }
+#ifndef PSF_TS_NT
+#define PSF_TS_NT 1      /* -DPSF_TS_NT=0: plain loads (A/B builds) */
+#endif
 // the same load with the non-temporal hint, for bytes that are read ONCE per call (the factor with one column group): 0.632-0.665 -> 0.605-0.629 ms for the product of one
 // preimage at C3, same box (round 6).  Measured and not kept elsewhere: non-temporal LDS-DMA of the factor's pieces in k_trmm_stream_wg32 / _wg (0.69 -> 0.82 ms at 32,
 // 0.92-0.96 -> 0.99-1.00 at 64 preimages), non-temporal loads of A in k_round_syndrome_small (28 -> 29-30 us).
 template <int OFF> __device__ inline void ts_load_nt(double& dst, uint32_t voff, const double* base) {
-  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(dst) : "v"(voff), "s"(base), "n"(OFF) : "memory");
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(dst) : "v"(voff), "s"(base), "n"(OFF) : "memory");      // (with sc1 / sc0 sc1 / sc0 beside nt: within the noise)
 }
-#ifndef PSF_TS_NT
-#define PSF_TS_NT 1      /* -DPSF_TS_NT=0: plain loads (A/B builds) */
-#endif
 template <int I, int N, class F> __device__ inline void ts_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); ts_for<I + 1, N>(f); }
 }
