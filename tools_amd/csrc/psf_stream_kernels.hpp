@@ -416,12 +416,11 @@ __global__ __launch_bounds__(256 * WCN, 1) void k_trmm_stream_wg(const double* _
 
 // 17 ... 32 preimages: the same ring for tiles of 64 rows x 32 preimages -- wave w of a half owns the 16-row tile w and both column fragments (two MFMAs per
 // k-step), a k-step is 2 KiB of the factor (pieces 0, 1: waves 0, 1) and 1 KiB of the normals (piece 2: wave 2; wave 3 brings nothing).  Here the launch is bound by
-// reading the factor once (0.85 ms with the one-wave tasks, whose operand fetches are three fragments per two MFMAs), so the round is the plain one: wait, barrier,
-// refill, read, multiply.
+// reading the factor once (0.85 ms with the one-wave tasks, whose operand fetches are three fragments per two MFMAs).
 template <int H, int NBUF, int CD>
 __global__ __launch_bounds__(512, 1) void k_trmm_stream_wg32(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
                                                              StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
-  static_assert((NBUF - 2) * H <= 63 && NBUF >= 3, "vmcnt is a 6-bit counter");
+  static_assert(H == 4 && NBUF == 4, "rounds of four k-steps in a ring of four");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int KS_D = 384;                                          // doubles per k-step of a half: 4 fragments of the factor | 2 of the normals
   const int lane = threadIdx.x & 63;
@@ -447,31 +446,48 @@ __global__ __launch_bounds__(512, 1) void k_trmm_stream_wg32(const double* __res
   const char* sbase = reinterpret_cast<const char*>(src);
   const size_t round_bytes = (size_t)H * sstride * 8;
   const bool brings = w4 < 3;                                        // wave-uniform
-  auto fill = [&](int r) {
-    if (brings) {
-#pragma unroll
-      for (int u = 0; u < H; ++u) tsw_dma(lds0 + (uint32_t)(((r % NBUF) * H + u) * KS_D * 8), voff[u], sbase);
-    }
-    sbase += round_bytes;
-  };
   d4 acc[2];
   acc[0] = d4{0.0, 0.0, 0.0, 0.0}; acc[1] = d4{0.0, 0.0, 0.0, 0.0};
   const double* rdA = ring + w4 * 64 + lane;
   const double* rdB = ring + 256 + lane;
 #pragma unroll
-  for (int r = 0; r < NBUF - 1; ++r) fill(r);
-  for (int r = 0; r < nround; ++r) {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NBUF - 2) * H) : "memory");      // (a wave without loads passes the wait at once)
-    fill(r + NBUF - 1);
-    const int off = (r % NBUF) * (H * KS_D);
-    double a[H], b[H][2];
+  for (int r = 0; r < NBUF; ++r) {
 #pragma unroll
-    for (int u = 0; u < H; ++u) { a[u] = rdA[off + u * KS_D]; b[u][0] = rdB[off + u * KS_D]; b[u][1] = rdB[off + u * KS_D + 64]; }
+    for (int u = 0; u < H; ++u) if (brings) tsw_dma(lds0 + (uint32_t)((r * H + u) * KS_D * 8), voff[u], sbase);
+    sbase += round_bytes;
+  }
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NBUF - 1) * H) : "memory");      // round 0 is there (a wave without loads passes the wait at once)
+  // the round of k_trmm_stream_wg with two MFMAs per k-step: k-steps 2, 3 are read while the first four MFMAs run, ONE barrier behind them, then each of the last four
+  // MFMAs is followed by one refill of buffer r (round r + NBUF) and one read of round r + 1
+  double a0[2], b0[2][2], a1[2], b1[2][2];
+  auto mm = [&](double x, double y, int j) { acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[j], 0, 0, 0); };
 #pragma unroll
-    for (int u = 0; u < H; ++u)
+  for (int u = 0; u < 2; ++u) { a0[u] = rdA[u * KS_D]; b0[u][0] = rdB[u * KS_D]; b0[u][1] = rdB[u * KS_D + 64]; }
+  auto round = [&](auto BUFC) {
+    constexpr int BUF = decltype(BUFC)::value;
+    constexpr int cur = BUF * H * KS_D, nxt = ((BUF + 1) % NBUF) * H * KS_D;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][j], acc[j], 0, 0, 0);
-    asm volatile("" ::: "memory");
+    for (int u = 0; u < 2; ++u) { a1[u] = rdA[cur + (2 + u) * KS_D]; b1[u][0] = rdB[cur + (2 + u) * KS_D]; b1[u][1] = rdB[cur + (2 + u) * KS_D + 64]; }
+    __builtin_amdgcn_sched_barrier(0);
+    mm(a0[0], b0[0][0], 0); mm(a0[0], b0[0][1], 1); mm(a0[1], b0[1][0], 0); mm(a0[1], b0[1][1], 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((NBUF - 2) * H) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    ts_for<0, 4>([&](auto EC) {
+      constexpr int e = decltype(EC)::value, u = e / 2, j = e % 2;
+      mm(a1[u], b1[u][j], j);
+      if (brings) tsw_dma(lds0 + (uint32_t)((BUF * H + e) * KS_D * 8), voff[e], sbase);
+      if constexpr (e == 3) sbase += round_bytes;
+      if constexpr (j == 0) a0[u] = rdA[nxt + u * KS_D];
+      else { b0[u][0] = rdB[nxt + u * KS_D]; b0[u][1] = rdB[nxt + u * KS_D + 64]; }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  for (int r = 0; r < nround; r += NBUF) {
+    round(std::integral_constant<int, 0>{});
+    round(std::integral_constant<int, 1>{});
+    round(std::integral_constant<int, 2>{});
+    round(std::integral_constant<int, 3>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
