@@ -296,6 +296,11 @@ __global__ __launch_bounds__(128 * HALF, (HALF + 1) / 2) void k_trmm_stream(cons
 //   balance: waves 0-3 take the long task `slot`, waves 4-7 its mirror (the two lengths add up to the same for every slot), wave w and w + 4 share a SIMD; the
 //   short half leaves when it is done (s_barrier counts the surviving waves only).
 constexpr int TSW_H = 4, TSW_NBUF = 4;                                // k-steps per round, rounds in the ring
+#ifndef PSF_TSW64_H
+#define PSF_TSW64_H 4
+#define PSF_TSW64_NBUF 4
+#endif
+constexpr int TSW64_H = PSF_TSW64_H, TSW64_NBUF = PSF_TSW64_NBUF;      // the 64 x 64 tiles' rounds (A/B builds: -DPSF_TSW64_H=2 -DPSF_TSW64_NBUF=8: same LDS, shorter rounds, deeper ring)
 constexpr size_t TSW_LDS = (size_t)2 * TSW_NBUF * TSW_H * 4096;       // 128 KiB: one workgroup per CU
 constexpr size_t TSW128_LDS = (size_t)2 * TSW_NBUF * 2 * 6144;            // 96 KiB (halves of eight waves: 6 KiB per k-step, rounds of two k-steps)
 constexpr size_t TSW32_LDS = (size_t)2 * TSW_NBUF * TSW_H * 3072;     // 96 KiB (k_trmm_stream_wg32: 3 KiB per k-step)
@@ -310,7 +315,7 @@ __device__ __forceinline__ void tsw_dma(uint32_t lds, uint32_t voff, const void*
 template <int H, int NBUF, int CD, int WCN = 2>
 __global__ __launch_bounds__(256 * WCN, 1) void k_trmm_stream_wg(const double* __restrict__ Lt, const double* __restrict__ Dt, double* __restrict__ X,
                                                            StreamGeom g, size_t nkb, size_t ldx, size_t row_hi) {
-  static_assert((H == 4 || H == 2) && NBUF == 4, "rounds of four or two k-steps in a ring of four");
+  static_assert((H == 4 || H == 2) && (NBUF == 4 || NBUF == 8) && (NBUF - 2) * H <= 63, "rounds of four or two k-steps in a ring of four or eight");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NP = 2 + WCN;                                        // 1 KiB pieces per k-step of a half: 2 of the factor (4 fragments) | WCN of the normals (2 WCN fragments)
   constexpr int KS_D = NP * 128;                                     // doubles per k-step of a half
@@ -396,12 +401,7 @@ __global__ __launch_bounds__(256 * WCN, 1) void k_trmm_stream_wg(const double* _
       __builtin_amdgcn_sched_barrier(0);
     });
   };
-  for (int r = 0; r < nround; r += NBUF) {
-    round(std::integral_constant<int, 0>{});
-    round(std::integral_constant<int, 1>{});
-    round(std::integral_constant<int, 2>{});
-    round(std::integral_constant<int, 3>{});
-  }
+  for (int r = 0; r < nround; r += NBUF) ts_for<0, NBUF>([&](auto BC) { round(BC); });      // (nround is a multiple of NBUF: 4 (tg + 1) rounds of four, 8 (tg + 1) of two k-steps)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the over-read pieces land before the workgroup's LDS is released
 #pragma unroll
   for (int i = 0; i < 2; ++i)

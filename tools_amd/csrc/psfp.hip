@@ -585,8 +585,8 @@ static psf_status psfp_init(psfp_handle* h, const psfp_params* prm) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<2, TSW_NBUF, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW128_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<2, TSW_NBUF, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW128_LDS));
 #endif
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW_H, TSW_NBUF, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TSW_LDS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gadget_queue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gadget_queue_lds_bytes(h->k)));
   if (const char* env = psf_exp_env("PSF_GADGET_QUEUE")) h->gadget_queue = std::atoi(env) != 0;
@@ -1337,8 +1337,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       g.bc = 0;
       const unsigned nwg = (unsigned)((g.ntask + 1) / 2);
       if (NB == 4) {         // <= 64 preimages: one workgroup of 2 x 4 waves per CU, rounds of four k-steps
-        if (compact) hipLaunchKernelGGL((k_trmm_stream_wg<TSW_H, TSW_NBUF, 1, 2>), dim3(nwg), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
-        else hipLaunchKernelGGL((k_trmm_stream_wg<TSW_H, TSW_NBUF, 0, 2>), dim3(nwg), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+        if (compact) hipLaunchKernelGGL((k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 1, 2>), dim3(nwg), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+        else hipLaunchKernelGGL((k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 0, 2>), dim3(nwg), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
       }
 #ifdef PSF_EXPERIMENTS
       else {                 // column groups of 128 preimages: 2 x 8 waves, rounds of two k-steps (96 KiB); the column groups of a tile group on one XCD.  Measured against the
