@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void k_transpose_A32(const uint64_t* __restric
 // lane r holds c_r, the 64 lanes evaluate attempts t0 .. t0 + 63 of the current draw at once (exact rule, sz_attempt) and the lowest accepted attempt
 // is taken -- the first accepted attempt of the draw's own Philox stream, i.e. the value every other sampler of the library returns.
 // A draw costs one round (64 attempts miss with probability (11/12)^64 = 0.4 %) and the chain k of them.  Every lane pays an exact attempt, so this
-// form only pays while there are about as many problems as SIMDs; the host switches at n B <= 8192 (psfp.hip).
+// form only pays while there are about as many problems as SIMDs; the host uses it up to n B = 2048 (psfp.hip; k_gadget_quad beyond).
 // Checks mirror k_gadget_queue (|z_i| <= 16000, c in int16): the failure flag is raised by the same inputs.
 // one problem (row j of v, preimage index `index`, value v = v_j mod q) on ONE WAVE; out(row r, z_r) is called by lane r < k.  Returns the failure flag.
 template <class Out>
