@@ -21,6 +21,11 @@ CASES = [  # (n, k, m_bar, base, q, r, s, B, expect_hi)
     (24, 16, 1000, 2, 65536, 3.0, 700.0, 33, False),     # K = 384: three slots, fewer than the ring holds
     (64, 2, 512, 32, 1024, 6.0, 12000.0, 48, True),      # the second plane: a second pass over the ring
     (64, 2, 512, 32, 1024, 6.0, 12000.0, 9, True),
+    (8, 10, 700, 2, 1024, 3.0, 450.0, 100, False),       # 65 ... 128 preimages: two column groups of 64, the second one ragged
+    (64, 2, 512, 32, 1024, 6.0, 12000.0, 128, True),     # ... with the second plane
+    (8, 10, 300, 2, 1024, 3.0, 300.0, 65, False),
+    (8, 10, 700, 2, 1024, 3.0, 450.0, 300, False),       # five column groups, the last one of 44 preimages
+    (64, 2, 512, 32, 1024, 6.0, 12000.0, 448, True),
     (8, 2, 512, 32, 1024, 6.0, 12000.0, 16, True),       # K = 64 is not a multiple of 128: the 128 x 128 kernel with K splits
 ]
 

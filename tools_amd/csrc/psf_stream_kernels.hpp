@@ -902,6 +902,11 @@ __global__ __launch_bounds__(64 * NW) void k_recombine_wg(const int8_t* __restri
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wq = wave & 3, f0 = (wave >> 2) * FPW;                   // coordinates 16 wq ..., fragments f0 ... f0 + FPW - 1 (those below NBF)
   const size_t i0 = (size_t)blockIdx.x * 64;
+  {  // blockIdx.y: the column group of 64 preimages (65 ... 128 preimages: two groups, R comes from L2 / the Infinity Cache for the second)
+    const size_t bg = (size_t)blockIdx.y * 64;
+    Zlo += 16 * bg; Zhi += 16 * bg; P += bg; E += bg * m;
+    B = B - bg < 64 ? B - bg : 64;
+  }
   const bool use_hi = flags[1] != 0;
   // DMA sources per slot: piece wq of the 4 KiB tiles (R half 0, R half 1, z half 0, z half 1); with eight waves, waves 0-3 bring the first halves, 4-7 the second
   const int pp = wq * 64 + lane;                                     // 16-byte position inside a 4 KiB tile

@@ -1519,16 +1519,18 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
         else hipLaunchKernelGGL(k_recombine_small<4>, dim3(wgs), dim3(512), small_lds, sx, h->dR, h->ldr, h->mb, h->w, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m);
         return;
       }
-      // 5 ... 64 preimages: 64 x 64 tiles over all of K, operands through an LDS-DMA ring, no atomics (k_recombine_wg); PSF_RECOMBINE_STREAM=0: the tiled kernel below
+      // 5 ... 448 preimages: 64 x 64 tiles over all of K, operands through an LDS-DMA ring, no atomics (k_recombine_wg); PSF_RECOMBINE_STREAM=0: the tiled kernel below
       // (experiments build; same rows): 0.067 against 0.091 ms at 16, 0.081 against 0.155 at 64 preimages of C3 (tools/tail_ab.py)
-      size_t rs_max = 64;
-      if (const char* e = psf_exp_env("PSF_RECOMBINE_STREAM")) rs_max = (size_t)std::min<long>(std::atol(e), 64);
+      size_t rs_max = 448;      // column groups of 64 preimages beyond 64 (blockIdx.y; R comes from L2 / the Infinity Cache for all but the first): 0.157 -> 0.107 ms at 65, 0.266 -> 0.115 at 128,
+                                // 0.247 -> 0.174 at 192, 0.238 -> 0.210 at 256, 0.353 -> 0.299 at 384; 0.248 -> 0.390 at 512 (the 256 x 256 tiles), 0.575 -> 0.729 at 1000 preimages
+      if (const char* e = psf_exp_env("PSF_RECOMBINE_STREAM")) rs_max = (size_t)std::min<long>(std::atol(e), 1024);
       if (Bh <= rs_max && h->ldr % 128 == 0 && h->mb >= 64) {
-        const int nbf = (int)((Bh + 15) / 16), nk2 = (int)(h->ldr / 128);
+        const int nbf = Bh > 64 ? 4 : (int)((Bh + 15) / 16), nk2 = (int)(h->ldr / 128);
+        const unsigned ngy = (unsigned)((Bh + 63) / 64);
         hipLaunchKernelGGL(k_recombine_bottom, dim3((unsigned)((Bh + 63) / 64), (unsigned)((h->w + 63) / 64)), dim3(256), 0, sx, h->mb, h->w,
                            h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, h->dP + b0, Bh, d_e + b0 * m, m, 0);
         const unsigned grid = (unsigned)((h->mb + 63) / 64);
-#define RW_GO(nb, nw) hipLaunchKernelGGL((k_recombine_wg<nb, nw>), dim3(grid), dim3(64 * nw), RW_LDS, sx, h->dR, h->ldr, h->mb, nk2, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, \
+#define RW_GO(nb, nw) hipLaunchKernelGGL((k_recombine_wg<nb, nw>), dim3(grid, ngy), dim3(64 * nw), RW_LDS, sx, h->dR, h->ldr, h->mb, nk2, h->dZlo + 16 * b0, h->dZhi + 16 * b0, ld, \
                                          h->dFail, h->dP + b0, Bh, d_e + b0 * m, m)
         if (nbf == 1) RW_GO(1, 4); else if (nbf == 2) RW_GO(2, 8); else if (nbf == 3) RW_GO(3, 8); else RW_GO(4, 8);      // (four waves at 33 ... 64 preimages: 0.147 against 0.081 ms)
 #undef RW_GO
