@@ -102,7 +102,7 @@ def test_c3_single_calls_match_the_oracle_in_every_stage(oracle):
     A, R = psf.export_A_R()
     orc = oracle.PSFPerturbation(oracle.gadget_params_default(n, q), r, s, with_L=False)
     orc.load_key(A, R)
-    for S, first in ((1, 123456), (16, 7), (24, 900), (40, 2**33 + 5)):      # k_trmm_stream (dense normals stream), k_trmm_stream_wg32, k_trmm_stream_wg; k_gadget_wave / quad<., 16> / quad<., 4>
+    for S, first in ((1, 123456), (16, 7), (24, 900), (40, 2**33 + 5), (72, 31)):      # k_trmm_stream (dense normals stream), k_trmm_stream_wg32, k_trmm_stream_wg, both over six fragments; k_gadget_wave / quad<., 16> / quad<., 4>
         uh = oracle.uniform_targets(5, S, n, q)
         st = psf.samp_p_stages(uh, seed=42, first_index=first)
         assert (psf.samp_p(uh, seed=42, first_index=first) == st["e"]).all()

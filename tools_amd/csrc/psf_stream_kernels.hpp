@@ -49,6 +49,8 @@ struct StreamGeom {
   int ncg;          // column groups of 16 NB preimages
   int ntask;        // ntile * ncg
   int bc;           // CD == 2: preimages the dense normals stream stores per k-step (1, 2, 4, 8 or 16)
+  int ncf = 0;      // k_trmm_stream_wg / _wg32 only: fragments per k-step of the compact normals stream when it is NOT ncg x (the kernel's own group width) -- a batch of
+  int cf_base = 0;  // 65 ... 96 preimages is one launch of each (64 + 32 columns) over one stream of 6 fragments; cf_base = the launch's first fragment
 };
 
 // ---- rounding and the syndrome of ONE or TWO preimages in one launch (round 6) -----------------------------------------------------------------------------
@@ -337,8 +339,8 @@ __global__ __launch_bounds__(256 * WCN, 1) void k_trmm_stream_wg(const double* _
   const int t0 = tg * 4;
   const int nround = (t0 + 4) * 4 / H;                               // 4 (t0 + 4) k-steps to the diagonal of the group's last tile; a multiple of NBUF
   const int bi = t0 >> 3, tl = t0 & 7;
-  const int cf0 = cg * 2 * WCN;
-  const size_t strideB = CD ? (size_t)g.ncg * 2 * WCN * 64 : 512;    // doubles per k-step of the normals stream (compact: [k-step][fragment][lane] over the fragments in use)
+  const int cf0 = g.cf_base + cg * 2 * WCN;
+  const size_t strideB = CD ? (size_t)(g.ncf ? g.ncf : g.ncg * 2 * WCN) * 64 : 512;      // doubles per k-step of the normals stream (compact: [k-step][fragment][lane] over the fragments in use)
   // piece w4 of a k-step: 0, 1 = the factor's four fragments (2 KiB, contiguous in the chunk stream), 2 ... = the normals' 2 WCN fragments (contiguous)
   const double* src = w4 < 2 ? Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK + (size_t)tl * 64 + (size_t)w4 * 128
                              : (CD ? Dt + (size_t)cf0 * 64 : Dt + (size_t)(cf0 >> 3) * nkb * TR_CHUNK + (size_t)(cf0 & 7) * 64) + (size_t)(w4 - 2) * 128;
@@ -433,8 +435,8 @@ __global__ __launch_bounds__(512, 1) void k_trmm_stream_wg32(const double* __res
   const int t0 = tg * 4;
   const int nround = (t0 + 4) * 4 / H;
   const int bi = t0 >> 3, tl = t0 & 7;
-  const int cf0 = cg * 2;
-  const size_t strideB = CD ? (size_t)g.ncg * 2 * 64 : 512;
+  const int cf0 = g.cf_base + cg * 2;
+  const size_t strideB = CD ? (size_t)(g.ncf ? g.ncf : g.ncg * 2) * 64 : 512;
   const double* src = w4 < 2 ? Lt + tr_rowblock_base((size_t)bi) * TR_CHUNK + (size_t)tl * 64 + (size_t)w4 * 128
                              : (CD ? Dt + (size_t)cf0 * 64 : Dt + (size_t)(cf0 >> 3) * nkb * TR_CHUNK + (size_t)(cf0 & 7) * 64);
   const size_t sstride = w4 < 2 ? (size_t)512 : strideB;

@@ -1273,8 +1273,11 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   const bool wg = stream && B >= wg_min && B <= wg_max && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
   // 17 ... 32 preimages: 64 x 32 tiles of the same ring (k_trmm_stream_wg32); PSF_STREAM_WG32=0 keeps the one-wave tasks (experiments build; same bits)
   const bool wg32 = stream && !wg && B >= 17 && B <= 32 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE") && !(psf_exp_env("PSF_STREAM_WG32") && std::atoi(psf_exp_env("PSF_STREAM_WG32")) == 0);
+  // 65 ... 96 preimages: the first 64 on the 64 x 64 tiles, the rest on the 64 x 32 tiles, two launches over one normals stream of six fragments (0.94 + 0.65 ms against 1.80 for
+  // the one-wave tasks, which pay for 128 columns); PSF_STREAM_WG96=0 keeps those (experiments build; same bits)
+  const bool wg96 = stream && !wg && B >= 65 && B <= 96 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE") && !(psf_exp_env("PSF_STREAM_WG96") && std::atoi(psf_exp_env("PSF_STREAM_WG96")) == 0);
   if (wg) { RT = 2; NB = B <= 64 ? 4 : 8; }      // column groups of 64 (halves of four waves) or 128 preimages (halves of eight waves)
-  if (wg32) { RT = 2; NB = 2; }
+  if (wg32 || wg96) { RT = 2; NB = 2; }          // (wg96: three column groups of 32 = the six fragments of the stream)
   if (const char* e = psf_exp_env("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
   if (!(NB == 1 || NB == 2 || NB == 4 || NB == 8)) NB = 1;
   const int ncg = (int)((B + 16 * (size_t)NB - 1) / (16 * (size_t)NB));
@@ -1319,7 +1322,22 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     const char* venv = psf_exp_env("PSF_TRMM_VARIANT");      // read per call: the tests compare the kernels inside one process
     const int variant = venv ? std::atoi(venv) : 2;
     const size_t row_hi = h->structured ? h->mb : h->M_pad;
-    if (stream && wg32) {
+    if (stream && wg96) {
+      StreamGeom g;
+      g.ntile = ((int)((h->mL + 15) / 16) + 3) / 4;
+      g.ncg = 1;
+      g.ntask = g.ntile;
+      g.bc = 0;
+      g.ncf = 6;
+      const unsigned grid = (unsigned)((g.ntask + 1) / 2);
+      g.cf_base = 0;
+      if (compact) hipLaunchKernelGGL((k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 1, 2>), dim3(grid), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      else hipLaunchKernelGGL((k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 0, 2>), dim3(grid), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      g.cf_base = 4;
+      if (compact) hipLaunchKernelGGL((k_trmm_stream_wg32<TSW_H, TSW_NBUF, 1>), dim3(grid), dim3(512), TSW32_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      else hipLaunchKernelGGL((k_trmm_stream_wg32<TSW_H, TSW_NBUF, 0>), dim3(grid), dim3(512), TSW32_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+    }
+    else if (stream && wg32) {
       StreamGeom g;
       g.ntile = ((int)((h->mL + 15) / 16) + 3) / 4;
       g.ncg = ncg;
