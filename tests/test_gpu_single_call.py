@@ -276,18 +276,18 @@ def _with_env(env, fn):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("B", [17, 24, 32, 33, 48, 64, 65, 80, 96, 97, 100, 128, 129, 300, 1000])
+@pytest.mark.parametrize("B", [17, 24, 32, 33, 48, 64, 65, 80, 96, 97, 100, 128, 129, 160, 192, 300, 449, 1000])
 def test_shared_operand_tiles_give_the_batch_kernels_bits(exp_pair, exp_lib, oracle, B):
     """k_trmm_stream_wg (64 x 64 tiles, operands shared through LDS; the default at 33 ... 64 preimages; beyond 64 the experiments build's column groups of 128 on
     halves of eight waves) at every batch size the experiments build lets it serve (PSF_STREAM_WG = smallest batch, PSF_STREAM_WG_MAX = largest), the default form of
-    the batch size (17 ... 32: k_trmm_stream_wg32, 64 x 32 tiles; 65 ... 96: one launch of each over a stream of six fragments) and the one-wave tasks: the bits of k_trmm_f64_big (PSF_TRMM_STREAM_MAX = 0).  The shapes have 31 / 59 / 83 sixteen-row
+    the batch size (17 ... 32: k_trmm_stream_wg32, 64 x 32 tiles; 65 ... 96: one launch of each over a stream of six fragments; beyond 128 with an odd number of column groups of 64: the 64 x 64 tiles again) and the one-wave tasks: the bits of k_trmm_f64_big (PSF_TRMM_STREAM_MAX = 0).  The shapes have 31 / 59 / 83 sixteen-row
     tiles: the last tile group is ragged, the task count odd or even, and the ring runs 16 k-steps past the diagonal."""
     psf, orc, n, q = exp_pair
     u = oracle.uniform_targets(6, B, n, q)
     ref = _with_env({"PSF_TRMM_STREAM_MAX": "0", "PSF_STREAM_WG": None, "PSF_STREAM_WG_MAX": None}, lambda: psf.samp_p_stages(u, seed=19, first_index=7))
     got = _with_env({"PSF_TRMM_STREAM_MAX": "4096", "PSF_STREAM_WG": "17", "PSF_STREAM_WG_MAX": "1024"}, lambda: psf.samp_p_stages(u, seed=19, first_index=7))
-    one = _with_env({"PSF_TRMM_STREAM_MAX": "4096", "PSF_STREAM_WG": "0", "PSF_STREAM_WG32": "0", "PSF_STREAM_WG96": "0"}, lambda: psf.samp_p_stages(u, seed=19, first_index=7))
-    dflt = _with_env({"PSF_TRMM_STREAM_MAX": None, "PSF_STREAM_WG": None, "PSF_STREAM_WG_MAX": None, "PSF_STREAM_WG32": None, "PSF_STREAM_WG96": None}, lambda: psf.samp_p_stages(u, seed=19, first_index=7))
+    one = _with_env({"PSF_TRMM_STREAM_MAX": "4096", "PSF_STREAM_WG": "0", "PSF_STREAM_WG32": "0", "PSF_STREAM_WG96": "0", "PSF_STREAM_WG192": "0"}, lambda: psf.samp_p_stages(u, seed=19, first_index=7))
+    dflt = _with_env({"PSF_TRMM_STREAM_MAX": None, "PSF_STREAM_WG": None, "PSF_STREAM_WG_MAX": None, "PSF_STREAM_WG32": None, "PSF_STREAM_WG96": None, "PSF_STREAM_WG192": None}, lambda: psf.samp_p_stages(u, seed=19, first_index=7))
     assert (dflt["x"].view(np.uint64) == ref["x"].view(np.uint64)).all(), "the default form of this batch size differs from k_trmm_f64_big"
     assert (got["x"].view(np.uint64) == ref["x"].view(np.uint64)).all(), "the shared-operand tiles differ from k_trmm_f64_big"
     assert (one["x"].view(np.uint64) == ref["x"].view(np.uint64)).all(), "the one-wave tasks differ from k_trmm_f64_big"

@@ -1270,13 +1270,23 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
                                  // chains: 0.87 ms would be the matrix pipe's time on 241 CUs.  Beyond 64 preimages the forms tried (column groups of 64 with one or two
                                  // workgroups per CU, column groups of 128 on halves of eight waves) end within 5 % of the one-wave tasks: PSF_STREAM_WG_MAX (<= 1024)
   if (const char* e = psf_exp_env("PSF_STREAM_WG_MAX")) wg_max = std::min<size_t>((size_t)std::atol(e), 1024);      // (beyond 64: the experiments build's halves of eight waves)
-  const bool wg = stream && B >= wg_min && B <= wg_max && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
+  // Beyond 128 preimages with an ODD number of column groups of 64 (129-192, 257-320, ... 897-960): the same tiles, the column groups of a tile group on one XCD -- the
+  // one-wave tasks take as long as for the next even count there (192 preimages cost what 256 do: their eight-wave workgroups hold 4 + 4 tasks, column groups of a
+  // tile group side by side), the tiles' workgroups are all of one length: 2.8-2.9 against 3.7-3.9 ms at 129-192, 4.8 / 5.9 at 320, 6.6 / 7.9 at 448, 8.6 / 9.9 at 576,
+  // 14.5 / 15.9 at 960; with an even count the two forms tie (1.96 / 1.94 at 128, 7.70 / 7.69 at 512, 15.5 / 15.0 at 1024).  PSF_STREAM_WG192=0 keeps the one-wave
+  // tasks, "lo:hi" forces the tiles for every batch size in the range (experiments build; same bits)
+  bool wg192 = stream && B > 128 && B <= 960 && (((B + 63) / 64) & 1) != 0 && wg_max <= 64 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
+  if (const char* e = psf_exp_env("PSF_STREAM_WG192")) {
+    long lo = 0, hi = 0;
+    wg192 = std::sscanf(e, "%ld:%ld", &lo, &hi) == 2 && lo >= 65 && hi <= 1024 && stream && B >= (size_t)lo && B <= (size_t)hi && wg_max <= 64 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
+  }
+  const bool wg = stream && ((B >= wg_min && B <= wg_max) || wg192) && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
   // 17 ... 32 preimages: 64 x 32 tiles of the same ring (k_trmm_stream_wg32); PSF_STREAM_WG32=0 keeps the one-wave tasks (experiments build; same bits)
   const bool wg32 = stream && !wg && B >= 17 && B <= 32 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE") && !(psf_exp_env("PSF_STREAM_WG32") && std::atoi(psf_exp_env("PSF_STREAM_WG32")) == 0);
   // 65 ... 96 preimages: the first 64 on the 64 x 64 tiles, the rest on the 64 x 32 tiles, two launches over one normals stream of six fragments (0.94 + 0.65 ms against 1.80 for
   // the one-wave tasks, which pay for 128 columns); PSF_STREAM_WG96=0 keeps those (experiments build; same bits)
   const bool wg96 = stream && !wg && B >= 65 && B <= 96 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE") && !(psf_exp_env("PSF_STREAM_WG96") && std::atoi(psf_exp_env("PSF_STREAM_WG96")) == 0);
-  if (wg) { RT = 2; NB = B <= 64 ? 4 : 8; }      // column groups of 64 (halves of four waves) or 128 preimages (halves of eight waves)
+  if (wg) { RT = 2; NB = (B <= 64 || wg192) ? 4 : 8; }      // column groups of 64 (halves of four waves) or 128 preimages (halves of eight waves)
   if (wg32 || wg96) { RT = 2; NB = 2; }          // (wg96: three column groups of 32 = the six fragments of the stream)
   if (const char* e = psf_exp_env("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
   if (!(NB == 1 || NB == 2 || NB == 4 || NB == 8)) NB = 1;
@@ -1354,9 +1364,10 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
       g.ntask = g.ntile * g.ncg;
       g.bc = 0;
       const unsigned nwg = (unsigned)((g.ntask + 1) / 2);
-      if (NB == 4) {         // <= 64 preimages: one workgroup of 2 x 4 waves per CU, rounds of four k-steps
-        if (compact) hipLaunchKernelGGL((k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 1, 2>), dim3(nwg), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
-        else hipLaunchKernelGGL((k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 0, 2>), dim3(nwg), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+      if (NB == 4) {         // column groups of 64 preimages: one workgroup of 2 x 4 waves per CU, rounds of four k-steps; several groups: those of a tile group on one XCD
+        const unsigned grid64 = ncg > 1 ? 8 * ((nwg + 7) / 8) : nwg;
+        if (compact) hipLaunchKernelGGL((k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 1, 2>), dim3(grid64), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
+        else hipLaunchKernelGGL((k_trmm_stream_wg<TSW64_H, TSW64_NBUF, 0, 2>), dim3(grid64), dim3(512), TSW_LDS, st, h->dLt, h->dDt, h->dX, g, h->nkb, ld, row_hi);
       }
 #ifdef PSF_EXPERIMENTS
       else {                 // column groups of 128 preimages: 2 x 8 waves, rounds of two k-steps (96 KiB); the column groups of a tile group on one XCD.  Measured against the
