@@ -276,7 +276,7 @@ def _with_env(env, fn):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("B", [17, 24, 32, 33, 48, 64, 65, 80, 96, 97, 100, 128, 129, 160, 192, 300, 449, 1000])
+@pytest.mark.parametrize("B", [17, 24, 32, 33, 48, 64, 65, 80, 96, 97, 100, 128, 129, 160, 192, 300, 449, 1000, 1100, 1300, 1472, 1600, 1728])
 def test_shared_operand_tiles_give_the_batch_kernels_bits(exp_pair, exp_lib, oracle, B):
     """k_trmm_stream_wg (64 x 64 tiles, operands shared through LDS; the default at 33 ... 64 preimages; beyond 64 the experiments build's column groups of 128 on
     halves of eight waves) at every batch size the experiments build lets it serve (PSF_STREAM_WG = smallest batch, PSF_STREAM_WG_MAX = largest), the default form of

@@ -20,7 +20,7 @@
 // PD k-steps of operands are in flight per wave in a register ring (loads and waits are asm volatile: hipcc drains an unrolled ring with vmcnt(0));
 // the 6-bit vmcnt allows 63 loads in flight, so PD <= 63 / (RT + NB) + 1.  Eight waves per CU with eight k-steps each already saturate what a CU
 // takes from HBM (tools/probe_stream.hip: PD 8 / 16 / 32 within 4 %); what a wave must not do is spend issue cycles per k-step beside its loads.
-constexpr size_t TS_SLACK_DOUBLES = 4 * 32 * 512;      // doubles (512 KiB) the host allocates behind the factor's and the normals' streams: PD k-steps of over-read, at most 8 x 64 fragments x 512 B for the compact normals stream at 1024 preimages
+constexpr size_t TS_SLACK_DOUBLES = 2 * 16 * 128 * 64;      // doubles (2 MiB) the host allocates behind the factor's and the normals' streams: up to 16 k-steps of over-read (2 PD of k_trmm_stream, the ring of k_trmm_stream_wg), 128 fragments x 512 B each for the compact normals stream at 2048 preimages = 1 MiB
 #include <type_traits>
 #include "psf_kernels.hpp"
 

@@ -1255,10 +1255,15 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // Small batches (one samp_p call of the reference is ONE preimage, psf.rs:48-80): the streaming product, bound by reading the factor once, fed by
   // the compact normals stream.  PSF_TRMM_STREAM_MAX = largest batch it serves (0 switches it off); PSF_TRMM_STREAM_SHAPE = "RT,NB" forces a tile
   // shape, PSF_COMPACT_D=0 the chunk-stream layout of the normals (experiments; same bits).
-  size_t stream_max = 1024;      // measured at C3 (profiles/r04_notes.md): the streaming form wins up to ~1024 preimages, k_trmm_f64_big beyond
-  if (const char* e = psf_exp_env("PSF_TRMM_STREAM_MAX")) stream_max = (size_t)std::atol(e);
-  if (stream_max > 2048) stream_max = 2048;      // 128 column fragments: beyond, the over-read of the compact normals stream would leave TS_SLACK_DOUBLES
-  const bool stream = B <= stream_max;
+  // measured at C3: the streaming forms win up to 1472 preimages and again at 1537 ... 1728 (round 6, tools/tail_ab.py k_trmm_f64: k_trmm_f64_big costs 22.2-22.5 ms for anything
+  // between 1025 and 1536 preimages and 27.2 up to 2048, the 64 x 64 tiles ~0.97 ms per round of 256 workgroups: 16.5 ms at 1152, 18.6 at 1280, 21.8 at 1472, 23.8 at 1600, 26.9 at 1792)
+  size_t stream_max = 1472;
+  bool stream = B <= stream_max || (B >= 1537 && B <= 1728);
+  if (const char* e = psf_exp_env("PSF_TRMM_STREAM_MAX")) {
+    stream_max = (size_t)std::atol(e);
+    if (stream_max > 2048) stream_max = 2048;      // 128 column fragments: beyond, the over-read of the compact normals stream would leave TS_SLACK_DOUBLES
+    stream = B <= stream_max;
+  }
   // tile shape per wave (RT 16-row tiles x NB fragments of 16 preimages) and workgroup form, from tools/probe_stream.hip at the C3 shape
   // (profiles/r04_probe_stream.log): <= 16 preimages the launch is bound by reading the factor, beyond that by the longest MFMA chain
   int RT = 2, NB = B <= 16 ? 1 : B <= 64 ? 2 : 4;
@@ -1275,10 +1280,10 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // tile group side by side), the tiles' workgroups are all of one length: 2.8-2.9 against 3.7-3.9 ms at 129-192, 4.8 / 5.9 at 320, 6.6 / 7.9 at 448, 8.6 / 9.9 at 576,
   // 14.5 / 15.9 at 960; with an even count the two forms tie (1.96 / 1.94 at 128, 7.70 / 7.69 at 512, 15.5 / 15.0 at 1024).  PSF_STREAM_WG192=0 keeps the one-wave
   // tasks, "lo:hi" forces the tiles for every batch size in the range (experiments build; same bits)
-  bool wg192 = stream && B > 128 && B <= 960 && (((B + 63) / 64) & 1) != 0 && wg_max <= 64 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
+  bool wg192 = stream && ((B > 128 && B <= 960 && (((B + 63) / 64) & 1) != 0) || B > 1088) && wg_max <= 64 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");      // (1025-1088: 15.9 against 16.5)
   if (const char* e = psf_exp_env("PSF_STREAM_WG192")) {
     long lo = 0, hi = 0;
-    wg192 = std::sscanf(e, "%ld:%ld", &lo, &hi) == 2 && lo >= 65 && hi <= 1024 && stream && B >= (size_t)lo && B <= (size_t)hi && wg_max <= 64 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
+    wg192 = std::sscanf(e, "%ld:%ld", &lo, &hi) == 2 && lo >= 65 && hi <= 2048 && stream && B >= (size_t)lo && B <= (size_t)hi && wg_max <= 64 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
   }
   const bool wg = stream && ((B >= wg_min && B <= wg_max) || wg192) && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
   // 17 ... 32 preimages: 64 x 32 tiles of the same ring (k_trmm_stream_wg32); PSF_STREAM_WG32=0 keeps the one-wave tasks (experiments build; same bits)
