@@ -1409,6 +1409,9 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
     }
     else if (variant == 2 || !psf_experiments_build) {
       int GR = 8, GC = 4;                                     // super-tile of an XCD's 32 resident workgroups; PSF_TRMM_GR x PSF_TRMM_GC for experiments (product = 32)
+      // below 4096 preimages, or with a number of 128-column blocks that is not a multiple of four: 16 x 2 -- the grid is padded to whole super-columns, and 8 x 4 pays for up
+      // to three empty column blocks (round 6, tools/tail_ab.py: 34.9 -> 32.3 ms at 2176, 47.8 -> 44.1 at 3200, 27.2 -> 26.3 at 2048; 51.9 against 52.5 at 4096: 8 x 4 stays there)
+      if (B < 4096 || nbj % 4 != 0) { GR = 16; GC = 2; }
       if (const char* e1 = psf_exp_env("PSF_TRMM_GR")) if (const char* e2 = psf_exp_env("PSF_TRMM_GC")) { GR = std::atoi(e1); GC = std::atoi(e2); }
       if (GR < 1 || GC < 1 || GR * GC != 32) { GR = 8; GC = 4; }
       hipLaunchKernelGGL(k_trmm_f64_big, dim3(tr_grid_size(((int)h->nbiL + 1) / 2, (int)nbj, GR, GC)), dim3(256), 0, st, h->dLt, h->dDt, h->dX, (int)h->nbiL, (int)nbj, h->nkb, ld, GR, GC, row_hi);
