@@ -25,6 +25,9 @@ CASES = [  # (n, k, m_bar, base, q, r, s, B, expect_hi)
     (64, 2, 512, 32, 1024, 6.0, 12000.0, 128, True),     # ... with the second plane
     (8, 10, 300, 2, 1024, 3.0, 300.0, 65, False),
     (8, 10, 700, 2, 1024, 3.0, 450.0, 300, False),       # five column groups, the last one of 44 preimages
+    (8, 10, 700, 2, 1024, 3.0, 450.0, 500, False),       # beyond 448: the 256 x 256 tiles with a ragged last tile
+    (64, 2, 512, 32, 1024, 6.0, 12000.0, 600, True),     # ... and the second plane: they leave the call to the 128 x 128 kernel
+    (8, 10, 700, 2, 1024, 3.0, 450.0, 1000, False),
     (64, 2, 512, 32, 1024, 6.0, 12000.0, 448, True),
     (8, 2, 512, 32, 1024, 6.0, 12000.0, 16, True),       # K = 64 is not a multiple of 128: the 128 x 128 kernel with K splits
 ]

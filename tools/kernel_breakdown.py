@@ -1,0 +1,20 @@
+import json, os, sys
+sys.path.insert(0, "/root/repo")
+os.chdir("/root/repo")
+import torch, bench
+import tools_amd as T
+_, n, q, r, s, _ = bench.CONFIGS["c3"]
+gp = T.GadgetParameters.init_default(n, q); psf = T.PSFPerturbation(gp, r, s); psf.trap_gen(1)
+m = gp.m_bar + gp.n * gp.k; dev = torch.device("cuda:0")
+sizes=[int(x) for x in sys.argv[1:]]
+u = (torch.randint(0, 2**62, (max(sizes), n), dtype=torch.int64) % q).to(dev)
+st = torch.cuda.current_stream().cuda_stream
+for B in sizes:
+    e = torch.zeros((B, m), dtype=torch.int64, device=dev)
+    call = lambda: psf.samp_p_dev(u.data_ptr(), e.data_ptr(), B, seed=9, first_index=1000, stream=st)
+    call(); call()
+    acc={}
+    for _ in range(5):
+        psf.enable_timing(True); call(); tm=dict(psf.get_timing()); psf.enable_timing(False)
+        for k,v in tm.items(): acc.setdefault(k,[]).append(v)
+    print(B, {k: round(sorted(v)[2],3) for k,v in acc.items()}, flush=True)
