@@ -1,6 +1,8 @@
+"""Per-stage HIP-event times (the handle's own timers, median of five calls) of one samp_p_dev call at C3 for a list of batch sizes: where a batch size's time goes.
+   python tools/kernel_breakdown.py 64 128 704 768 ..."""
 import json, os, sys
-sys.path.insert(0, "/root/repo")
-os.chdir("/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch, bench
 import tools_amd as T
 _, n, q, r, s, _ = bench.CONFIGS["c3"]
