@@ -241,6 +241,10 @@ static NpCols np_cols(const psfgpv_handle* g, size_t col0) {
 // does a batch of B preimages fit the one-launch walk?  (one sampler workgroup per CU at most beside the updaters that hold d/64 - 2 row blocks per column group)
 static bool np_walk_fits(const psfgpv_handle* g, size_t B, int* Gw_out, unsigned* nSw_out, unsigned* ngroups_out, unsigned* ug_out) {
   if (g->np_walk == 0 || g->np_walk == 3 || g->cus <= 0 || g->nblk < 3) return false;      // (PSF_NP_WALK=3: k_np_walk2 for every batch, tests)
+  // One preimage per sampler wave only: with two (k_np_walk<2>, 1025 ... 2048 preimages where it fits: 124 bytes of scratch per lane) the walk measured SLOWER than the
+  // launch-per-block form with one preimage per wave (C4 shape, round 6, tools/np_batch_sweep.py: 2.71 / 2.82 / 2.87 ms at 1025 / 1536 / 1792 preimages against 2.14 / 2.40 /
+  // 2.59); the experiments build keeps it behind PSF_NP_G=2
+  if (!psf_experiments_build && g->np_g != 1 && B > 4 * (size_t)g->cus) return false;
   const int Gw = (g->np_g == 1 || g->np_g == 2) ? g->np_g : (B <= 4 * (size_t)g->cus ? 1 : 2);
   const unsigned nSw = (unsigned)((B + 4 * (size_t)Gw - 1) / (4 * (size_t)Gw));
   const unsigned per = (unsigned)(NP_GW / (4 * Gw)), ngroups = (nSw + per - 1) / per;
@@ -268,7 +272,8 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
   if (pass == 0) hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, v.C0p, g->nkc, (int)g->nkc, v.Tm, ld);
   else hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBfull, g->nkd, v.C1, g->nkd, (int)g->nkd, v.Tm, ld);
   int G = g->np_g;
-  if (G != 1 && G != 2) G = B <= 1536 ? 1 : 2;      // one or two wave pairs per SIMD of the chip (1024 SIMDs)
+  if (G != 1 && G != 2) G = B <= 2048 ? 1 : 2;      // one wave pair per preimage while the sampler workgroups fit the chip's 512 slots at once (C4 shape: 2.45 / 2.80 ms at 1537 /
+                                                    // 2048 preimages against 3.06 / 3.25 with two preimages per pair); two rounds of them lose to two preimages per pair
   NpSampleArgs a{v.Tm, ld, g->dGin, g->dGnx, g->dRows, g->dSz, v.Zf, g->nkb, v.Z8, g->zplane, ld, flags};
   // The whole walk in one launch (k_np_walk) where every workgroup can be resident at once: one sampler workgroup per CU at most (B <= 4 G CUs) beside one
   // updater workgroup per CU, and at most 2 * NP_WALK_SLOTS blocks of T per updater.  Otherwise one launch per block (k_np_step).
@@ -285,13 +290,17 @@ static psf_status launch_nearest_plane(psfgpv_handle* g, hipStream_t st, uint64_
         WalkTurn turn(g->base->prm.device, st);
         hipMemsetAsync(g->dWalk, 0, g->walk_words * sizeof(unsigned), st);
         if (Gw == 1) hipLaunchKernelGGL((k_np_walk<1>), dim3(ntot), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, nSw, ngroups, ug, g->dGp, g->dTm, sy);
+#ifdef PSF_EXPERIMENTS
         else hipLaunchKernelGGL((k_np_walk<2>), dim3(ntot), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, nSw, ngroups, ug, g->dGp, g->dTm, sy);
+#endif
       }
       // a walk that gave up (the abort word) is walked again without waits between workgroups, from a fresh projection; both launches return at once otherwise
       if (pass == 0) hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBpiv, g->nkc, g->dC0p, g->nkc, (int)g->nkc, g->dTm, ld, (const unsigned*)sy.abort);
       else hipLaunchKernelGGL(k_np_project, dim3((unsigned)nbj, (unsigned)g->nrb), dim3(256), lds_gemm, st, g->dBfull, g->nkd, g->dC1, g->nkd, (int)g->nkd, g->dTm, ld, (const unsigned*)sy.abort);
       if (Gw == 1) hipLaunchKernelGGL((k_np_walk_solo<1>), dim3(nSw), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, g->dGp, g->dTm, (const unsigned*)sy.abort, reruns);
+#ifdef PSF_EXPERIMENTS
       else hipLaunchKernelGGL((k_np_walk_solo<2>), dim3(nSw), dim3(512), 65536, st, aw, g->dim, g->nblk, seed, tag, first_index, B, g->dGp, g->dTm, (const unsigned*)sy.abort, reruns);
+#endif
       g->last_form = 1; g->last_G = Gw;
       return launch_np_recombination(g, st, B, d_e, pass, col0);
     }
@@ -461,7 +470,9 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+#ifdef PSF_EXPERIMENTS
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+#endif
 #ifdef PSF_EXPERIMENTS
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -470,10 +481,14 @@ static psf_status psfgpv_init(psfgpv_handle* g) {
 #endif
   { int cu = 0; HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, g->base->prm.device)); g->cus = cu; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk_solo<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+#ifdef PSF_EXPERIMENTS
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_walk_solo<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+#endif
   // workgroups of the one-launch walk a compute unit really holds (registers, LDS): the residency test of launch_nearest_plane multiplies by the CU count
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&g->walk_slots[1], reinterpret_cast<const void*>(k_np_walk<1>), 512, 65536));
+#ifdef PSF_EXPERIMENTS
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&g->walk_slots[2], reinterpret_cast<const void*>(k_np_walk<2>), 512, 65536));
+#endif
   if (const char* e = psf_exp_env("PSF_NP_WALK")) g->np_walk = std::atoi(e);
   if (const char* e = psf_exp_env("PSF_NP_WALK_SPINS")) { const long v = std::atol(e); if (v >= 1) g->walk_spins = (unsigned)v; }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_np_combine8_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 768));
