@@ -1,6 +1,6 @@
 """A/B of one stage of a small-batch call at C3 under experiment switches (experiments build): HIP-event time of the stage's launches (the handle's own timers), the
 median call, and the rows of every variant compared bit for bit with the first.
-   python tools/tail_ab.py <timer name, e.g. k_recombine> <sizes, comma separated> <name>:<K=V,K=V> [<name>:<K=V> ...]      ("name:" alone = no switch)"""
+   python tools/tail_ab.py [--config=bench64] <timer name, e.g. k_recombine> <sizes, comma separated> <name>:<K=V,K=V> [<name>:<K=V> ...]      ("name:" alone = no switch)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +10,9 @@ import bench  # noqa: E402
 import tools_amd as T  # noqa: E402
 
 def main():
+    cfg = "c3"
+    if len(sys.argv) > 1 and sys.argv[1].startswith("--config="):      # another PSFPerturbation configuration of bench.CONFIGS (bench64, c1, c3prime)
+        cfg = sys.argv.pop(1).split("=", 1)[1]
     key = sys.argv[1]
     sizes = [int(x) for x in sys.argv[2].split(",")]
     variants = []
@@ -17,7 +20,7 @@ def main():
         name, _, kv = a.partition(":")
         variants.append((name, dict(x.split("=", 1) for x in kv.split(",") if x)))
     allkeys = sorted({k for _, env in variants for k in env})
-    _, n, q, r, s, _ = bench.CONFIGS["c3"]
+    _, n, q, r, s, _ = bench.CONFIGS[cfg]
     gp = T.GadgetParameters.init_default(n, q)
     psf = T.PSFPerturbation(gp, r, s)
     psf.trap_gen(1)

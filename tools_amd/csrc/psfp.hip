@@ -1258,7 +1258,8 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // measured at C3: the streaming forms win up to 1472 preimages and again at 1537 ... 1728 (round 6, tools/tail_ab.py k_trmm_f64: k_trmm_f64_big costs 22.2-22.5 ms for anything
   // between 1025 and 1536 preimages and 27.2 up to 2048, the 64 x 64 tiles ~0.97 ms per round of 256 workgroups: 16.5 ms at 1152, 18.6 at 1280, 21.8 at 1472, 23.8 at 1600, 26.9 at 1792)
   size_t stream_max = 1472;
-  bool stream = B <= stream_max || (B >= 1537 && B <= 1728);
+  bool stream = B <= stream_max || (B >= 1537 && B <= 1728) || (h->mL < 16384 && B <= 2048);      // (a small factor: k_trmm_f64_big is a fixed 0.23 ms at m = 932 whatever the batch, the
+                                                                                                  // tiles 0.04 ms at 1100 ... 2048 preimages: no reason to leave them before the stream's limit)
   if (const char* e = psf_exp_env("PSF_TRMM_STREAM_MAX")) {
     stream_max = (size_t)std::atol(e);
     if (stream_max > 2048) stream_max = 2048;      // 128 column fragments: beyond, the over-read of the compact normals stream would leave TS_SLACK_DOUBLES
