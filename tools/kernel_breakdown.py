@@ -1,11 +1,13 @@
 """Per-stage HIP-event times (the handle's own timers, median of five calls) of one samp_p_dev call at C3 for a list of batch sizes: where a batch size's time goes.
-   python tools/kernel_breakdown.py 64 128 704 768 ..."""
+   python tools/kernel_breakdown.py [--config=bench64] 64 128 704 768 ..."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, bench
 import tools_amd as T
-_, n, q, r, s, _ = bench.CONFIGS["c3"]
+cfg = "c3"
+if len(sys.argv) > 1 and sys.argv[1].startswith("--config="): cfg = sys.argv.pop(1).split("=", 1)[1]
+_, n, q, r, s, _ = bench.CONFIGS[cfg]
 gp = T.GadgetParameters.init_default(n, q); psf = T.PSFPerturbation(gp, r, s); psf.trap_gen(1)
 m = gp.m_bar + gp.n * gp.k; dev = torch.device("cuda:0")
 sizes=[int(x) for x in sys.argv[1:]]

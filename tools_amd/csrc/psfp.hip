@@ -1281,7 +1281,10 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   // tile group side by side), the tiles' workgroups are all of one length: 2.8-2.9 against 3.7-3.9 ms at 129-192, 4.8 / 5.9 at 320, 6.6 / 7.9 at 448, 8.6 / 9.9 at 576,
   // 14.5 / 15.9 at 960; with an even count the two forms tie (1.96 / 1.94 at 128, 7.70 / 7.69 at 512, 15.5 / 15.0 at 1024).  PSF_STREAM_WG192=0 keeps the one-wave
   // tasks, "lo:hi" forces the tiles for every batch size in the range (experiments build; same bits)
-  bool wg192 = stream && ((B > 128 && B <= 960 && (((B + 63) / 64) & 1) != 0) || B > 1088) && wg_max <= 64 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");      // (1025-1088: 15.9 against 16.5)
+  // a small factor (m < 16 384: few tile groups, the launch lasts one chain): the tiles' waves hold 2 x 2 MFMA tiles against the one-wave tasks' 2 x 4 -- half the chain
+  // (m = 932: 0.035 against 0.061 ms at 97 ... 1024 preimages, whatever the parity): the tiles from 65 preimages on
+  const bool small_factor = h->mL < 16384;
+  bool wg192 = stream && ((B > 128 && B <= 960 && (((B + 63) / 64) & 1) != 0) || B > 1088 || (small_factor && B > 64)) && wg_max <= 64 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");      // (1025-1088: 15.9 against 16.5)
   if (const char* e = psf_exp_env("PSF_STREAM_WG192")) {
     long lo = 0, hi = 0;
     wg192 = std::sscanf(e, "%ld:%ld", &lo, &hi) == 2 && lo >= 65 && hi <= 2048 && stream && B >= (size_t)lo && B <= (size_t)hi && wg_max <= 64 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE");
@@ -1291,7 +1294,7 @@ static psf_status run_samp_p(psfp_handle* h, uint64_t seed, uint64_t first_index
   const bool wg32 = stream && !wg && B >= 17 && B <= 32 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE") && !(psf_exp_env("PSF_STREAM_WG32") && std::atoi(psf_exp_env("PSF_STREAM_WG32")) == 0);
   // 65 ... 96 preimages: the first 64 on the 64 x 64 tiles, the rest on the 64 x 32 tiles, two launches over one normals stream of six fragments (0.94 + 0.65 ms against 1.80 for
   // the one-wave tasks, which pay for 128 columns); PSF_STREAM_WG96=0 keeps those (experiments build; same bits)
-  const bool wg96 = stream && !wg && B >= 65 && B <= 96 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE") && !(psf_exp_env("PSF_STREAM_WG96") && std::atoi(psf_exp_env("PSF_STREAM_WG96")) == 0);
+  const bool wg96 = stream && !wg && !small_factor && B >= 65 && B <= 96 && !psf_exp_env("PSF_TRMM_STREAM_SHAPE") && !(psf_exp_env("PSF_STREAM_WG96") && std::atoi(psf_exp_env("PSF_STREAM_WG96")) == 0);
   if (wg) { RT = 2; NB = (B <= 64 || wg192) ? 4 : 8; }      // column groups of 64 (halves of four waves) or 128 preimages (halves of eight waves)
   if (wg32 || wg96) { RT = 2; NB = 2; }          // (wg96: three column groups of 32 = the six fragments of the stream)
   if (const char* e = psf_exp_env("PSF_TRMM_STREAM_SHAPE")) std::sscanf(e, "%d,%d", &RT, &NB);
