@@ -80,6 +80,35 @@ def test_the_default_form_equals_the_oracle(oracle):
     psf.close()
 
 
+@pytest.mark.parametrize("kind,B", [("gpv", 1100), ("gpv", 2048), ("ring", 1025), ("ring", 1800), ("ring", 2100)])
+def test_batches_between_one_and_two_thousand_take_one_preimage_per_wave(oracle, kind, B):
+    """round 6: beyond 4 x CUs preimages the release library walks per block, with ONE preimage per sampler wave up to 2048 preimages (k_np_step<1>) and two beyond
+    (k_np_step<2>); the one-launch walk with two per wave (k_np_walk<2>) left it.  The form the handle reports, and sampled rows against the oracle."""
+    import math
+    import tools_amd as T
+    if kind == "gpv":
+        n, q, s = 14, 2**9, 70.0
+        psf = T.PSFGPV(T.GadgetParameters.init_default(n, q), s)
+        A, (bt, gt) = psf.trap_gen(21)
+        orc = oracle.PSFGPV(oracle.gadget_params_default(n, q), s)
+        orc.load_key(A, bt, gt)
+    else:
+        n, q = 16, 3329
+        s = ((2 * 2 * 1.005 * math.sqrt(n) + 1) * 2) * 4
+        psf = T.PSFGPVRing(T.GadgetParametersRing.init_default(n, q), s, 1.005)
+        psf.trap_gen(22)
+        a, r, e, bt, gt = psf.export_key()
+        orc = oracle.PSFGPVRing(oracle.gadget_params_ring_default(n, q), s, 1.005)
+        orc.load_key(a, r, e, gso_t=gt)
+    u = oracle.uniform_targets(9, B, n, q)
+    got = psf.samp_p(u, seed=50, first_index=3)
+    form, G, blocks, reruns = psf.nearest_plane_form()
+    assert form == 0 and G == (1 if B <= 2048 else 2) and reruns == 0, (kind, B, form, G)
+    for b in (0, 1, 1023, 1024, B // 2, B - 1):
+        assert (got[b] == orc.samp_p(50, u[b:b + 1], first_index=3 + b)[0]).all(), (kind, B, b)
+    psf.close()
+
+
 def test_a_wait_that_gives_up_is_walked_again_inside_the_call(oracle):
     """A poll limit of 1 makes the first wait of the one-launch walk that is not satisfied at once give up: the abort word is raised, every workgroup leaves at its next
     wait, and the launches enqueued behind the walk (a fresh projection + k_np_walk_solo, no waits between workgroups) walk the batch again.  The call returns
